@@ -1,0 +1,390 @@
+"""CPU oracle for the Bayesian attack / expected-loss-gradient hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under robustbnns_amd/ may import this module; it is
+used by tests/, by __graft_entry__.smoke() and by bench.py's `cpu_baseline` leg, and
+there only as the checker / the reported CPU baseline, never as the product path.
+
+Parity status: PINNED for rows a1, a3-a10 of SURVEY.md section 8 — every function here is
+checked in tests/test_oracle_golden.py against tests/golden/*.npz, which were produced
+by running the reference's own functions (tests/golden/make_golden.py).  Row a2 (the SVI
+weight draw) is "parity unpinned": its arithmetic lives in pyro-ppl==1.3.0 / torch==1.4.0
+(requirements.txt:45,56), neither present here; `svi_materialize` restates
+model_bnn.py:121-130 (w = loc + softplus(scale) * eps) given explicit eps.
+
+Two restatements of the same algorithm live here:
+
+* closed form, batched over all points and samples (fp32 or fp64) — what the HIP
+  kernels are compared with;
+* `loop_*`: the reference's own loop nest (adversarialAttacks.py:118 -> :95 ->
+  model_bnn.py:251; batch 1, autograd, one Python iteration per point / PGD iteration /
+  posterior sample) — the honest "reference --device=cpu" stand-in timed by bench.py.
+
+A posterior is a dict of stacked tensors (one leading axis S = posterior samples), keyed
+like the reference's state_dict (model_nn.py:77-91):
+  fc :  "model.1.weight" [S,H,D]  "model.1.bias" [S,H]  "model.3.weight" [S,C,H]  "model.3.bias" [S,C]
+  fc2:  + "model.3.*" [S,H,H]/[S,H] and "model.5.*" [S,C,H]/[S,C]
+  conv: "model.0.*" [S,32,Cin,5,5], "model.3.*" [S,Hc,32,5,5], "model.7.*" [S,C,F]
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LEAKY_SLOPE = 0.01          # torch.nn.LeakyReLU() default, model_nn.py:68-69
+
+
+# --------------------------------------------------------------------------- helpers
+def _act(a, act):
+    """model_nn.py:66-75"""
+    if act == "relu":
+        return torch.relu(a)
+    if act == "leaky":
+        return torch.where(a > 0, a, a * LEAKY_SLOPE)
+    if act == "sigm":
+        return torch.sigmoid(a)
+    if act == "tanh":
+        return torch.tanh(a)
+    raise AssertionError("\nWrong activation name.")
+
+
+def _act_grad(a, act):
+    if act == "relu":
+        return (a > 0).to(a.dtype)
+    if act == "leaky":
+        return torch.where(a > 0, torch.ones_like(a), torch.full_like(a, LEAKY_SLOPE))
+    if act == "sigm":
+        s = torch.sigmoid(a)
+        return s * (1 - s)
+    if act == "tanh":
+        t = torch.tanh(a)
+        return 1 - t * t
+    raise AssertionError("\nWrong activation name.")
+
+
+def mlp_layers(post, arch):
+    """Stacked (W[S,out,in], b[S,out]) per Linear of the fc / fc2 nets (model_nn.py:77-91)."""
+    if arch == "fc":
+        ks = ["model.1", "model.3"]
+    elif arch == "fc2":
+        ks = ["model.1", "model.3", "model.5"]
+    else:
+        raise NotImplementedError(arch)
+    return [(post[k + ".weight"], post[k + ".bias"]) for k in ks]
+
+
+def select(post, idx):
+    """model_bnn.py:246-252: `seeds` are indices into the stored samples."""
+    idx = torch.as_tensor(list(idx), dtype=torch.long)
+    return {k: v[idx] for k, v in post.items()}
+
+
+def cast(post, dtype):
+    return {k: v.to(dtype) for k, v in post.items()}
+
+
+# ------------------------------------------------------------ a1: per-sample network
+def nn_logits(x, post, arch, act):
+    """NN.forward for every stacked sample at once -> logits [S,N,C] (model_nn.py:126-141)."""
+    if arch in ("fc", "fc2"):
+        h = x.reshape(x.shape[0], -1).unsqueeze(0)                       # nn.Flatten
+        layers = mlp_layers(post, arch)
+        for li, (W, b) in enumerate(layers):
+            h = torch.matmul(h, W.transpose(1, 2)) + b.unsqueeze(1)      # nn.Linear
+            if li + 1 < len(layers):
+                h = _act(h, act)
+        return h
+    if arch == "conv":                                                   # model_nn.py:98-106
+        outs = []
+        for s in range(post["model.0.weight"].shape[0]):
+            h = F.conv2d(x, post["model.0.weight"][s], post["model.0.bias"][s])
+            h = F.max_pool2d(_act(h, act), 2)
+            h = F.conv2d(h, post["model.3.weight"][s], post["model.3.bias"][s])
+            h = F.max_pool2d(_act(h, act), 2, stride=1)
+            h = h.flatten(1)
+            outs.append(F.linear(h, post["model.7.weight"][s], post["model.7.bias"][s]))
+        return torch.stack(outs)
+    raise NotImplementedError(arch)
+
+
+def _mlp_forward_cache(xf, layers, act):
+    """xf [N,D] -> (logits [S,N,C], pre-activations list)."""
+    h = xf.unsqueeze(0)
+    pre = []
+    for li, (W, b) in enumerate(layers):
+        a = torch.matmul(h, W.transpose(1, 2)) + b.unsqueeze(1)
+        if li + 1 < len(layers):
+            pre.append(a)
+            h = _act(a, act)
+        else:
+            h = a
+    return h, pre
+
+
+def _mlp_input_grad(dz, layers, pre, act):
+    """dz [S,N,C] = dL/dlogits -> per-sample dL/dx [S,N,D] (hand-rolled backward)."""
+    d = dz
+    for li in range(len(layers) - 1, -1, -1):
+        W, _ = layers[li]
+        d = torch.matmul(d, W)                                           # [S,N,in]
+        if li > 0:
+            d = d * _act_grad(pre[li - 1], act)
+    return d
+
+
+# ------------------------------------------------------------ a3/a4: BNN.forward
+def bnn_forward(x, post, arch, act, n_samples=10, seeds=None):
+    """BNN.forward HMC branch, model_bnn.py:198-202,243-258: mean over samples of softmax."""
+    if seeds:
+        if len(seeds) != n_samples:
+            raise ValueError("Number of seeds should match number of samples.")
+    if seeds is None:
+        seeds = range(n_samples)
+    z = nn_logits(x, select(post, seeds), arch, act)
+    return torch.softmax(z, dim=-1).mean(0)
+
+
+def ensemble_forward(x, post, arch, act, n_samples):
+    """Ensemble_NN.forward, model_ensemble.py:57-67: mean of LOGITS of the first n members."""
+    S = next(iter(post.values())).shape[0]
+    if n_samples is not None and n_samples > S:
+        raise ValueError("Maximum number of samples allowed is ", S)
+    return nn_logits(x, select(post, range(S)[:n_samples]), arch, act).mean(0)
+
+
+# ------------------------------------------------- dL/dlogits for the loss definitions
+def _onehot(label, C, dtype):
+    return F.one_hot(label, C).to(dtype)
+
+
+def dz_mean_prob(p, label):
+    """fgsm/pgd loss (adversarialAttacks.py:74-78): L = CE(mean_s p_s, y) = -log softmax(pbar)[y]
+    — CrossEntropyLoss applied to PROBABILITIES (the double softmax)."""
+    S, _, C = p.shape
+    G = (torch.softmax(p.mean(0), -1) - _onehot(label, C, p.dtype)) / S          # dL/dp_s
+    return p * (G.unsqueeze(0) - (G.unsqueeze(0) * p).sum(-1, keepdim=True))
+
+
+def dz_per_sample(p, label):
+    """loss_gradient (lossGradients.py:29-40): CE per sample on that sample's probabilities,
+    gradients averaged afterwards (the 1/S is folded in here)."""
+    S, _, C = p.shape
+    G = (torch.softmax(p, -1) - _onehot(label, C, p.dtype).unsqueeze(0)) / S
+    return p * (G - (G * p).sum(-1, keepdim=True))
+
+
+def dz_mean_logit(z, label):
+    """Ensemble_NN / deterministic NN under fgsm/pgd: CE on (mean) logits."""
+    S, _, C = z.shape
+    G = (torch.softmax(z.mean(0), -1) - _onehot(label, C, z.dtype)) / S
+    return G.unsqueeze(0).expand(S, -1, -1)
+
+
+# ------------------------------------------------------------ a5/a6: loss_gradient(s)
+def _input_grad(x, label, post, arch, act, mode):
+    """Summed-over-samples input gradient [N,*x.shape[1:]] under `mode`."""
+    if arch in ("fc", "fc2"):
+        layers = mlp_layers(post, arch)
+        z, pre = _mlp_forward_cache(x.reshape(x.shape[0], -1), layers, act)
+        if mode == "mean_logit":
+            dz = dz_mean_logit(z, label)
+        else:
+            p = torch.softmax(z, -1)
+            dz = dz_mean_prob(p, label) if mode == "mean_prob" else dz_per_sample(p, label)
+        return _mlp_input_grad(dz, layers, pre, act).sum(0).reshape(x.shape)
+    # conv: the oracle lets autograd do the backward (checker only)
+    xr = x.detach().clone().requires_grad_(True)
+    z = nn_logits(xr, post, arch, act)
+    S, N, C = z.shape
+    if mode == "mean_logit":
+        loss = F.cross_entropy(z.mean(0), label, reduction="sum")
+    elif mode == "mean_prob":
+        loss = F.cross_entropy(torch.softmax(z, -1).mean(0), label, reduction="sum")
+    else:
+        loss = F.cross_entropy(torch.softmax(z, -1).reshape(S * N, C), label.repeat(S), reduction="sum") / S
+    loss.backward()
+    return xr.grad.detach()
+
+
+def loss_gradients(x, y_onehot, post, arch, act, n_samples):
+    """lossGradients.loss_gradient for every point of x at once (lossGradients.py:20-40,52-62):
+    mean_i d/dx CE(p_i(x), y), i = seeds 0..n_samples-1.  Returns x's shape."""
+    label = y_onehot.argmax(-1)
+    return _input_grad(x, label, select(post, range(n_samples)), arch, act, "per_sample")
+
+
+def meanprob_gradients(x, label, post, arch, act, n_samples, kind="bnn"):
+    """The gradient whose sign fgsm/pgd take (adversarialAttacks.py:74-79)."""
+    mode = "mean_prob" if kind == "bnn" else "mean_logit"
+    return _input_grad(x, label, select(post, range(n_samples)), arch, act, mode)
+
+
+# ------------------------------------------------------------ a7/a8: fgsm / pgd
+def fgsm_attack(x, label, post, arch, act, n_samples, hyperparams=None, kind="bnn"):
+    """adversarialAttacks.py:69-83, all points at once."""
+    epsilon = hyperparams["epsilon"] if hyperparams is not None else 0.3
+    g = meanprob_gradients(x, label, post, arch, act, n_samples, kind)
+    return torch.clamp(x + epsilon * g.sign(), 0, 1)
+
+
+def pgd_params(x, hyperparams):
+    """adversarialAttacks.py:88-91: alpha = 2/image.max() per image (from the clean image)."""
+    if hyperparams is not None:
+        flat = x.reshape(x.shape[0], -1)
+        alpha = (2 / flat.max(dim=1)[0]).reshape((-1,) + (1,) * (x.dim() - 1))
+        return hyperparams["epsilon"], alpha, 40
+    return 0.5, torch.full((x.shape[0],) + (1,) * (x.dim() - 1), 2 / 225, dtype=x.dtype), 40
+
+
+def pgd_attack(x, label, post, arch, act, n_samples, hyperparams=None, kind="bnn", iters=None):
+    """adversarialAttacks.py:86-108, all points at once."""
+    epsilon, alpha, it = pgd_params(x, hyperparams)
+    it = it if iters is None else iters
+    x0 = x.clone()
+    xi = x.clone()
+    for _ in range(it):
+        g = meanprob_gradients(xi, label, post, arch, act, n_samples, kind)
+        pert = xi + alpha.to(xi.dtype) * g.sign()
+        eta = torch.clamp(pert - x0, min=-epsilon, max=epsilon)
+        xi = torch.clamp(x0 + eta, min=0, max=1)
+    return xi
+
+
+# ------------------------------------------------------------ a10: evaluation
+def softmax_difference(orig, adv):
+    """adversarialAttacks.py:30-51 (softmax applied AGAIN to whatever forward returned)."""
+    d = (torch.softmax(orig, -1) - torch.softmax(adv, -1)).abs().max(dim=-1)[0]
+    if d.min() < 0. or d.max() > 1.:
+        raise ValueError("Softmax difference should be in [0,1]")
+    return d
+
+
+def attack_evaluation(x, x_attack, y_onehot, post, arch, act, n_samples, kind="bnn"):
+    """adversarialAttacks.py:151-198 -> (orig_acc %, adv_acc %, softmax_rob [N])."""
+    def fwd(v):
+        if kind == "bnn":
+            return bnn_forward(v, post, arch, act, n_samples)
+        return ensemble_forward(v, post, arch, act, n_samples)
+    o, a = fwd(x), fwd(x_attack)
+    lab = y_onehot.argmax(-1)
+    oc = float((o.argmax(-1) == lab).sum().item())
+    ac = float((a.argmax(-1) == lab).sum().item())
+    return 100 * oc / len(x), 100 * ac / len(x), 1 - softmax_difference(o, a)
+
+
+# ------------------------------------------------------------ a2: SVI draw (unpinned)
+def svi_materialize(loc, scale_raw, eps):
+    """model_bnn.py:124-130: Normal(loc, softplus(scale)).rsample() = loc + softplus(scale)*eps.
+    loc/scale_raw: dict key -> tensor; eps: dict key -> [S,...].  PARITY UNPINNED (pyro absent)."""
+    return {k: loc[k].unsqueeze(0) + F.softplus(scale_raw[k]).unsqueeze(0) * eps[k] for k in loc}
+
+
+# =====================================================================================
+# Loop-structured port: the reference's nest, batch 1, autograd.  CPU baseline for bench.py.
+# =====================================================================================
+def _net_forward_one(image, post, s, arch, act):
+    """One stored sample's NN.forward on a batch-1 image (model_nn.py:126-141)."""
+    if arch in ("fc", "fc2"):
+        h = image.flatten(1)
+        layers = mlp_layers(post, arch)
+        for li, (W, b) in enumerate(layers):
+            h = F.linear(h, W[s], b[s])
+            if li + 1 < len(layers):
+                h = _act(h, act)
+        return h
+    return nn_logits(image, select(post, [s]), arch, act)[0]
+
+
+def loop_bnn_forward(image, post, arch, act, n_samples, seeds=None):
+    """model_bnn.py:243-258"""
+    preds = []
+    for seed in (range(n_samples) if seeds is None else seeds):
+        preds.append(torch.softmax(_net_forward_one(image, post, seed, arch, act), dim=-1))
+    return torch.stack(preds).mean(0)
+
+
+def loop_loss_gradient(image, label_onehot, post, arch, act, n_samples):
+    """lossGradients.py:20-40: one backward per sample."""
+    image = image.unsqueeze(0)
+    label = label_onehot.argmax(-1).unsqueeze(0)
+    grads = []
+    for i in range(n_samples):
+        x_copy = image.clone().requires_grad_(True)
+        out = loop_bnn_forward(x_copy, post, arch, act, 1, seeds=[i])
+        F.cross_entropy(out, label).backward()
+        grads.append(x_copy.grad.detach()[0].clone())
+    return torch.stack(grads, 0).mean(0)
+
+
+def loop_fgsm_attack(image, label, post, arch, act, n_samples, hyperparams=None):
+    """adversarialAttacks.py:69-83"""
+    epsilon = hyperparams["epsilon"] if hyperparams is not None else 0.3
+    image = image.clone().requires_grad_(True)
+    out = loop_bnn_forward(image, post, arch, act, n_samples)
+    F.cross_entropy(out, label).backward()
+    return torch.clamp(image + epsilon * image.grad.sign(), 0, 1).detach()
+
+
+def loop_pgd_attack(image, label, post, arch, act, n_samples, hyperparams=None, iters=40):
+    """adversarialAttacks.py:86-108"""
+    if hyperparams is not None:
+        epsilon, alpha = hyperparams["epsilon"], 2 / image.max()
+    else:
+        epsilon, alpha = 0.5, 2 / 225
+    original = image.clone()
+    for _ in range(iters):
+        image = image.detach().requires_grad_(True)
+        out = loop_bnn_forward(image, post, arch, act, n_samples)
+        F.cross_entropy(out, label).backward()
+        pert = image + alpha * image.grad.sign()
+        eta = torch.clamp(pert - original, min=-epsilon, max=epsilon)
+        image = torch.clamp(original + eta, min=0, max=1).detach()
+    return image
+
+
+def loop_attack(x, y_onehot, post, arch, act, method, n_samples, hyperparams=None):
+    """adversarialAttacks.py:118-133 (no file side effects)."""
+    res = []
+    for idx in range(len(x)):
+        image = x[idx].unsqueeze(0)
+        label = y_onehot[idx].argmax(-1).unsqueeze(0)
+        fn = loop_fgsm_attack if method == "fgsm" else loop_pgd_attack
+        res.append(fn(image, label, post, arch, act, n_samples, hyperparams))
+    return torch.cat(res)
+
+
+# ------------------------------------------------------------ synthetic posteriors
+def param_shapes(arch, D, H, C, in_ch=1):
+    if arch == "fc":
+        return [("model.1.weight", (H, D)), ("model.1.bias", (H,)),
+                ("model.3.weight", (C, H)), ("model.3.bias", (C,))]
+    if arch == "fc2":
+        return [("model.1.weight", (H, D)), ("model.1.bias", (H,)),
+                ("model.3.weight", (H, H)), ("model.3.bias", (H,)),
+                ("model.5.weight", (C, H)), ("model.5.bias", (C,))]
+    if arch == "conv":
+        return [("model.0.weight", (32, in_ch, 5, 5)), ("model.0.bias", (32,)),
+                ("model.3.weight", (H, 32, 5, 5)), ("model.3.bias", (H,)),
+                ("model.7.weight", (C, int(H / 16) * D)), ("model.7.bias", (C,))]
+    raise NotImplementedError(arch)
+
+
+def synthetic_posterior(arch, D, H, C, S, std, in_ch=1):
+    """The HMC-style synthetic posterior of tests/golden/make_golden.py::fill_net:
+    sample i = manual_seed(100+i), every parameter tensor ~ N(0, std^2) in
+    nn.Module.parameters() order.  Bit-identical to the fixtures' weights (checked by sha256)."""
+    shapes = param_shapes(arch, D, H, C, in_ch)
+    out = {k: torch.empty((S,) + shp, dtype=torch.float32) for k, shp in shapes}
+    for i in range(S):
+        torch.manual_seed(100 + i)
+        for k, shp in shapes:
+            out[k][i] = torch.empty(shp, dtype=torch.float32).normal_(0.0, std)
+    return out
+
+
+def synthetic_inputs(n, shape, n_classes, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((n,) + tuple(shape), generator=g, dtype=torch.float32)
+    y = torch.randint(0, n_classes, (n,), generator=g)
+    onehot = torch.zeros(n, n_classes, dtype=torch.float32)
+    onehot[torch.arange(n), y] = 1.0
+    return x, onehot

@@ -1,0 +1,64 @@
+import ast
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """One tests/golden/*.npz fixture: inputs, stacked posterior weights, reference outputs."""
+
+    def __init__(self, name):
+        d = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.name = name
+        self.meta = ast.literal_eval(str(d["meta"]))
+        self.arr = {k: d[k] for k in d.files if k != "meta"}
+
+    def t(self, key):
+        return torch.from_numpy(np.asarray(self.arr[key]))
+
+    def posterior(self):
+        """Stacked weights: stored ones, or regenerated from the recorded seeds (sha256-checked)."""
+        w = {k[2:]: torch.from_numpy(v) for k, v in self.arr.items() if k.startswith("w:")}
+        if w:
+            return w
+        import hashlib
+        from oracle import bnn_oracle as O
+        m = self.meta
+        D = int(np.prod(m["shape"]))
+        w = O.synthetic_posterior(m["arch"], D, m["hidden"], m["n_classes"], m["S"], m["std"], m["shape"][0])
+        h = hashlib.sha256()
+        for k in sorted("w:" + k for k in w):
+            h.update(np.ascontiguousarray(w[k[2:]].numpy()).tobytes())
+        assert h.hexdigest() == m["weights_sha256"], "regenerated posterior differs from the fixture's"
+        return w
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|, per leading row, then max over rows (relative to each point's scale)."""
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(a.shape[0], -1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(b.shape[0], -1)
+    den = b.abs().max(dim=1)[0].clamp_min(1e-300)
+    return float(((a - b).abs().max(dim=1)[0] / den).max())

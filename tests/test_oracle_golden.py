@@ -1,0 +1,125 @@
+"""The oracle (oracle/bnn_oracle.py) against the reference-generated golden vectors.
+
+CPU only.  This is what pins the oracle: every closed-form and
+loop-structured restatement must reproduce what the reference's own functions returned.
+Tolerance: the north star's 1e-5, relative to each point's largest component.  Observed: MNIST-shaped
+cases ~5e-7; the ill-conditioned half-moons case 8.5e-6 (fp32 closed form vs the reference's fp32
+autograd; the reference itself is 4e-6 from an fp64 evaluation there).  Adversarial images must be
+equal except where the gradient component is below the sign-flip threshold tau.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import bnn_oracle as O
+
+BNN_CASES = ["halfmoons_fc_h64_s10_n100", "mnist_fc_h32_s8_n8_leaky", "mnist_fc_h32_s8_n8_relu",
+             "mnist_fc_h16_s4_n6_sigm", "mnist_fc_h16_s4_n6_tanh", "mnist_fc_h512_s8_n8_leaky",
+             "mnist_fc_h512_s8_n8_relu", "mnist_fc2_h32_s4_n6_leaky", "halfmoons_fc2_h32_s6_n40",
+             "mnist_conv_h16_s2_n4_leaky"]
+TOL = 1e-5
+TAU = 1e-3      # |g| below tau * max|g| of that point may legitimately flip sign
+
+
+def adv_equal(adv, ref, grad, eps_step):
+    """Adversarial images equal, except components whose gradient is within noise of zero."""
+    adv, ref, grad = (torch.as_tensor(v).reshape(len(ref), -1) for v in (adv, ref, grad))
+    safe = grad.abs() > TAU * grad.abs().max(dim=1, keepdim=True)[0]
+    bad = ((adv - ref).abs() > 1e-6) & safe
+    assert not bad.any(), f"{int(bad.sum())} non-marginal pixels differ"
+    assert float((adv - ref).abs().max()) <= 2 * eps_step + 1e-6
+
+
+@pytest.mark.parametrize("name", BNN_CASES)
+def test_forward(golden, name):
+    g = golden(name); m = g.meta; post = g.posterior(); x = g.t("x")
+    p = O.bnn_forward(x, post, m["arch"], m["act"], m["S"])
+    assert rel_err(p, g.t("forward_probs")) < TOL
+    seeds = [int(s) for s in g.arr["forward_seeds"]]
+    p = O.bnn_forward(x, post, m["arch"], m["act"], len(seeds), seeds=seeds)
+    assert rel_err(p, g.t("forward_probs_seeds")) < TOL
+    p = O.bnn_forward(x, post, m["arch"], m["act"], 1)
+    assert rel_err(p, g.t("forward_probs_s1")) < TOL
+    with pytest.raises(ValueError):
+        O.bnn_forward(x, post, m["arch"], m["act"], 2, seeds=[0])
+    # loop-structured port, first 3 points
+    for i in range(3):
+        p = O.loop_bnn_forward(x[i:i + 1], post, m["arch"], m["act"], m["S"])
+        assert rel_err(p, g.t("forward_probs")[i:i + 1]) < TOL
+
+
+@pytest.mark.parametrize("name", BNN_CASES)
+def test_loss_gradients(golden, name):
+    g = golden(name); m = g.meta; post = g.posterior(); x = g.t("x"); y = g.t("y")
+    for key, S in (("loss_gradients", m["S"]), ("loss_gradients_half", m["S_half"])):
+        lg = O.loss_gradients(x, y, post, m["arch"], m["act"], S)
+        assert lg.shape == g.arr[key].shape
+        assert rel_err(lg, g.t(key)) < TOL
+        lg64 = O.loss_gradients(x.double(), y, O.cast(post, torch.float64), m["arch"], m["act"], S)
+        assert rel_err(lg64, g.t(key)) < TOL
+    for i in range(2):
+        lg = O.loop_loss_gradient(x[i], y[i], post, m["arch"], m["act"], m["S"])
+        assert rel_err(lg[None], g.t("loss_gradients")[i:i + 1]) < TOL
+
+
+@pytest.mark.parametrize("name", BNN_CASES)
+def test_attacks(golden, name):
+    g = golden(name); m = g.meta; post = g.posterior(); x = g.t("x"); y = g.t("y")
+    lab = y.argmax(-1)
+    S, arch, act, eps = m["S"], m["arch"], m["act"], m["eps"]
+    gm = O.meanprob_gradients(x, lab, post, arch, act, S)
+    assert rel_err(gm, g.t("meanprob_grad")) < TOL
+    ref_g = g.t("meanprob_grad")
+    adv_equal(O.fgsm_attack(x, lab, post, arch, act, S, {"epsilon": eps}), g.t("fgsm"), ref_g, eps)
+    adv_equal(O.fgsm_attack(x, lab, post, arch, act, S, None), g.t("fgsm_default_eps"), ref_g, 0.3)
+    idx = torch.from_numpy(g.arr["pgd_idx"])
+    pg = O.pgd_attack(x[idx], lab[idx], post, arch, act, S, {"epsilon": eps})
+    # PGD compounds sign flips over 40 iterations: bounded by the eps-ball; exact on most pixels
+    ref = g.t("pgd")
+    assert float((pg - ref).abs().max()) <= 2 * eps + 1e-6
+    assert float(((pg - ref).abs() > 1e-6).double().mean()) < 0.02
+    if "pgd_default" in g.arr:
+        pg = O.pgd_attack(x[idx], lab[idx], post, arch, act, S, None)
+        assert float(((pg - g.t("pgd_default")).abs() > 1e-6).double().mean()) < 0.02
+    # loop-structured port
+    adv = O.loop_attack(x[:3], y[:3], post, arch, act, "fgsm", S, {"epsilon": eps})
+    adv_equal(adv, g.t("fgsm")[:3], ref_g[:3], eps)
+    adv = O.loop_attack(x[:1], y[:1], post, arch, act, "pgd", S, {"epsilon": eps})
+    assert float(((adv - g.t("pgd")[:1]).abs() > 1e-6).double().mean()) < 0.02
+
+
+@pytest.mark.parametrize("name", BNN_CASES)
+def test_attack_evaluation(golden, name):
+    g = golden(name); m = g.meta; post = g.posterior()
+    oa, aa, rob = O.attack_evaluation(g.t("x"), g.t("fgsm"), g.t("y"), post, m["arch"], m["act"], m["S"])
+    assert oa == float(g.arr["eval_orig_acc"]) and aa == float(g.arr["eval_adv_acc"])
+    assert float((rob - g.t("eval_softmax_rob")).abs().max()) < 1e-6
+
+
+def test_attack_and_loss_gradients_drivers(golden):
+    g = golden("halfmoons_fc_h64_s10_n100")
+    np.testing.assert_array_equal(g.arr["attack_fn_fgsm"], g.arr["fgsm"])
+    np.testing.assert_array_equal(g.arr["loss_gradients_fn"], g.arr["loss_gradients"].squeeze())
+
+
+def test_deterministic_and_ensemble(golden):
+    g = golden("mnist_det_ens_fc_h32_m4_n6"); m = g.meta; post = g.posterior()
+    x, y = g.t("x"), g.t("y"); lab = y.argmax(-1); M, arch, act, eps = m["M"], m["arch"], m["act"], m["eps"]
+    assert rel_err(O.ensemble_forward(x, post, arch, act, M), g.t("ens_logits")) < TOL
+    assert rel_err(O.ensemble_forward(x, post, arch, act, 2), g.t("ens_logits_2")) < TOL
+    assert rel_err(O.ensemble_forward(x, post, arch, act, 1), g.t("nn0_logits")) < TOL
+    with pytest.raises(ValueError):
+        O.ensemble_forward(x, post, arch, act, M + 1)
+    ge = O.meanprob_gradients(x, lab, post, arch, act, M, kind="ensemble")
+    adv_equal(O.fgsm_attack(x, lab, post, arch, act, M, {"epsilon": eps}, kind="ensemble"), g.t("ens_fgsm"), ge, eps)
+    g1 = O.meanprob_gradients(x, lab, post, arch, act, 1, kind="ensemble")
+    adv_equal(O.fgsm_attack(x, lab, post, arch, act, 1, {"epsilon": eps}, kind="ensemble"), g.t("nn0_fgsm"), g1, eps)
+    pg = O.pgd_attack(x, lab, post, arch, act, M, {"epsilon": eps}, kind="ensemble")
+    assert float(((pg - g.t("ens_pgd")).abs() > 1e-6).double().mean()) < 0.02
+    oa, aa, rob = O.attack_evaluation(x, g.t("ens_fgsm"), y, post, arch, act, M, kind="ensemble")
+    assert (oa, aa) == (float(g.arr["ens_eval_orig_acc"]), float(g.arr["ens_eval_adv_acc"]))
+    assert float((rob - g.t("ens_eval_softmax_rob")).abs().max()) < 1e-6
+    oa, aa, rob = O.attack_evaluation(x, g.t("nn0_fgsm"), y, post, arch, act, 1, kind="ensemble")
+    assert (oa, aa) == (float(g.arr["nn0_eval_orig_acc"]), float(g.arr["nn0_eval_adv_acc"]))
+    assert float((rob - g.t("nn0_eval_softmax_rob")).abs().max()) < 1e-6
