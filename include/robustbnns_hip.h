@@ -1,0 +1,174 @@
+/*
+ * robustbnns_hip.h — C-ABI of the MI355X (gfx950) Bayesian attack / expected-loss-gradient
+ * hot path.  Plain pointers and sizes only: no torch types, no C++ in the signatures.
+ *
+ * The reference (ginevracoal/robustBNNs) has NO native boundary for this path: it is a
+ * Python loop nest that dispatches stock torch ops with batch 1.  Each entry point below
+ * therefore cites the Python statements it replaces (file:line in the reference); the
+ * reference-side binding a maintainer would add is the ctypes stub in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.empty(device="cuda")) unless
+ *     marked [host]; all floating-point data is IEEE fp32, row-major, 16-byte aligned;
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it,
+ *     re-entrant, keeps no global state and allocates nothing: the caller owns every buffer;
+ *   - return value: RBNN_OK (0) or a negative rbnn_status; nothing throws;
+ *   - a *posterior* is S_total stacked weight samples (HMC chain / SVI draws / ensemble
+ *     members); `sample_idx` (int32[S], may be NULL = 0..S-1) selects which stored samples
+ *     a call uses, in order — model_bnn.py:246-252 (`seeds` index the stored samples).
+ *
+ * Padding contract (lets every kernel run whole 16-wide MFMA tiles, no tail code in the
+ * K loops): D_pad = round_up(D,16) is the row stride of X, W1 and of gradient buffers;
+ * columns [D, D_pad) are ZERO.  hidden is a multiple of 32 (the reference only allows
+ * powers of two >= 16, model_nn.py:39-40; 16 is zero-padded to 32 by the host, which is
+ * exact: a padded unit has zero outgoing weights).  n_classes <= 16.
+ */
+#ifndef ROBUSTBNNS_HIP_H
+#define ROBUSTBNNS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBNN_ABI_VERSION 1
+#define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
+
+typedef enum rbnn_status {
+    RBNN_OK = 0,
+    RBNN_ERR_NULL = -1,            /* required pointer is NULL                      */
+    RBNN_ERR_SHAPE = -2,           /* dimension violates the padding contract       */
+    RBNN_ERR_UNSUPPORTED = -3,     /* arch / activation / mode not implemented      */
+    RBNN_ERR_LAUNCH = -4,          /* HIP reported an error at launch               */
+    RBNN_ERR_ALIGN = -5            /* pointer not 16-byte aligned                   */
+} rbnn_status;
+
+/* model_nn.py:66-75 */
+typedef enum rbnn_activation { RBNN_ACT_RELU = 0, RBNN_ACT_LEAKY = 1, RBNN_ACT_SIGM = 2, RBNN_ACT_TANH = 3 } rbnn_activation;
+/* model_nn.py:77-91 */
+typedef enum rbnn_arch { RBNN_ARCH_FC = 0, RBNN_ARCH_FC2 = 1 } rbnn_arch;
+
+/* What the stacked forward leaves in `P`:
+ *   RBNN_OUT_PROBS  softmax(logits)  — BNN.forward, model_bnn.py:133-134, :253-255
+ *   RBNN_OUT_LOGITS raw logits       — NN.forward / Ensemble_NN.forward, model_nn.py:139, model_ensemble.py:64 */
+typedef enum rbnn_out_kind { RBNN_OUT_PROBS = 0, RBNN_OUT_LOGITS = 1 } rbnn_out_kind;
+
+/* Which loss the input gradient is taken of:
+ *   RBNN_LOSS_MEAN_PROB   CE(mean_s p_s, y)        fgsm/pgd on a BNN   adversarialAttacks.py:74-78, :97-101
+ *   RBNN_LOSS_PER_SAMPLE  mean_s CE(p_s, y)        loss_gradient       lossGradients.py:29-40
+ *   RBNN_LOSS_MEAN_LOGIT  CE(mean_s z_s, y)        fgsm/pgd on NN / Ensemble_NN (P holds logits)
+ *   RBNN_LOSS_UPSTREAM    caller supplies dL/d(mean_s p_s) [N,C] (autograd hook) */
+typedef enum rbnn_loss_mode { RBNN_LOSS_MEAN_PROB = 0, RBNN_LOSS_PER_SAMPLE = 1, RBNN_LOSS_MEAN_LOGIT = 2, RBNN_LOSS_UPSTREAM = 3 } rbnn_loss_mode;
+
+/* Stacked posterior of a fully-connected net (model_nn.py:77-91; state_dict keys in comments). */
+typedef struct rbnn_posterior {
+    int32_t arch;                  /* rbnn_arch                                                  */
+    int32_t activation;            /* rbnn_activation                                            */
+    int32_t in_features;           /* D  (784 MNIST, 2 half-moons)                               */
+    int32_t in_stride;             /* D_pad, multiple of 16: row stride of W1                    */
+    int32_t hidden;                /* H, multiple of 32                                          */
+    int32_t n_classes;             /* C <= 16                                                    */
+    int32_t n_stored;              /* S_total                                                    */
+    int32_t reserved;
+    const float *W1, *b1;          /* model.1.weight [S_total,H,D_pad], model.1.bias [S_total,H] */
+    const float *Wm, *bm;          /* fc2 only: model.3.weight [S_total,H,H], model.3.bias       */
+    const float *W2, *b2;          /* output layer (model.3 for fc, model.5 for fc2): [S_total,C,H], [S_total,C] */
+} rbnn_posterior;
+
+/* Caller-owned scratch for one (N, S) problem; sizes from rbnn_workspace_query(). */
+typedef struct rbnn_workspace {
+    float    *P;                   /* [S,N,16]      per-sample probabilities (or logits)         */
+    float    *dZ;                  /* [S,N,16]      dL/dlogits per sample                        */
+    uint32_t *mask1;               /* [S,N,H/32]    bit h%32 of word h/32 = (pre-activation > 0) */
+    float    *dact1;               /* [S,N,H]       act'(pre-activation), sigm/tanh only         */
+    float    *hid1;                /* [S,N,H]       fc2: first hidden activations                */
+    uint32_t *mask2;               /* fc2: as mask1 for the second hidden layer                  */
+    float    *dact2;               /* fc2, sigm/tanh                                             */
+    float    *dhid1;               /* [S,N,H]       fc2: dL/d(pre-activation 1)                  */
+    float    *slabs;               /* [n_slabs,N,D_pad] partial input gradients                  */
+} rbnn_workspace;
+
+typedef struct rbnn_workspace_sizes {  /* bytes; 0 = not needed for this posterior */
+    size_t P, dZ, mask1, dact1, hid1, mask2, dact2, dhid1, slabs;
+    int32_t n_slabs;               /* slabs rbnn_fc_input_grad will write for (S, chunk)         */
+    int32_t chunk;                 /* samples accumulated per slab (chosen if chunk<=0 passed)   */
+} rbnn_workspace_sizes;
+
+int rbnn_abi_version(void);
+const char *rbnn_strerror(int status);
+
+/* Sizes of every workspace buffer for N points x S used samples.  chunk<=0: library picks. [host] */
+int rbnn_workspace_query(const rbnn_posterior *net, int32_t n_points, int32_t n_samples,
+                         int32_t chunk, rbnn_workspace_sizes *out);
+
+/* Stacked per-sample forward: for every used sample s, P[s] = softmax(NN_s(X)) (or logits),
+ * and the activation-derivative stash the backward needs.
+ * Replaces: the `for seed in seeds: net.forward(inputs); softmax` loop, model_bnn.py:251-255,
+ * with NN.forward = model_nn.py:126-141 (fc :77-82, fc2 :84-91), batched over all N points.
+ * X: [N, ldx], ldx >= D_pad, multiple of 4. */
+int rbnn_fc_forward(const rbnn_posterior *net, const float *X, int32_t ldx, int32_t n_points,
+                    const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
+                    const rbnn_workspace *ws, void *stream);
+
+/* out[n,c] = scale * sum_s P[s,n,c]   (c < C; out row stride ldo floats).
+ * Replaces torch.stack(preds).mean(0), model_bnn.py:257 (scale = 1/S); with scale = 1 it is the
+ * local partial sum that the multi-GPU path all-reduces. */
+int rbnn_reduce_samples(const float *P, int32_t n_samples, int32_t n_points, int32_t n_classes,
+                        float scale, float *out, int32_t ldo, void *stream);
+
+/* dZ[s,n,:] = dL/dlogits_s for the chosen loss; `Psum` [N,ldp] is sum_s P[s] over ALL samples of
+ * the job (after the all-reduce when samples are sharded), `inv_S` = 1/(total samples),
+ * `labels` int32[N] (argmax of the one-hot, lossGradients.py:23, adversarialAttacks.py:120),
+ * `G_up` [N,ldp] only for RBNN_LOSS_UPSTREAM.
+ * Replaces CrossEntropyLoss()(output,label) + the softmax part of loss.backward():
+ * adversarialAttacks.py:76-78, :99-101; lossGradients.py:34-36 (closed form). */
+int rbnn_loss_dlogits(int32_t mode, const float *P, const float *Psum, int32_t ldp, const float *G_up,
+                      const int32_t *labels, int32_t n_samples, float inv_S, int32_t n_points,
+                      int32_t n_classes, float *dZ, void *stream);
+
+/* Partial expected input gradients: slabs[k,n,:] = sum_{s in chunk k} dA_s[n,:] . W1_s, with
+ * dA_s = act'(A_s) * (dZ_s . W2_s) built on the fly from ws->dZ and the stash of rbnn_fc_forward.
+ * Replaces the rest of loss.backward() down to image.grad (adversarialAttacks.py:78-79, :101;
+ * lossGradients.py:36-40).  Writes *n_slabs_out slabs of [N, D_pad] into ws->slabs. [n_slabs_out: host] */
+int rbnn_fc_input_grad(const rbnn_posterior *net, const int32_t *sample_idx, int32_t n_samples,
+                       int32_t n_points, int32_t chunk, const rbnn_workspace *ws,
+                       int32_t *n_slabs_out, void *stream);
+
+/* out[n,d] = scale * sum_k slabs[k,n,d]  (d < D_pad; out row stride ldo).
+ * Replaces torch.stack(loss_gradients,0).mean(0), lossGradients.py:40 (1/S is already in dZ). */
+int rbnn_sum_slabs(const float *slabs, int32_t n_slabs, int32_t n_points, int32_t d_pad, float scale,
+                   float *out, int32_t ldo, void *stream);
+
+/* alpha[n] = 2 / max_d X0[n,d]   — adversarialAttacks.py:89 (per image, from the clean image). */
+int rbnn_pgd_alpha(const float *X0, int32_t ldx, int32_t n_points, int32_t in_features,
+                   float *alpha, void *stream);
+
+/* One attack step on all points, g = sum_k G[k] (n_slabs partial gradients, slab stride in floats):
+ *   project == 0 (FGSM):  X = clamp(X + step*sign(g), 0, 1)                      adversarialAttacks.py:81-82
+ *   project == 1 (PGD):   X = clamp(X0 + clamp(X + step*sign(g) - X0, -eps, eps), 0, 1)   :103-105
+ * step = alpha[n] if alpha != NULL else alpha_scalar.  X is updated in place (X0 untouched);
+ * only columns d < D are touched. */
+int rbnn_attack_step(float *X, const float *X0, int32_t ldx, const float *G, int32_t n_slabs,
+                     size_t slab_stride, int32_t ldg, const float *alpha, float alpha_scalar,
+                     float eps, int32_t project, int32_t n_points, int32_t in_features, void *stream);
+
+/* attack_evaluation's reductions, adversarialAttacks.py:179,186 (argmax == label counts) and
+ * :30-51,60 (softmax applied again to the outputs, 1 - Linf difference).
+ * out_orig/out_adv: [N,ldp] forward outputs (mean probs, or logits for NN/ensemble).
+ * counts: int32[2] = {#correct original, #correct adversarial}, zeroed by this call; rob: [N]. */
+int rbnn_eval_metrics(const float *out_orig, const float *out_adv, int32_t ldp, const int32_t *labels,
+                      int32_t n_points, int32_t n_classes, int32_t *counts, float *rob, void *stream);
+
+/* W[s,i] = loc[i] + softplus(scale_raw[i]) * eps[s,i]   — the SVI guide's draw, model_bnn.py:124-130
+ * (Normal(loc, softplus(scale)).rsample()).  PARITY UNPINNED: pyro-ppl 1.3.0 is not available;
+ * eps is supplied by the caller.  out row stride ld_out >= n_elem (lets W1 be written D_pad-strided
+ * by calling once per row block). */
+int rbnn_svi_materialize(const float *loc, const float *scale_raw, const float *eps, int64_t n_elem,
+                         int32_t n_samples, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBUSTBNNS_HIP_H */

@@ -1,0 +1,178 @@
+"""ctypes binding of librbnn_hip.so (include/robustbnns_hip.h) — the only compute backend.
+
+There is no CPU fallback: if the shared library is missing or a call fails, this raises.
+torch is used for device memory and streams only; every kernel is launched through the C-ABI
+with raw device pointers (`tensor.data_ptr()`) on torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch          # must be imported first: the .so then binds to torch's already-loaded libamdhip64.so.7
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librbnn_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "robustbnns_hip.h")
+
+CPAD = 16
+ACTIVATIONS = {"relu": 0, "leaky": 1, "sigm": 2, "tanh": 3}          # model_nn.py:66-75
+ARCHS = {"fc": 0, "fc2": 1}                                           # model_nn.py:77-91
+OUT_PROBS, OUT_LOGITS = 0, 1
+LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_MEAN_LOGIT, LOSS_UPSTREAM = 0, 1, 2, 3
+
+_fp = C.c_void_p
+
+
+class Posterior(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("activation", C.c_int32), ("in_features", C.c_int32),
+                ("in_stride", C.c_int32), ("hidden", C.c_int32), ("n_classes", C.c_int32),
+                ("n_stored", C.c_int32), ("reserved", C.c_int32),
+                ("W1", _fp), ("b1", _fp), ("Wm", _fp), ("bm", _fp), ("W2", _fp), ("b2", _fp)]
+
+
+class Workspace(C.Structure):
+    _fields_ = [(k, _fp) for k in ("P", "dZ", "mask1", "dact1", "hid1", "mask2", "dact2", "dhid1", "slabs")]
+
+
+class WorkspaceSizes(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in ("P", "dZ", "mask1", "dact1", "hid1", "mask2", "dact2", "dhid1", "slabs")] + \
+               [("n_slabs", C.c_int32), ("chunk", C.c_int32)]
+
+
+WS_KEYS = ("P", "dZ", "mask1", "dact1", "hid1", "mask2", "dact2", "dhid1", "slabs")
+
+_i32, _f32, _sz, _i64 = C.c_int32, C.c_float, C.c_size_t, C.c_int64
+_PP, _PW, _PS = C.POINTER(Posterior), C.POINTER(Workspace), C.POINTER(WorkspaceSizes)
+
+# name -> (restype, argtypes): exactly the declarations of include/robustbnns_hip.h
+SIGNATURES = {
+    "rbnn_abi_version": (_i32, []),
+    "rbnn_strerror": (C.c_char_p, [_i32]),
+    "rbnn_workspace_query": (_i32, [_PP, _i32, _i32, _i32, _PS]),
+    "rbnn_fc_forward": (_i32, [_PP, _fp, _i32, _i32, _fp, _i32, _i32, _PW, _fp]),
+    "rbnn_reduce_samples": (_i32, [_fp, _i32, _i32, _i32, _f32, _fp, _i32, _fp]),
+    "rbnn_loss_dlogits": (_i32, [_i32, _fp, _fp, _i32, _fp, _fp, _i32, _f32, _i32, _i32, _fp, _fp]),
+    "rbnn_fc_input_grad": (_i32, [_PP, _fp, _i32, _i32, _i32, _PW, C.POINTER(_i32), _fp]),
+    "rbnn_sum_slabs": (_i32, [_fp, _i32, _i32, _i32, _f32, _fp, _i32, _fp]),
+    "rbnn_pgd_alpha": (_i32, [_fp, _i32, _i32, _i32, _fp, _fp]),
+    "rbnn_attack_step": (_i32, [_fp, _fp, _i32, _fp, _i32, _sz, _i32, _fp, _f32, _f32, _i32, _i32, _i32, _fp]),
+    "rbnn_eval_metrics": (_i32, [_fp, _fp, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
+    "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librbnn_hip.so (built by __graft_entry__.build()).  Raises if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. "
+                           "robustbnns_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.rbnn_abi_version() != 1:
+            raise HipError("librbnn_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HipError(f"{what} failed: {load().rbnn_strerror(rc).decode()} ({rc})")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(t, name="tensor"):
+    if t.device.type != "cuda":
+        raise HipError(f"{name} is on {t.device}: the MI355X HIP kernels are the only compute path "
+                       "(no CPU fallback); move it to 'cuda'.")
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise HipError(f"{name} must be float32/int32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipError(f"{name} must be contiguous")
+
+
+class HipKernels:
+    """Tensor-level façade over the C-ABI.  `net` is a robustbnns_amd.posterior.StackedPosterior,
+    `ws` a dict of torch tensors keyed like rbnn_workspace."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load()
+
+    # -- host-only --------------------------------------------------------------------------------
+    def workspace_sizes(self, net, N, S, chunk=0):
+        out = WorkspaceSizes()
+        check(self.lib.rbnn_workspace_query(C.byref(net.descriptor()), N, S, chunk, C.byref(out)), "rbnn_workspace_query")
+        d = {k: getattr(out, k) for k in WS_KEYS}
+        d["n_slabs"], d["chunk"] = out.n_slabs, out.chunk
+        return d
+
+    @staticmethod
+    def _ws(ws):
+        w = Workspace()
+        for k in WS_KEYS:
+            setattr(w, k, ptr(ws.get(k)))
+        return w
+
+    # -- device -----------------------------------------------------------------------------------
+    def fc_forward(self, net, X, sidx, S, out_kind, ws):
+        require_gpu(X, "X")
+        w = self._ws(ws)
+        check(self.lib.rbnn_fc_forward(C.byref(net.descriptor()), ptr(X), X.stride(0), X.shape[0], ptr(sidx), S,
+                                       out_kind, C.byref(w), stream_of(X)), "rbnn_fc_forward")
+
+    def reduce_samples(self, P, S, N, Cn, scale, out):
+        require_gpu(P, "P")
+        check(self.lib.rbnn_reduce_samples(ptr(P), S, N, Cn, scale, ptr(out), out.stride(0), stream_of(P)), "rbnn_reduce_samples")
+
+    def loss_dlogits(self, mode, P, Psum, G_up, labels, S, inv_S, N, Cn, dZ):
+        require_gpu(P, "P")
+        ldp = Psum.stride(0) if Psum is not None else (G_up.stride(0) if G_up is not None else CPAD)
+        check(self.lib.rbnn_loss_dlogits(mode, ptr(P), ptr(Psum), ldp, ptr(G_up), ptr(labels), S, inv_S, N, Cn,
+                                         ptr(dZ), stream_of(P)), "rbnn_loss_dlogits")
+
+    def fc_input_grad(self, net, sidx, S, N, chunk, ws):
+        w = self._ws(ws)
+        n = C.c_int32(0)
+        check(self.lib.rbnn_fc_input_grad(C.byref(net.descriptor()), ptr(sidx), S, N, chunk, C.byref(w), C.byref(n),
+                                          stream_of(ws["dZ"])), "rbnn_fc_input_grad")
+        return n.value
+
+    def sum_slabs(self, slabs, K, N, Dp, scale, out):
+        require_gpu(slabs, "slabs")
+        check(self.lib.rbnn_sum_slabs(ptr(slabs), K, N, Dp, scale, ptr(out), out.stride(0), stream_of(slabs)), "rbnn_sum_slabs")
+
+    def pgd_alpha(self, X0, D, alpha):
+        require_gpu(X0, "X0")
+        check(self.lib.rbnn_pgd_alpha(ptr(X0), X0.stride(0), X0.shape[0], D, ptr(alpha), stream_of(X0)), "rbnn_pgd_alpha")
+
+    def attack_step(self, X, X0, G, K, slab_stride, ldg, alpha, alpha_scalar, eps, project, D):
+        require_gpu(X, "X")
+        check(self.lib.rbnn_attack_step(ptr(X), ptr(X0), X.stride(0), ptr(G), K, slab_stride, ldg, ptr(alpha),
+                                        alpha_scalar, eps, int(project), X.shape[0], D, stream_of(X)), "rbnn_attack_step")
+
+    def eval_metrics(self, A, B, labels, Cn, counts, rob):
+        require_gpu(A, "outputs")
+        check(self.lib.rbnn_eval_metrics(ptr(A), ptr(B), A.stride(0), ptr(labels), A.shape[0], Cn, ptr(counts), ptr(rob),
+                                         stream_of(A)), "rbnn_eval_metrics")
+
+    def svi_materialize(self, loc, scale_raw, eps, out):
+        require_gpu(loc, "loc")
+        check(self.lib.rbnn_svi_materialize(ptr(loc), ptr(scale_raw), ptr(eps), loc.numel(), eps.shape[0], ptr(out),
+                                            stream_of(loc)), "rbnn_svi_materialize")

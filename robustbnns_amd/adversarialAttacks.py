@@ -1,0 +1,145 @@
+"""FGSM / PGD Bayesian attacks and robustness measures — the call surface of the reference's
+adversarialAttacks.py:30-198, driven through the batched HIP path (robustbnns_amd.engine).
+
+`attack()` no longer loops over points: x_test goes to the GPU once, every iteration processes all
+points x all posterior samples, and the result comes back once.  Numerical contract per point is the
+reference's: gradient of CrossEntropyLoss applied to the mean probabilities (the double softmax,
+adversarialAttacks.py:74-76), sign, step, clamp.
+"""
+import random
+
+import torch
+
+from . import _hip
+from .model_bnn import BNN, set_rng_seed
+from .model_ensemble import Ensemble_NN
+from .savedir import TESTS
+from .utils import load_from_pickle, plot_save_grid_images, save_to_pickle
+
+DEBUG = False
+PGD_ITERS = 40                                  # adversarialAttacks.py:89,91
+
+
+#######################
+# robustness measures #
+#######################
+
+def softmax_difference(original_predictions, adversarial_predictions):
+    """adversarialAttacks.py:30-51: Linf distance between the softmaxes of the two outputs, per point."""
+    if len(original_predictions) != len(adversarial_predictions):
+        raise ValueError("\nInput arrays should have the same length.")
+    o = original_predictions.detach().to(torch.float32).contiguous()
+    a = adversarial_predictions.detach().to(torch.float32).contiguous()
+    n, c = o.shape
+    labels = torch.zeros(n, dtype=torch.int32, device=o.device)
+    counts = torch.zeros(2, dtype=torch.int32, device=o.device)
+    rob = torch.empty(n, dtype=torch.float32, device=o.device)
+    _hip.HipKernels().eval_metrics(o, a, labels, c, counts, rob)
+    softmax_diff_norms = 1 - rob
+    if softmax_diff_norms.min() < 0. or softmax_diff_norms.max() > 1.:
+        raise ValueError("Softmax difference should be in [0,1]")
+    return softmax_diff_norms
+
+
+def softmax_robustness(original_outputs, adversarial_outputs):
+    """adversarialAttacks.py:53-62"""
+    softmax_differences = softmax_difference(original_outputs, adversarial_outputs)
+    robustness = (torch.ones_like(softmax_differences) - softmax_differences)
+    print(f"avg softmax robustness = {robustness.mean().item():.2f}")
+    return robustness
+
+
+#######################
+# adversarial attacks #
+#######################
+
+def _hot_path(net, n_samples, avg_posterior):
+    """(engine, S, seeds, loss mode) for any of the three net kinds the reference attacks."""
+    if isinstance(net, BNN):
+        eng, S, seeds, logits = net.hot_path(n_samples, avg_posterior)
+        return eng, S, seeds, (_hip.LOSS_MEAN_LOGIT if logits else _hip.LOSS_MEAN_PROB)
+    if isinstance(net, Ensemble_NN):
+        if n_samples is not None and n_samples > net.ensemble_size:
+            raise ValueError("Maximum number of samples allowed is ", net.ensemble_size)
+        S = len(net.ensemble_models) if n_samples is None else n_samples
+        return net.engine(net.device), S, None, _hip.LOSS_MEAN_LOGIT
+    return net.engine(net.device), 1, None, _hip.LOSS_MEAN_LOGIT          # deterministic NN: CE on its logits
+
+
+def _redraw(net, n_samples, avg_posterior):
+    """SVI draws fresh weights at every forward (model_bnn.py:230-232): a new engine per gradient."""
+    return isinstance(net, BNN) and net.inference == "svi" and avg_posterior is not True
+
+
+def fgsm_attack(net, image, label, hyperparams=None, n_samples=None, avg_posterior=False):
+    """adversarialAttacks.py:69-83.  image [B,C,H,W] (B=1 in the reference), label int [B]."""
+    epsilon = hyperparams["epsilon"] if hyperparams is not None else 0.3
+    if image.is_leaf:
+        image.requires_grad = True                         # the reference's visible side effect (:73)
+    eng, S, seeds, mode = _hot_path(net, n_samples, avg_posterior)
+    return eng.fgsm(image, label, S, epsilon, seeds=seeds, mode=mode).to(image.device)
+
+
+def pgd_attack(net, image, label, hyperparams=None, n_samples=None, avg_posterior=False):
+    """adversarialAttacks.py:86-108.  With hyperparams: alpha = 2/image.max() PER IMAGE (:89)."""
+    if hyperparams is not None:
+        epsilon, alpha = hyperparams["epsilon"], None
+    else:
+        epsilon, alpha = 0.5, 2 / 225
+    if _redraw(net, n_samples, avg_posterior):
+        x0, x = image.detach(), image.detach()
+        for _ in range(PGD_ITERS):
+            eng, S, seeds, mode = _hot_path(net, n_samples, avg_posterior)
+            x = eng.pgd_continue(x, x0, label, S, epsilon, alpha, mode=mode)
+        return x.to(image.device)
+    eng, S, seeds, mode = _hot_path(net, n_samples, avg_posterior)
+    return eng.pgd(image, label, S, epsilon, alpha=alpha, iters=PGD_ITERS, seeds=seeds, mode=mode).to(image.device)
+
+
+def attack(net, x_test, y_test, dataset_name, device, method, filename, savedir=None,
+           hyperparams=None, n_samples=None, avg_posterior=False):
+    """adversarialAttacks.py:111-143: all of x_test in one batched run (was: a Python loop over points)."""
+    print(f"\nProducing {method} attacks on {dataset_name}:")
+    images = x_test.to(device)
+    labels = y_test.argmax(-1).to(device)
+    if method == "fgsm":
+        adversarial_attack = fgsm_attack(net=net, image=images, label=labels, hyperparams=hyperparams,
+                                         n_samples=n_samples, avg_posterior=avg_posterior)
+    elif method == "pgd":
+        adversarial_attack = pgd_attack(net=net, image=images, label=labels, hyperparams=hyperparams,
+                                        n_samples=n_samples, avg_posterior=avg_posterior)
+    else:
+        raise UnboundLocalError("local variable 'perturbed_image' referenced before assignment")   # :131
+
+    path = TESTS + filename + "/" if savedir is None else TESTS + savedir + "/"
+    name = filename + "_" + str(method)
+    plot_save_grid_images(images=x_test, filename=name + "_original.png", savedir=path)
+    plot_save_grid_images(images=adversarial_attack, filename=name + "_attack.png", savedir=path)
+    name = name + "_attackSamp=" + str(n_samples) + "_attack.pkl" if n_samples else name + "_attack.pkl"
+    save_to_pickle(data=adversarial_attack, path=path, filename=name)
+    return adversarial_attack
+
+
+def load_attack(method, filename, savedir=None, n_samples=None, rel_path=TESTS):
+    """adversarialAttacks.py:145-149"""
+    path = TESTS + filename + "/" if savedir is None else TESTS + savedir + "/"
+    name = filename + "_" + str(method)
+    name = name + "_attackSamp=" + str(n_samples) + "_attack.pkl" if n_samples else name + "_attack.pkl"
+    return load_from_pickle(path=path + name)
+
+
+def attack_evaluation(net, x_test, x_attack, y_test, device, n_samples=None):
+    """adversarialAttacks.py:151-198 -> (original accuracy %, adversarial accuracy %, softmax_rob [N])."""
+    print(f"\nEvaluating against the attacks", end="")
+    if n_samples:
+        print(f" with {n_samples} defence samples")
+    random.seed(0)
+    set_rng_seed(0)                                        # :160-161
+    eng, S, _, mode = _hot_path(net, n_samples, False)
+    original_accuracy, adversarial_accuracy, rob, _, _ = eng.evaluate(
+        x_test.to(device), x_attack.to(device), y_test, S, logits=(mode == _hip.LOSS_MEAN_LOGIT))
+    print(f"\ntest accuracy = {original_accuracy}\tadversarial accuracy = {adversarial_accuracy}", end="\t")
+    if rob.min() < 0. or rob.max() > 1.:
+        raise ValueError("Softmax difference should be in [0,1]")          # :48-49
+    print(f"avg softmax robustness = {rob.mean().item():.2f}")
+    return original_accuracy, adversarial_accuracy, rob

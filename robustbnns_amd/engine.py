@@ -1,0 +1,228 @@
+"""Batched driver of the hot path: every test point x every posterior sample per launch.
+
+Reference loop nest (adversarialAttacks.py:118 -> :95 -> model_bnn.py:251, batch 1 at the leaves) vs here:
+
+    per PGD iteration (1 for FGSM / loss_gradients), for ALL N points at once:
+      rbnn_fc_forward      P[s,n,:] = softmax(NN_s(x_n))  + activation-derivative stash      (MFMA GEMM)
+      rbnn_reduce_samples  Psum[n,:] = sum_s P[s,n,:]         -> all-reduce when samples are sharded
+      rbnn_loss_dlogits    dZ[s,n,:] for the loss in use (mean-prob / per-sample / mean-logit)
+      rbnn_fc_input_grad   slabs[k,n,:] = sum_{s in chunk k} dA_s[n,:] . W1_s                 (MFMA GEMM)
+      rbnn_attack_step     x <- clamp(x0 + clamp(x + a*sign(sum_k slabs) - x0, +-eps), 0, 1)
+                           (sharded: rbnn_sum_slabs -> all-reduce -> rbnn_attack_step)
+
+x, x0, the posterior and every intermediate stay resident in HBM for the whole attack.
+torch supplies device memory, the current HIP stream and torch.distributed (RCCL); all arithmetic is
+in the HIP kernels behind `kernels` (robustbnns_amd._hip.HipKernels — there is no other backend in
+this package; tests inject a CPU fake to exercise the multi-process orchestration under gloo).
+"""
+import torch
+
+from . import _hip
+from ._hip import (LOSS_MEAN_LOGIT, LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_UPSTREAM, OUT_LOGITS, OUT_PROBS)
+
+_WS_DTYPE = {"mask1": torch.int32, "mask2": torch.int32}
+
+
+def to_labels(y, device):
+    """one-hot float [N,C] (utils.py:90-91,110) or integer labels [N] -> int32 [N] on `device`."""
+    y = torch.as_tensor(y)
+    if y.dim() >= 2:
+        y = y.argmax(-1)                       # lossGradients.py:23, adversarialAttacks.py:120
+    return y.to(device=device, dtype=torch.int32).contiguous()
+
+
+class AttackEngine:
+    def __init__(self, posterior, kernels=None, group=None, total_samples=None):
+        """posterior: StackedPosterior holding THIS rank's samples.  group: a torch.distributed process
+        group when the posterior is sample-sharded across ranks; total_samples: samples over
+        all ranks (default: all-reduced once)."""
+        self.post = posterior
+        self.k = kernels if kernels is not None else _hip.HipKernels()
+        self.group = group
+        self.world = 1
+        if group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+        self._S_total = total_samples
+        self._ws_cache = {}
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return self.post.device
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def total_samples(self, S_local):
+        """Samples over all ranks taking part in this call."""
+        if self.world == 1:
+            return S_local
+        if self._S_total is not None and S_local == self.post.S:
+            return self._S_total
+        t = torch.tensor([float(S_local)], device=self.device)
+        self._allreduce(t)
+        return int(round(t.item()))
+
+    def pad_inputs(self, x, clone=False):
+        """[N, *input_shape] -> contiguous fp32 [N, D_pad] on the device (zero columns beyond D)."""
+        p = self.post
+        xf = x.detach().reshape(x.shape[0], -1).to(self.device, torch.float32)
+        if xf.shape[1] != p.D:
+            raise ValueError(f"inputs flatten to {xf.shape[1]} features, posterior expects {p.D}")
+        if p.Dp == p.D:
+            return xf.clone() if clone else xf.contiguous()
+        out = torch.zeros(x.shape[0], p.Dp, dtype=torch.float32, device=self.device)
+        out[:, :p.D] = xf
+        return out
+
+    def unpad(self, Xp, like):
+        return Xp[:, :self.post.D].reshape(like.shape).clone()
+
+    def sample_index(self, n_samples, seeds=None):
+        """model_bnn.py:200-202,246-252: first n_samples stored samples, or `seeds` as indices."""
+        if seeds:
+            if len(seeds) != n_samples:
+                raise ValueError("Number of seeds should match number of samples.")
+        idx = list(range(n_samples)) if seeds is None else [int(s) for s in seeds]
+        for i in idx:
+            if i >= self.post.S or i < -self.post.S:
+                raise IndexError("list index out of range")     # posterior_predictive[seed], model_bnn.py:252
+        if idx == list(range(self.post.S)):
+            return None, len(idx)
+        if idx == list(range(len(idx))):
+            return None, len(idx)                               # prefix: identity map, no index buffer
+        return torch.tensor([i % self.post.S for i in idx], dtype=torch.int32, device=self.device), len(idx)
+
+    def workspace(self, N, S, chunk=0):
+        key = (N, S, chunk)
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            sizes = self.k.workspace_sizes(self.post, N, S, chunk)
+            ws = {"n_slabs": sizes["n_slabs"], "chunk": sizes["chunk"]}
+            for name in _hip.WS_KEYS:
+                if sizes[name]:
+                    ws[name] = torch.empty(sizes[name] // 4, dtype=_WS_DTYPE.get(name, torch.float32), device=self.device)
+            ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
+            ws["G"] = torch.empty(N, self.post.Dp, dtype=torch.float32, device=self.device)
+            if len(self._ws_cache) > 4:
+                self._ws_cache.clear()
+            self._ws_cache[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward_padded(self, Xp, sidx, S, out_kind=OUT_PROBS, out=None):
+        """mean over samples of P (probabilities or logits) -> [N, 16] buffer (columns >= C are zero)."""
+        N = Xp.shape[0]
+        ws = self.workspace(N, S)
+        self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
+        if out is None:
+            out = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
+        if self.world == 1:
+            self.k.reduce_samples(ws["P"], S, N, self.post.C, 1.0 / S, out)         # model_bnn.py:257
+        else:
+            self.k.reduce_samples(ws["P"], S, N, self.post.C, 1.0, out)
+            self._allreduce(out)
+            out.mul_(1.0 / self.total_samples(S))
+        return out
+
+    def forward(self, x, n_samples, seeds=None, logits=False):
+        sidx, S = self.sample_index(n_samples, seeds)
+        out = self.forward_padded(self.pad_inputs(x), sidx, S, OUT_LOGITS if logits else OUT_PROBS)
+        return out[:, :self.post.C]
+
+    # ------------------------------------------------------------------ expected input gradient
+    def gradient_slabs(self, Xp, labels, sidx, S, mode, G_up=None, chunk=0):
+        """Runs forward + loss + backward; leaves n_slabs partial gradients [N, D_pad] in ws['slabs']."""
+        N, C = Xp.shape[0], self.post.C
+        ws = self.workspace(N, S, chunk)
+        S_tot = self.total_samples(S)
+        self.k.fc_forward(self.post, Xp, sidx, S, OUT_LOGITS if mode == LOSS_MEAN_LOGIT else OUT_PROBS, ws)
+        Psum = None
+        if mode in (LOSS_MEAN_PROB, LOSS_MEAN_LOGIT):
+            Psum = ws["Psum"]
+            self.k.reduce_samples(ws["P"], S, N, C, 1.0, Psum)
+            self._allreduce(Psum)                               # 64 B per point: the only exchange before the backward
+        # per-sample losses are averaged at the very end (lossGradients.py:40), the others inside the loss
+        inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
+        self.k.loss_dlogits(mode, ws["P"], Psum, G_up, labels, S, inv_S, N, C, ws["dZ"])
+        n_slabs = self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
+        return ws, n_slabs, S_tot
+
+    def gradient(self, Xp, labels, sidx, S, mode, G_up=None):
+        """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad]."""
+        ws, n_slabs, S_tot = self.gradient_slabs(Xp, labels, sidx, S, mode, G_up)
+        scale = 1.0 / S_tot if mode == LOSS_PER_SAMPLE else 1.0
+        G = ws["G"]
+        self.k.sum_slabs(ws["slabs"], n_slabs, Xp.shape[0], self.post.Dp, scale, G)
+        self._allreduce(G)                                      # N x D_pad fp32: the one large exchange
+        return G
+
+    def loss_gradients(self, x, y, n_samples):
+        """lossGradients.loss_gradient for every row of x (lossGradients.py:20-40) -> x's shape."""
+        sidx, S = self.sample_index(n_samples)
+        G = self.gradient(self.pad_inputs(x), to_labels(y, self.device), sidx, S, LOSS_PER_SAMPLE)
+        return self.unpad(G, x)
+
+    # ------------------------------------------------------------------ attacks
+    def _step(self, X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project):
+        p = self.post
+        ws, n_slabs, _ = self.gradient_slabs(X, labels, sidx, S, mode)
+        if self.world == 1:
+            self.k.attack_step(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D)
+        else:
+            G = ws["G"]
+            self.k.sum_slabs(ws["slabs"], n_slabs, X.shape[0], p.Dp, 1.0, G)
+            self._allreduce(G)
+            self.k.attack_step(X, X0, G, 1, 0, p.Dp, alpha, alpha_scalar, eps, project, p.D)
+
+    def fgsm(self, x, y, n_samples, epsilon=0.3, seeds=None, mode=LOSS_MEAN_PROB):
+        """adversarialAttacks.fgsm_attack on every row of x (adversarialAttacks.py:69-83)."""
+        sidx, S = self.sample_index(n_samples, seeds)
+        X = self.pad_inputs(x, clone=True)
+        self._step(X, None, to_labels(y, self.device), sidx, S, mode, None, float(epsilon), 0.0, False)
+        return self.unpad(X, x)
+
+    def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=LOSS_MEAN_PROB):
+        """adversarialAttacks.pgd_attack on every row of x (adversarialAttacks.py:86-108).
+        alpha=None: 2/max(image) per image (:89); a float: the same step for all (2/225, :91)."""
+        sidx, S = self.sample_index(n_samples, seeds)
+        labels = to_labels(y, self.device)
+        X0 = self.pad_inputs(x, clone=True)
+        X = X0.clone()
+        alpha_t = None
+        if alpha is None:
+            alpha_t = torch.empty(X.shape[0], dtype=torch.float32, device=self.device)
+            self.k.pgd_alpha(X0, self.post.D, alpha_t)
+        for _ in range(iters):
+            self._step(X, X0, labels, sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
+        return self.unpad(X, x)
+
+    def pgd_continue(self, x, x0, y, n_samples, epsilon, alpha=None, mode=LOSS_MEAN_PROB):
+        """ONE PGD iteration from x towards the eps-ball around x0 (SVI: the caller redraws weights between iterations)."""
+        sidx, S = self.sample_index(n_samples)
+        X0 = self.pad_inputs(x0, clone=True)
+        X = self.pad_inputs(x, clone=True)
+        alpha_t = None
+        if alpha is None:
+            alpha_t = torch.empty(X.shape[0], dtype=torch.float32, device=self.device)
+            self.k.pgd_alpha(X0, self.post.D, alpha_t)
+        self._step(X, X0, to_labels(y, self.device), sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
+        return self.unpad(X, x)
+
+    # ------------------------------------------------------------------ evaluation
+    def evaluate(self, x, x_attack, y, n_samples, logits=False):
+        """attack_evaluation's numbers (adversarialAttacks.py:173-196): (orig acc %, adv acc %, rob [N])."""
+        sidx, S = self.sample_index(n_samples)
+        kind = OUT_LOGITS if logits else OUT_PROBS
+        labels = to_labels(y, self.device)
+        o = self.forward_padded(self.pad_inputs(x), sidx, S, kind)
+        a = self.forward_padded(self.pad_inputs(x_attack), sidx, S, kind)
+        counts = torch.zeros(2, dtype=torch.int32, device=self.device)
+        rob = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        self.k.eval_metrics(o, a, labels, self.post.C, counts, rob)
+        c = counts.cpu()
+        n = x.shape[0]
+        return 100 * float(c[0]) / n, 100 * float(c[1]) / n, rob, o[:, :self.post.C], a[:, :self.post.C]

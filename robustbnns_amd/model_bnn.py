@@ -1,0 +1,219 @@
+"""Bayesian network — the call surface of the reference's model_bnn.BNN (model_bnn.py:69-391).
+
+`forward(inputs, n_samples, avg_posterior, seeds)` is the Monte-Carlo posterior predictive of
+model_bnn.py:198-258, computed for the whole batch and all samples by the HIP kernels:
+
+  hmc  the stored chain is one StackedPosterior; `seeds` index it (model_bnn.py:246-252);
+  svi  weights are drawn as loc + softplus(scale) * eps (model_bnn.py:124-130) by rbnn_svi_materialize,
+       then run through the same kernels.  PARITY UNPINNED for the draw itself (pyro-ppl 1.3.0 is not
+       available to check RNG order against); everything downstream of explicit weights is pinned.
+
+Inference (SVI/HMC training, model_bnn.py:260-365) is out of scope: posteriors are inputs here.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _hip
+from .engine import AttackEngine
+from .model_nn import NN
+from .posterior import StackedPosterior
+from .savedir import TESTS
+
+saved_BNNs = {"model_0": ["mnist", {"hidden_size": 512, "activation": "leaky", "architecture": "conv", "inference": "svi", "epochs": 5, "lr": 0.01, "n_samples": None, "warmup": None}],
+              "model_1": ["mnist", {"hidden_size": 512, "activation": "leaky", "architecture": "fc2", "inference": "hmc", "epochs": None, "lr": None, "n_samples": 100, "warmup": 50}],
+              "model_2": ["fashion_mnist", {"hidden_size": 1024, "activation": "leaky", "architecture": "conv", "inference": "svi", "epochs": 10, "lr": 0.001, "n_samples": None, "warmup": None}],
+              "model_3": ["fashion_mnist", {"hidden_size": 1024, "activation": "leaky", "architecture": "fc2", "inference": "hmc", "epochs": None, "lr": None, "n_samples": 100, "warmup": 50}],
+              "model_4": ["fashion_mnist", {"hidden_size": 1024, "activation": "leaky", "architecture": "conv", "inference": "svi", "epochs": 5, "lr": 0.01, "n_samples": None, "warmup": None}],
+              "model_5": ["mnist", {"hidden_size": 512, "activation": "leaky", "architecture": "fc2", "inference": "svi", "epochs": 10, "lr": 0.01, "n_samples": None, "warmup": None}],
+              "model_6": ["mnist", {"hidden_size": 256, "activation": "leaky", "architecture": "conv", "inference": "svi", "epochs": 10, "lr": 0.05, "n_samples": None, "warmup": None}],
+              "model_7": ["mnist", {"hidden_size": 1024, "activation": "leaky", "architecture": "fc2", "inference": "svi", "epochs": 5, "lr": 0.02, "n_samples": None, "warmup": None}],
+              "model_8": ["mnist", {"hidden_size": 1024, "activation": "leaky", "architecture": "conv", "inference": "svi", "epochs": 10, "lr": 0.02, "n_samples": None, "warmup": None}],
+              "model_9": ["fashion_mnist", {"hidden_size": 512, "activation": "leaky", "architecture": "fc", "inference": "hmc", "epochs": None, "lr": None, "n_samples": 100, "warmup": 100}]}
+
+
+def set_rng_seed(seed):
+    """What pyro.set_rng_seed does (torch + random + numpy) — model_bnn.py:224,358,374."""
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+class BNN(nn.Module):
+
+    def __init__(self, dataset_name, hidden_size, activation, architecture, inference, epochs, lr, n_samples, warmup,
+                 input_shape, output_size, step_size=0.005, num_steps=10):
+        super(BNN, self).__init__()
+        self.dataset_name = dataset_name
+        self.inference = inference
+        self.architecture = architecture
+        self.epochs = epochs
+        self.lr = lr
+        self.n_samples = n_samples
+        self.warmup = warmup
+        self.step_size = step_size
+        self.num_steps = num_steps
+        self.basenet = NN(dataset_name=dataset_name, input_shape=input_shape, output_size=output_size,
+                          hidden_size=hidden_size, activation=activation, architecture=architecture, epochs=epochs, lr=lr)
+        self.name = self.get_name()
+        self.posterior = None                 # hmc: StackedPosterior of the chain
+        self.svi_loc = self.svi_scale = None  # svi: dict key -> tensor (raw scale, softplus applied at draw)
+        self.svi_rng = "host"                 # "host": CPU generator in the guide's draw order; "device": on-GPU randn
+        self._engine = None
+
+    def get_name(self, n_inputs=None):
+        """model_bnn.py:90-103"""
+        name = str(self.dataset_name) + "_bnn_" + str(self.inference) + "_hid=" + str(self.basenet.hidden_size) + \
+               "_act=" + str(self.basenet.activation) + "_arch=" + str(self.basenet.architecture)
+        if n_inputs:
+            name = name + "_inp=" + str(n_inputs)
+        if self.inference == "svi":
+            return name + "_ep=" + str(self.epochs) + "_lr=" + str(self.lr)
+        elif self.inference == "hmc":
+            return name + "_samp=" + str(self.n_samples) + "_warm=" + str(self.warmup) + \
+                   "_stepsize=" + str(self.step_size) + "_numsteps=" + str(self.num_steps)
+
+    # ------------------------------------------------------------------ posterior in
+    def _make_posterior(self, stacked, device):
+        b = self.basenet
+        return StackedPosterior(b.architecture, b.activation, b.input_shape, b.output_size, b.hidden_size, stacked, device)
+
+    def set_posterior_samples(self, samples, device):
+        """hmc: `samples` = list of NN.state_dict()s (what load() reads from disk), or a dict key -> [S,...]."""
+        self.device = device
+        self.basenet.device = device
+        if isinstance(samples, dict):
+            self.posterior = self._make_posterior(samples, device)
+        else:
+            b = self.basenet
+            self.posterior = StackedPosterior.from_state_dicts(samples, b.architecture, b.activation, b.input_shape,
+                                                               b.output_size, b.hidden_size, device)
+        self._engine = AttackEngine(self.posterior)
+
+    def set_variational_params(self, loc, scale, device):
+        """svi: dicts state_dict-key -> tensor, the `<key>_loc` / `<key>_scale` params of model_bnn.py:125-126."""
+        self.device = device
+        self.basenet.device = device
+        self.svi_loc = {k: v.detach().to(device, torch.float32).contiguous() for k, v in loc.items()}
+        self.svi_scale = {k: v.detach().to(device, torch.float32).contiguous() for k, v in scale.items()}
+        self._engine = None
+
+    @property
+    def posterior_predictive(self):
+        """dict idx -> NN carrying sample idx (the reference's attribute, model_bnn.py:186-190); built on demand."""
+        import copy
+        out = {}
+        for i in range(self.posterior.S):
+            net = copy.deepcopy(self.basenet)
+            net.load_state_dict(self.posterior.state_dict(i))
+            out[i] = net
+        return out
+
+    def save(self, rel_path=TESTS, filename=None):
+        """hmc branch of model_bnn.py:138-165: one state_dict file per stored sample."""
+        if filename is None:
+            filename = self.name + "_weights"
+        path = rel_path + self.name + "/"
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        if self.inference == "hmc":
+            for key, value in self.posterior_predictive.items():
+                torch.save(value.state_dict(), path + filename + "_" + str(key) + ".pt")
+        else:
+            torch.save({"params": {**{k + "_loc": v.cpu() for k, v in self.svi_loc.items()},
+                                   **{k + "_scale": v.cpu() for k, v in self.svi_scale.items()}}}, path + filename + ".pt")
+
+    def load(self, device, rel_path=TESTS, filename=None):
+        """model_bnn.py:167-196"""
+        if filename is None:
+            filename = self.name + "_weights"
+        path = rel_path + self.name + "/"
+        if self.inference == "svi":
+            store = torch.load(path + filename + ".pt", map_location="cpu", weights_only=False)
+            params = store["params"] if "params" in store else store
+            keys = list(self.basenet.state_dict().keys())
+            self.set_variational_params({k: params[k + "_loc"] for k in keys}, {k: params[k + "_scale"] for k in keys}, device)
+            print("\nLoading ", path + filename + ".pt\n")
+        elif self.inference == "hmc":
+            sds = [torch.load(path + filename + "_" + str(i) + ".pt", map_location="cpu") for i in range(self.n_samples)]
+            if len(sds) != self.n_samples:
+                raise AttributeError("wrong number of posterior models")
+            self.set_posterior_samples(sds, device)
+
+    # ------------------------------------------------------------------ svi draws
+    def _svi_eps(self, n_samples, seeds):
+        """eps per draw in the order the guide consumes the RNG ([recalled]): for every
+        state_dict key two discarded randn_like (the eagerly evaluated pyro.param initialisers,
+        model_bnn.py:125-126), then one standard normal per parameter in named_parameters() order."""
+        shapes = [(k, tuple(v.shape)) for k, v in self.basenet.state_dict().items()]
+        total = sum(int(np.prod(s)) for _, s in shapes)
+        if self.svi_rng == "device" and not seeds:
+            return torch.randn(n_samples, total, device=self.device, dtype=torch.float32)
+        eps = torch.empty(n_samples, total, dtype=torch.float32)
+        for i in range(n_samples):
+            if seeds:
+                set_rng_seed(seeds[i])
+            for _, shp in shapes:
+                torch.randn(shp)
+                torch.randn(shp)
+            off = 0
+            for _, shp in shapes:
+                n = int(np.prod(shp))
+                eps[i, off:off + n] = torch.randn(shp).reshape(-1)
+                off += n
+        return eps.to(self.device)
+
+    def draw_posterior(self, n_samples, seeds=None):
+        """n_samples weight draws as a StackedPosterior (model_bnn.py:124-130, :222-232)."""
+        keys = list(self.basenet.state_dict().keys())
+        loc = torch.cat([self.svi_loc[k].reshape(-1) for k in keys])
+        scale = torch.cat([self.svi_scale[k].reshape(-1) for k in keys])
+        eps = self._svi_eps(n_samples, seeds).contiguous()
+        out = torch.empty_like(eps)
+        _hip.HipKernels().svi_materialize(loc, scale, eps, out)
+        stacked, off = {}, 0
+        for k in keys:
+            shp = tuple(self.svi_loc[k].shape)
+            n = int(np.prod(shp))
+            stacked[k] = out[:, off:off + n].reshape((n_samples,) + shp)
+            off += n
+        return self._make_posterior(stacked, self.device)
+
+    # ------------------------------------------------------------------ hot path handles
+    def hot_path(self, n_samples, avg_posterior=False, seeds=None):
+        """(engine, n_samples, seeds, logits) to run `n_samples` posterior samples through the kernels."""
+        if seeds:
+            if len(seeds) != n_samples:
+                raise ValueError("Number of seeds should match number of samples.")     # model_bnn.py:200-202
+        if self.inference == "hmc":
+            return self._engine, n_samples, seeds, False
+        if avg_posterior is True:                         # model_bnn.py:206-216: logits of the mean weights
+            stacked = {k: v.unsqueeze(0) for k, v in self.svi_loc.items()}
+            return AttackEngine(self._make_posterior(stacked, self.device)), 1, None, True
+        return AttackEngine(self.draw_posterior(n_samples, seeds)), n_samples, None, False
+
+    def forward(self, inputs, n_samples=10, avg_posterior=False, seeds=None):
+        """model_bnn.py:198-258 -> mean probabilities [B, C] (raw logits if avg_posterior, :216)."""
+        eng, S, sd, logits = self.hot_path(n_samples, avg_posterior, seeds)
+        return eng.forward(inputs.to(self.device), S, seeds=sd, logits=logits)
+
+    def train(self, *args, **kwargs):
+        if args and isinstance(args[0], bool) or "mode" in kwargs:
+            return super().train(*args, **kwargs)
+        raise NotImplementedError("SVI/HMC inference is outside the accelerated hot path (SURVEY.md section 2, row 8): "
+                                  "run it with the reference and load the posterior here")
+
+    def evaluate(self, test_loader, device, n_samples=10, seeds_list=None):
+        """model_bnn.py:367-391"""
+        random.seed(0)
+        set_rng_seed(0)
+        bnn_seeds = list(range(n_samples)) if seeds_list is None else seeds_list
+        correct = 0.0
+        for x_batch, y_batch in test_loader:
+            outputs = self.forward(x_batch.to(device), n_samples=n_samples, seeds=bnn_seeds)
+            correct += float((outputs.argmax(-1) == y_batch.to(device).argmax(-1)).sum())
+        accuracy = 100 * correct / len(test_loader.dataset)
+        print("Accuracy: %.2f%%" % (accuracy))
+        return accuracy

@@ -1,0 +1,115 @@
+"""Stacked posterior: S weight samples of one fully-connected net, laid out for the HIP kernels.
+
+The reference keeps an HMC posterior as a dict idx -> NN module (model_bnn.py:186-190) and an
+ensemble as a dict seed -> NN (model_ensemble.py:44-55), and walks them in Python.  Here the S
+state-dicts are stacked once into contiguous device tensors
+
+    W1 [S, H, D_pad]   b1 [S, H]   (Wm [S, H, H]  bm [S, H])   W2 [S, C, H]   b2 [S, C]
+
+padded to the kernels' tile contract (include/robustbnns_hip.h): D_pad = round_up(D, 16) with zero
+columns, hidden 16 -> 32 with zero rows/columns (exact: a padded unit has no outgoing weight).
+At MNIST fc-512 one sample is 1.63 MB, so S=2000 is 3.3 GB of the 288 GB HBM3E: the whole posterior
+stays resident and every kernel indexes it by sample.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+
+# state_dict keys per Linear, in network order (model_nn.py:77-91)
+LAYER_KEYS = {"fc": ("model.1", "model.3"), "fc2": ("model.1", "model.3", "model.5")}
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def padded_hidden(H):
+    return max(32, H)
+
+
+class StackedPosterior:
+    def __init__(self, arch, activation, input_shape, n_classes, hidden, stacked, device):
+        """`stacked`: dict state_dict-key -> tensor [S, ...] (unpadded, any device, fp32)."""
+        if arch not in LAYER_KEYS:
+            raise NotImplementedError(f"architecture {arch!r}: the HIP path covers fc and fc2 (conv is SURVEY 8f 'next')")
+        if activation not in _hip.ACTIVATIONS:
+            raise AssertionError("\nWrong activation name.")                      # model_nn.py:74-75
+        if n_classes > _hip.CPAD:
+            raise ValueError(f"n_classes={n_classes} > {_hip.CPAD}")
+        self.arch, self.activation = arch, activation
+        self.input_shape = tuple(int(v) for v in input_shape)
+        self.D = int(torch.tensor(self.input_shape).prod())
+        self.Dp = round_up(self.D, 16)
+        self.H, self.Hp, self.C = int(hidden), padded_hidden(int(hidden)), int(n_classes)
+        self.device = torch.device(device)
+        keys = LAYER_KEYS[arch]
+        S = stacked[keys[0] + ".weight"].shape[0]
+        self.S = int(S)
+
+        def pad(t, shape):
+            out = torch.zeros((S,) + shape, dtype=torch.float32, device=self.device)
+            out[(slice(None),) + tuple(slice(0, d) for d in t.shape[1:])] = t.to(self.device, torch.float32)
+            return out.contiguous()
+
+        w = lambda k: stacked[k]
+        self.W1 = pad(w(keys[0] + ".weight").reshape(S, self.H, self.D), (self.Hp, self.Dp))
+        self.b1 = pad(w(keys[0] + ".bias"), (self.Hp,))
+        if arch == "fc2":
+            self.Wm = pad(w(keys[1] + ".weight"), (self.Hp, self.Hp))
+            self.bm = pad(w(keys[1] + ".bias"), (self.Hp,))
+        else:
+            self.Wm = self.bm = None
+        self.W2 = pad(w(keys[-1] + ".weight"), (self.C, self.Hp))
+        self.b2 = pad(w(keys[-1] + ".bias"), (self.C,))
+        self._desc = None
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_state_dicts(cls, state_dicts, arch, activation, input_shape, n_classes, hidden, device):
+        keys = [k + sfx for k in LAYER_KEYS[arch] for sfx in (".weight", ".bias")]
+        stacked = {k: torch.stack([sd[k].detach().to("cpu", torch.float32) for sd in state_dicts]) for k in keys}
+        return cls(arch, activation, input_shape, n_classes, hidden, stacked, device)
+
+    @classmethod
+    def from_modules(cls, nets, device):
+        n0 = nets[0]
+        return cls.from_state_dicts([n.state_dict() for n in nets], n0.architecture, n0.activation,
+                                    n0.input_shape, n0.output_size, n0.hidden_size, device)
+
+    # ------------------------------------------------------------------ C-ABI view
+    def descriptor(self):
+        if self._desc is None:
+            d = _hip.Posterior()
+            d.arch, d.activation = _hip.ARCHS[self.arch], _hip.ACTIVATIONS[self.activation]
+            d.in_features, d.in_stride, d.hidden, d.n_classes, d.n_stored = self.D, self.Dp, self.Hp, self.C, self.S
+            for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
+                t = getattr(self, name)
+                setattr(d, name, None if t is None else C.c_void_p(t.data_ptr()))
+            self._desc = d
+        return self._desc
+
+    def state_dict(self, i):
+        """Sample i as an unpadded CPU state_dict with the reference's keys (model_nn.py:77-91)."""
+        keys = LAYER_KEYS[self.arch]
+        H, D = self.H, self.D
+        sd = {keys[0] + ".weight": self.W1[i, :H, :D], keys[0] + ".bias": self.b1[i, :H],
+              keys[-1] + ".weight": self.W2[i, :, :H], keys[-1] + ".bias": self.b2[i]}
+        if self.arch == "fc2":
+            sd[keys[1] + ".weight"], sd[keys[1] + ".bias"] = self.Wm[i, :H, :H], self.bm[i, :H]
+        return {k: v.detach().cpu().clone() for k, v in sd.items()}
+
+    def nbytes(self):
+        return sum(t.numel() * 4 for t in (self.W1, self.b1, self.Wm, self.bm, self.W2, self.b2) if t is not None)
+
+    def shard(self, rank, world):
+        """Samples [rank*S/world, (rank+1)*S/world) as a new posterior (sample-sharded multi-GPU)."""
+        lo, hi = rank * self.S // world, (rank + 1) * self.S // world
+        out = object.__new__(StackedPosterior)
+        out.__dict__.update(self.__dict__)
+        for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
+            t = getattr(self, name)
+            setattr(out, name, None if t is None else t[lo:hi].contiguous())
+        out.S, out._desc = hi - lo, None
+        return out
