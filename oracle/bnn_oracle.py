@@ -179,6 +179,18 @@ def dz_mean_logit(z, label):
     return G.unsqueeze(0).expand(S, -1, -1)
 
 
+def kink_margin(x, post, arch, act, n_samples):
+    """Per point: the smallest |pre-activation| over the used samples and hidden units (fc/fc2, relu/leaky).
+    act' jumps at 0, so the input gradient of a point whose margin is within fp32 rounding of the
+    pre-activation (~1e-6 at these sizes) legitimately depends on summation order; parity tests exclude
+    such points explicitly (same status as the sign(g) rule for adversarial images)."""
+    if act not in ("relu", "leaky") or arch not in ("fc", "fc2"):
+        return torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
+    layers = mlp_layers(select(post, range(n_samples)), arch)
+    _, pre = _mlp_forward_cache(x.reshape(x.shape[0], -1), layers, act)
+    return torch.stack([a.abs().amin(dim=(0, 2)) for a in pre]).amin(0).double()
+
+
 # ------------------------------------------------------------ a5/a6: loss_gradient(s)
 def _input_grad(x, label, post, arch, act, mode):
     """Summed-over-samples input gradient [N,*x.shape[1:]] under `mode`."""

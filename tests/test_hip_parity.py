@@ -1,0 +1,265 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+  (1) the golden vectors produced by the reference's own functions (tests/golden/*.npz),
+  (2) the fp64 oracle on seeded inputs at sizes it finishes in seconds (ragged N, every H config),
+  (3) size-independent properties at BASELINE.json's full size (N=10 000, S=100).
+Tolerance: 1e-5 relative to each point's largest component (north star), fp32 arithmetic throughout.
+Adversarial images: equal except where |g| < tau * max|g| (a sign flip there is within fp32 noise)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import bnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+TAU = 1e-3
+KINK = 2e-6      # points with a hidden pre-activation this close to 0 are excluded: act' jumps there (oracle.kink_margin)
+DEV = "cuda:0"
+FC_CASES = ["halfmoons_fc_h64_s10_n100", "mnist_fc_h32_s8_n8_leaky", "mnist_fc_h32_s8_n8_relu", "mnist_fc_h16_s4_n6_sigm",
+            "mnist_fc_h16_s4_n6_tanh", "mnist_fc_h512_s8_n8_leaky", "mnist_fc_h512_s8_n8_relu",
+            "mnist_fc2_h32_s4_n6_leaky", "halfmoons_fc2_h32_s6_n40"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from robustbnns_amd import _hip
+    _hip.load()
+
+
+def make_bnn(g):
+    from robustbnns_amd.model_bnn import BNN
+    m = g.meta
+    bnn = BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], 0, tuple(m["shape"]), m["n_classes"])
+    bnn.set_posterior_samples(g.posterior(), DEV)
+    return bnn
+
+
+def adv_equal(adv, ref, grad):
+    adv, ref, grad = (torch.as_tensor(v).cpu().reshape(len(ref), -1) for v in (adv, ref, grad))
+    safe = grad.abs() > TAU * grad.abs().max(dim=1, keepdim=True)[0]
+    bad = ((adv - ref).abs() > 1e-6) & safe
+    assert not bad.any(), f"{int(bad.sum())} non-marginal pixels differ"
+
+
+# ------------------------------------------------------------------ (1) golden vectors, through the reference's call surface
+@pytest.mark.parametrize("name", FC_CASES)
+def test_golden_forward_and_gradients(golden, name):
+    from robustbnns_amd import lossGradients
+    g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
+    seeds = [int(s) for s in g.arr["forward_seeds"]]
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=len(seeds), seeds=seeds).cpu(), g.t("forward_probs_seeds")) < TOL
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=1).cpu(), g.t("forward_probs_s1")) < TOL
+    with pytest.raises(ValueError):
+        bnn.forward(x.to(DEV), n_samples=2, seeds=[0])
+    with pytest.raises(IndexError):
+        bnn.forward(x.to(DEV), n_samples=1, seeds=[m["S"]])
+    eng = bnn._engine
+    assert rel_err(eng.loss_gradients(x, y, m["S"]).cpu(), g.t("loss_gradients")) < TOL
+    assert rel_err(eng.loss_gradients(x, y, m["S_half"]).cpu(), g.t("loss_gradients_half")) < TOL
+    lg = lossGradients.loss_gradient(bnn, x[1].to(DEV), y[1].to(DEV), n_samples=m["S"])
+    assert lg.shape == x[1].shape and rel_err(lg.cpu()[None], g.t("loss_gradients")[1:2]) < TOL
+    from robustbnns_amd import _hip
+    G = eng.gradient(eng.pad_inputs(x), y.argmax(-1).int().to(DEV), None, m["S"], _hip.LOSS_MEAN_PROB)
+    assert rel_err(G[:, :eng.post.D].cpu().reshape(x.shape), g.t("meanprob_grad")) < TOL
+
+
+@pytest.mark.parametrize("name", FC_CASES)
+def test_golden_attacks_and_evaluation(golden, name):
+    from robustbnns_amd import adversarialAttacks as A
+    g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
+    lab = y.argmax(-1)
+    hyper = {"epsilon": m["eps"]}
+    ref_g = g.t("meanprob_grad")
+    adv = A.fgsm_attack(bnn, x.to(DEV), lab.to(DEV), hyper, n_samples=m["S"])
+    assert adv.shape == x.shape
+    adv_equal(adv, g.t("fgsm"), ref_g)
+    adv_equal(A.fgsm_attack(bnn, x.to(DEV), lab.to(DEV), None, n_samples=m["S"]), g.t("fgsm_default_eps"), ref_g)
+    one = A.fgsm_attack(bnn, x[2:3].clone(), lab[2:3], hyper, n_samples=m["S"])            # the reference's batch-1 call shape
+    adv_equal(one, g.t("fgsm")[2:3], ref_g[2:3])
+    idx = torch.from_numpy(g.arr["pgd_idx"])
+    pg = A.pgd_attack(bnn, x[idx].to(DEV), lab[idx].to(DEV), hyper, n_samples=m["S"]).cpu()
+    assert float((pg - g.t("pgd")).abs().max()) <= 2 * m["eps"] + 1e-6
+    assert float(((pg - g.t("pgd")).abs() > 1e-6).double().mean()) < 0.02
+    if "pgd_default" in g.arr:
+        pg = A.pgd_attack(bnn, x[idx].to(DEV), lab[idx].to(DEV), None, n_samples=m["S"]).cpu()
+        assert float(((pg - g.t("pgd_default")).abs() > 1e-6).double().mean()) < 0.02
+    oa, aa, rob = A.attack_evaluation(bnn, x, g.t("fgsm"), y, DEV, n_samples=m["S"])
+    assert (oa, aa) == (float(g.arr["eval_orig_acc"]), float(g.arr["eval_adv_acc"]))
+    assert float((rob.cpu() - g.t("eval_softmax_rob")).abs().max()) < 1e-6
+    rob2 = A.softmax_robustness(bnn.forward(x.to(DEV), m["S"]), bnn.forward(g.t("fgsm").to(DEV), m["S"]))
+    assert float((rob2.cpu() - g.t("eval_softmax_rob")).abs().max()) < 1e-6
+
+
+def test_golden_deterministic_and_ensemble(golden):
+    from robustbnns_amd import adversarialAttacks as A
+    from robustbnns_amd.model_ensemble import Ensemble_NN
+    from robustbnns_amd.model_nn import NN
+    g = golden("mnist_det_ens_fc_h32_m4_n6"); m = g.meta; post = g.posterior()
+    x, y = g.t("x"), g.t("y"); lab = y.argmax(-1); M = m["M"]; hyper = {"epsilon": m["eps"]}
+    ens = Ensemble_NN("mnist", m["hidden"], m["act"], m["arch"], 1, 0.01, tuple(m["shape"]), m["n_classes"], M)
+    ens.device = DEV
+    for i in range(M):
+        net = NN("mnist", tuple(m["shape"]), m["n_classes"], m["hidden"], m["act"], m["arch"], 0.01, 1)
+        net.load_state_dict({k: v[i] for k, v in post.items()})
+        net.device = DEV
+        ens.ensemble_models[str(i)] = net
+    nn0 = ens.ensemble_models["0"]
+    assert rel_err(nn0.forward(x.to(DEV)).cpu(), g.t("nn0_logits")) < TOL
+    assert rel_err(ens.forward(x.to(DEV), n_samples=M).cpu(), g.t("ens_logits")) < TOL
+    assert rel_err(ens.forward(x.to(DEV), n_samples=2).cpu(), g.t("ens_logits_2")) < TOL
+    with pytest.raises(ValueError):
+        ens.forward(x.to(DEV), n_samples=M + 1)
+    ge = O.meanprob_gradients(x, lab, post, m["arch"], m["act"], M, kind="ensemble")
+    g1 = O.meanprob_gradients(x, lab, post, m["arch"], m["act"], 1, kind="ensemble")
+    adv_equal(A.fgsm_attack(ens, x.to(DEV), lab.to(DEV), hyper, n_samples=M), g.t("ens_fgsm"), ge)
+    adv_equal(A.fgsm_attack(nn0, x.to(DEV), lab.to(DEV), hyper, n_samples=None), g.t("nn0_fgsm"), g1)
+    pg = A.pgd_attack(ens, x.to(DEV), lab.to(DEV), hyper, n_samples=M).cpu()
+    assert float(((pg - g.t("ens_pgd")).abs() > 1e-6).double().mean()) < 0.02
+    pg = A.pgd_attack(nn0, x.to(DEV), lab.to(DEV), hyper, n_samples=None).cpu()
+    assert float(((pg - g.t("nn0_pgd")).abs() > 1e-6).double().mean()) < 0.02
+    oa, aa, rob = A.attack_evaluation(ens, x, g.t("ens_fgsm"), y, DEV, n_samples=M)
+    assert (oa, aa) == (float(g.arr["ens_eval_orig_acc"]), float(g.arr["ens_eval_adv_acc"]))
+    assert float((rob.cpu() - g.t("ens_eval_softmax_rob")).abs().max()) < 1e-6
+    oa, aa, rob = A.attack_evaluation(nn0, x, g.t("nn0_fgsm"), y, DEV, n_samples=None)
+    assert (oa, aa) == (float(g.arr["nn0_eval_orig_acc"]), float(g.arr["nn0_eval_adv_acc"]))
+    assert float((rob.cpu() - g.t("nn0_eval_softmax_rob")).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------ (2) fp64 oracle, every tile configuration, ragged sizes
+ORACLE_CASES = [  # arch, act, shape, C, H, S, N, std
+    ("fc", "leaky", (1, 28, 28), 10, 512, 7, 333, 0.05), ("fc", "relu", (1, 28, 28), 10, 512, 5, 257, 0.05),
+    ("fc", "leaky", (1, 28, 28), 10, 1024, 2, 65, 0.05), ("fc", "leaky", (1, 28, 28), 10, 256, 3, 129, 0.05),
+    ("fc", "tanh", (1, 28, 28), 10, 128, 3, 70, 0.05), ("fc", "sigm", (1, 28, 28), 10, 64, 3, 40, 0.05),
+    ("fc", "leaky", (1, 28, 28), 10, 32, 9, 1, 0.05), ("fc", "leaky", (1, 2, 1), 2, 16, 4, 300, 0.5),
+    ("fc", "leaky", (3, 8, 8), 16, 64, 3, 50, 0.1), ("fc", "relu", (1, 5, 5), 3, 128, 2, 17, 0.2),
+    ("fc2", "leaky", (1, 28, 28), 10, 512, 3, 200, 0.05), ("fc2", "relu", (1, 28, 28), 10, 64, 3, 33, 0.08),
+    ("fc2", "tanh", (1, 2, 1), 2, 32, 6, 40, 0.4), ("fc2", "sigm", (1, 28, 28), 10, 128, 2, 20, 0.08),
+]
+
+
+@pytest.mark.parametrize("arch,act,shape,C,H,S,N,std", ORACLE_CASES)
+def test_against_fp64_oracle(arch, act, shape, C, H, S, N, std):
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    D = int(np.prod(shape))
+    post = O.synthetic_posterior(arch, D, H, C, S, std)
+    x, y = O.synthetic_inputs(N, shape, C, seed=H + N)
+    lab = y.argmax(-1)
+    p64 = O.cast(post, torch.float64)
+    eng = AttackEngine(StackedPosterior(arch, act, shape, C, H, post, DEV))
+    assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, arch, act, S)) < TOL
+    assert rel_err(eng.forward(x, S, logits=True).cpu(), O.ensemble_forward(x.double(), p64, arch, act, S)) < TOL
+    ok = O.kink_margin(x.double(), p64, arch, act, S) > KINK                  # gradients: away from activation kinks
+    assert int((~ok).sum()) <= max(3, N // 20)
+    assert rel_err(eng.loss_gradients(x, y, S).cpu()[ok], O.loss_gradients(x.double(), y, p64, arch, act, S)[ok]) < TOL
+    labd = lab.int().to(DEV)
+    for mode, kind in ((_hip.LOSS_MEAN_PROB, "bnn"), (_hip.LOSS_MEAN_LOGIT, "ensemble")):
+        G = eng.gradient(eng.pad_inputs(x), labd, None, S, mode)[:, :D].cpu().reshape(x.shape)
+        ref = O.meanprob_gradients(x.double(), lab, p64, arch, act, S, kind=kind)
+        assert rel_err(G[ok], ref[ok]) < TOL
+        adv = eng.fgsm(x, y, S, 0.1, mode=mode).cpu()
+        adv_equal(adv[ok], torch.clamp(x + 0.1 * ref.sign().float(), 0, 1)[ok], ref[ok])
+    # a seeds subset in shuffled order == the same samples gathered on the host
+    if S >= 3:
+        sub = [S - 1, 0, 1]
+        assert rel_err(eng.forward(x, 3, seeds=sub).cpu(), O.bnn_forward(x.double(), p64, arch, act, 3, seeds=sub)) < TOL
+
+
+def test_upstream_gradient_mode_matches_autograd():
+    """RBNN_LOSS_UPSTREAM: vector-Jacobian product of the mean-probability forward for an arbitrary dL/dp."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    D, H, C, S, N = 784, 64, 10, 4, 20
+    post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
+    x, _ = O.synthetic_inputs(N, (1, 28, 28), C, seed=3)
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV))
+    gup = torch.randn(N, 16, generator=torch.Generator().manual_seed(1))
+    G = eng.gradient(eng.pad_inputs(x), None, None, S, _hip.LOSS_UPSTREAM, G_up=gup.to(DEV))[:, :D].cpu()
+    xr = x.double().requires_grad_(True)
+    p = O.bnn_forward(xr, O.cast(post, torch.float64), "fc", "leaky", S)
+    (p * gup[:, :C].double()).sum().backward()
+    assert rel_err(G, xr.grad.reshape(N, -1)) < TOL
+
+
+# ------------------------------------------------------------------ (3) properties at BASELINE.json's full size
+@pytest.fixture(scope="module")
+def full_size():
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    D, H, C, S, N = 784, 512, 10, 100, 10000
+    g = torch.Generator().manual_seed(7)
+    post = {"model.1.weight": torch.randn(S, H, D, generator=g) * 0.05, "model.1.bias": torch.randn(S, H, generator=g) * 0.05,
+            "model.3.weight": torch.randn(S, C, H, generator=g) * 0.05, "model.3.bias": torch.randn(S, C, generator=g) * 0.05}
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=11)
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV))
+    return eng, post, x, y
+
+
+def test_full_size_properties(full_size):
+    from robustbnns_amd import _hip
+    eng, post, x, y = full_size
+    S, N, D = 100, 10000, 784
+    lab = y.argmax(-1).int().to(DEV)
+    X = eng.pad_inputs(x)
+    p = eng.forward(x, S)
+    assert float((p.sum(-1) - 1).abs().max()) < 1e-5 and float(p.min()) >= 0                    # probabilities
+    G = eng.gradient(X, lab, None, S, _hip.LOSS_MEAN_PROB).clone()
+    # (a) a subset of rows run alone gives the same rows (tile / grid independence), and matches the fp64 oracle
+    rows = torch.tensor([0, 1, 63, 64, 255, 256, 4999, 9983, 9984, 9999])
+    Gs = eng.gradient(eng.pad_inputs(x[rows]), lab[rows.to(DEV)], None, S, _hip.LOSS_MEAN_PROB).clone()
+    assert rel_err(Gs.cpu(), G[rows.to(DEV)].cpu()) < 2e-6
+    ref = O.meanprob_gradients(x[rows].double(), y[rows].argmax(-1), O.cast(post, torch.float64), "fc", "leaky", S)
+    ok = O.kink_margin(x[rows].double(), O.cast(post, torch.float64), "fc", "leaky", S) > KINK
+    assert int(ok.sum()) >= len(rows) - 2
+    assert rel_err(G[rows.to(DEV)].cpu()[ok], ref.reshape(len(rows), -1)[ok]) < TOL
+    # (b) slab chunking is only a summation-order choice
+    for chunk in (1, 8):
+        ws, n_slabs, _ = eng.gradient_slabs(X, lab, None, S, _hip.LOSS_MEAN_PROB, chunk=chunk)
+        Gc = torch.empty_like(G)
+        eng.k.sum_slabs(ws["slabs"], n_slabs, N, D, 1.0, Gc)
+        assert rel_err(Gc.cpu(), G.cpu()) < 2e-6
+    # (c) the expected gradient is additive over disjoint sample sets (what the sample-sharded all-reduce relies on)
+    lg = eng.loss_gradients(x[:512], y[:512], S)
+    a = eng.gradient(eng.pad_inputs(x[:512]), lab[:512], torch.arange(0, 50, dtype=torch.int32, device=DEV), 50, _hip.LOSS_PER_SAMPLE).clone()
+    b = eng.gradient(eng.pad_inputs(x[:512]), lab[:512], torch.arange(50, 100, dtype=torch.int32, device=DEV), 50, _hip.LOSS_PER_SAMPLE).clone()
+    assert rel_err(((a + b) / 2).cpu(), lg.reshape(512, -1).cpu()) < 5e-6
+    # (d) FGSM output is exactly x +- eps (or x where g == 0), clamped; PGD stays in the eps-ball and in [0,1]
+    adv = eng.fgsm(x, y, S, 0.3).cpu()
+    step = (adv - x).reshape(N, -1)
+    expect = torch.clamp(x.reshape(N, -1) + 0.3 * G.cpu().sign(), 0, 1) - x.reshape(N, -1)
+    assert float((step - expect).abs().max()) == 0.0
+    pg = eng.pgd(x[:256], y[:256], S, 0.2, iters=3).cpu()
+    assert float((pg - x[:256]).abs().max()) <= 0.2 + 1e-6 and float(pg.min()) >= 0 and float(pg.max()) <= 1
+    # (e) determinism: same inputs, same bits
+    G2 = eng.gradient(X, lab, None, S, _hip.LOSS_MEAN_PROB)
+    assert torch.equal(G2, G)
+    # (f) evaluation counts agree with a host argmax of the same outputs
+    oa, aa, rob, o, a_ = eng.evaluate(x, adv, y, S)
+    assert oa == 100 * float((o.argmax(-1).cpu() == y.argmax(-1)).sum()) / N
+    assert aa == 100 * float((a_.argmax(-1).cpu() == y.argmax(-1)).sum()) / N
+    assert float(rob.min()) >= 0 and float(rob.max()) <= 1
+
+
+def test_svi_materialize_and_forward():
+    """rbnn_svi_materialize (parity unpinned vs pyro; pinned here against the oracle restatement)."""
+    from robustbnns_amd.model_bnn import BNN
+    C, H, S, N = 10, 32, 5, 16
+    bnn = BNN("mnist", H, "leaky", "fc", "svi", 1, 0.01, None, None, (1, 28, 28), C)
+    g = torch.Generator().manual_seed(3)
+    loc = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in bnn.basenet.state_dict().items()}
+    scale = {k: torch.full(v.shape, -3.0) for k, v in bnn.basenet.state_dict().items()}
+    scale["model.1.bias"][:4] = 25.0                                       # softplus threshold branch
+    bnn.set_variational_params(loc, scale, DEV)
+    x, _ = O.synthetic_inputs(N, (1, 28, 28), C, seed=2)
+    seeds = list(range(S))
+    out = bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu()
+    eps = bnn._svi_eps(S, seeds).cpu()
+    keys = list(loc); off = 0; epsd = {}
+    for k in keys:
+        n = loc[k].numel(); epsd[k] = eps[:, off:off + n].reshape((S,) + tuple(loc[k].shape)); off += n
+    post = O.svi_materialize(loc, scale, epsd)
+    assert rel_err(out, O.bnn_forward(x, post, "fc", "leaky", S)) < TOL
+    out2 = bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu()
+    assert torch.equal(out, out2)                                          # same seeds, same draws
+    avg = bnn.forward(x.to(DEV), n_samples=S, avg_posterior=True).cpu()    # logits of the mean weights (model_bnn.py:206-216)
+    assert rel_err(avg, O.nn_logits(x, {k: v[None] for k, v in loc.items()}, "fc", "leaky")[0]) < TOL
