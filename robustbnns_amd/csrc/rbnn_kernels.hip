@@ -24,12 +24,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 
 #include "../../include/robustbnns_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// Diagnostic ablation bits (tools/ablate.hip builds this file with RBNN_ABL != 0 to price each part of the K loops;
+// results are then wrong by construction).  1: no LDS-DMA in the loop  2: no barrier in the loop
+// 4: operands not re-read from LDS  8: skip the epilogue
+#ifndef RBNN_ABL
+#define RBNN_ABL 0
+#endif
 #define LEAKY_SLOPE 0.01f                       // torch.nn.LeakyReLU() default (model_nn.py:68-69)
 
 namespace {
@@ -46,9 +53,21 @@ __device__ __forceinline__ bool item_of_block(int b, int M, int& id) {
     return true;
 }
 
+// compile-time loop: the body sees its index as a constant (sched_group_barrier sizes must be constant expressions)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 // 16-float (64 B) LDS rows read with ds_read_b128 by lane (row li, 16-B chunk lg): physical chunk =
 // lg ^ swz(row) with swz = [0,2,3,1][(row>>2)&3] makes every 16-lane b128 group hit 16 distinct slots.
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+// Asynchronous 16-B-per-lane global -> LDS copy (global_load_lds_dwordx4): per-lane source, LDS destination =
+// wave-uniform base + lane*16.  Completion is tracked by vmcnt; __syncthreads() drains it before the barrier.
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)l, 16, 0, 0);
+}
 
 template <int ACT> __device__ __forceinline__ float act_fwd(float a) {
     if (ACT == RBNN_ACT_RELU)  return a > 0.f ? a : 0.f;
@@ -78,16 +97,18 @@ struct FwdArgs {
 };
 
 template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
-__global__ void __launch_bounds__(256, 2) fc_forward_kernel(const FwdArgs a) {
+__global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) / 2)) fc_forward_kernel(const FwdArgs a) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
-    constexpr int WLOADS = (BH * 4 + 255) / 256, XLOADS = (BN * 4 + 255) / 256;
+    constexpr int TILE = (BH + BN) * 16;                       // floats per LDS buffer: BH W-rows then BN X-rows of 16 floats
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);
-    static_assert(WH * WN == 4, "4 waves per block");
+    constexpr int NW = WH * WN;                                // waves per block (4 or 8)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(HTW % 2 == 0 && HTW <= 8, "a wave's h range is whole 32-bit mask words, at most 4");
-    __shared__ __attribute__((aligned(16))) float lds[BH * 16 + BN * 16 + (LAYER2 ? WH * BN * 16 : 0)];
-    float* const Wt = lds;
-    float* const Xt = lds + BH * 16;
-    float* const zred = Xt + BN * 16;
+    static_assert(WH * BN * 16 <= 2 * TILE, "the Z^T reduction scratch aliases the tile buffers");
+    // ONE LDS array (tile double buffer; the softmax scratch aliases it after the K loop): global_load_lds
+    // staging beside a second __shared__ object makes hipcc drain vmcnt before every ds_read.
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    float* const zred = lds;
 
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.S, id)) return;
@@ -99,6 +120,11 @@ __global__ void __launch_bounds__(256, 2) fc_forward_kernel(const FwdArgs a) {
     const float* const Xs = a.X + (long long)s * a.x_sample_stride;
     const int n0 = ntile * BN;
     const int HW = a.H >> 5;
+    // LDS-DMA piece = one wave instruction = 1 KiB = 16 tile rows; lane p lands at row p>>2, physical 16-B chunk p&3,
+    // so it FETCHES logical chunk (p&3)^swz(row): the swizzle lives on the source address, the LDS image is linear.
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ swz(prow);
+    const int pch = 4 * (lg ^ swz(li));                        // fragment read: row li, logical chunk lg
 
     f32x4 zacc[NTW];
 #pragma unroll
@@ -111,52 +137,64 @@ __global__ void __launch_bounds__(256, 2) fc_forward_kernel(const FwdArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        f32x4 wreg[WLOADS], xreg[XLOADS];
-        auto gload = [&](int kt) {
-            const int k0 = kt * 16;
-#pragma unroll
-            for (int j = 0; j < WLOADS; ++j) {
-                const int idx = j * 256 + tid, row = idx >> 2, ch = idx & 3;
-                if (BH * 4 >= 256 || idx < BH * 4)
-                    wreg[j] = *(const f32x4*)(Ws + (long long)(hc0 + row) * a.ldw + k0 + 4 * ch);
-            }
-#pragma unroll
-            for (int j = 0; j < XLOADS; ++j) {
-                const int idx = j * 256 + tid, row = idx >> 2, ch = idx & 3;
-                const int n = n0 + row;
-                xreg[j] = (n < a.N) ? *(const f32x4*)(Xs + (long long)n * a.ldx + k0 + 4 * ch)
-                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto stage = [&](int kt, int buf) {                    // K tile kt -> LDS buffer buf, asynchronously, no VGPRs
+            float* const Wt = lds + buf * TILE;
+            float* const Xt = Wt + BH * 16;
+            const int k0 = kt * 16 + 4 * lchunk;
+            for (int q = wave; q < BH / 16; q += NW)
+                glds16(Ws + (long long)(hc0 + q * 16 + prow) * a.ldw + k0, Wt + q * 256);
+            for (int q = wave; q < BN / 16; q += NW) {
+                const int n = min(n0 + q * 16 + prow, a.N - 1);    // rows past N repeat the last point; never stored
+                glds16(Xs + (long long)n * a.ldx + k0, Xt + q * 256);
             }
         };
-        gload(0);
+        stage(0, 0);
+        __syncthreads();                                       // vmcnt(0) + barrier: tile 0 landed for every wave
+        f32x4 bf[NTW], a_cur, a_nxt;
         for (int kt = 0; kt < a.KT; ++kt) {
-            __syncthreads();                                   // every wave is done reading the previous tile
+            const int buf = kt & 1;
+            if (!(RBNN_ABL & 1) && kt + 1 < a.KT) stage(kt + 1, buf ^ 1);   // lands while this tile's 128 MFMAs per wave run
+            const float* const Wt = lds + buf * TILE;
+            const float* const Xt = Wt + BH * 16;
+            // Fragment reads are software-pipelined one h-tile ahead of the MFMAs that consume them, and the
+            // order is pinned (sched_group_barrier): left alone, hipcc waits lgkmcnt(0) right after each read.
+            if (!(RBNN_ABL & 4) || kt == 0) {
 #pragma unroll
-            for (int j = 0; j < WLOADS; ++j) {
-                const int idx = j * 256 + tid, row = idx >> 2, ch = idx & 3;
-                if (BH * 4 >= 256 || idx < BH * 4) *(f32x4*)(Wt + row * 16 + 4 * (ch ^ swz(row))) = wreg[j];
+                for (int nt = 0; nt < NTW; ++nt) bf[nt] = *(const f32x4*)(Xt + ((wave_n * NTW + nt) * 16 + li) * 16 + pch);
+                a_cur = *(const f32x4*)(Wt + ((wave_h * HTW) * 16 + li) * 16 + pch);
+                a_nxt = a_cur;
             }
-#pragma unroll
-            for (int j = 0; j < XLOADS; ++j) {
-                const int idx = j * 256 + tid, row = idx >> 2, ch = idx & 3;
-                *(f32x4*)(Xt + row * 16 + 4 * (ch ^ swz(row))) = xreg[j];
-            }
-            __syncthreads();
-            if (kt + 1 < a.KT) gload(kt + 1);                  // next tile's HBM/L2 latency hides under the MFMAs
-
-            f32x4 bf[NTW];
-            const int pch = 4 * (lg ^ swz(li));
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-                bf[nt] = *(const f32x4*)(Xt + ((wave_n * NTW + nt) * 16 + li) * 16 + pch);
 #pragma unroll
             for (int ht = 0; ht < HTW; ++ht) {
-                const f32x4 af = *(const f32x4*)(Wt + ((wave_h * HTW + ht) * 16 + li) * 16 + pch);
+                if (!(RBNN_ABL & 4) && ht + 1 < HTW) a_nxt = *(const f32x4*)(Wt + ((wave_h * HTW + ht + 1) * 16 + li) * 16 + pch);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA16(af[j], bf[nt][j], acc[ht][nt]);
+                    for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA16(a_cur[j], bf[nt][j], acc[ht][nt]);
+                a_cur = a_nxt;
             }
+            // hipcc's waits are lgkmcnt(0): keep every prefetch read half a tile (8 MFMAs = 256 cycles) ahead of
+            // the wait that follows it, so that draining it is free.
+            if (!(RBNN_ABL & 4)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NTW + 1, 0);           // DS reads: bf[*], a(0)
+#pragma unroll
+                for (int ht = 0; ht < HTW; ++ht) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);                // 8 MFMAs on a(ht)
+                    if (ht + 1 < HTW) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read a(ht+1)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);                // 8 MFMAs on a(ht)
+                }
+            }
+            if (!(RBNN_ABL & 2)) __syncthreads();              // next tile landed (vmcnt(0)); everyone is done with this one
+        }
+        if (RBNN_ABL & 2) __syncthreads();
+        if (RBNN_ABL & 8) {                                    // diagnostic: keep the accumulators live, skip the epilogue
+            float t = 0.f;
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) t += acc[ht][nt][0] + acc[ht][nt][1] + acc[ht][nt][2] + acc[ht][nt][3];
+            if (t == 12345.678f) a.P[tid] = t;
+            continue;
         }
 
         // ---- epilogue of this h chunk: bias, activation, derivative stash, skinny output layer ----
@@ -269,16 +307,17 @@ struct GradArgs {
     const uint32_t* omask;  const float* odact;  int OHW;                              // PER_SAMPLE epilogue: derivative of the layer below
 };
 
-template <int ACT, int TD, int CT, bool A_MEM, bool PER_SAMPLE>
+template <int ACT, int TD, int CQ, bool A_MEM, bool PER_SAMPLE>
 __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     constexpr int NTW = 4, BM = 256, HSTG = 32;               // 4 waves x 64 points; 32 hidden units per LDS stage
-    constexpr int LDB = TD * 16 + 4;                           // 4*LDB = 16 (mod 32): the two lg rows of a half-wave hit disjoint banks
-    constexpr int CP = (CT + 3) & ~3;
-    constexpr int WLOADS = (HSTG * TD * 4 + 255) / 256;
+    constexpr int LD = TD * 16;                                // W1 stage tile: [32 h][TD*16 d], unpadded (LDS-DMA image)
+    constexpr int W2ROWS = (4 * CQ + 7) / 8 * 8;               // W2 stage tile: [classes, whole 8-row pieces][32 h]
+    constexpr int W1SZ = HSTG * LD, W2SZ = W2ROWS * HSTG;
+    constexpr int BUF = W1SZ + W2SZ;
+    constexpr int NPIECE = 2 * TD, PPW = (NPIECE + 3) / 4;     // 1-KiB LDS-DMA pieces per W1 tile / per wave
+    constexpr int NT2 = HSTG / 16;                             // h tiles per stage
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);
-    __shared__ __attribute__((aligned(16))) float lds[HSTG * LDB + HSTG * CP];
-    float* const W1t = lds;
-    float* const W2t = lds + HSTG * LDB;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];   // one array: see fc_forward_kernel
 
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
@@ -290,7 +329,24 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     const int s_begin = ch * a.chunk, s_end = min(a.S, s_begin + a.chunk);
     const int HS = a.H / HSTG, nst = (s_end - s_begin) * HS;
 
-    for (int i = tid; i < HSTG * CP; i += 256) W2t[i] = 0.f;  // pad classes stay zero
+    // LDS image of the W1 tile: row h holds its TD 16-float segments rotated by one segment when (h>>2)&1, so the
+    // two rows (4*lg + r, lg = 0/1) a half-wave reads per B operand sit in opposite bank halves although the row
+    // stride (TD*64 B) is a multiple of 128 B.  LDS-DMA writes linearly, so the rotation is applied to the SOURCE
+    // column of each lane; the read side adds it back.  goff: per-lane source offset of this wave's pieces.
+    int goff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int f = (wave + 4 * i) * 256 + 4 * lane, row = f / LD, pc = f % LD;
+        int col = pc - 16 * ((row >> 2) & 1);
+        if (col < 0) col += LD;
+        goff[i] = row * a.ldw + min(dc0 + col, Dp - 4);       // columns past D_pad: any valid address, never stored
+    }
+    const int boff = li + 16 * (lg & 1);                       // read side: segment dt of row 4*lg+r is at (dt + (lg&1)) % TD
+    const int blast = (lg & 1) ? li : (TD - 1) * 16 + li;
+    // W2 tile: piece q = classes 8q..8q+7, lane p -> class 8q + (p>>3), 16-B chunk p&7 of its 32 hidden units; odd
+    // classes are stored with their two 64-B halves swapped (same bank argument: a half-wave reads classes c, c+1).
+    const int w2row = lane >> 3;
+    const int w2goff_col = 4 * ((lane & 7) ^ (4 * (w2row & 1)));
 
     f32x4 acc[NTW][TD];
 #pragma unroll
@@ -298,23 +354,21 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
 #pragma unroll
         for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 wreg[WLOADS], w2reg = (f32x4){0.f, 0.f, 0.f, 0.f};
     unsigned mreg[NTW], mw[NTW];
-    float dz[NTW][CT];
-    auto prefetch = [&](int st) {
+    float dzb[NTW][CQ];                                        // B operand of the dA product: dZ[s][n = li][c = 4j + lg]
+    // stage st -> LDS buffer buf, all by LDS-DMA (asynchronous, no VGPRs); mask words to registers
+    auto stage_issue = [&](int st, int buf) {
         const int s = s_begin + st / HS, h0 = (st % HS) * HSTG;
         const int sw = a.sidx ? a.sidx[s] : s;
-        const float* const Ws = a.W1 + (long long)sw * a.w1_sample_stride;
+        const float* const Ws = a.W1 + (long long)sw * a.w1_sample_stride + (long long)h0 * a.ldw;
 #pragma unroll
-        for (int j = 0; j < WLOADS; ++j) {
-            const int idx = j * 256 + tid, row = idx / (TD * 4), c4 = idx % (TD * 4);
-            const int col = dc0 + 4 * c4;
-            wreg[j] = (idx < HSTG * TD * 4 && col < Dp) ? *(const f32x4*)(Ws + (long long)(h0 + row) * a.ldw + col)
-                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < PPW; ++i)
+            if (wave + 4 * i < NPIECE) glds16(Ws + goff[i], lds + buf * BUF + (wave + 4 * i) * 256);
         if (!A_MEM) {
-            if (tid < a.C * 8)
-                w2reg = *(const f32x4*)(a.W2 + ((long long)sw * a.C + (tid >> 3)) * a.H + h0 + 4 * (tid & 7));
+            if (wave * 8 < W2ROWS) {                           // W2 rows past C repeat row C-1: they meet dZ columns that are 0
+                const int c = min(wave * 8 + w2row, a.C - 1);
+                glds16(a.W2 + ((long long)sw * a.C + c) * a.H + h0 + w2goff_col, lds + buf * BUF + W1SZ + wave * 256);
+            }
             if (BITMASK) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
@@ -325,92 +379,92 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
         }
     };
 
-    prefetch(0);
+    stage_issue(0, 0);
+    __syncthreads();
     for (int st = 0; st < nst; ++st) {
-        const int s = s_begin + st / HS, h0 = (st % HS) * HSTG;
-        if (!A_MEM && st % HS == 0) {                          // new sample: its dL/dlogits rows into registers
+        const int s = s_begin + st / HS, h0 = (st % HS) * HSTG, buf = st & 1;
+        if (!A_MEM && BITMASK) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
+            for (int nt = 0; nt < NTW; ++nt) mw[nt] = mreg[nt] >> (4 * lg);   // bit (16*t2 + r) = unit 16*t2 + 4*lg + r
+        }
+        if (!A_MEM && st % HS == 0) {                          // new sample: its dL/dlogits into B-operand registers
+#pragma unroll                                                 // (before this stage's LDS-DMA is issued: waiting on
+            for (int nt = 0; nt < NTW; ++nt) {                 //  these loads would drain it)
                 const int n = nb + nt * 16 + li;
-                const float* const src = a.dZ + ((long long)s * a.N + n) * RBNN_CPAD;
 #pragma unroll
-                for (int q = 0; q < CP / 4; ++q) {
-                    const f32x4 v = (n < a.N) ? *(const f32x4*)(src + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (4 * q + r < CT) dz[nt][4 * q + r] = v[r];
-                }
+                for (int j = 0; j < CQ; ++j)
+                    dzb[nt][j] = (n < a.N) ? a.dZ[((long long)s * a.N + n) * RBNN_CPAD + 4 * j + lg] : 0.f;
             }
+            // Retire these ordinary loads NOW (s_waitcnt vmcnt(0), visible to hipcc's wait insertion): with an
+            // LDS-DMA in flight hipcc waits vmcnt(0) at their first use, which would drain the DMA every stage.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < WLOADS; ++j) {
-            const int idx = j * 256 + tid, row = idx / (TD * 4), c4 = idx % (TD * 4);
-            if (idx < HSTG * TD * 4) *(f32x4*)(W1t + row * LDB + 4 * c4) = wreg[j];
-        }
-        if (!A_MEM) {
-            if (tid < a.C * 8) {
-                const int c = tid >> 3, q = tid & 7;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) W2t[(4 * q + e) * CP + c] = w2reg[e];
-            }
-            if (BITMASK) {
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) mw[nt] = mreg[nt];
-            }
-        }
-        __syncthreads();
-        if (st + 1 < nst) prefetch(st + 1);
+        if (!(RBNN_ABL & 1) && st + 1 < nst) stage_issue(st + 1, buf ^ 1);   // lands while this stage's MFMAs run
 
-#pragma unroll
-        for (int t2 = 0; t2 < HSTG / 16; ++t2) {
-            f32x4 am[NTW];                                     // A_MEM / smooth-activation: 4 K steps per 16-B load
-            if (A_MEM || !BITMASK) {
+        const float* const W1t = lds + buf * BUF;
+        const float* const W2t = W1t + W1SZ;
+        // dA tile of h tile t2 for this wave's 64 points: (dA^T)[h][n] = sum_c W2[c][h] * dZ[n][c] on the matrix pipe
+        // (A = W2 fragment, i = h; B = dzb, j = n).  Its accumulator layout, register r <-> h = 16*t2 + 4*lg + r on
+        // lane (n = li, lg), IS the main product's A-operand layout for K step (t2, r): no data movement.
+        f32x4 da[2][NTW];
+        auto make_da = [&](int t2, int slot) {
+            if (A_MEM || !BITMASK) {                           // A from memory, or smooth act': 16-B loads, 4 K steps each
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int n = nb + nt * 16 + li;
                     const float* const src = (A_MEM ? a.amem : a.dact) + ((long long)s * a.N + n) * a.H + h0 + t2 * 16 + 4 * lg;
-                    am[nt] = (n < a.N) ? *(const f32x4*)src : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    da[slot][nt] = (n < a.N) ? *(const f32x4*)src : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
+                if (A_MEM) return;
             }
+            float w2a[CQ];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int hrow = t2 * 16 + 4 * lg + r;         // K step (t2, r): k = lg <-> hidden unit h0 + hrow
-                float bfr[TD];
+            for (int j = 0; j < CQ; ++j) w2a[j] = W2t[(4 * j + lg) * HSTG + li + 16 * ((t2 ^ lg) & 1)];   // class 4j+lg, unit 16*t2+li
+            f32x4 g[NTW];
 #pragma unroll
-                for (int dt = 0; dt < TD; ++dt) bfr[dt] = W1t[hrow * LDB + dt * 16 + li];
-                float av[NTW];
-                if (A_MEM) {
+            for (int nt = 0; nt < NTW; ++nt) g[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) av[nt] = am[nt][r];
-                } else {
-                    float w2v[CP];
+            for (int j = 0; j < CQ; ++j)                       // class quad outer: the 4 accumulation chains interleave
 #pragma unroll
-                    for (int q = 0; q < CP / 4; ++q) {
-                        const f32x4 v = *(const f32x4*)(W2t + hrow * CP + 4 * q);
+                for (int nt = 0; nt < NTW; ++nt) g[nt] = MFMA16(w2a[j], dzb[nt][j], g[nt]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) w2v[4 * q + e] = v[e];
-                    }
+            for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        float v = 0.f;
-#pragma unroll
-                        for (int c = 0; c < CT; ++c) v = fmaf(dz[nt][c], w2v[c], v);
-                        if (BITMASK) {
-                            const bool pos = (mw[nt] >> hrow) & 1u;
-                            av[nt] = pos ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
-                        } else {
-                            av[nt] = v * am[nt][r];
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    if (BITMASK) {
+                        const bool pos = (mw[nt] >> (16 * t2 + r)) & 1u;
+                        g[nt][r] = pos ? g[nt][r] : (ACT == RBNN_ACT_RELU ? 0.f : g[nt][r] * LEAKY_SLOPE);
+                    } else {
+                        g[nt][r] *= da[slot][nt][r];
                     }
                 }
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                    for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = MFMA16(av[nt], bfr[dt], acc[nt][dt]);
+                da[slot][nt] = g[nt];
             }
-        }
+        };
+        float bfr[2][TD];
+        auto read_b = [&](int k, int slot) {                   // B operand of K step k = (t2, r): W1 rows 16*t2 + 4*lg + r
+            const int hrow = (k >> 2) * 16 + 4 * lg + (k & 3);
+#pragma unroll
+            for (int dt = 0; dt < TD - 1; ++dt) bfr[slot][dt] = W1t[hrow * LD + dt * 16 + boff];
+            bfr[slot][TD - 1] = W1t[hrow * LD + blast];
+        };
+        make_da(0, 0);
+        read_b(0, 0);
+        static_for<0, 4 * NT2>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, t2 = k >> 2, r = k & 3, cur = k & 1;
+            constexpr bool more = (k + 1 < 4 * NT2), gen = (r == 0 && t2 + 1 < NT2 && !A_MEM);
+            if (!(RBNN_ABL & 20) && r == 0 && t2 + 1 < NT2) make_da(t2 + 1, (t2 + 1) & 1);   // next h tile's dA ahead of this tile's 4 K steps
+            if (!(RBNN_ABL & 4) && more) read_b(k + 1, cur ^ 1);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int dt = 0; dt < TD; ++dt)
+                    acc[nt][dt] = MFMA16(da[(RBNN_ABL & 20) ? 0 : (t2 & 1)][nt][r], bfr[(RBNN_ABL & 4) ? 0 : cur][dt], acc[nt][dt]);
+        });
+        if (!(RBNN_ABL & 2)) __syncthreads();                  // vmcnt(0): next tiles landed; everyone is done with these
     }
 
+    if (RBNN_ABL & 2) __syncthreads();
     // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li]
     const int sidx_out = PER_SAMPLE ? s_begin : ch;
 #pragma unroll
@@ -634,15 +688,25 @@ int launch_forward_cfg(const FwdArgs& a, bool layer2, hipStream_t st) {
     FwdArgs b = a;
     b.NT = (a.N + BN - 1) / BN;
     const int grid = grid_for_items((long long)b.NT * a.S);
-    if (layer2) hipLaunchKernelGGL((fc_forward_kernel<ACT, WH, HTW, WN, NTW, true>), dim3(grid), dim3(256), 0, st, b);
-    else        hipLaunchKernelGGL((fc_forward_kernel<ACT, WH, HTW, WN, NTW, false>), dim3(grid), dim3(256), 0, st, b);
+    if (layer2) hipLaunchKernelGGL((fc_forward_kernel<ACT, WH, HTW, WN, NTW, true>), dim3(grid), dim3(64 * WH * WN), 0, st, b);
+    else        hipLaunchKernelGGL((fc_forward_kernel<ACT, WH, HTW, WN, NTW, false>), dim3(grid), dim3(64 * WH * WN), 0, st, b);
     return launch_status();
 }
 
 template <int ACT>
 int launch_forward_act(const FwdArgs& a, bool layer2, hipStream_t st) {
     const int H = a.H;
+#if defined(RBNN_FWD8)
+    if (H % 512 == 0) return launch_forward_cfg<ACT, 4, 8, 2, 2>(a, layer2, st);   // 512 h x  64 n per block, 8 waves of 128 h x 32 n
+#elif defined(RBNN_FWD512)
     if (H % 512 == 0) return launch_forward_cfg<ACT, 4, 8, 1, 4>(a, layer2, st);   // 512 h x  64 n per block
+#elif defined(RBNN_FWD256W8)
+    if (H % 512 == 0) return launch_forward_cfg<ACT, 2, 8, 4, 4>(a, layer2, st);   // 256 h x 256 n per block, 8 waves
+#else
+    // 256 h x 128 n per block, H/256 chunks per item: 33% fewer L2->LDS bytes per MAC than 512 h x 64 n (measured
+    // 83.8% vs 81.0% of the fp32 MFMA peak at C2; the Z^T accumulators persist across the h chunks)
+    if (H % 512 == 0) return launch_forward_cfg<ACT, 2, 8, 2, 4>(a, layer2, st);
+#endif
     if (H == 256)     return launch_forward_cfg<ACT, 2, 8, 2, 4>(a, layer2, st);   // 256 h x 128 n
     if (H == 128)     return launch_forward_cfg<ACT, 1, 8, 4, 4>(a, layer2, st);   // 128 h x 256 n
     if (H == 64)      return launch_forward_cfg<ACT, 1, 4, 4, 4>(a, layer2, st);   //  64 h x 256 n
@@ -652,10 +716,14 @@ int launch_forward_act(const FwdArgs& a, bool layer2, hipStream_t st) {
 
 int launch_forward(int act, const FwdArgs& a, bool layer2, hipStream_t st) {
     switch (act) {
+#ifndef RBNN_FAST_BUILD
         case RBNN_ACT_RELU:  return launch_forward_act<RBNN_ACT_RELU>(a, layer2, st);
+#endif
         case RBNN_ACT_LEAKY: return launch_forward_act<RBNN_ACT_LEAKY>(a, layer2, st);
+#ifndef RBNN_FAST_BUILD
         case RBNN_ACT_SIGM:  return launch_forward_act<RBNN_ACT_SIGM>(a, layer2, st);
         case RBNN_ACT_TANH:  return launch_forward_act<RBNN_ACT_TANH>(a, layer2, st);
+#endif
     }
     return RBNN_ERR_UNSUPPORTED;
 }
@@ -663,14 +731,13 @@ int launch_forward(int act, const FwdArgs& a, bool layer2, hipStream_t st) {
 template <int ACT, int TD, bool A_MEM, bool PER_SAMPLE>
 int launch_grad_c(const GradArgs& a, hipStream_t st) {
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
-    if (A_MEM)
-        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 2, true, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
-    else if (a.C <= 2)
-        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 2, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
-    else if (a.C <= 10)
-        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 10, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 16, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+    if constexpr (A_MEM) {
+        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, true, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+    } else {                          // CQ = MFMA K steps (4 classes each) of the dA product
+        if (a.C <= 4)       hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+        else if (a.C <= 12) hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 3, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+        else                hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 4, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+    }
     return launch_status();
 }
 
@@ -687,10 +754,14 @@ int launch_grad_td(GradArgs a, hipStream_t st) {
 template <bool A_MEM, bool PER_SAMPLE>
 int launch_grad(int act, const GradArgs& a, hipStream_t st) {
     switch (act) {
+#ifndef RBNN_FAST_BUILD
         case RBNN_ACT_RELU:  return launch_grad_td<RBNN_ACT_RELU, A_MEM, PER_SAMPLE>(a, st);
+#endif
         case RBNN_ACT_LEAKY: return launch_grad_td<RBNN_ACT_LEAKY, A_MEM, PER_SAMPLE>(a, st);
+#ifndef RBNN_FAST_BUILD
         case RBNN_ACT_SIGM:  return launch_grad_td<RBNN_ACT_SIGM, A_MEM, PER_SAMPLE>(a, st);
         case RBNN_ACT_TANH:  return launch_grad_td<RBNN_ACT_TANH, A_MEM, PER_SAMPLE>(a, st);
+#endif
     }
     return RBNN_ERR_UNSUPPORTED;
 }
