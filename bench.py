@@ -102,7 +102,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("RBNN_FORCE_COLLECTIVES") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)           # nccl == RCCL on ROCm
@@ -145,6 +145,7 @@ def main():
     kern = TimedKernels()
     if args.shard == "samples":
         eng = AttackEngine(sp, kernels=kern, group=group, total_samples=w["S"] * world)
+        eng._S_total = w["S"] * world
         xs, ys, S_job, N_job = x, y, w["S"] * world, w["N"]
     else:
         eng = AttackEngine(sp, kernels=kern)
@@ -214,7 +215,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

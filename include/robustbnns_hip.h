@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 1
+#define RBNN_ABI_VERSION 2
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {
@@ -75,13 +75,17 @@ typedef struct rbnn_posterior {
     const float *W1, *b1;          /* model.1.weight [S_total,H,D_pad], model.1.bias [S_total,H] */
     const float *Wm, *bm;          /* fc2 only: model.3.weight [S_total,H,H], model.3.bias       */
     const float *W2, *b2;          /* output layer (model.3 for fc, model.5 for fc2): [S_total,C,H], [S_total,C] */
+    /* rbnn_pack_rows4() images of W1 / Wm: [S_total, H/4, cols, 4] — four consecutive hidden units interleaved per
+     * column, so the backward GEMM's B operand (4 K steps of one column) is one 16-byte LDS read.  Required by
+     * rbnn_fc_input_grad (Wm_pack4 for fc2 only); the forward reads the plain row-major W1 / Wm. */
+    const float *W1_pack4, *Wm_pack4;
 } rbnn_posterior;
 
 /* Caller-owned scratch for one (N, S) problem; sizes from rbnn_workspace_query(). */
 typedef struct rbnn_workspace {
     float    *P;                   /* [S,N,16]      per-sample probabilities (or logits)         */
     float    *dZ;                  /* [S,N,16]      dL/dlogits per sample                        */
-    uint32_t *mask1;               /* [S,N,H/32]    bit h%32 of word h/32 = (pre-activation > 0) */
+    uint32_t *mask1;               /* [S,H/32,N]    bit h%32 of word [s][h/32][n] = (pre-activation > 0) */
     float    *dact1;               /* [S,N,H]       act'(pre-activation), sigm/tanh only         */
     float    *hid1;                /* [S,N,H]       fc2: first hidden activations                */
     uint32_t *mask2;               /* fc2: as mask1 for the second hidden layer                  */
@@ -160,6 +164,11 @@ int rbnn_attack_step(float *X, const float *X0, int32_t ldx, const float *G, int
  * counts: int32[2] = {#correct original, #correct adversarial}, zeroed by this call; rob: [N]. */
 int rbnn_eval_metrics(const float *out_orig, const float *out_adv, int32_t ldp, const int32_t *labels,
                       int32_t n_points, int32_t n_classes, int32_t *counts, float *rob, void *stream);
+
+/* out[(r/4), c, r%4] = W[r, c] for a row-major [rows, cols] matrix (rows % 4 == 0): the packed weight image that
+ * rbnn_fc_input_grad reads (rows = S_total*H of W1 [cols = D_pad] or of Wm [cols = H]).  One-off layout
+ * transform at posterior-load time; no counterpart in the reference. */
+int rbnn_pack_rows4(const float *W, int64_t rows, int32_t cols, float *out, void *stream);
 
 /* W[s,i] = loc[i] + softplus(scale_raw[i]) * eps[s,i]   — the SVI guide's draw, model_bnn.py:124-130
  * (Normal(loc, softplus(scale)).rsample()).  PARITY UNPINNED: pyro-ppl 1.3.0 is not available;

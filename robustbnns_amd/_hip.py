@@ -26,7 +26,8 @@ class Posterior(C.Structure):
     _fields_ = [("arch", C.c_int32), ("activation", C.c_int32), ("in_features", C.c_int32),
                 ("in_stride", C.c_int32), ("hidden", C.c_int32), ("n_classes", C.c_int32),
                 ("n_stored", C.c_int32), ("reserved", C.c_int32),
-                ("W1", _fp), ("b1", _fp), ("Wm", _fp), ("bm", _fp), ("W2", _fp), ("b2", _fp)]
+                ("W1", _fp), ("b1", _fp), ("Wm", _fp), ("bm", _fp), ("W2", _fp), ("b2", _fp),
+                ("W1_pack4", _fp), ("Wm_pack4", _fp)]
 
 
 class Workspace(C.Structure):
@@ -56,6 +57,7 @@ SIGNATURES = {
     "rbnn_pgd_alpha": (_i32, [_fp, _i32, _i32, _i32, _fp, _fp]),
     "rbnn_attack_step": (_i32, [_fp, _fp, _i32, _fp, _i32, _sz, _i32, _fp, _f32, _f32, _i32, _i32, _i32, _fp]),
     "rbnn_eval_metrics": (_i32, [_fp, _fp, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
+    "rbnn_pack_rows4": (_i32, [_fp, _i64, _i32, _fp, _fp]),
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
 }
 
@@ -77,7 +79,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 1:
+        if lib.rbnn_abi_version() != 2:
             raise HipError("librbnn_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -171,6 +173,12 @@ class HipKernels:
         require_gpu(A, "outputs")
         check(self.lib.rbnn_eval_metrics(ptr(A), ptr(B), A.stride(0), ptr(labels), A.shape[0], Cn, ptr(counts), ptr(rob),
                                          stream_of(A)), "rbnn_eval_metrics")
+
+    def pack_rows4(self, W, out):
+        """[rows, cols] row-major -> [rows/4, cols, 4] (rows = leading dims of W flattened)."""
+        require_gpu(W, "W")
+        cols = W.shape[-1]
+        check(self.lib.rbnn_pack_rows4(ptr(W), W.numel() // cols, cols, ptr(out), stream_of(W)), "rbnn_pack_rows4")
 
     def svi_materialize(self, loc, scale_raw, eps, out):
         require_gpu(loc, "loc")

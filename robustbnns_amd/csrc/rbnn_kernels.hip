@@ -33,10 +33,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // Diagnostic ablation bits (tools/ablate.hip builds this file with RBNN_ABL != 0 to price each part of the K loops;
 // results are then wrong by construction).  1: no LDS-DMA in the loop  2: no barrier in the loop
-// 4: operands not re-read from LDS  8: skip the epilogue
+// 4: operands not re-read from LDS  8: skip the epilogue  16: grad: no dA generation in the loop
+// 32: grad: no mask-word loads in the loop  64: grad: no W1/W2 LDS-DMA in the loop (mask loads kept)
 #ifndef RBNN_ABL
 #define RBNN_ABL 0
 #endif
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
+#define VMCNT(n) ((((n) & 15) | (((n) >> 4) << 14)) | 0x0F70)
+#define VMCNT_LGKM0(n) ((((n) & 15) | (((n) >> 4) << 14)) | 0x0070)
 #define LEAKY_SLOPE 0.01f                       // torch.nn.LeakyReLU() default (model_nn.py:68-69)
 
 namespace {
@@ -67,6 +71,16 @@ __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)l, 16, 0, 0);
+}
+
+// Ring hand-off: this wave's DMA pieces except the N youngest have landed and its LDS reads are done (counted
+// s_waitcnt), then a raw s_barrier (no vmcnt(0) drain).  The empty asm statements stop hipcc from moving LDS
+// accesses across the pair (the raw barrier is not a memory fence to the compiler).
+template <int N> __device__ __forceinline__ void ring_wait_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(VMCNT_LGKM0(N));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
 template <int ACT> __device__ __forceinline__ float act_fwd(float a) {
@@ -105,9 +119,21 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
     static_assert(HTW % 2 == 0 && HTW <= 8, "a wave's h range is whole 32-bit mask words, at most 4");
     static_assert(WH * BN * 16 <= 2 * TILE, "the Z^T reduction scratch aliases the tile buffers");
-    // ONE LDS array (tile double buffer; the softmax scratch aliases it after the K loop): global_load_lds
+    // K tiles go through a ring of LDS buffers filled by LDS-DMA.  When every wave issues the same number of DMA
+    // pieces per tile (OPS) the ring is 3 deep and tile kt+2 is in flight while tile kt is multiplied: the wait
+    // before the barrier is a COUNTED vmcnt(OPS) (tile kt+1 landed, kt+2 may still fly) and the barrier is a raw
+    // s_barrier — __syncthreads() would drain vmcnt(0) and expose one full L2/HBM latency per tile.
+    // (Measured at C2: the 3-deep ring is NOT faster than the 2-deep one — 6.34 vs 6.23 ms — the forward kernel is
+    // bound by the CU's memory-pipe throughput for the DMA pieces, not by their latency.  Kept behind RBNN_RING3.)
+#ifdef RBNN_RING3
+    constexpr bool RING3 = (BH / 16) % NW == 0 && (BN / 16) % NW == 0;
+#else
+    constexpr bool RING3 = false;
+#endif
+    constexpr int NBUF = RING3 ? 3 : 2, OPS = BH / 16 / NW + BN / 16 / NW;
+    // ONE LDS array (tile ring; the softmax scratch aliases it after the K loop): global_load_lds
     // staging beside a second __shared__ object makes hipcc drain vmcnt before every ds_read.
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * TILE];
     float* const zred = lds;
 
     int id;
@@ -149,11 +175,13 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
             }
         };
         stage(0, 0);
-        __syncthreads();                                       // vmcnt(0) + barrier: tile 0 landed for every wave
+        if (RING3 && a.KT > 1) stage(1, 1);
+        if (RING3 && a.KT > 1) ring_wait_barrier<OPS>(); else ring_wait_barrier<0>();   // tile 0 landed for every wave
         f32x4 bf[NTW], a_cur, a_nxt;
+        int buf = 0, nbuf = RING3 ? 2 : 1;                     // buffer of tile kt / of the tile staged in this iteration
         for (int kt = 0; kt < a.KT; ++kt) {
-            const int buf = kt & 1;
-            if (!(RBNN_ABL & 1) && kt + 1 < a.KT) stage(kt + 1, buf ^ 1);   // lands while this tile's 128 MFMAs per wave run
+            const bool more = kt + (RING3 ? 2 : 1) < a.KT;
+            if (!(RBNN_ABL & 1) && more) stage(kt + (RING3 ? 2 : 1), nbuf);   // lands while this (and the next) tile is multiplied
             const float* const Wt = lds + buf * TILE;
             const float* const Xt = Wt + BH * 16;
             // Fragment reads are software-pipelined one h-tile ahead of the MFMAs that consume them, and the
@@ -184,7 +212,12 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTW, 0);                // 8 MFMAs on a(ht)
                 }
             }
-            if (!(RBNN_ABL & 2)) __syncthreads();              // next tile landed (vmcnt(0)); everyone is done with this one
+            if (!(RBNN_ABL & 2)) {
+                // tile kt+1 landed (this wave's share; the barrier covers the others); everyone is done with tile kt
+                if (RING3 && more) ring_wait_barrier<OPS>(); else ring_wait_barrier<0>();
+            }
+            buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+            nbuf = (nbuf + 1 == NBUF) ? 0 : nbuf + 1;
         }
         if (RBNN_ABL & 2) __syncthreads();
         if (RBNN_ABL & 8) {                                    // diagnostic: keep the accumulators live, skip the epilogue
@@ -243,7 +276,7 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int n = n0 + (wave_n * NTW + nt) * 16 + li;
-                if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * a.N + n) * HW + (hw0 >> 5) + lg] = mine[nt];
+                if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * HW + (hw0 >> 5) + lg) * a.N + n] = mine[nt];   // [S][H/32][N]: 16 lanes = 64 B
             }
         }
     }
@@ -329,20 +362,17 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     const int s_begin = ch * a.chunk, s_end = min(a.S, s_begin + a.chunk);
     const int HS = a.H / HSTG, nst = (s_end - s_begin) * HS;
 
-    // LDS image of the W1 tile: row h holds its TD 16-float segments rotated by one segment when (h>>2)&1, so the
-    // two rows (4*lg + r, lg = 0/1) a half-wave reads per B operand sit in opposite bank halves although the row
-    // stride (TD*64 B) is a multiple of 128 B.  LDS-DMA writes linearly, so the rotation is applied to the SOURCE
-    // column of each lane; the read side adds it back.  goff: per-lane source offset of this wave's pieces.
+    // W1 comes from its rbnn_pack_rows4 image [H/4][ldw][4]: a stage tile is [8 h-quads][TD*16 d][4] floats, and the
+    // B operand of the 4 K steps of h tile t2 — W1[16*t2 + 4*lg + r][d], r = 0..3 — is ONE 16-byte LDS read at
+    // [(4*t2 + lg)][dt*16 + li][0..3]; a 16-lane ds_read_b128 group then covers 16 distinct 16-B slots (the quad
+    // stride TD*256 B is a multiple of 256 B), so the linear LDS-DMA image needs no swizzle.
+    // goff: per-lane source offset (floats) of this wave's 1-KiB pieces inside a stage.
     int goff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int f = (wave + 4 * i) * 256 + 4 * lane, row = f / LD, pc = f % LD;
-        int col = pc - 16 * ((row >> 2) & 1);
-        if (col < 0) col += LD;
-        goff[i] = row * a.ldw + min(dc0 + col, Dp - 4);       // columns past D_pad: any valid address, never stored
+        const int f = (wave + 4 * i) * 256 + 4 * lane, hq = f / (4 * LD), d = (f % (4 * LD)) >> 2;
+        goff[i] = (hq * a.ldw + min(dc0 + d, Dp - 1)) * 4;    // columns past D_pad: any valid address, never stored
     }
-    const int boff = li + 16 * (lg & 1);                       // read side: segment dt of row 4*lg+r is at (dt + (lg&1)) % TD
-    const int blast = (lg & 1) ? li : (TD - 1) * 16 + li;
     // W2 tile: piece q = classes 8q..8q+7, lane p -> class 8q + (p>>3), 16-B chunk p&7 of its 32 hidden units; odd
     // classes are stored with their two 64-B halves swapped (same bank argument: a half-wave reads classes c, c+1).
     const int w2row = lane >> 3;
@@ -360,20 +390,21 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     auto stage_issue = [&](int st, int buf) {
         const int s = s_begin + st / HS, h0 = (st % HS) * HSTG;
         const int sw = a.sidx ? a.sidx[s] : s;
-        const float* const Ws = a.W1 + (long long)sw * a.w1_sample_stride + (long long)h0 * a.ldw;
+        const float* const Ws = a.W1 + (long long)sw * a.w1_sample_stride + (long long)h0 * a.ldw;   // quad h0/4 of the packed image
+        const bool dma = !(RBNN_ABL & 64) || st == 0;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-            if (wave + 4 * i < NPIECE) glds16(Ws + goff[i], lds + buf * BUF + (wave + 4 * i) * 256);
+            if (dma && wave + 4 * i < NPIECE) glds16(Ws + goff[i], lds + buf * BUF + (wave + 4 * i) * 256);
         if (!A_MEM) {
-            if (wave * 8 < W2ROWS) {                           // W2 rows past C repeat row C-1: they meet dZ columns that are 0
+            if (dma && wave * 8 < W2ROWS) {                    // W2 rows past C repeat row C-1: they meet dZ columns that are 0
                 const int c = min(wave * 8 + w2row, a.C - 1);
                 glds16(a.W2 + ((long long)sw * a.C + c) * a.H + h0 + w2goff_col, lds + buf * BUF + W1SZ + wave * 256);
             }
-            if (BITMASK) {
+            if (BITMASK && (!(RBNN_ABL & 32) || st == 0)) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int n = nb + nt * 16 + li;
-                    mreg[nt] = (n < a.N) ? a.mask[((long long)s * a.N + n) * a.HW + (h0 >> 5)] : 0u;
+                    mreg[nt] = (n < a.N) ? a.mask[((long long)s * a.HW + (h0 >> 5)) * a.N + n] : 0u;
                 }
             }
         }
@@ -441,25 +472,32 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
                 da[slot][nt] = g[nt];
             }
         };
-        float bfr[2][TD];
-        auto read_b = [&](int k, int slot) {                   // B operand of K step k = (t2, r): W1 rows 16*t2 + 4*lg + r
-            const int hrow = (k >> 2) * 16 + 4 * lg + (k & 3);
-#pragma unroll
-            for (int dt = 0; dt < TD - 1; ++dt) bfr[slot][dt] = W1t[hrow * LD + dt * 16 + boff];
-            bfr[slot][TD - 1] = W1t[hrow * LD + blast];
+        // B operand: one ds_read_b128 per (h tile, column tile) = 4 K steps.  The MFMAs of an h tile run column-tile
+        // major (dt outer; r, nt inner: 16 MFMAs per register quad), so b4[dt] is dead as soon as its 16 MFMAs have
+        // issued and is re-read for the NEXT h tile right there — the read hides under the other column tiles'
+        // MFMAs with no second register set.  Per accumulator the K order (t2, r ascending) is unchanged.
+        f32x4 b4[TD];
+        auto read_b = [&](int t2, int dt) {
+            b4[dt] = *(const f32x4*)(W1t + ((4 * t2 + lg) * LD + dt * 16 + li) * 4);
         };
         make_da(0, 0);
-        read_b(0, 0);
-        static_for<0, 4 * NT2>([&](auto kc) {
-            constexpr int k = decltype(kc)::value, t2 = k >> 2, r = k & 3, cur = k & 1;
-            constexpr bool more = (k + 1 < 4 * NT2), gen = (r == 0 && t2 + 1 < NT2 && !A_MEM);
-            if (!(RBNN_ABL & 20) && r == 0 && t2 + 1 < NT2) make_da(t2 + 1, (t2 + 1) & 1);   // next h tile's dA ahead of this tile's 4 K steps
-            if (!(RBNN_ABL & 4) && more) read_b(k + 1, cur ^ 1);
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
+        for (int dt = 0; dt < TD; ++dt) read_b(0, dt);
+        static_for<0, NT2>([&](auto tc) {
+            constexpr int t2 = decltype(tc)::value;
+            if (!(RBNN_ABL & 20) && t2 + 1 < NT2) make_da(t2 + 1, (t2 + 1) & 1);   // next h tile's dA ahead of this tile's MFMAs
 #pragma unroll
-                for (int dt = 0; dt < TD; ++dt)
-                    acc[nt][dt] = MFMA16(da[(RBNN_ABL & 20) ? 0 : (t2 & 1)][nt][r], bfr[(RBNN_ABL & 4) ? 0 : cur][dt], acc[nt][dt]);
+            for (int dt = 0; dt < TD; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[nt][dt] = MFMA16(da[(RBNN_ABL & 20) ? 0 : (t2 & 1)][nt][r], b4[dt][r], acc[nt][dt]);
+                if (!(RBNN_ABL & 4) && t2 + 1 < NT2) read_b(t2 + 1, dt);
+#ifndef RBNN_NO_PIN
+                __builtin_amdgcn_sched_barrier(0);             // keep the re-read HERE: hipcc would sink it to its consumer
+#endif
+            }
         });
         if (!(RBNN_ABL & 2)) __syncthreads();                  // vmcnt(0): next tiles landed; everyone is done with these
     }
@@ -481,7 +519,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
                 float v = acc[nt][dt][r];
                 if (PER_SAMPLE) {
                     if (BITMASK) {
-                        const unsigned w = a.omask[((long long)s_begin * a.N + n) * a.OHW + (d >> 5)];
+                        const unsigned w = a.omask[((long long)s_begin * a.OHW + (d >> 5)) * a.N + n];
                         v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
                     } else {
                         v *= a.odact[((long long)s_begin * a.N + n) * a.ldo + d];
@@ -622,6 +660,14 @@ __global__ void eval_metrics_kernel(const float* __restrict__ A, const float* __
         if (ba) atomicAdd(&counts[0], __popcll(ba));
         if (bb) atomicAdd(&counts[1], __popcll(bb));
     }
+}
+
+__global__ void pack_rows4_kernel(const float* __restrict__ W, long long quads, int cols, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (row quad, column): 16-B store
+    if (i >= quads * cols) return;
+    const long long q = i / cols, c = i % cols;
+    const float* const src = W + (4 * q) * cols + c;
+    *(f32x4*)(out + 4 * i) = (f32x4){src[0], src[cols], src[2LL * cols], src[3LL * cols]};
 }
 
 __global__ void svi_materialize_kernel(const float* __restrict__ loc, const float* __restrict__ scale_raw,
@@ -871,6 +917,8 @@ int rbnn_fc_input_grad(const rbnn_posterior* net, const int32_t* sidx, int32_t S
     if (N < 1 || S < 1) return RBNN_ERR_SHAPE;
     const bool bm = is_bitmask(net->activation), fc2 = net->arch == RBNN_ARCH_FC2;
     if (bm ? !ws->mask1 : !ws->dact1) return RBNN_ERR_NULL;
+    if (!net->W1_pack4 || (fc2 && !net->Wm_pack4)) return RBNN_ERR_NULL;
+    if (!aligned16(net->W1_pack4) || (fc2 && !aligned16(net->Wm_pack4))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int H = net->hidden, Dp = net->in_stride;
     if (chunk <= 0) chunk = pick_chunk(N, Dp / 16, S);
@@ -882,14 +930,14 @@ int rbnn_fc_input_grad(const rbnn_posterior* net, const int32_t* sidx, int32_t S
     g.W2 = net->W2; g.C = net->n_classes; g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N;
     if (!fc2) {
         g.dZ = ws->dZ; g.mask = ws->mask1; g.dact = ws->dact1;
-        g.W1 = net->W1; g.w1_sample_stride = (long long)H * Dp; g.ldw = Dp; g.Dt = Dp / 16;
+        g.W1 = net->W1_pack4; g.w1_sample_stride = (long long)H * Dp; g.ldw = Dp; g.Dt = Dp / 16;
         g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
         return launch_grad<false, false>(net->activation, g, st);
     }
     // fc2 step 1, per sample: dhid1[s] = act'(A1_s) * ((act'(A2_s) * (dZ_s . W2_s)) . Wm_s)
     if (!ws->dhid1 || (bm ? !ws->mask2 : !ws->dact2)) return RBNN_ERR_NULL;
     g.dZ = ws->dZ; g.mask = ws->mask2; g.dact = ws->dact2;
-    g.W1 = net->Wm; g.w1_sample_stride = (long long)H * H; g.ldw = H; g.Dt = H / 16;
+    g.W1 = net->Wm_pack4; g.w1_sample_stride = (long long)H * H; g.ldw = H; g.Dt = H / 16;
     g.chunk = 1; g.nchunks = S; g.out = ws->dhid1; g.ldo = H;
     g.omask = ws->mask1; g.odact = ws->dact1; g.OHW = H / 32;
     rc = launch_grad<false, true>(net->activation, g, st);
@@ -897,7 +945,7 @@ int rbnn_fc_input_grad(const rbnn_posterior* net, const int32_t* sidx, int32_t S
     // fc2 step 2: slabs[k] = sum_{s in chunk k} dhid1[s] . W1_s
     GradArgs h = {};
     h.amem = ws->dhid1; h.C = net->n_classes; h.H = H; h.HW = H / 32; h.sidx = sidx; h.S = S; h.N = N;
-    h.W1 = net->W1; h.w1_sample_stride = (long long)H * Dp; h.ldw = Dp; h.Dt = Dp / 16;
+    h.W1 = net->W1_pack4; h.w1_sample_stride = (long long)H * Dp; h.ldw = Dp; h.Dt = Dp / 16;
     h.chunk = chunk; h.nchunks = nchunks; h.out = ws->slabs; h.ldo = Dp;
     return launch_grad<true, false>(net->activation, h, st);
 }
@@ -936,6 +984,15 @@ int rbnn_eval_metrics(const float* out_orig, const float* out_adv, int32_t ldp, 
     if (hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) return RBNN_ERR_LAUNCH;
     hipLaunchKernelGGL(eval_metrics_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        out_orig, out_adv, ldp, labels, N, C, counts, rob);
+    return launch_status();
+}
+
+int rbnn_pack_rows4(const float* W, int64_t rows, int32_t cols, float* out, void* stream) {
+    if (!W || !out) return RBNN_ERR_NULL;
+    if (rows < 4 || (rows & 3) || cols < 1) return RBNN_ERR_SHAPE;
+    if (!aligned16(out)) return RBNN_ERR_ALIGN;
+    const long long total = (rows / 4) * (long long)cols;
+    hipLaunchKernelGGL(pack_rows4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, (long long)(rows / 4), cols, out);
     return launch_status();
 }
 

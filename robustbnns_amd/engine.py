@@ -15,6 +15,8 @@ torch supplies device memory, the current HIP stream and torch.distributed (RCCL
 in the HIP kernels behind `kernels` (robustbnns_amd._hip.HipKernels — there is no other backend in
 this package; tests inject a CPU fake to exercise the multi-process orchestration under gloo).
 """
+import os
+
 import torch
 
 from . import _hip
@@ -43,6 +45,8 @@ class AttackEngine:
         if group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(group)
+            if os.environ.get("RBNN_FORCE_COLLECTIVES") == "1":
+                self.world = max(self.world, 2)    # diagnostics: run the all-reduce path even in a 1-rank group
         self._S_total = total_samples
         self._ws_cache = {}
 

@@ -63,7 +63,22 @@ class StackedPosterior:
             self.Wm = self.bm = None
         self.W2 = pad(w(keys[-1] + ".weight"), (self.C, self.Hp))
         self.b2 = pad(w(keys[-1] + ".bias"), (self.C,))
+        self._pack()
         self._desc = None
+
+    def _pack(self):
+        """rbnn_pack_rows4 images [S, H/4, cols, 4] of W1 (and Wm): the backward GEMM's B-operand layout."""
+        def pack(W):
+            if W is None:
+                return None
+            out = torch.empty_like(W)
+            if W.device.type == "cuda":
+                _hip.HipKernels().pack_rows4(W, out)
+            else:       # layout-only transform for the CPU-side tests (no arithmetic): same image via a permute
+                S, H, cols = W.shape
+                out.copy_(W.view(S, H // 4, 4, cols).permute(0, 1, 3, 2).reshape(S, H, cols))
+            return out
+        self.W1p, self.Wmp = pack(self.W1), pack(self.Wm)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -87,6 +102,8 @@ class StackedPosterior:
             for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
                 t = getattr(self, name)
                 setattr(d, name, None if t is None else C.c_void_p(t.data_ptr()))
+            d.W1_pack4 = C.c_void_p(self.W1p.data_ptr())
+            d.Wm_pack4 = None if self.Wmp is None else C.c_void_p(self.Wmp.data_ptr())
             self._desc = d
         return self._desc
 
@@ -101,7 +118,7 @@ class StackedPosterior:
         return {k: v.detach().cpu().clone() for k, v in sd.items()}
 
     def nbytes(self):
-        return sum(t.numel() * 4 for t in (self.W1, self.b1, self.Wm, self.bm, self.W2, self.b2) if t is not None)
+        return sum(t.numel() * 4 for t in (self.W1, self.b1, self.Wm, self.bm, self.W2, self.b2, self.W1p, self.Wmp) if t is not None)
 
     def shard(self, rank, world):
         """Samples [rank*S/world, (rank+1)*S/world) as a new posterior (sample-sharded multi-GPU)."""
@@ -112,4 +129,5 @@ class StackedPosterior:
             t = getattr(self, name)
             setattr(out, name, None if t is None else t[lo:hi].contiguous())
         out.S, out._desc = hi - lo, None
+        out._pack()
         return out

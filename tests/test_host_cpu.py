@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rbnn_abi_version() == 1
+    assert lib.rbnn_abi_version() == 2
     assert lib.rbnn_strerror(0) == b"ok" and b"NULL" in lib.rbnn_strerror(-1)
 
 
@@ -68,6 +68,7 @@ def test_argument_validation_without_gpu():
     assert lib.rbnn_attack_step(None, None, 16, None, 1, 0, 16, None, 0.1, 0.1, 0, 4, 2, None) == -1
     assert lib.rbnn_pgd_alpha(C.c_void_p(16), 1, 4, 2, C.c_void_p(16), None) == -2                  # ldx < D
     assert lib.rbnn_svi_materialize(None, None, None, 4, 1, None, None) == -1
+    assert lib.rbnn_pack_rows4(C.c_void_p(16), 6, 8, C.c_void_p(16), None) == -2                    # rows % 4
 
 
 def test_compute_refuses_cpu_tensors():
@@ -91,6 +92,9 @@ def test_stacked_posterior_padding_and_roundtrip():
         assert torch.equal(v, post[k][1])
     d = sp.descriptor()
     assert (d.arch, d.activation, d.in_features, d.in_stride, d.hidden, d.n_classes, d.n_stored) == (1, 3, 2, 16, 32, 2, 3)
+    # packed image [S, H/4, cols, 4]: element (q, c, j) is row 4q+j, column c
+    assert sp.W1p.shape == sp.W1.shape and torch.equal(sp.W1p.view(3, 8, 16, 4)[1, 2, 5], sp.W1[1, 8:12, 5])
+    assert torch.equal(sp.Wmp.view(3, 8, 32, 4)[2, 7, 31], sp.Wm[2, 28:32, 31])
     sh = sp.shard(1, 2)
     assert sh.S == 2 and torch.equal(sh.W1, sp.W1[1:3])
     with pytest.raises(NotImplementedError):

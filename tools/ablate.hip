@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     net.arch = RBNN_ARCH_FC; net.activation = RBNN_ACT_LEAKY; net.in_features = D; net.in_stride = D; net.hidden = H; net.n_classes = C; net.n_stored = S;
     net.W1 = dev_rand((size_t)S * H * D, 0.05f, 1); net.b1 = dev_rand((size_t)S * H, 0.05f, 2);
     net.W2 = dev_rand((size_t)S * C * H, 0.05f, 3); net.b2 = dev_rand((size_t)S * C, 0.05f, 4);
+    { float* p4; hipMalloc(&p4, (size_t)S * H * D * sizeof(float)); rbnn_pack_rows4(net.W1, (int64_t)S * H, D, p4, nullptr); net.W1_pack4 = p4; }
     float* X = dev_rand((size_t)N * D, 0.5f, 5);
     rbnn_workspace_sizes sz; rbnn_workspace_query(&net, N, S, 0, &sz);
     rbnn_workspace ws = {};
