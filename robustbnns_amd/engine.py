@@ -33,6 +33,23 @@ def to_labels(y, device):
     return y.to(device=device, dtype=torch.int32).contiguous()
 
 
+class _DifferentiableForward(torch.autograd.Function):
+    """BNN/NN forward as an autograd node: output = mean over samples, backward = the hand-rolled HIP input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, engine, sidx, S, logits):
+        ctx.engine, ctx.sidx, ctx.S, ctx.logits = engine, sidx, S, logits
+        ctx.save_for_backward(x.detach())
+        out = engine.forward_padded(engine.pad_inputs(x), sidx, S, OUT_LOGITS if logits else OUT_PROBS)
+        return out[:, :engine.post.C].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        g = ctx.engine.vjp(x, grad_out.contiguous(), ctx.sidx, ctx.S, ctx.logits)
+        return g.to(x.device), None, None, None, None
+
+
 class AttackEngine:
     def __init__(self, posterior, kernels=None, group=None, total_samples=None):
         """posterior: StackedPosterior holding THIS rank's samples.  group: a torch.distributed process
@@ -134,8 +151,32 @@ class AttackEngine:
 
     def forward(self, x, n_samples, seeds=None, logits=False):
         sidx, S = self.sample_index(n_samples, seeds)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # callers that differentiate the forward themselves (the reference's own fgsm_attack does:
+            # adversarialAttacks.py:73-79): the backward is the HIP input-gradient path with the upstream dL/dout
+            return _DifferentiableForward.apply(x, self, sidx, S, bool(logits))
         out = self.forward_padded(self.pad_inputs(x), sidx, S, OUT_LOGITS if logits else OUT_PROBS)
         return out[:, :self.post.C]
+
+    def vjp(self, x, grad_out, sidx, S, logits):
+        """d<grad_out, forward(x)>/dx for forward = mean over samples of probabilities (or logits)."""
+        N, C = x.shape[0], self.post.C
+        Xp = self.pad_inputs(x)
+        ws = self.workspace(N, S)
+        S_tot = self.total_samples(S)
+        self.k.fc_forward(self.post, Xp, sidx, S, OUT_LOGITS if logits else OUT_PROBS, ws)
+        gup = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
+        gup[:, :C] = grad_out.to(self.device, torch.float32)
+        if logits:      # d mean_s z_s: dZ_s = grad/S for every sample -> write it through the upstream mode on "P = 1"
+            dZ = ws["dZ"].view(S, N, _hip.CPAD)
+            dZ.copy_((gup / S_tot).unsqueeze(0).expand(S, N, _hip.CPAD))
+        else:
+            self.k.loss_dlogits(LOSS_UPSTREAM, ws["P"], None, gup, None, S, 1.0 / S_tot, N, C, ws["dZ"])
+        n_slabs = self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
+        G = ws["G"]
+        self.k.sum_slabs(ws["slabs"], n_slabs, N, self.post.Dp, 1.0, G)
+        self._allreduce(G)
+        return self.unpad(G, x)
 
     # ------------------------------------------------------------------ expected input gradient
     def gradient_slabs(self, Xp, labels, sidx, S, mode, G_up=None, chunk=0):

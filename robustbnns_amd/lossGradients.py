@@ -4,6 +4,7 @@ The reference computes, per test point, one forward + one backward per posterior
 gradients (lossGradients.py:29-40).  Here all points and samples go through the HIP kernels at once with
 the per-sample loss (RBNN_LOSS_PER_SAMPLE).
 """
+import numpy as np
 import torch
 
 from .savedir import DATA
@@ -42,3 +43,39 @@ def save_loss_gradients(loss_gradients, n_samples, filename, savedir, relpath=DA
 def load_loss_gradients(n_samples, filename, savedir, relpath=DATA):
     """lossGradients.py:74-76"""
     return load_from_pickle(path=relpath + savedir + filename + "_samp=" + str(n_samples) + "_lossGrads.pkl")
+
+
+def compute_vanishing_norms_idxs(loss_gradients, n_samples_list, norm):
+    """lossGradients.py:78-127: indices of the images whose expected-gradient norm never increases along
+    `n_samples_list`.  loss_gradients: np.ndarray [n_images, len(n_samples_list), ...] (host post-processing of the
+    pickled results; same classification rule, including the running `<=` comparison against the last accepted norm)."""
+    if loss_gradients.shape[1] != len(n_samples_list):
+        raise ValueError("Second dimension should equal the length of `n_samples_list`")
+    flat = np.asarray(loss_gradients).reshape(loss_gradients.shape[0], loss_gradients.shape[1], -1)
+    if norm == "linfty":
+        norms = np.abs(flat).max(axis=-1)
+    elif norm == "l2":
+        norms = np.stack([[np.linalg.norm(flat[i, j]) for j in range(flat.shape[1])] for i in range(flat.shape[0])])
+    else:
+        raise UnboundLocalError("local variable 'gradient_norm' referenced before assignment")
+    vanishing, count_incr, count_null = [], 0, 0
+    for image_idx in range(norms.shape[0]):
+        gradient_norm = norms[image_idx, 0]
+        if gradient_norm != 0.0:
+            count = 0
+            for j in range(norms.shape[1]):
+                if norms[image_idx, j] <= gradient_norm:
+                    gradient_norm = norms[image_idx, j]
+                    count += 1
+            if count == norms.shape[1]:
+                vanishing.append(image_idx)
+            else:
+                count_incr += 1
+        else:
+            count_null += 1
+    n = len(norms)
+    print(f"vanishing gradients = {len(vanishing)/n} %")
+    print(f"increasing gradients = {count_incr/n} %")
+    print(f"null gradients = {count_null/n} %")
+    print("\nvanishing_gradients_idxs = ", vanishing)
+    return vanishing

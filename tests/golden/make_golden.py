@@ -285,10 +285,72 @@ def run_det_and_ensemble(name, *, shape, n_classes, hidden, act, arch, M, N, std
     print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
 
 
+def run_eps_grid(name, *, S, N, std, seed, epsilon_list, n_samples_list, method):
+    """plot_eps_attacks.build_eps_attacks_df (plot_eps_attacks.py:9-39): the eps x n_samples grid and its CSV."""
+    import copy
+    import model_bnn, plot_eps_attacks
+    shape, n_classes, hidden = (1, 2, 1), 2, 32
+    bnn = model_bnn.BNN(dataset_name="half_moons", hidden_size=hidden, activation="leaky", architecture="fc",
+                        inference="hmc", epochs=None, lr=None, n_samples=S, warmup=0, input_shape=shape,
+                        output_size=n_classes)
+    bnn.device = "cpu"; bnn.basenet.device = "cpu"
+    nets = []
+    for i in range(S):
+        net = copy.deepcopy(bnn.basenet); fill_net(net, i, std); nets.append(net)
+    bnn.posterior_predictive = {i: nets[i] for i in range(S)}
+    x, y = synth_inputs(N, shape, n_classes, seed)
+    with tempfile.TemporaryDirectory() as tmp:
+        cwd = os.getcwd(); os.chdir(tmp)
+        try:
+            df = plot_eps_attacks.build_eps_attacks_df(bnn=bnn, dataset="half_moons", device="cpu", method=method,
+                                                       x_test=x, y_test=y, epsilon_list=epsilon_list,
+                                                       n_samples_list=n_samples_list, savedir=bnn.name)
+            files = []
+            for root, _, fs in os.walk(tmp):
+                files += [os.path.relpath(os.path.join(root, f), tmp) for f in fs if f.endswith(".csv")]
+        finally:
+            os.chdir(cwd)
+    out = {"x": x.numpy(), "y": y.numpy()}
+    out.update(state_arrays(nets))
+    for col in ("epsilon", "test_acc", "adv_acc", "softmax_rob", "n_samples"):
+        out["df_" + col] = df[col].to_numpy().astype("float64")
+    meta = dict(dataset="half_moons", shape=list(shape), n_classes=n_classes, hidden=hidden, act="leaky", arch="fc",
+                S=S, N=N, std=std, seed=seed, epsilon_list=list(epsilon_list), n_samples_list=list(n_samples_list),
+                method=method, columns=list(df.columns), csv_files=sorted(files), bnn_name=bnn.name)
+    out["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.0f} KiB)")
+
+
+def run_vanishing_norms(name):
+    """lossGradients.compute_vanishing_norms_idxs (lossGradients.py:78-127) on random + crafted gradients."""
+    import contextlib, io
+    import lossGradients as ref
+    rng = np.random.default_rng(0)
+    g = rng.normal(size=(40, 4, 1, 6, 6)).astype("float32")
+    g[:, 1] *= np.linspace(0.2, 1.5, 40)[:, None, None, None]
+    g[:, 2] *= 0.5
+    g[:, 3] *= np.linspace(0.1, 1.2, 40)[::-1][:, None, None, None] * 0.5
+    g[3] = 0
+    g[7, 1:] = g[7, 0]                       # a null image and an all-equal one
+    out = {}
+    for norm in ("linfty", "l2"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            out[norm] = np.array(ref.compute_vanishing_norms_idxs(g, [1, 10, 50, 100], norm))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), grads=g, n_samples_list=np.array([1, 10, 50, 100]), **out)
+    print("wrote", name)
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
     torch.set_num_threads(1)          # one thread: bit-stable reductions for the fixtures
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "eps":
+        run_eps_grid("halfmoons_eps_grid_fgsm", S=6, N=30, std=0.5, seed=12, epsilon_list=[0.1, 0.3],
+                     n_samples_list=[1, 3, 6], method="fgsm")
+        return
     mn = (1, 28, 28)
     hm = (1, 2, 1)
     # (1) BASELINE config C1: half-moons fc 2->64->2, S=10, N=100
@@ -317,6 +379,11 @@ def main():
     # (5) conv on 1x28x28 (the only input size the reference's conv head is correct for)
     run_case("mnist_conv_h16_s2_n4_leaky", dataset="mnist", shape=mn, n_classes=10, hidden=16,
              act="leaky", arch="conv", S=2, N=4, std=0.05, seed=10, pgd_points=2)
+    # (7) the eps x n_samples grid driver
+    run_eps_grid("halfmoons_eps_grid_fgsm", S=6, N=30, std=0.5, seed=12, epsilon_list=[0.1, 0.3],
+                 n_samples_list=[1, 3, 6], method="fgsm")
+    # (8) vanishing-gradient classification (host post-processing)
+    run_vanishing_norms("vanishing_norms")
     # (6) deterministic NN + Ensemble_NN (mean of logits)
     run_det_and_ensemble("mnist_det_ens_fc_h32_m4_n6", shape=mn, n_classes=10, hidden=32, act="leaky",
                          arch="fc", M=4, N=6, std=0.05, seed=11)

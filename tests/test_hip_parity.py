@@ -263,3 +263,15 @@ def test_svi_materialize_and_forward():
     assert torch.equal(out, out2)                                          # same seeds, same draws
     avg = bnn.forward(x.to(DEV), n_samples=S, avg_posterior=True).cpu()    # logits of the mean weights (model_bnn.py:206-216)
     assert rel_err(avg, O.nn_logits(x, {k: v[None] for k, v in loc.items()}, "fc", "leaky")[0]) < TOL
+
+
+def test_autograd_through_forward(golden):
+    """The reference's own fgsm recipe, run by the caller: requires_grad + CrossEntropyLoss + backward + sign."""
+    g = golden("mnist_fc_h512_s8_n8_leaky"); m = g.meta; bnn = make_bnn(g)
+    x = g.t("x").to(DEV).requires_grad_(True)
+    out = bnn.forward(x, n_samples=m["S"])
+    loss = torch.nn.CrossEntropyLoss(reduction="sum")(out, g.t("y").argmax(-1).to(DEV))
+    loss.backward()
+    assert rel_err(x.grad.cpu(), g.t("meanprob_grad")) < TOL
+    adv = torch.clamp(x.detach() + m["eps"] * x.grad.sign(), 0, 1)
+    adv_equal(adv, g.t("fgsm"), g.t("meanprob_grad"))

@@ -259,3 +259,55 @@ def test_hmc_files_roundtrip(golden, tmp_path):
         assert torch.equal(getattr(b2.posterior, nm), getattr(bnn.posterior, nm))
     pp = bnn.posterior_predictive
     assert sorted(pp) == list(range(m["S"])) and torch.equal(pp[2].state_dict()["model.3.weight"], g.posterior()["model.3.weight"][2])
+
+
+def test_eps_grid_driver_matches_reference(golden, tmp_path, monkeypatch):
+    """plot_eps_attacks.build_eps_attacks_df: same rows, same CSV path and schema as the reference's."""
+    import pandas
+    from robustbnns_amd import plot_eps_attacks
+    g = golden("halfmoons_eps_grid_fgsm"); m = g.meta
+    bnn = model_bnn.BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], 0, tuple(m["shape"]), m["n_classes"])
+    bnn.set_posterior_samples(g.posterior(), "cpu")
+    bnn._engine = AttackEngine(bnn.posterior, kernels=FakeKernels())
+    assert bnn.name == m["bnn_name"]
+    monkeypatch.chdir(tmp_path)
+    df = plot_eps_attacks.build_eps_attacks_df(bnn=bnn, dataset=m["dataset"], device="cpu", method=m["method"], x_test=g.t("x"),
+                                               y_test=g.t("y"), epsilon_list=m["epsilon_list"], n_samples_list=m["n_samples_list"],
+                                               savedir=bnn.name)
+    assert list(df.columns) == m["columns"] and len(df) == len(g.arr["df_epsilon"])
+    for col in ("epsilon", "test_acc", "adv_acc", "n_samples"):
+        assert np.array_equal(df[col].to_numpy().astype("float64"), g.arr["df_" + col]), col
+    assert np.abs(df["softmax_rob"].to_numpy() - g.arr["df_softmax_rob"]).max() < 1e-6
+    assert set(df["attack_method"]) == {m["method"]}
+    assert os.path.exists(m["csv_files"][0])
+    back = plot_eps_attacks.load_eps_attacks_df(m["dataset"], m["method"], bnn.name)
+    assert len(back) == len(df) and list(back.columns) == m["columns"]
+
+
+def test_forward_is_differentiable_like_the_reference_expects(golden):
+    """A caller that runs CrossEntropyLoss(net.forward(x)).backward() itself (adversarialAttacks.py:73-79) gets the
+    same input gradient as the reference's autograd."""
+    g = golden("mnist_fc_h32_s8_n8_leaky"); m = g.meta
+    sp = StackedPosterior(m["arch"], m["act"], m["shape"], m["n_classes"], m["hidden"], g.posterior(), "cpu")
+    eng = AttackEngine(sp, kernels=FakeKernels())
+    x = g.t("x").clone().requires_grad_(True)
+    out = eng.forward(x, m["S"])
+    assert out.requires_grad
+    torch.nn.CrossEntropyLoss(reduction="sum")(out, g.t("y").argmax(-1)).backward()
+    assert rel_err(x.grad, g.t("meanprob_grad")) < 1e-5
+    x2 = g.t("x").clone().requires_grad_(True)
+    z = eng.forward(x2, m["S"], logits=True)
+    torch.nn.CrossEntropyLoss(reduction="sum")(z, g.t("y").argmax(-1)).backward()
+    ref = O.meanprob_gradients(g.t("x"), g.t("y").argmax(-1), g.posterior(), m["arch"], m["act"], m["S"], kind="ensemble")
+    assert rel_err(x2.grad, ref) < 1e-5
+    with torch.no_grad():
+        assert not eng.forward(x, m["S"]).requires_grad
+
+
+def test_compute_vanishing_norms_idxs_matches_reference():
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "vanishing_norms.npz"))
+    for norm in ("linfty", "l2"):
+        got = lossGradients.compute_vanishing_norms_idxs(d["grads"], list(d["n_samples_list"]), norm)
+        assert got == list(d[norm])
+    with pytest.raises(ValueError):
+        lossGradients.compute_vanishing_norms_idxs(d["grads"], [1, 2], "l2")
