@@ -170,6 +170,42 @@ int rbnn_eval_metrics(const float *out_orig, const float *out_adv, int32_t ldp, 
  * transform at posterior-load time; no counterpart in the reference. */
 int rbnn_pack_rows4(const float *W, int64_t rows, int32_t cols, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * `conv` architecture (model_nn.py:93-106) on 1x28x28 inputs (mnist / fashion_mnist only, as the reference guards,
+ * :95-96): Conv2d(1,32,5) -> act -> MaxPool2d(2) -> Conv2d(32,Hc,5) -> act -> MaxPool2d(2, stride 1) -> Flatten ->
+ * Linear(49*Hc, C).  relu / leaky only.  state_dict keys: model.0.* model.3.* model.7.* (SURVEY 8a row a1).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct rbnn_conv_posterior {
+    int32_t activation;            /* RBNN_ACT_RELU or RBNN_ACT_LEAKY                              */
+    int32_t hidden;                /* Hc = conv2 output channels, multiple of 16                   */
+    int32_t n_classes;             /* C <= 16                                                      */
+    int32_t n_stored;              /* S_total                                                      */
+    const float *K1w, *K1b;        /* model.0.weight [S_total,32,1,5,5], model.0.bias [S_total,32] */
+    const float *K2w, *K2b;        /* model.3.weight [S_total,Hc,32,5,5], model.3.bias [S_total,Hc] */
+    const float *Fw, *Fb;          /* model.7.weight [S_total,C,49*Hc], model.7.bias [S_total,C]   */
+    const float *K2w_tap;          /* [S_total,25,32,Hc]: model.3.weight regrouped tap-major (backward only) */
+} rbnn_conv_posterior;
+
+typedef struct rbnn_conv_workspace {
+    float   *P, *dZ;               /* [S,N,16]                                                     */
+    float   *P1;                   /* [S,N,32*12*12]  pooled+activated conv1 output                */
+    uint8_t *st1;                  /* [S,N,32*12*12]  pool-1 stash: argmax (bits 0-1) | pre-activation > 0 (bit 2) */
+    float   *Q2;                   /* [S,N,Hc*49]     pooled+activated conv2 output (the Linear's input) */
+    uint8_t *st2;                  /* [S,N,Hc*49]     pool-2 stash, same encoding                  */
+    float   *G;                    /* [S,N,784]       per-sample input gradients (backward)        */
+} rbnn_conv_workspace;
+
+typedef struct rbnn_conv_workspace_sizes { size_t P, dZ, P1, st1, Q2, st2, G; } rbnn_conv_workspace_sizes;
+
+int rbnn_conv_workspace_query(const rbnn_conv_posterior *net, int32_t n_points, int32_t n_samples,
+                              rbnn_conv_workspace_sizes *out);
+
+/* Stacked per-sample forward of the conv net: P[s] = softmax(NN_s(X)) (or logits) + the two pooling stashes.
+ * Replaces the sample loop of BNN.forward (model_bnn.py:251-255) with NN.forward = model_nn.py:98-106,126-141. */
+int rbnn_conv_forward(const rbnn_conv_posterior *net, const float *X, int32_t ldx, int32_t n_points,
+                      const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
+                      const rbnn_conv_workspace *ws, void *stream);
+
 /* W[s,i] = loc[i] + softplus(scale_raw[i]) * eps[s,i]   — the SVI guide's draw, model_bnn.py:124-130
  * (Normal(loc, softplus(scale)).rsample()).  PARITY UNPINNED: pyro-ppl 1.3.0 is not available;
  * eps is supplied by the caller.  out row stride ld_out >= n_elem (lets W1 be written D_pad-strided

@@ -39,6 +39,22 @@ class WorkspaceSizes(C.Structure):
                [("n_slabs", C.c_int32), ("chunk", C.c_int32)]
 
 
+class ConvPosterior(C.Structure):
+    _fields_ = [("activation", C.c_int32), ("hidden", C.c_int32), ("n_classes", C.c_int32), ("n_stored", C.c_int32),
+                ("K1w", _fp), ("K1b", _fp), ("K2w", _fp), ("K2b", _fp), ("Fw", _fp), ("Fb", _fp), ("K2w_tap", _fp)]
+
+
+CONV_WS_KEYS = ("P", "dZ", "P1", "st1", "Q2", "st2", "G")
+
+
+class ConvWorkspace(C.Structure):
+    _fields_ = [(k, _fp) for k in CONV_WS_KEYS]
+
+
+class ConvWorkspaceSizes(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in CONV_WS_KEYS]
+
+
 WS_KEYS = ("P", "dZ", "mask1", "dact1", "hid1", "mask2", "dact2", "dhid1", "slabs")
 
 _i32, _f32, _sz, _i64 = C.c_int32, C.c_float, C.c_size_t, C.c_int64
@@ -58,6 +74,8 @@ SIGNATURES = {
     "rbnn_attack_step": (_i32, [_fp, _fp, _i32, _fp, _i32, _sz, _i32, _fp, _f32, _f32, _i32, _i32, _i32, _fp]),
     "rbnn_eval_metrics": (_i32, [_fp, _fp, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "rbnn_pack_rows4": (_i32, [_fp, _i64, _i32, _fp, _fp]),
+    "rbnn_conv_workspace_query": (_i32, [C.POINTER(ConvPosterior), _i32, _i32, C.POINTER(ConvWorkspaceSizes)]),
+    "rbnn_conv_forward": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
 }
 
@@ -179,6 +197,25 @@ class HipKernels:
         require_gpu(W, "W")
         cols = W.shape[-1]
         check(self.lib.rbnn_pack_rows4(ptr(W), W.numel() // cols, cols, ptr(out), stream_of(W)), "rbnn_pack_rows4")
+
+    # -- conv architecture ---------------------------------------------------------------------------
+    def conv_workspace_sizes(self, net, N, S):
+        out = ConvWorkspaceSizes()
+        check(self.lib.rbnn_conv_workspace_query(C.byref(net.descriptor()), N, S, C.byref(out)), "rbnn_conv_workspace_query")
+        return {k: getattr(out, k) for k in CONV_WS_KEYS}
+
+    @staticmethod
+    def _conv_ws(ws):
+        w = ConvWorkspace()
+        for k in CONV_WS_KEYS:
+            setattr(w, k, ptr(ws.get(k)))
+        return w
+
+    def conv_forward(self, net, X, sidx, S, out_kind, ws):
+        require_gpu(X, "X")
+        w = self._conv_ws(ws)
+        check(self.lib.rbnn_conv_forward(C.byref(net.descriptor()), ptr(X), X.stride(0), X.shape[0], ptr(sidx), S, out_kind,
+                                         C.byref(w), stream_of(X)), "rbnn_conv_forward")
 
     def svi_materialize(self, loc, scale_raw, eps, out):
         require_gpu(loc, "loc")

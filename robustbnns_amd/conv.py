@@ -1,0 +1,90 @@
+"""The reference's `conv` architecture (model_nn.py:93-106) on the HIP path: stacked posterior + batched engine.
+
+Layout in HBM (all S samples resident): K1w [S,32,25], K1b [S,32], K2w [S,Hc,800] (k = ci*25 + ky*5 + kx, exactly
+nn.Conv2d's [out,in,kh,kw] flattened), K2b [S,Hc], Fw [S,C,49*Hc], Fb [S,C].  Activations per (sample, point):
+P1 18 KB, Q2 196*Hc B, two byte stashes — 148 KB at Hc=512, so large jobs are run in blocks of samples.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+from .engine import AttackEngine, to_labels
+from ._hip import OUT_LOGITS, OUT_PROBS
+
+CONV_KEYS = ("model.0", "model.3", "model.7")
+_U8 = {"st1", "st2"}
+
+
+class ConvStackedPosterior:
+    arch = "conv"
+
+    def __init__(self, activation, input_shape, n_classes, hidden, stacked, device):
+        if tuple(int(v) for v in input_shape) != (1, 28, 28):
+            raise NotImplementedError()                                   # model_nn.py:95-96: mnist / fashion_mnist only
+        if activation not in ("relu", "leaky"):
+            raise NotImplementedError(f"conv on the HIP path supports relu/leaky, not {activation!r}")
+        self.activation, self.input_shape = activation, (1, 28, 28)
+        self.D = self.Dp = 784
+        self.H, self.C = int(hidden), int(n_classes)
+        self.device = torch.device(device)
+        S = stacked["model.0.weight"].shape[0]
+        self.S = int(S)
+        f = lambda k, shape: stacked[k].to(self.device, torch.float32).reshape((S,) + shape).contiguous()
+        self.K1w, self.K1b = f("model.0.weight", (32, 25)), f("model.0.bias", (32,))
+        self.K2w, self.K2b = f("model.3.weight", (self.H, 800)), f("model.3.bias", (self.H,))
+        self.Fw, self.Fb = f("model.7.weight", (self.C, 49 * self.H)), f("model.7.bias", (self.C,))
+        # tap-major image of model.3.weight for the backward: [S, 25 taps, 32 ci, Hc]
+        self.K2tap = self.K2w.view(S, self.H, 32, 25).permute(0, 3, 2, 1).contiguous()
+        self._desc = None
+
+    @classmethod
+    def from_state_dicts(cls, sds, activation, input_shape, n_classes, hidden, device):
+        keys = [k + sfx for k in CONV_KEYS for sfx in (".weight", ".bias")]
+        stacked = {k: torch.stack([sd[k].detach().to("cpu", torch.float32) for sd in sds]) for k in keys}
+        return cls(activation, input_shape, n_classes, hidden, stacked, device)
+
+    def descriptor(self):
+        if self._desc is None:
+            d = _hip.ConvPosterior()
+            d.activation, d.hidden, d.n_classes, d.n_stored = _hip.ACTIVATIONS[self.activation], self.H, self.C, self.S
+            for name, t in (("K1w", self.K1w), ("K1b", self.K1b), ("K2w", self.K2w), ("K2b", self.K2b), ("Fw", self.Fw),
+                            ("Fb", self.Fb), ("K2w_tap", self.K2tap)):
+                setattr(d, name, C.c_void_p(t.data_ptr()))
+            self._desc = d
+        return self._desc
+
+    def state_dict(self, i):
+        sd = {"model.0.weight": self.K1w[i].view(32, 1, 5, 5), "model.0.bias": self.K1b[i],
+              "model.3.weight": self.K2w[i].view(self.H, 32, 5, 5), "model.3.bias": self.K2b[i],
+              "model.7.weight": self.Fw[i], "model.7.bias": self.Fb[i]}
+        return {k: v.detach().cpu().clone() for k, v in sd.items()}
+
+
+class ConvEngine(AttackEngine):
+    """AttackEngine whose forward / gradient calls go to the conv kernels; the attack loops, the reductions over
+    samples, the loss kernels and the evaluation are inherited unchanged."""
+
+    def workspace(self, N, S, chunk=0):
+        key = (N, S)
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            sizes = self.k.conv_workspace_sizes(self.post, N, S)
+            ws = {"n_slabs": S, "chunk": 1}
+            for name in _hip.CONV_WS_KEYS:
+                if name in _U8:
+                    ws[name] = torch.empty(sizes[name], dtype=torch.uint8, device=self.device)
+                else:
+                    ws[name] = torch.empty(sizes[name] // 4, dtype=torch.float32, device=self.device)
+            ws["slabs"] = ws["G"]                                          # per-sample gradients play the role of the slabs
+            ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
+            ws["Gsum"] = torch.empty(N, 784, dtype=torch.float32, device=self.device)
+            self._ws_cache.clear()
+            self._ws_cache[key] = ws
+        return ws
+
+    def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
+        self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)
+
+    def _grad_kernels(self, sidx, S, N, ws):
+        return self.k.conv_input_grad(self.post, sidx, S, N, ws)

@@ -21,79 +21,9 @@
 //   C/D        acc[r] = D[i = 4*lg + r][j = li]
 // The k <-> memory-index map of a K step is free as long as A and B agree; both kernels use
 // "step r of a 16-wide k block: k = lg  <->  index 4*lg + r", so one 16-byte load feeds four K steps.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <math.h>
-#include <type_traits>
-
-#include "../../include/robustbnns_hip.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-// Diagnostic ablation bits (tools/ablate.hip builds this file with RBNN_ABL != 0 to price each part of the K loops;
-// results are then wrong by construction).  1: no LDS-DMA in the loop  2: no barrier in the loop
-// 4: operands not re-read from LDS  8: skip the epilogue  16: grad: no dA generation in the loop
-// 32: grad: no mask-word loads in the loop  64: grad: no W1/W2 LDS-DMA in the loop (mask loads kept)
-#ifndef RBNN_ABL
-#define RBNN_ABL 0
-#endif
-// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
-#define VMCNT(n) ((((n) & 15) | (((n) >> 4) << 14)) | 0x0F70)
-#define VMCNT_LGKM0(n) ((((n) & 15) | (((n) >> 4) << 14)) | 0x0070)
-#define LEAKY_SLOPE 0.01f                       // torch.nn.LeakyReLU() default (model_nn.py:68-69)
+#include "rbnn_common.hpp"
 
 namespace {
-
-// ---------------------------------------------------------------------------------------------------
-// Work-item <-> block map.  Blocks b and b+8 share an XCD (observed round-robin dispatch; speed only):
-// give every XCD one contiguous run of the item space so that blocks resident together on an XCD work on
-// the same sample / the same W1 column slice and share it in that XCD's L2.  Bijective for any M.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool item_of_block(int b, int M, int& id) {
-    const int q = M >> 3, r = M & 7, x = b & 7, j = b >> 3;
-    if (j >= q + (x < r ? 1 : 0)) return false;
-    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    return true;
-}
-
-// compile-time loop: the body sees its index as a constant (sched_group_barrier sizes must be constant expressions)
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
-// 16-float (64 B) LDS rows read with ds_read_b128 by lane (row li, 16-B chunk lg): physical chunk =
-// lg ^ swz(row) with swz = [0,2,3,1][(row>>2)&3] makes every 16-lane b128 group hit 16 distinct slots.
-__device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
-
-// Asynchronous 16-B-per-lane global -> LDS copy (global_load_lds_dwordx4): per-lane source, LDS destination =
-// wave-uniform base + lane*16.  Completion is tracked by vmcnt; __syncthreads() drains it before the barrier.
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)l, 16, 0, 0);
-}
-
-// Ring hand-off: this wave's DMA pieces except the N youngest have landed and its LDS reads are done (counted
-// s_waitcnt), then a raw s_barrier (no vmcnt(0) drain).  The empty asm statements stop hipcc from moving LDS
-// accesses across the pair (the raw barrier is not a memory fence to the compiler).
-template <int N> __device__ __forceinline__ void ring_wait_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(VMCNT_LGKM0(N));
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-template <int ACT> __device__ __forceinline__ float act_fwd(float a) {
-    if (ACT == RBNN_ACT_RELU)  return a > 0.f ? a : 0.f;
-    if (ACT == RBNN_ACT_LEAKY) return a > 0.f ? a : a * LEAKY_SLOPE;
-    if (ACT == RBNN_ACT_SIGM)  return 1.f / (1.f + expf(-a));
-    return tanhf(a);
-}
-// derivative from the activation VALUE (sigmoid / tanh only)
-template <int ACT> __device__ __forceinline__ float act_grad_from_value(float h) {
-    if (ACT == RBNN_ACT_SIGM) return h * (1.f - h);
-    return 1.f - h * h;
-}
 
 // ===================================================================================================
 // K1: stacked forward.  One block = one (point tile, sample) item:
@@ -683,10 +613,6 @@ __global__ void svi_materialize_kernel(const float* __restrict__ loc, const floa
 // ---------------------------------------------------------------------------------------------------
 // host-side helpers
 // ---------------------------------------------------------------------------------------------------
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-inline int launch_status() { return hipGetLastError() == hipSuccess ? RBNN_OK : RBNN_ERR_LAUNCH; }
-inline int grid_for_items(long long M) { return (int)(8 * ((M + 7) / 8)); }
-
 int validate_net(const rbnn_posterior* net) {
     if (!net || !net->W1 || !net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
     if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;

@@ -133,12 +133,19 @@ class AttackEngine:
             self._ws_cache[key] = ws
         return ws
 
+    # ------------------------------------------------------------------ kernel hooks (overridden for the conv architecture)
+    def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
+        self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
+
+    def _grad_kernels(self, sidx, S, N, ws):
+        return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
+
     # ------------------------------------------------------------------ forward
     def forward_padded(self, Xp, sidx, S, out_kind=OUT_PROBS, out=None):
         """mean over samples of P (probabilities or logits) -> [N, 16] buffer (columns >= C are zero)."""
         N = Xp.shape[0]
         ws = self.workspace(N, S)
-        self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
+        self._forward_kernels(Xp, sidx, S, out_kind, ws)
         if out is None:
             out = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
         if self.world == 1:
@@ -164,7 +171,7 @@ class AttackEngine:
         Xp = self.pad_inputs(x)
         ws = self.workspace(N, S)
         S_tot = self.total_samples(S)
-        self.k.fc_forward(self.post, Xp, sidx, S, OUT_LOGITS if logits else OUT_PROBS, ws)
+        self._forward_kernels(Xp, sidx, S, OUT_LOGITS if logits else OUT_PROBS, ws)
         gup = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
         gup[:, :C] = grad_out.to(self.device, torch.float32)
         if logits:      # d mean_s z_s: dZ_s = grad/S for every sample -> write it through the upstream mode on "P = 1"
@@ -172,8 +179,8 @@ class AttackEngine:
             dZ.copy_((gup / S_tot).unsqueeze(0).expand(S, N, _hip.CPAD))
         else:
             self.k.loss_dlogits(LOSS_UPSTREAM, ws["P"], None, gup, None, S, 1.0 / S_tot, N, C, ws["dZ"])
-        n_slabs = self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
-        G = ws["G"]
+        n_slabs = self._grad_kernels(sidx, S, N, ws)
+        G = ws["Gsum"] if "Gsum" in ws else ws["G"]
         self.k.sum_slabs(ws["slabs"], n_slabs, N, self.post.Dp, 1.0, G)
         self._allreduce(G)
         return self.unpad(G, x)
@@ -184,7 +191,7 @@ class AttackEngine:
         N, C = Xp.shape[0], self.post.C
         ws = self.workspace(N, S, chunk)
         S_tot = self.total_samples(S)
-        self.k.fc_forward(self.post, Xp, sidx, S, OUT_LOGITS if mode == LOSS_MEAN_LOGIT else OUT_PROBS, ws)
+        self._forward_kernels(Xp, sidx, S, OUT_LOGITS if mode == LOSS_MEAN_LOGIT else OUT_PROBS, ws)
         Psum = None
         if mode in (LOSS_MEAN_PROB, LOSS_MEAN_LOGIT):
             Psum = ws["Psum"]
@@ -193,14 +200,14 @@ class AttackEngine:
         # per-sample losses are averaged at the very end (lossGradients.py:40), the others inside the loss
         inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
         self.k.loss_dlogits(mode, ws["P"], Psum, G_up, labels, S, inv_S, N, C, ws["dZ"])
-        n_slabs = self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
+        n_slabs = self._grad_kernels(sidx, S, N, ws)
         return ws, n_slabs, S_tot
 
     def gradient(self, Xp, labels, sidx, S, mode, G_up=None):
         """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad]."""
         ws, n_slabs, S_tot = self.gradient_slabs(Xp, labels, sidx, S, mode, G_up)
         scale = 1.0 / S_tot if mode == LOSS_PER_SAMPLE else 1.0
-        G = ws["G"]
+        G = ws["Gsum"] if "Gsum" in ws else ws["G"]
         self.k.sum_slabs(ws["slabs"], n_slabs, Xp.shape[0], self.post.Dp, scale, G)
         self._allreduce(G)                                      # N x D_pad fp32: the one large exchange
         return G
@@ -218,7 +225,7 @@ class AttackEngine:
         if self.world == 1:
             self.k.attack_step(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D)
         else:
-            G = ws["G"]
+            G = ws["Gsum"] if "Gsum" in ws else ws["G"]
             self.k.sum_slabs(ws["slabs"], n_slabs, X.shape[0], p.Dp, 1.0, G)
             self._allreduce(G)
             self.k.attack_step(X, X0, G, 1, 0, p.Dp, alpha, alpha_scalar, eps, project, p.D)
