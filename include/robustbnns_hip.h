@@ -206,6 +206,11 @@ int rbnn_conv_forward(const rbnn_conv_posterior *net, const float *X, int32_t ld
                       const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                       const rbnn_conv_workspace *ws, void *stream);
 
+/* Per-sample input gradients of the conv net: G[s,n,:] = dL_s/dx_n for the dZ left in ws->dZ by rbnn_loss_dlogits
+ * (sum them with rbnn_sum_slabs(G, S, N, 784, ...)).  Replaces loss.backward() through model_nn.py:98-106. */
+int rbnn_conv_input_grad(const rbnn_conv_posterior *net, const int32_t *sample_idx, int32_t n_samples,
+                         int32_t n_points, const rbnn_conv_workspace *ws, void *stream);
+
 /* W[s,i] = loc[i] + softplus(scale_raw[i]) * eps[s,i]   — the SVI guide's draw, model_bnn.py:124-130
  * (Normal(loc, softplus(scale)).rsample()).  PARITY UNPINNED: pyro-ppl 1.3.0 is not available;
  * eps is supplied by the caller.  out row stride ld_out >= n_elem (lets W1 be written D_pad-strided

@@ -184,7 +184,24 @@ def kink_margin(x, post, arch, act, n_samples):
     act' jumps at 0, so the input gradient of a point whose margin is within fp32 rounding of the
     pre-activation (~1e-6 at these sizes) legitimately depends on summation order; parity tests exclude
     such points explicitly (same status as the sign(g) rule for adversarial images)."""
-    if act not in ("relu", "leaky") or arch not in ("fc", "fc2"):
+    if act not in ("relu", "leaky"):
+        return torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
+    if arch == "conv":
+        # conv: the gradient is discontinuous where (i) the maximum of a pooling window changes (gap between its two
+        # largest pre-activations) and (ii) the pre-activation AT a window's maximum changes sign
+        post = select(post, range(n_samples))
+        margin = torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
+        for s in range(n_samples):
+            a1 = F.conv2d(x, post["model.0.weight"][s], post["model.0.bias"][s])
+            for a, k, st in ((a1, 2, 2), (None, 2, 1)):
+                if a is None:
+                    a = F.conv2d(F.max_pool2d(_act(a1, act), 2), post["model.3.weight"][s], post["model.3.bias"][s])
+                win = F.unfold(a.reshape(-1, 1, a.shape[2], a.shape[3]), k, stride=st)          # [N*C, 4, L]
+                top2 = win.topk(2, dim=1)[0]
+                m = torch.minimum(top2[:, 0] - top2[:, 1], top2[:, 0].abs()).reshape(x.shape[0], -1).amin(1)
+                margin = torch.minimum(margin, m.double())
+        return margin
+    if arch not in ("fc", "fc2"):
         return torch.full((x.shape[0],), float("inf"), dtype=torch.float64)
     layers = mlp_layers(select(post, range(n_samples)), arch)
     _, pre = _mlp_forward_cache(x.reshape(x.shape[0], -1), layers, act)

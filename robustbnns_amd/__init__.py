@@ -6,6 +6,7 @@ same signatures, results within 1e-5 of the reference's CPU path; the arithmetic
 gfx950 HIP kernels behind the C-ABI of include/robustbnns_hip.h.  See DESIGN.md.
 """
 from . import adversarialAttacks, lossGradients, model_bnn, model_ensemble, model_nn, plot_eps_attacks   # noqa: F401
+from .conv import ConvEngine, ConvStackedPosterior                                      # noqa: F401
 from .engine import AttackEngine                                                        # noqa: F401
 from .posterior import StackedPosterior                                                 # noqa: F401
 

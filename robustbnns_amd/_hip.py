@@ -75,6 +75,7 @@ SIGNATURES = {
     "rbnn_eval_metrics": (_i32, [_fp, _fp, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "rbnn_pack_rows4": (_i32, [_fp, _i64, _i32, _fp, _fp]),
     "rbnn_conv_workspace_query": (_i32, [C.POINTER(ConvPosterior), _i32, _i32, C.POINTER(ConvWorkspaceSizes)]),
+    "rbnn_conv_input_grad": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
 }
@@ -216,6 +217,12 @@ class HipKernels:
         w = self._conv_ws(ws)
         check(self.lib.rbnn_conv_forward(C.byref(net.descriptor()), ptr(X), X.stride(0), X.shape[0], ptr(sidx), S, out_kind,
                                          C.byref(w), stream_of(X)), "rbnn_conv_forward")
+
+    def conv_input_grad(self, net, sidx, S, N, ws):
+        w = self._conv_ws(ws)
+        check(self.lib.rbnn_conv_input_grad(C.byref(net.descriptor()), ptr(sidx), S, N, C.byref(w), stream_of(ws["dZ"])),
+              "rbnn_conv_input_grad")
+        return S                                                          # one "slab" per sample
 
     def svi_materialize(self, loc, scale_raw, eps, out):
         require_gpu(loc, "loc")

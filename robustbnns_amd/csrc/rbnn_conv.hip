@@ -255,3 +255,139 @@ int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ld
 }
 
 }  // extern "C"
+
+// =====================================================================================================
+// Backward to the input.  One block = one (sample, point); everything between dZ and dX stays in LDS:
+//   1. per chunk of 64 output channels: dQ2[f] = sum_c dZ[c] * Fw[c][f]  (Linear^T), routed through the pool-2
+//      argmax and the activation derivative into dO2t[64 hc][64 positions]  (LDS float atomics; 2x2 windows overlap);
+//   2. conv2^T as 25 tap-GEMMs on the matrix pipe:  T_t[ci][pos] = sum_hc W2[hc][ci][tap t] * dO2t[hc][pos]
+//      (A = the tap-major image K2w_tap[t][ci][hc], LDS-DMA double buffer; B = dO2t), scatter-added at the tap's
+//      shift into dP1s[32][12][12];
+//   3. pool-1 routing + activation derivative, and conv1^T as a scatter of 25 taps per pooled element into dXs[28][28].
+// =====================================================================================================
+namespace {
+
+struct ConvBwdArgs {
+    const float* dZ; const uint8_t* st1; const uint8_t* st2;
+    const float* K1w; const float* K2tap; const float* Fw;
+    int Hc; int C; int N; int S; const int* sidx; int act;
+    float* G;                                                            // [S][N][784]
+};
+
+template <int ACT>
+__global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
+    constexpr int HCH = 64, DLD = 68;                                    // channels per chunk; dO2t row stride (4 rows apart = 16 banks apart)
+    constexpr int WT = C1 * HCH;                                         // floats per tap tile [32 ci][64 hc]
+    __shared__ __attribute__((aligned(16))) float lds[P1SZ + HCH * DLD + 2 * WT + 784];
+    float* const dP1s = lds;
+    float* const dO2t = lds + P1SZ;
+    float* const Wt = dO2t + HCH * DLD;
+    float* const dXs = Wt + 2 * WT;
+
+    int id;
+    if (!item_of_block(blockIdx.x, a.N * a.S, id)) return;
+    const int n = id % a.N, s = id / a.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const long long sn = (long long)s * a.N + n;
+    const int F = a.Hc * NP2;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+
+    for (int i = tid; i < P1SZ; i += 256) dP1s[i] = 0.f;
+    for (int i = tid; i < 784; i += 256) dXs[i] = 0.f;
+    float dz[RBNN_CPAD];
+#pragma unroll
+    for (int c = 0; c < RBNN_CPAD; ++c) dz[c] = a.dZ[sn * RBNN_CPAD + c];  // zero beyond C
+    // tap tile DMA: piece q = rows 4q..4q+3 (256 B each); lane p -> row 4q + (p>>4), physical 16-B chunk p&15 holds
+    // logical chunk (p&15) ^ (row&15): a b128 fragment read (16 rows, one chunk) then hits 16 distinct slots.
+    const int trow = lane >> 4, tchunk = lane & 15;
+    const int y0 = 2 * wave + (li >> 3), x0 = li & 7;                     // this lane's output position in pos tile `wave`
+
+    for (int hc0 = 0; hc0 < a.Hc; hc0 += HCH) {
+        __syncthreads();                                                 // previous chunk's GEMMs are done with dO2t / Wt
+        for (int i = tid; i < HCH * DLD; i += 256) dO2t[i] = 0.f;
+        __syncthreads();
+        // 1. Linear^T + pool-2 routing for channels hc0 .. hc0+63
+        const int nch = min(HCH, a.Hc - hc0);
+        for (int e = tid; e < nch * NP2; e += 256) {
+            const long long f = (long long)hc0 * NP2 + e;
+            float dq = 0.f;
+#pragma unroll
+            for (int c = 0; c < RBNN_CPAD; ++c)
+                if (c < a.C) dq = fmaf(dz[c], a.Fw[((long long)sw * a.C + c) * F + f], dq);
+            const int st = a.st2[sn * F + f], hl = e / NP2, p = e % NP2;
+            const int pos = (p / P2W + ((st >> 1) & 1)) * O2W + (p % P2W) + (st & 1);
+            atomicAdd(&dO2t[hl * DLD + pos], (st & 4) ? dq : dq * slope);
+        }
+        auto stage = [&](int t, int buf) {                               // tap t: K2tap[s][t][ci][hc0 .. hc0+63]
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = wave + 4 * q2, row = 4 * q + trow;         // ci
+                const int lch = tchunk ^ (row & 15);
+                const int hc = min(hc0 + 4 * lch, a.Hc - 4);             // columns past Hc: any valid address (their dO2t rows are zero)
+                glds16(a.K2tap + (((long long)sw * 25 + t) * C1 + row) * a.Hc + hc, Wt + buf * WT + q * 256);
+            }
+        };
+        stage(0, 0);
+        __syncthreads();                                                 // dO2t complete, tap 0 landed
+        for (int t = 0; t < 25; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < 25) stage(t + 1, buf ^ 1);
+            const float* const W = Wt + buf * WT;
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int kk = 0; kk < HCH / 16; ++kk) {
+                const int ch = 4 * kk + lg;                              // logical 16-B chunk = hidden units 16kk + 4lg .. +3
+                const f32x4 a0 = *(const f32x4*)(W + li * HCH + 4 * (ch ^ (li & 15)));
+                const f32x4 a1 = *(const f32x4*)(W + (16 + li) * HCH + 4 * (ch ^ ((16 + li) & 15)));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float b = dO2t[(16 * kk + 4 * lg + r) * DLD + wave * 16 + li];
+                    acc0 = MFMA16(a0[r], b, acc0);
+                    acc1 = MFMA16(a1[r], b, acc1);
+                }
+            }
+            // acc0[r] = T_t[ci = 4lg + r][pos], acc1[r] = T_t[16 + 4lg + r][pos]; conv2^T: dP1[ci][y + ky][x + kx] += T_t
+            const int tgt = (y0 + t / 5) * P1W + x0 + t % 5;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomicAdd(&dP1s[(4 * lg + r) * (P1W * P1W) + tgt], acc0[r]);
+                atomicAdd(&dP1s[(16 + 4 * lg + r) * (P1W * P1W) + tgt], acc1[r]);
+            }
+            __syncthreads();                                             // next tap landed (vmcnt(0)); this one is free
+        }
+    }
+    __syncthreads();
+    // 3. pool-1 routing + conv1^T (in_channels = 1): scatter 25 taps per pooled element
+    for (int e = tid; e < P1SZ; e += 256) {
+        const int st = a.st1[sn * P1SZ + e], c = e / (P1W * P1W), py = (e / P1W) % P1W, px = e % P1W;
+        const float g = (st & 4) ? dP1s[e] : dP1s[e] * slope;
+        if (g == 0.f) continue;
+        const int Y = 2 * py + ((st >> 1) & 1), X = 2 * px + (st & 1);
+        const float* const w = a.K1w + ((long long)sw * C1 + c) * 25;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) atomicAdd(&dXs[(Y + ky) * 28 + X + kx], g * w[ky * 5 + kx]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 784; i += 256) a.G[sn * 784 + i] = dXs[i];
+}
+
+}  // namespace
+
+extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_t* sidx, int32_t S, int32_t N,
+                                    const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (!net->K2w_tap || !ws || !ws->dZ || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || (net->hidden & 3)) return RBNN_ERR_SHAPE;
+    if (!aligned16(net->K2w_tap)) return RBNN_ERR_ALIGN;
+    ConvBwdArgs a = {};
+    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2tap = net->K2w_tap; a.Fw = net->Fw;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.G = ws->G;
+    const int grid = grid_for_items((long long)N * S);
+    if (net->activation == RBNN_ACT_LEAKY) hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    else                                   hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}

@@ -18,9 +18,8 @@ import torch
 from torch import nn
 
 from . import _hip
-from .engine import AttackEngine
+from .factory import make_engine, posterior_from_stacked, posterior_from_state_dicts
 from .model_nn import NN
-from .posterior import StackedPosterior
 from .savedir import TESTS
 
 saved_BNNs = {"model_0": ["mnist", {"hidden_size": 512, "activation": "leaky", "architecture": "conv", "inference": "svi", "epochs": 5, "lr": 0.01, "n_samples": None, "warmup": None}],
@@ -79,7 +78,7 @@ class BNN(nn.Module):
     # ------------------------------------------------------------------ posterior in
     def _make_posterior(self, stacked, device):
         b = self.basenet
-        return StackedPosterior(b.architecture, b.activation, b.input_shape, b.output_size, b.hidden_size, stacked, device)
+        return posterior_from_stacked(b.architecture, b.activation, b.input_shape, b.output_size, b.hidden_size, stacked, device)
 
     def set_posterior_samples(self, samples, device):
         """hmc: `samples` = list of NN.state_dict()s (what load() reads from disk), or a dict key -> [S,...]."""
@@ -89,9 +88,9 @@ class BNN(nn.Module):
             self.posterior = self._make_posterior(samples, device)
         else:
             b = self.basenet
-            self.posterior = StackedPosterior.from_state_dicts(samples, b.architecture, b.activation, b.input_shape,
-                                                               b.output_size, b.hidden_size, device)
-        self._engine = AttackEngine(self.posterior)
+            self.posterior = posterior_from_state_dicts(samples, b.architecture, b.activation, b.input_shape,
+                                                        b.output_size, b.hidden_size, device)
+        self._engine = make_engine(self.posterior)
 
     def set_variational_params(self, loc, scale, device):
         """svi: dicts state_dict-key -> tensor, the `<key>_loc` / `<key>_scale` params of model_bnn.py:125-126."""
@@ -191,8 +190,8 @@ class BNN(nn.Module):
             return self._engine, n_samples, seeds, False
         if avg_posterior is True:                         # model_bnn.py:206-216: logits of the mean weights
             stacked = {k: v.unsqueeze(0) for k, v in self.svi_loc.items()}
-            return AttackEngine(self._make_posterior(stacked, self.device)), 1, None, True
-        return AttackEngine(self.draw_posterior(n_samples, seeds)), n_samples, None, False
+            return make_engine(self._make_posterior(stacked, self.device)), 1, None, True
+        return make_engine(self.draw_posterior(n_samples, seeds)), n_samples, None, False
 
     def forward(self, inputs, n_samples=10, avg_posterior=False, seeds=None):
         """model_bnn.py:198-258 -> mean probabilities [B, C] (raw logits if avg_posterior, :216)."""

@@ -3,9 +3,7 @@
 forward = mean of the LOGITS of the first n_samples members (model_ensemble.py:57-67): the same stacked
 kernels as the BNN with RBNN_OUT_LOGITS / RBNN_LOSS_MEAN_LOGIT.
 """
-from .engine import AttackEngine
 from .model_nn import NN
-from .posterior import StackedPosterior
 from .savedir import TESTS
 
 
@@ -37,8 +35,8 @@ class Ensemble_NN(NN):
 
     def engine(self, device):
         if self._ens_engine is None or str(self._ens_engine.device) != str(device):
-            post = StackedPosterior.from_modules(list(self.ensemble_models.values()), device)
-            self._ens_engine = AttackEngine(post)
+            from .factory import make_engine, posterior_from_modules
+            self._ens_engine = make_engine(posterior_from_modules(list(self.ensemble_models.values()), device))
         return self._ens_engine
 
     def forward(self, inputs, n_samples, *args, **kwargs):

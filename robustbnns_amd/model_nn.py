@@ -11,8 +11,6 @@ import os
 import torch
 from torch import nn
 
-from .engine import AttackEngine
-from .posterior import StackedPosterior
 from .savedir import TESTS
 
 saved_NNs = {"model_0": {"dataset": "mnist", "hidden_size": 512, "activation": "leaky", "architecture": "conv", "epochs": 5, "lr": 0.01},
@@ -76,8 +74,8 @@ class NN(nn.Module):
         """One-sample stacked posterior of the current parameters (rebuilt when they change)."""
         key = (str(device),) + tuple(p._version for p in self.parameters()) + tuple(p.data_ptr() for p in self.parameters())
         if self._engine is None or self._engine_key != key:
-            post = StackedPosterior.from_modules([self], device)
-            self._engine, self._engine_key = AttackEngine(post), key
+            from .factory import make_engine, posterior_from_modules
+            self._engine, self._engine_key = make_engine(posterior_from_modules([self], device)), key
         return self._engine
 
     def forward(self, inputs, device=None, *args, **kwargs):

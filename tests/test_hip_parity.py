@@ -275,3 +275,56 @@ def test_autograd_through_forward(golden):
     assert rel_err(x.grad.cpu(), g.t("meanprob_grad")) < TOL
     adv = torch.clamp(x.detach() + m["eps"] * x.grad.sign(), 0, 1)
     adv_equal(adv, g.t("fgsm"), g.t("meanprob_grad"))
+
+
+# ------------------------------------------------------------------ conv architecture (model_nn.py:93-106)
+KINK_CONV = 3e-7   # conv nets have 50k-100k activations + pooling windows per (point, sample); fp32 noise of a pre-activation ~1e-7
+
+
+def test_conv_golden(golden):
+    """The reference-generated conv fixture through the reference's call surface."""
+    from robustbnns_amd import adversarialAttacks as A, lossGradients, _hip
+    g = golden("mnist_conv_h16_s2_n4_leaky"); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
+    assert type(bnn._engine).__name__ == "ConvEngine"
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=1).cpu(), g.t("forward_probs_s1")) < TOL
+    eng = bnn._engine
+    assert rel_err(eng.loss_gradients(x, y, m["S"]).cpu(), g.t("loss_gradients")) < TOL
+    G = eng.gradient(eng.pad_inputs(x), y.argmax(-1).int().to(DEV), None, m["S"], _hip.LOSS_MEAN_PROB)
+    assert rel_err(G.cpu().reshape(x.shape), g.t("meanprob_grad")) < TOL
+    lab = y.argmax(-1); hyper = {"epsilon": m["eps"]}
+    adv_equal(A.fgsm_attack(bnn, x.to(DEV), lab.to(DEV), hyper, n_samples=m["S"]), g.t("fgsm"), g.t("meanprob_grad"))
+    idx = torch.from_numpy(g.arr["pgd_idx"])
+    pg = A.pgd_attack(bnn, x[idx].to(DEV), lab[idx].to(DEV), hyper, n_samples=m["S"]).cpu()
+    assert float(((pg - g.t("pgd")).abs() > 1e-6).double().mean()) < 0.02
+    oa, aa, rob = A.attack_evaluation(bnn, x, g.t("fgsm"), y, DEV, n_samples=m["S"])
+    assert (oa, aa) == (float(g.arr["eval_orig_acc"]), float(g.arr["eval_adv_acc"]))
+    assert float((rob.cpu() - g.t("eval_softmax_rob")).abs().max()) < 1e-6
+    sd = bnn.posterior.state_dict(1)
+    assert all(torch.equal(sd[k], g.posterior()[k][1]) for k in sd)
+
+
+@pytest.mark.parametrize("act,C,Hc,S,N", [("leaky", 10, 16, 2, 5), ("relu", 10, 32, 2, 19), ("leaky", 10, 64, 3, 33),
+                                          ("leaky", 10, 512, 2, 12), ("leaky", 3, 272, 1, 5)])
+def test_conv_against_fp64_oracle(act, C, Hc, S, N):
+    from robustbnns_amd import _hip
+    from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
+    post = O.synthetic_posterior("conv", 784, Hc, C, S, 0.05 if Hc < 512 else 0.03)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=Hc + N)
+    lab = y.argmax(-1); p64 = O.cast(post, torch.float64)
+    eng = ConvEngine(ConvStackedPosterior(act, (1, 28, 28), C, Hc, post, DEV))
+    assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, "conv", act, S)) < TOL
+    assert rel_err(eng.forward(x, S, logits=True).cpu(), O.ensemble_forward(x.double(), p64, "conv", act, S)) < TOL
+    ok = O.kink_margin(x.double(), p64, "conv", act, S) > KINK_CONV
+    assert int(ok.sum()) >= 2          # at Hc=512 only ~1 point in 4 is this far from every kink
+    ref = O.loss_gradients(x.double(), y, p64, "conv", act, S)
+    assert rel_err(eng.loss_gradients(x, y, S).cpu()[ok], ref[ok]) < TOL
+    ref = O.meanprob_gradients(x.double(), lab, p64, "conv", act, S)
+    G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB).cpu().reshape(x.shape)
+    assert rel_err(G[ok], ref[ok]) < TOL
+    # every point, kinks included: a flipped pooling maximum / activation sign moves the gradient by one element's worth
+    assert rel_err(G, ref) < 5e-2
+    adv = eng.fgsm(x, y, S, 0.1).cpu()
+    adv_equal(adv[ok], torch.clamp(x + 0.1 * ref.sign().float(), 0, 1)[ok], ref[ok])
+    pg = eng.pgd(x[:3], y[:3], S, 0.2, iters=3).cpu()
+    assert float((pg - x[:3]).abs().max()) <= 0.2 + 1e-6 and float(pg.min()) >= 0 and float(pg.max()) <= 1

@@ -98,7 +98,7 @@ def test_stacked_posterior_padding_and_roundtrip():
     sh = sp.shard(1, 2)
     assert sh.S == 2 and torch.equal(sh.W1, sp.W1[1:3])
     with pytest.raises(NotImplementedError):
-        StackedPosterior("conv", "leaky", (1, 28, 28), 10, 16, {}, "cpu")
+        StackedPosterior("conv", "leaky", (1, 28, 28), 10, 16, {}, "cpu")       # conv has its own stacked posterior
 
 
 def test_padded_hidden_is_exact(golden):
@@ -311,3 +311,26 @@ def test_compute_vanishing_norms_idxs_matches_reference():
         assert got == list(d[norm])
     with pytest.raises(ValueError):
         lossGradients.compute_vanishing_norms_idxs(d["grads"], [1, 2], "l2")
+
+
+def test_conv_posterior_layout_and_roundtrip(golden):
+    from robustbnns_amd.conv import ConvStackedPosterior
+    g = golden("mnist_conv_h16_s2_n4_leaky"); m = g.meta; post = g.posterior()
+    sp = ConvStackedPosterior(m["act"], m["shape"], m["n_classes"], m["hidden"], post, "cpu")
+    assert sp.K1w.shape == (2, 32, 25) and sp.K2w.shape == (2, 16, 800) and sp.Fw.shape == (2, 10, 49 * 16)
+    # tap-major image [S, tap, ci, hc] of model.3.weight [hc, ci, ky, kx]
+    assert torch.equal(sp.K2tap[1, 7, 5, 3], post["model.3.weight"][1, 3, 5, 1, 2])
+    sd = sp.state_dict(0)
+    assert all(torch.equal(sd[k], post[k][0]) for k in sd)
+    d = sp.descriptor()
+    assert (d.activation, d.hidden, d.n_classes, d.n_stored) == (1, 16, 10, 2)
+    with pytest.raises(NotImplementedError):
+        ConvStackedPosterior("leaky", (3, 32, 32), 10, 16, post, "cpu")          # model_nn.py:95-96
+    lib = _hip.load()
+    out = _hip.ConvWorkspaceSizes()
+    assert lib.rbnn_conv_workspace_query(C.byref(d), 100, 3, C.byref(out)) == 0
+    assert out.P1 == 3 * 100 * 4608 * 4 and out.st1 == 3 * 100 * 4608 and out.Q2 == 3 * 100 * 16 * 49 * 4 and out.G == 3 * 100 * 784 * 4
+    assert lib.rbnn_conv_forward(C.byref(d), None, 784, 4, None, 2, 0, None, None) == -1
+    bnn = model_bnn.BNN("mnist", 16, "leaky", "conv", "hmc", None, None, 2, 0, (1, 28, 28), 10)
+    bnn.set_posterior_samples(post, "cpu")
+    assert type(bnn._engine).__name__ == "ConvEngine" and bnn.posterior.S == 2
