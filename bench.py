@@ -41,6 +41,8 @@ WORKLOADS = {
                desc="MNIST fc-BNN 784->512->10 (leaky), FGSM eps=0.3, N=10000 points, S=100 samples/GPU"),
     "c3": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=500, N=10000, method="pgd", iters=40, eps=0.3,
                desc="F-MNIST fc-BNN 784->512->10 (leaky), PGD T=40 eps=0.3, N=10000 points, S=500 samples/GPU"),
+    "conv": dict(shape=(1, 28, 28), H=512, C=10, arch="conv", act="leaky", S=16, N=2048, method="fgsm", iters=1, eps=0.3,
+                 desc="MNIST conv-BNN (conv5x5x32 - pool - conv5x5x512 - pool - fc, leaky), FGSM eps=0.3, N=2048 points, S=16 samples/GPU"),
     "c1": dict(shape=(1, 2, 1), H=64, C=2, arch="fc", act="leaky", S=10, N=100, method="fgsm", iters=1, eps=0.3,
                desc="half-moons fc-BNN 2->64->2 (leaky), FGSM eps=0.3, N=100 points, S=10 samples/GPU"),
 }
@@ -55,6 +57,11 @@ def make_problem(w, rank, device):
     gw = torch.Generator().manual_seed(100 + rank)
     std = 0.5 if D < 16 else 0.05
     S, H, C = w["S"], w["H"], w["C"]
+    if w["arch"] == "conv":
+        r = lambda *shape: torch.randn(S, *shape, generator=gw) * 0.03
+        post = {"model.0.weight": r(32, 1, 5, 5), "model.0.bias": r(32), "model.3.weight": r(H, 32, 5, 5), "model.3.bias": r(H),
+                "model.7.weight": r(C, 49 * H), "model.7.bias": r(C)}
+        return x, y, post
     post = {"model.1.weight": torch.randn(S, H, D, generator=gw) * std, "model.1.bias": torch.randn(S, H, generator=gw) * std,
             "model.3.weight": torch.randn(S, C, H, generator=gw) * std, "model.3.bias": torch.randn(S, C, generator=gw) * std}
     return x, y, post
@@ -117,13 +124,14 @@ def main():
         w["S"] = args.samples
     x, y, post = make_problem(w, rank if args.shard == "samples" else 0, device)
     D = x[0].numel()
-    sp = StackedPosterior(w["arch"], w["act"], w["shape"], w["C"], w["H"], post, device)
+    from robustbnns_amd.factory import make_engine, posterior_from_stacked
+    sp = posterior_from_stacked(w["arch"], w["act"], w["shape"], w["C"], w["H"], post, device)
 
     class TimedKernels(_hip.HipKernels):
         """HIP events around the two GEMM kernels, on the stream they are launched on (torch's current stream)."""
         def __init__(self):
             super().__init__()
-            self.ev = {"fc_forward": [], "fc_input_grad": []}
+            self.ev = {"fc_forward": [], "fc_input_grad": []} if w["arch"] != "conv" else {"conv_forward": [], "conv_input_grad": []}
             self.on = False
 
         def _timed(self, name, fn, *a):
@@ -142,13 +150,19 @@ def main():
         def fc_input_grad(self, *a):
             return self._timed("fc_input_grad", super().fc_input_grad, *a)
 
+        def conv_forward(self, *a):
+            return self._timed("conv_forward", super().conv_forward, *a)
+
+        def conv_input_grad(self, *a):
+            return self._timed("conv_input_grad", super().conv_input_grad, *a)
+
     kern = TimedKernels()
     if args.shard == "samples":
-        eng = AttackEngine(sp, kernels=kern, group=group, total_samples=w["S"] * world)
+        eng = make_engine(sp, kernels=kern, group=group, total_samples=w["S"] * world)
         eng._S_total = w["S"] * world
         xs, ys, S_job, N_job = x, y, w["S"] * world, w["N"]
     else:
-        eng = AttackEngine(sp, kernels=kern)
+        eng = make_engine(sp, kernels=kern)
         g = torch.Generator().manual_seed(4321 + rank)                # weak scaling: every rank its own N points
         xs = torch.rand((w["N"],) + w["shape"], generator=g, dtype=torch.float32) if rank else x
         ys, S_job, N_job = y, w["S"], w["N"] * world
@@ -189,6 +203,8 @@ def main():
         units = N_job * S_job * w["iters"] * args.steps
         # per-launch algorithmic flops of each GEMM kernel: half of SURVEY 8(d)'s 4*(D*H + H*C) per attack-sample
         per_launch = 2.0 * (D * w["H"] + w["H"] * w["C"]) * w["N"] * w["S"]
+        if w["arch"] == "conv":       # 2*(460800 + 26214400*H/512 + 49*H*C) flop per (point, sample) per direction
+            per_launch = 2.0 * (460800 + 51200.0 * w["H"] + 49 * w["H"] * w["C"]) * w["N"] * w["S"]
         kernels = {}
         for name, evs in kern.ev.items():
             ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
@@ -205,7 +221,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job,
                        "iters": w["iters"], "shard": args.shard if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel"}[dom],
+            "roofline": {"bound": "mfma", "kernel": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel", "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel"}[dom],
                          "achieved": kernels[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": kernels[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels},

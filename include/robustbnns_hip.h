@@ -183,7 +183,7 @@ typedef struct rbnn_conv_posterior {
     const float *K1w, *K1b;        /* model.0.weight [S_total,32,1,5,5], model.0.bias [S_total,32] */
     const float *K2w, *K2b;        /* model.3.weight [S_total,Hc,32,5,5], model.3.bias [S_total,Hc] */
     const float *Fw, *Fb;          /* model.7.weight [S_total,C,49*Hc], model.7.bias [S_total,C]   */
-    const float *K2w_tap;          /* [S_total,25,32,Hc]: model.3.weight regrouped tap-major (backward only) */
+    const float *K2w_ci;           /* [S_total,32,Hc/16,25,16]: model.3.weight regrouped [ci][hc block][tap][hc%16] (backward only) */
 } rbnn_conv_posterior;
 
 typedef struct rbnn_conv_workspace {

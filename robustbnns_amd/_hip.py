@@ -41,7 +41,7 @@ class WorkspaceSizes(C.Structure):
 
 class ConvPosterior(C.Structure):
     _fields_ = [("activation", C.c_int32), ("hidden", C.c_int32), ("n_classes", C.c_int32), ("n_stored", C.c_int32),
-                ("K1w", _fp), ("K1b", _fp), ("K2w", _fp), ("K2b", _fp), ("Fw", _fp), ("Fb", _fp), ("K2w_tap", _fp)]
+                ("K1w", _fp), ("K1b", _fp), ("K2w", _fp), ("K2b", _fp), ("Fw", _fp), ("Fb", _fp), ("K2w_ci", _fp)]
 
 
 CONV_WS_KEYS = ("P", "dZ", "P1", "st1", "Q2", "st2", "G")

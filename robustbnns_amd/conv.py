@@ -34,8 +34,9 @@ class ConvStackedPosterior:
         self.K1w, self.K1b = f("model.0.weight", (32, 25)), f("model.0.bias", (32,))
         self.K2w, self.K2b = f("model.3.weight", (self.H, 800)), f("model.3.bias", (self.H,))
         self.Fw, self.Fb = f("model.7.weight", (self.C, 49 * self.H)), f("model.7.bias", (self.C,))
-        # tap-major image of model.3.weight for the backward: [S, 25 taps, 32 ci, Hc]
-        self.K2tap = self.K2w.view(S, self.H, 32, 25).permute(0, 3, 2, 1).contiguous()
+        # model.3.weight regrouped [S, 32 ci, Hc/16 blocks, 25 taps, 16 hc]: the backward GEMM's A operand, K-contiguous
+        # with one K tile = one tap x 16 channels
+        self.K2ci = self.K2w.view(S, self.H // 16, 16, 32, 25).permute(0, 3, 1, 4, 2).reshape(S, 32, self.H * 25).contiguous()
         self._desc = None
 
     @classmethod
@@ -49,7 +50,7 @@ class ConvStackedPosterior:
             d = _hip.ConvPosterior()
             d.activation, d.hidden, d.n_classes, d.n_stored = _hip.ACTIVATIONS[self.activation], self.H, self.C, self.S
             for name, t in (("K1w", self.K1w), ("K1b", self.K1b), ("K2w", self.K2w), ("K2b", self.K2b), ("Fw", self.Fw),
-                            ("Fb", self.Fb), ("K2w_tap", self.K2tap)):
+                            ("Fb", self.Fb), ("K2w_ci", self.K2ci)):
                 setattr(d, name, C.c_void_p(t.data_ptr()))
             self._desc = d
         return self._desc

@@ -257,121 +257,198 @@ int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ld
 }  // extern "C"
 
 // =====================================================================================================
-// Backward to the input.  One block = one (sample, point); everything between dZ and dX stays in LDS:
-//   1. per chunk of 64 output channels: dQ2[f] = sum_c dZ[c] * Fw[c][f]  (Linear^T), routed through the pool-2
-//      argmax and the activation derivative into dO2t[64 hc][64 positions]  (LDS float atomics; 2x2 windows overlap);
-//   2. conv2^T as 25 tap-GEMMs on the matrix pipe:  T_t[ci][pos] = sum_hc W2[hc][ci][tap t] * dO2t[hc][pos]
-//      (A = the tap-major image K2w_tap[t][ci][hc], LDS-DMA double buffer; B = dO2t), scatter-added at the tap's
-//      shift into dP1s[32][12][12];
-//   3. pool-1 routing + activation derivative, and conv1^T as a scatter of 25 taps per pooled element into dXs[28][28].
+// Backward to the input.  One WAVE = one (sample, point); a block is 4 points of one sample and never synchronises:
+// the four waves only share the weight stream through L1.  Everything between dZ and dX stays in registers / LDS.
+//   per chunk of 16 conv2 channels:
+//     1. the wave zeroes its own zero-padded image dO2pad[16 hc][16][16] (8x8 gradients, border 4) in LDS and
+//        fills it: dQ2[f] = sum_c dZ[c] * Fw[c][f] (Linear^T, coalesced over f), routed through the pool-2 argmax
+//        and the activation derivative (LDS float atomics: the stride-1 windows overlap);
+//     2. conv2^T as an implicit GEMM on the matrix pipe, gather form:
+//          dP1^T[ci][(Y,X)] += sum_{k=(hc,ky,kx)} W2[hc][ci][ky][kx] * dO2pad[hc][Y - ky + 4][X - kx + 4]
+//        A = model.3.weight with its channel axes swapped, [ci][hc*25 + tap] (K-contiguous, read straight from
+//        memory, 16 B = 4 K steps per lane); B gathered from the image with a k -> offset table, exactly as the
+//        forward kernel gathers from P1.  The whole output, 2 ci tiles x 9 position tiles, lives in 18 accumulator
+//        tiles for the entire K = Hc*25 loop.  (56 % of these MFMAs multiply padding zeros; in exchange there are
+//        ~1800 MFMAs between any two waits.)
+//   3. pool-1 routing + activation derivative from the accumulators, conv1^T as a 25-tap scatter into dX[28][28].
 // =====================================================================================================
 namespace {
 
 struct ConvBwdArgs {
     const float* dZ; const uint8_t* st1; const uint8_t* st2;
-    const float* K1w; const float* K2tap; const float* Fw;
-    int Hc; int C; int N; int S; const int* sidx; int act;
+    const float* K1w; const float* K2cb; const float* Fw;
+    int Hc; int C; int N; int S; const int* sidx;
+    float* dQ2;                                                          // [S][N][Hc*49] dL/d(pooled conv2 output) = dZ . Fw: aliases the forward's Q2
+    float* dP1;                                                          // [S][N][4608] dL/d(pooled conv1 output): aliases the forward's P1
     float* G;                                                            // [S][N][784]
 };
 
+// Linear^T on the matrix pipe: dQ2[n][f] = sum_c dZ[n][c] * Fw[c][f].  One wave = 16 points x 64 features (4 MFMA tiles,
+// K = 16 padded classes); Fw is read once per 16 points.
+__global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+    const int F = a.Hc * NP2, FT = (F + 63) / 64, NT = (a.N + 15) / 16;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long long)a.S * NT * FT) return;
+    const int ft = (int)(item % FT), nt = (int)((item / FT) % NT), s = (int)(item / ((long long)FT * NT));
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const int n = min(nt * 16 + li, a.N - 1);
+    const f32x4 av = *(const f32x4*)(a.dZ + ((long long)s * a.N + n) * RBNN_CPAD + 4 * lg);     // A[i = n][k = lg] for K step r: class 4lg + r
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = ft * 64 + q * 16 + li;                                                  // F = 49*Hc is a multiple of 16
+        if (ft * 64 + q * 16 >= F) break;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * lg + r;
+            const float b = c < a.C ? a.Fw[((long long)sw * a.C + c) * F + f] : 0.f;          // B[k = lg][j = f]
+            d = MFMA16(av[r], b, d);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                                         // d[r] = dQ2[n = 16nt + 4lg + r][f]
+            const int nn = nt * 16 + 4 * lg + r;
+            if (nn < a.N) a.dQ2[((long long)s * a.N + nn) * F + f] = d[r];
+        }
+    }
+}
+
 template <int ACT>
 __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
-    constexpr int HCH = 64, DLD = 68;                                    // channels per chunk; dO2t row stride (4 rows apart = 16 banks apart)
-    constexpr int WT = C1 * HCH;                                         // floats per tap tile [32 ci][64 hc]
-    __shared__ __attribute__((aligned(16))) float lds[P1SZ + HCH * DLD + 2 * WT + 784];
-    float* const dP1s = lds;
-    float* const dO2t = lds + P1SZ;
-    float* const Wt = dO2t + HCH * DLD;
-    float* const dXs = Wt + 2 * WT;
-
-    int id;
-    if (!item_of_block(blockIdx.x, a.N * a.S, id)) return;
-    const int n = id % a.N, s = id / a.N;
+    constexpr int HCH = 16, IMG = HCH * 256, KCH = HCH * 25, NPT = 9;    // channels per chunk; image floats; K per chunk; 144/16 position tiles
+    __shared__ __attribute__((aligned(16))) float lds[4 * IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    float* const img = lds + wave * IMG;                                 // this wave's zero-padded gradient image [16 hc][16][16]
+
+    const int NB = (a.N + 3) / 4;                                        // blocks per sample
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, n = (id % NB) * 4 + wave;
     const int sw = a.sidx ? a.sidx[s] : s;
+    if (n >= a.N) return;                                                // whole wave idle (ragged last block); no block barrier anywhere
     const long long sn = (long long)s * a.N + n;
-    const int F = a.Hc * NP2;
+    const int F = a.Hc * NP2, KW = a.Hc * 25;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
 
-    for (int i = tid; i < P1SZ; i += 256) dP1s[i] = 0.f;
-    for (int i = tid; i < 784; i += 256) dXs[i] = 0.f;
-    float dz[RBNN_CPAD];
+    // K order inside a chunk is TAP-major: k = t*16 + hl, so one K tile = one tap (ky,kx) x 16 channels, and
+    // B[k = lg][j = li] of step r is img[(4lg + r)*256 + (Y - ky + 4)*16 + (X - kx + 4)].
+    int poff[NPT];
 #pragma unroll
-    for (int c = 0; c < RBNN_CPAD; ++c) dz[c] = a.dZ[sn * RBNN_CPAD + c];  // zero beyond C
-    // tap tile DMA: piece q = rows 4q..4q+3 (256 B each); lane p -> row 4q + (p>>4), physical 16-B chunk p&15 holds
-    // logical chunk (p&15) ^ (row&15): a b128 fragment read (16 rows, one chunk) then hits 16 distinct slots.
-    const int trow = lane >> 4, tchunk = lane & 15;
-    const int y0 = 2 * wave + (li >> 3), x0 = li & 7;                     // this lane's output position in pos tile `wave`
+    for (int pt = 0; pt < NPT; ++pt) { const int pos = pt * 16 + li; poff[pt] = (4 * lg) * 256 + (pos / P1W + 4) * 16 + pos % P1W + 4; }
+    const float* const Wr0 = a.K2cb + ((long long)sw * C1 + li) * KW + 4 * lg;          // ci = li; [ci][chunk][tap][16 hl]
+    const float* const Wr1 = Wr0 + (long long)16 * KW;                                   // ci = 16 + li
 
+    f32x4 acc[2][NPT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int i = lane; i < IMG / 4; i += 64) *(f32x4*)(img + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // the border stays zero
+    const int gy = lane >> 3, gx = lane & 7;                             // this lane's position (y, x) in the 8x8 gradient map
+    // the <= 4 stride-1 pooling windows (py,px) in {y-1,y} x {x-1,x} that contain (y,x); window q = 2dy+dx has (y,x) as its
+    // element q, so it routes here iff its stashed argmax == q
+    int woff[4];
+    bool wok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int py = gy - (q >> 1), px = gx - (q & 1);
+        wok[q] = py >= 0 && py < P2W && px >= 0 && px < P2W;
+        woff[q] = wok[q] ? py * P2W + px : 0;
+    }
     for (int hc0 = 0; hc0 < a.Hc; hc0 += HCH) {
-        __syncthreads();                                                 // previous chunk's GEMMs are done with dO2t / Wt
-        for (int i = tid; i < HCH * DLD; i += 256) dO2t[i] = 0.f;
-        __syncthreads();
-        // 1. Linear^T + pool-2 routing for channels hc0 .. hc0+63
-        const int nch = min(HCH, a.Hc - hc0);
-        for (int e = tid; e < nch * NP2; e += 256) {
-            const long long f = (long long)hc0 * NP2 + e;
-            float dq = 0.f;
+        // 1. interior of the padded image for channels hc0 .. hc0+15: pool-2 routing + activation derivative, gather form;
+        //    loads are unconditional and batched 4 channels at a time (32 independent loads in flight)
+#pragma unroll 1
+        for (int h4 = 0; h4 < HCH; h4 += 4) {
+            int st[4][4];
+            float dq[4][4];
 #pragma unroll
-            for (int c = 0; c < RBNN_CPAD; ++c)
-                if (c < a.C) dq = fmaf(dz[c], a.Fw[((long long)sw * a.C + c) * F + f], dq);
-            const int st = a.st2[sn * F + f], hl = e / NP2, p = e % NP2;
-            const int pos = (p / P2W + ((st >> 1) & 1)) * O2W + (p % P2W) + (st & 1);
-            atomicAdd(&dO2t[hl * DLD + pos], (st & 4) ? dq : dq * slope);
-        }
-        auto stage = [&](int t, int buf) {                               // tap t: K2tap[s][t][ci][hc0 .. hc0+63]
+            for (int j = 0; j < 4; ++j) {
+                const long long fb = sn * F + (long long)min(hc0 + h4 + j, a.Hc - 1) * NP2;
 #pragma unroll
-            for (int q2 = 0; q2 < 2; ++q2) {
-                const int q = wave + 4 * q2, row = 4 * q + trow;         // ci
-                const int lch = tchunk ^ (row & 15);
-                const int hc = min(hc0 + 4 * lch, a.Hc - 4);             // columns past Hc: any valid address (their dO2t rows are zero)
-                glds16(a.K2tap + (((long long)sw * 25 + t) * C1 + row) * a.Hc + hc, Wt + buf * WT + q * 256);
+                for (int q = 0; q < 4; ++q) { st[j][q] = a.st2[fb + woff[q]]; dq[j][q] = a.dQ2[fb + woff[q]]; }
             }
-        };
-        stage(0, 0);
-        __syncthreads();                                                 // dO2t complete, tap 0 landed
-        for (int t = 0; t < 25; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < 25) stage(t + 1, buf ^ 1);
-            const float* const W = Wt + buf * WT;
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
-            for (int kk = 0; kk < HCH / 16; ++kk) {
-                const int ch = 4 * kk + lg;                              // logical 16-B chunk = hidden units 16kk + 4lg .. +3
-                const f32x4 a0 = *(const f32x4*)(W + li * HCH + 4 * (ch ^ (li & 15)));
-                const f32x4 a1 = *(const f32x4*)(W + (16 + li) * HCH + 4 * (ch ^ ((16 + li) & 15)));
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (wok[q] && (st[j][q] & 3) == q) v += (st[j][q] & 4) ? dq[j][q] : dq[j][q] * slope;
+                img[(h4 + j) * 256 + (gy + 4) * 16 + gx + 4] = (hc0 + h4 + j < a.Hc) ? v : 0.f;
+            }
+        }
+        // 2. 25 K tiles = 25 taps x 16 channels.  A position tile spans rows Ya..Yb of the 12x12 output; tap row ky reaches it
+        //    only if some Y - ky lies in 0..7: the others multiply pure padding and are skipped (27 % of the MFMAs).
+        const float* const w0 = Wr0 + (long long)(hc0 / HCH) * KCH;
+        const float* const w1 = Wr1 + (long long)(hc0 / HCH) * KCH;
+        f32x4 a0 = *(const f32x4*)w0, a1 = *(const f32x4*)w1;
+#pragma unroll 1
+        for (int t = 0; t < 25; ++t) {
+            const f32x4 c0 = a0, c1 = a1;
+            if (t + 1 < 25) { a0 = *(const f32x4*)(w0 + 16 * (t + 1)); a1 = *(const f32x4*)(w1 + 16 * (t + 1)); }
+            const int ky = t / 5, toff = ky * 16 + t % 5;                // image offset is poff - toff (scalar)
+            const float* const src = img - toff;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                constexpr int dummy = 0; (void)dummy;
+                const int Ya = (16 * pt) / P1W, Yb = (16 * pt + 15) / P1W;
+                if (ky < Ya - 7 || ky > Yb) continue;                    // wave-uniform
+                const f32x4 b = (f32x4){src[poff[pt]], src[poff[pt] + 256], src[poff[pt] + 512], src[poff[pt] + 768]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float b = dO2t[(16 * kk + 4 * lg + r) * DLD + wave * 16 + li];
-                    acc0 = MFMA16(a0[r], b, acc0);
-                    acc1 = MFMA16(a1[r], b, acc1);
+                    acc[0][pt] = MFMA16(c0[r], b[r], acc[0][pt]);
+                    acc[1][pt] = MFMA16(c1[r], b[r], acc[1][pt]);
                 }
             }
-            // acc0[r] = T_t[ci = 4lg + r][pos], acc1[r] = T_t[16 + 4lg + r][pos]; conv2^T: dP1[ci][y + ky][x + kx] += T_t
-            const int tgt = (y0 + t / 5) * P1W + x0 + t % 5;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                atomicAdd(&dP1s[(4 * lg + r) * (P1W * P1W) + tgt], acc0[r]);
-                atomicAdd(&dP1s[(16 + 4 * lg + r) * (P1W * P1W) + tgt], acc1[r]);
-            }
-            __syncthreads();                                             // next tap landed (vmcnt(0)); this one is free
         }
     }
-    __syncthreads();
-    // 3. pool-1 routing + conv1^T (in_channels = 1): scatter 25 taps per pooled element
+    // 3. acc[ct][pt][r] = dL/dP1[ci = 16ct + 4lg + r][pos = 16pt + li] -> memory (the forward's P1 buffer is dead by now);
+    //    conv1_bwd_kernel finishes the path.  (An in-kernel scatter of the 25 conv1 taps needs LDS float atomics, which
+    //    cost ~250 cycles per wave instruction: measured, they made the LDS the bottleneck of this kernel.)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.dP1[sn * P1SZ + (16 * ct + 4 * lg + r) * (P1W * P1W) + 16 * pt + li] = acc[ct][pt][r];
+}
+
+// pool-1 routing + activation derivative + conv1^T (in_channels = 1), gather form: one thread per input pixel (Yo, Xo).
+// A pooled cell (c, py, px) routes its gradient to ONE conv1 output (Ya, Xa) = (2py + arg/2, 2px + arg%2); that output
+// touches pixel (Yo, Xo) through tap (Yo - Ya, Xo - Xa) if it lies in the 5x5 kernel.  Only cells with
+// py in [(Yo-4)/2, Yo/2], px likewise can qualify: at most 3 x 3 per channel.
+template <int ACT>
+__global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
+    // one block = one (sample, point): its 4608 pooled gradients (activation derivative and argmax position folded in)
+    // and the sample's 32x25 conv1 weights go to LDS once; each thread then gathers ~3 of the 784 pixels
+    __shared__ float gs[P1SZ];
+    __shared__ unsigned char as[P1SZ];
+    __shared__ float ws[C1 * 25];
+    const long long sn = blockIdx.x;
+    const int s = (int)(sn / a.N), sw = a.sidx ? a.sidx[s] : s, tid = threadIdx.x;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
     for (int e = tid; e < P1SZ; e += 256) {
-        const int st = a.st1[sn * P1SZ + e], c = e / (P1W * P1W), py = (e / P1W) % P1W, px = e % P1W;
-        const float g = (st & 4) ? dP1s[e] : dP1s[e] * slope;
-        if (g == 0.f) continue;
-        const int Y = 2 * py + ((st >> 1) & 1), X = 2 * px + (st & 1);
-        const float* const w = a.K1w + ((long long)sw * C1 + c) * 25;
-#pragma unroll
-        for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) atomicAdd(&dXs[(Y + ky) * 28 + X + kx], g * w[ky * 5 + kx]);
+        const int st = a.st1[sn * P1SZ + e];
+        const float d = a.dP1[sn * P1SZ + e];
+        gs[e] = (st & 4) ? d : d * slope;
+        as[e] = (unsigned char)(st & 3);
     }
+    for (int e = tid; e < C1 * 25; e += 256) ws[e] = a.K1w[(long long)sw * C1 * 25 + e];
     __syncthreads();
-    for (int i = tid; i < 784; i += 256) a.G[sn * 784 + i] = dXs[i];
+    for (int pix = tid; pix < 784; pix += 256) {
+        const int Yo = pix / 28, Xo = pix % 28;
+        const int py0 = max(0, (Yo - 4) >> 1), py1 = min(P1W - 1, Yo >> 1), px0 = max(0, (Xo - 4) >> 1), px1 = min(P1W - 1, Xo >> 1);
+        float g = 0.f;
+        for (int c = 0; c < C1; ++c)
+            for (int py = py0; py <= py1; ++py)
+                for (int px = px0; px <= px1; ++px) {
+                    const int e = c * (P1W * P1W) + py * P1W + px, arg = as[e];
+                    const int ky = Yo - (2 * py + (arg >> 1)), kx = Xo - (2 * px + (arg & 1));
+                    if (ky >= 0 && ky < 5 && kx >= 0 && kx < 5) g = fmaf(gs[e], ws[c * 25 + ky * 5 + kx], g);
+                }
+        a.G[sn * 784 + pix] = g;
+    }
 }
 
 }  // namespace
@@ -380,14 +457,24 @@ extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_
                                     const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);
     if (rc) return rc;
-    if (!net->K2w_tap || !ws || !ws->dZ || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
-    if (N < 1 || S < 1 || (net->hidden & 3)) return RBNN_ERR_SHAPE;
-    if (!aligned16(net->K2w_tap)) return RBNN_ERR_ALIGN;
+    if (!net->K2w_ci || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1) return RBNN_ERR_SHAPE;
+    if (!aligned16(net->K2w_ci) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
     ConvBwdArgs a = {};
-    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2tap = net->K2w_tap; a.Fw = net->Fw;
-    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.G = ws->G;
-    const int grid = grid_for_items((long long)N * S);
-    if (net->activation == RBNN_ACT_LEAKY) hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else                                   hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = net->K2w_ci; a.Fw = net->Fw;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
+    const int grid = grid_for_items((long long)((N + 3) / 4) * S);
+    const bool leaky = net->activation == RBNN_ACT_LEAKY;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const long long F = (long long)net->hidden * NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+        hipLaunchKernelGGL(conv_fc_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+        if ((rc = launch_status())) return rc;
+    }
+    if (leaky) hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
+    if ((rc = launch_status())) return rc;
+    if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
     return launch_status();
 }

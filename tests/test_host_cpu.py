@@ -318,8 +318,8 @@ def test_conv_posterior_layout_and_roundtrip(golden):
     g = golden("mnist_conv_h16_s2_n4_leaky"); m = g.meta; post = g.posterior()
     sp = ConvStackedPosterior(m["act"], m["shape"], m["n_classes"], m["hidden"], post, "cpu")
     assert sp.K1w.shape == (2, 32, 25) and sp.K2w.shape == (2, 16, 800) and sp.Fw.shape == (2, 10, 49 * 16)
-    # tap-major image [S, tap, ci, hc] of model.3.weight [hc, ci, ky, kx]
-    assert torch.equal(sp.K2tap[1, 7, 5, 3], post["model.3.weight"][1, 3, 5, 1, 2])
+    # regrouped image [S, ci, hc block, tap, hc % 16] of model.3.weight [hc, ci, ky, kx]
+    assert torch.equal(sp.K2ci.view(2, 32, 1, 25, 16)[1, 5, 0, 7, 3], post["model.3.weight"][1, 3, 5, 1, 2])
     sd = sp.state_dict(0)
     assert all(torch.equal(sd[k], post[k][0]) for k in sd)
     d = sp.descriptor()
