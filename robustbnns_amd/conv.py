@@ -5,6 +5,7 @@ nn.Conv2d's [out,in,kh,kw] flattened), K2b [S,Hc], Fw [S,C,49*Hc], Fb [S,C].  Ac
 P1 18 KB, Q2 196*Hc B, two byte stashes — 148 KB at Hc=512, so large jobs are run in blocks of samples.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -83,6 +84,53 @@ class ConvEngine(AttackEngine):
             self._ws_cache.clear()
             self._ws_cache[key] = ws
         return ws
+
+    # -------------------------------------------------------------- point blocking
+    # Activations cost 148 KB per (point, sample) at Hc=512 (P1 18 KB, Q2 100 KB, two byte stashes, per-sample
+    # gradients), and the mean-probability loss needs every sample's forward before any backward — so large jobs are
+    # split over POINTS (independent), never over samples.  Budget: RBNN_CONV_WS_GB (default 48 GB of the 288 GB).
+    def point_block(self, S):
+        per_point = S * (4608 * 5 + self.post.H * 49 * 5 + 784 * 4 + 2 * 64)
+        budget = float(os.environ.get("RBNN_CONV_WS_GB", "48")) * 2 ** 30
+        return max(16, int(budget // per_point) // 16 * 16)
+
+    def _blocked(self, fn, x, *rest, n_samples, cat=True):
+        nb = self.point_block(n_samples)
+        if x.shape[0] <= nb:
+            return fn(x, *rest)
+        outs = [fn(x[i:i + nb], *[r[i:i + nb] if torch.is_tensor(r) and r.shape[:1] == x.shape[:1] else r for r in rest])
+                for i in range(0, x.shape[0], nb)]
+        return torch.cat(outs) if cat else outs
+
+    def forward(self, x, n_samples, seeds=None, logits=False):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return super().forward(x, n_samples, seeds, logits)
+        return self._blocked(lambda xb: AttackEngine.forward(self, xb, n_samples, seeds, logits), x, n_samples=n_samples)
+
+    def loss_gradients(self, x, y, n_samples):
+        y = torch.as_tensor(y)
+        return self._blocked(lambda xb, yb: AttackEngine.loss_gradients(self, xb, yb, n_samples), x, y, n_samples=n_samples)
+
+    def fgsm(self, x, y, n_samples, epsilon=0.3, seeds=None, mode=_hip.LOSS_MEAN_PROB):
+        y = torch.as_tensor(y)
+        return self._blocked(lambda xb, yb: AttackEngine.fgsm(self, xb, yb, n_samples, epsilon, seeds, mode), x, y, n_samples=n_samples)
+
+    def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=_hip.LOSS_MEAN_PROB):
+        y = torch.as_tensor(y)
+        return self._blocked(lambda xb, yb: AttackEngine.pgd(self, xb, yb, n_samples, epsilon, alpha, iters, seeds, mode),
+                             x, y, n_samples=n_samples)
+
+    def evaluate(self, x, x_attack, y, n_samples, logits=False):
+        y = torch.as_tensor(y)
+        parts = self._blocked(lambda xb, ab, yb: AttackEngine.evaluate(self, xb, ab, yb, n_samples, logits), x, x_attack, y,
+                              n_samples=n_samples, cat=False)
+        if isinstance(parts, tuple):
+            return parts
+        n = x.shape[0]
+        sizes = [p[2].shape[0] for p in parts]
+        oa = sum(p[0] * m for p, m in zip(parts, sizes)) / n
+        aa = sum(p[1] * m for p, m in zip(parts, sizes)) / n
+        return oa, aa, torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts]), torch.cat([p[4] for p in parts])
 
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
         self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)

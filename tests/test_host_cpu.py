@@ -334,3 +334,16 @@ def test_conv_posterior_layout_and_roundtrip(golden):
     bnn = model_bnn.BNN("mnist", 16, "leaky", "conv", "hmc", None, None, 2, 0, (1, 28, 28), 10)
     bnn.set_posterior_samples(post, "cpu")
     assert type(bnn._engine).__name__ == "ConvEngine" and bnn.posterior.S == 2
+
+
+def test_conv_engine_point_blocking(monkeypatch, golden):
+    from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
+    g = golden("mnist_conv_h16_s2_n4_leaky"); m = g.meta
+    eng = ConvEngine(ConvStackedPosterior(m["act"], m["shape"], m["n_classes"], m["hidden"], g.posterior(), "cpu"), kernels=FakeKernels())
+    monkeypatch.setenv("RBNN_CONV_WS_GB", "0.001")                      # ~1 MB: forces blocks of 16 points
+    assert eng.point_block(2) == 16
+    calls = []
+    out = eng._blocked(lambda xb, yb: (calls.append((len(xb), len(yb))), xb * 2)[1], torch.arange(40.).reshape(40, 1), torch.arange(40), n_samples=2)
+    assert calls == [(16, 16), (16, 16), (8, 8)] and torch.equal(out, torch.arange(40.).reshape(40, 1) * 2)
+    monkeypatch.setenv("RBNN_CONV_WS_GB", "48")
+    assert eng.point_block(100) >= 2048
