@@ -270,15 +270,16 @@ struct GradArgs {
     const uint32_t* omask;  const float* odact;  int OHW;                              // PER_SAMPLE epilogue: derivative of the layer below
 };
 
-template <int ACT, int TD, int CQ, bool A_MEM, bool PER_SAMPLE>
+template <int ACT, int TD, int CQ, bool A_MEM, bool PER_SAMPLE, int HSTG>
 __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
-    constexpr int NTW = 4, BM = 256, HSTG = 32;               // 4 waves x 64 points; 32 hidden units per LDS stage
-    constexpr int LD = TD * 16;                                // W1 stage tile: [32 h][TD*16 d], unpadded (LDS-DMA image)
-    constexpr int W2ROWS = (4 * CQ + 7) / 8 * 8;               // W2 stage tile: [classes, whole 8-row pieces][32 h]
+    constexpr int NTW = 4, BM = 256;                           // 4 waves x 64 points; HSTG (32 or 64) hidden units per LDS stage
+    constexpr int LD = TD * 16;                                // W1 stage tile: [HSTG/4 h-quads][TD*16 d][4], linear LDS-DMA image
+    constexpr int W2RPP = 256 / HSTG;                          // W2 tile rows (classes) per 1-KiB piece
+    constexpr int W2ROWS = (4 * CQ + W2RPP - 1) / W2RPP * W2RPP;   // W2 stage tile: [classes, whole pieces][HSTG h]
     constexpr int W1SZ = HSTG * LD, W2SZ = W2ROWS * HSTG;
     constexpr int BUF = W1SZ + W2SZ;
-    constexpr int NPIECE = 2 * TD, PPW = (NPIECE + 3) / 4;     // 1-KiB LDS-DMA pieces per W1 tile / per wave
-    constexpr int NT2 = HSTG / 16;                             // h tiles per stage
+    constexpr int NPIECE = HSTG * TD / 16, PPW = (NPIECE + 3) / 4;   // 1-KiB LDS-DMA pieces per W1 tile / per wave
+    constexpr int NT2 = HSTG / 16, MWS = HSTG / 32;            // h tiles / mask words per stage
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);
     __shared__ __attribute__((aligned(16))) float lds[2 * BUF];   // one array: see fc_forward_kernel
 
@@ -303,10 +304,10 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
         const int f = (wave + 4 * i) * 256 + 4 * lane, hq = f / (4 * LD), d = (f % (4 * LD)) >> 2;
         goff[i] = (hq * a.ldw + min(dc0 + d, Dp - 1)) * 4;    // columns past D_pad: any valid address, never stored
     }
-    // W2 tile: piece q = classes 8q..8q+7, lane p -> class 8q + (p>>3), 16-B chunk p&7 of its 32 hidden units; odd
-    // classes are stored with their two 64-B halves swapped (same bank argument: a half-wave reads classes c, c+1).
-    const int w2row = lane >> 3;
-    const int w2goff_col = 4 * ((lane & 7) ^ (4 * (w2row & 1)));
+    // W2 tile: piece q = classes q*W2RPP .., lane p -> class row p / (HSTG/4), 16-B chunk p % (HSTG/4) of its HSTG hidden
+    // units; odd classes are stored rotated by 16 units (a half-wave reads classes c, c+1: opposite bank halves).
+    const int w2row = lane / (HSTG / 4);
+    const int w2goff_col = 4 * (((lane % (HSTG / 4)) + (HSTG / 4) - 4 * (w2row & 1)) % (HSTG / 4));
 
     f32x4 acc[NTW][TD];
 #pragma unroll
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
 #pragma unroll
         for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    unsigned mreg[NTW], mw[NTW];
+    unsigned mreg[NTW][MWS], mw[NTW][MWS];
     float dzb[NTW][CQ];                                        // B operand of the dA product: dZ[s][n = li][c = 4j + lg]
     // stage st -> LDS buffer buf, all by LDS-DMA (asynchronous, no VGPRs); mask words to registers
     auto stage_issue = [&](int st, int buf) {
@@ -326,15 +327,17 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
         for (int i = 0; i < PPW; ++i)
             if (dma && wave + 4 * i < NPIECE) glds16(Ws + goff[i], lds + buf * BUF + (wave + 4 * i) * 256);
         if (!A_MEM) {
-            if (dma && wave * 8 < W2ROWS) {                    // W2 rows past C repeat row C-1: they meet dZ columns that are 0
-                const int c = min(wave * 8 + w2row, a.C - 1);
+            if (dma && wave * W2RPP < W2ROWS) {                // W2 rows past C repeat row C-1: they meet dZ columns that are 0
+                const int c = min(wave * W2RPP + w2row, a.C - 1);
                 glds16(a.W2 + ((long long)sw * a.C + c) * a.H + h0 + w2goff_col, lds + buf * BUF + W1SZ + wave * 256);
             }
             if (BITMASK && (!(RBNN_ABL & 32) || st == 0)) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     const int n = nb + nt * 16 + li;
-                    mreg[nt] = (n < a.N) ? a.mask[((long long)s * a.HW + (h0 >> 5)) * a.N + n] : 0u;
+#pragma unroll
+                    for (int w = 0; w < MWS; ++w)
+                        mreg[nt][w] = (n < a.N) ? a.mask[((long long)s * a.HW + (h0 >> 5) + w) * a.N + n] : 0u;
                 }
             }
         }
@@ -346,7 +349,9 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
         const int s = s_begin + st / HS, h0 = (st % HS) * HSTG, buf = st & 1;
         if (!A_MEM && BITMASK) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) mw[nt] = mreg[nt] >> (4 * lg);   // bit (16*t2 + r) = unit 16*t2 + 4*lg + r
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int w = 0; w < MWS; ++w) mw[nt][w] = mreg[nt][w] >> (4 * lg);   // bit (16*(t2&1) + r) of word t2/2 = unit 16*t2 + 4*lg + r
         }
         if (!A_MEM && st % HS == 0) {                          // new sample: its dL/dlogits into B-operand registers
 #pragma unroll                                                 // (before this stage's LDS-DMA is issued: waiting on
@@ -380,7 +385,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
             }
             float w2a[CQ];
 #pragma unroll
-            for (int j = 0; j < CQ; ++j) w2a[j] = W2t[(4 * j + lg) * HSTG + li + 16 * ((t2 ^ lg) & 1)];   // class 4j+lg, unit 16*t2+li
+            for (int j = 0; j < CQ; ++j) w2a[j] = W2t[(4 * j + lg) * HSTG + (16 * t2 + li + 16 * (lg & 1)) % HSTG];   // class 4j+lg, unit 16*t2+li
             f32x4 g[NTW];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) g[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -393,7 +398,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (BITMASK) {
-                        const bool pos = (mw[nt] >> (16 * t2 + r)) & 1u;
+                        const bool pos = (mw[nt][t2 >> 1] >> (16 * (t2 & 1) + r)) & 1u;
                         g[nt][r] = pos ? g[nt][r] : (ACT == RBNN_ACT_RELU ? 0.f : g[nt][r] * LEAKY_SLOPE);
                     } else {
                         g[nt][r] *= da[slot][nt][r];
@@ -704,11 +709,19 @@ template <int ACT, int TD, bool A_MEM, bool PER_SAMPLE>
 int launch_grad_c(const GradArgs& a, hipStream_t st) {
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
     if constexpr (A_MEM) {
-        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, true, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, true, PER_SAMPLE, 32>), dim3(grid), dim3(256), 0, st, a);
     } else {                          // CQ = MFMA K steps (4 classes each) of the dA product
-        if (a.C <= 4)       hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
-        else if (a.C <= 12) hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 3, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
-        else                hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 4, false, PER_SAMPLE>), dim3(grid), dim3(256), 0, st, a);
+        // (64-unit stages — template parameter HSTG — halve the per-stage overhead but need 16 more mask registers: measured
+        //  256 VGPR + 164 B scratch and 7.82 ms vs 6.88 ms at C2, so only the 32-unit stage is dispatched.)
+#ifdef RBNN_GRAD_STAGE64
+        if (!PER_SAMPLE && TD == 7 && a.C > 4 && a.C <= 12 && a.H % 64 == 0) {
+            hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 3, false, PER_SAMPLE, 64>), dim3(grid), dim3(256), 0, st, a);
+            return launch_status();
+        }
+#endif
+        if (a.C <= 4)       hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, false, PER_SAMPLE, 32>), dim3(grid), dim3(256), 0, st, a);
+        else if (a.C <= 12) hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 3, false, PER_SAMPLE, 32>), dim3(grid), dim3(256), 0, st, a);
+        else                hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 4, false, PER_SAMPLE, 32>), dim3(grid), dim3(256), 0, st, a);
     }
     return launch_status();
 }

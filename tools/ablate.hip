@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
 #ifdef RBNN_FWD8
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)fc_forward_kernel<RBNN_ACT_LEAKY, 4, 8, 2, 2, true>, 512, 0);
 #endif
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&ng, (const void*)fc_grad_kernel<RBNN_ACT_LEAKY, 7, 3, false, false>, 256, 0);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&ng, (const void*)fc_grad_kernel<RBNN_ACT_LEAKY, 7, 3, false, false, 32>, 256, 0);
         printf("occupancy API: fwd %d blocks/CU, grad %d blocks/CU; chunk %d n_slabs %d\n", nf, ng, sz.chunk, sz.n_slabs);
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
