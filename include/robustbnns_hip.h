@@ -85,7 +85,7 @@ typedef struct rbnn_posterior {
 typedef struct rbnn_workspace {
     float    *P;                   /* [S,N,16]      per-sample probabilities (or logits)         */
     float    *dZ;                  /* [S,N,16]      dL/dlogits per sample                        */
-    uint32_t *mask1;               /* [S,H/32,N]    bit h%32 of word [s][h/32][n] = (pre-activation > 0) */
+    uint32_t *mask1;               /* [S,H/32,N_pad] bit h%32 of word [s][h/32][n] = (pre-activation > 0); N_pad = round_up(N,256) */
     float    *dact1;               /* [S,N,H]       act'(pre-activation), sigm/tanh only         */
     float    *hid1;                /* [S,N,H]       fc2: first hidden activations                */
     uint32_t *mask2;               /* fc2: as mask1 for the second hidden layer                  */

@@ -41,6 +41,10 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// row stride (in words) of the 1-bit activation stash [S][H/32][N_pad]: padded to the gradient kernel's 256-point block so that
+// a block's words of one row are one aligned 1-KiB LDS-DMA piece
+__host__ __device__ __forceinline__ long long mask_ld(int N) { return ((long long)N + 255) / 256 * 256; }
+
 // 16-float (64 B) LDS rows read with ds_read_b128 by lane (row li, 16-B chunk lg): physical chunk =
 // lg ^ swz(row) with swz = [0,2,3,1][(row>>2)&3] makes every 16-lane b128 group hit 16 distinct slots.
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }

@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int n = n0 + (wave_n * NTW + nt) * 16 + li;
-                if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * HW + (hw0 >> 5) + lg) * a.N + n] = mine[nt];   // [S][H/32][N]: 16 lanes = 64 B
+                if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * HW + (hw0 >> 5) + lg) * mask_ld(a.N) + n] = mine[nt];   // [S][H/32][N_pad]: 16 lanes = 64 B
             }
         }
     }
@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     constexpr int W2RPP = 256 / HSTG;                          // W2 tile rows (classes) per 1-KiB piece
     constexpr int W2ROWS = (4 * CQ + W2RPP - 1) / W2RPP * W2RPP;   // W2 stage tile: [classes, whole pieces][HSTG h]
     constexpr int W1SZ = HSTG * LD, W2SZ = W2ROWS * HSTG;
-    constexpr int BUF = W1SZ + W2SZ;
+    constexpr int MKSZ = (HSTG / 32) * BM;                      // mask words of the stage for the block's 256 points
+    constexpr int BUF = W1SZ + W2SZ + MKSZ;
     constexpr int NPIECE = HSTG * TD / 16, PPW = (NPIECE + 3) / 4;   // 1-KiB LDS-DMA pieces per W1 tile / per wave
     constexpr int NT2 = HSTG / 16, MWS = HSTG / 32;            // h tiles / mask words per stage
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);
@@ -315,7 +316,6 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
 #pragma unroll
         for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    unsigned mreg[NTW][MWS], mw[NTW][MWS];
     float dzb[NTW][CQ];                                        // B operand of the dA product: dZ[s][n = li][c = 4j + lg]
     // stage st -> LDS buffer buf, all by LDS-DMA (asynchronous, no VGPRs); mask words to registers
     auto stage_issue = [&](int st, int buf) {
@@ -331,14 +331,11 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
                 const int c = min(wave * W2RPP + w2row, a.C - 1);
                 glds16(a.W2 + ((long long)sw * a.C + c) * a.H + h0 + w2goff_col, lds + buf * BUF + W1SZ + wave * 256);
             }
-            if (BITMASK && (!(RBNN_ABL & 32) || st == 0)) {
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const int n = nb + nt * 16 + li;
-#pragma unroll
-                    for (int w = 0; w < MWS; ++w)
-                        mreg[nt][w] = (n < a.N) ? a.mask[((long long)s * a.HW + (h0 >> 5) + w) * a.N + n] : 0u;
-                }
+            // mask words [S][H/32][N_pad] (N_pad % 256 == 0): the block's 256 points of one word row are 1 KiB = one piece
+            if (BITMASK && dma && wave >= 4 - MWS) {
+                const int w = wave - (4 - MWS);
+                glds16((const float*)(a.mask + ((long long)s * a.HW + (h0 >> 5) + w) * mask_ld(a.N) + ntile * BM + 4 * lane),
+                       lds + buf * BUF + W1SZ + W2SZ + w * BM);
             }
         }
     };
@@ -347,12 +344,6 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
         const int s = s_begin + st / HS, h0 = (st % HS) * HSTG, buf = st & 1;
-        if (!A_MEM && BITMASK) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int w = 0; w < MWS; ++w) mw[nt][w] = mreg[nt][w] >> (4 * lg);   // bit (16*(t2&1) + r) of word t2/2 = unit 16*t2 + 4*lg + r
-        }
         if (!A_MEM && st % HS == 0) {                          // new sample: its dL/dlogits into B-operand registers
 #pragma unroll                                                 // (before this stage's LDS-DMA is issued: waiting on
             for (int nt = 0; nt < NTW; ++nt) {                 //  these loads would drain it)
@@ -369,6 +360,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
 
         const float* const W1t = lds + buf * BUF;
         const float* const W2t = W1t + W1SZ;
+        const unsigned* const Mk = (const unsigned*)(W2t + W2SZ) + wave * (NTW * 16) + li;   // + w*BM + nt*16
         // dA tile of h tile t2 for this wave's 64 points: (dA^T)[h][n] = sum_c W2[c][h] * dZ[n][c] on the matrix pipe
         // (A = W2 fragment, i = h; B = dzb, j = n).  Its accumulator layout, register r <-> h = 16*t2 + 4*lg + r on
         // lane (n = li, lg), IS the main product's A-operand layout for K step (t2, r): no data movement.
@@ -395,10 +387,12 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
                 for (int nt = 0; nt < NTW; ++nt) g[nt] = MFMA16(w2a[j], dzb[nt][j], g[nt]);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
+                unsigned mwv = 0;                               // bit r = unit 16*t2 + 4*lg + r of this lane's point
+                if (BITMASK) mwv = Mk[(t2 >> 1) * BM + nt * 16] >> (16 * (t2 & 1) + 4 * lg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (BITMASK) {
-                        const bool pos = (mw[nt][t2 >> 1] >> (16 * (t2 & 1) + r)) & 1u;
+                        const bool pos = (mwv >> r) & 1u;
                         g[nt][r] = pos ? g[nt][r] : (ACT == RBNN_ACT_RELU ? 0.f : g[nt][r] * LEAKY_SLOPE);
                     } else {
                         g[nt][r] *= da[slot][nt][r];
@@ -454,7 +448,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
                 float v = acc[nt][dt][r];
                 if (PER_SAMPLE) {
                     if (BITMASK) {
-                        const unsigned w = a.omask[((long long)s_begin * a.OHW + (d >> 5)) * a.N + n];
+                        const unsigned w = a.omask[((long long)s_begin * a.OHW + (d >> 5)) * mask_ld(a.N) + n];
                         v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
                     } else {
                         v *= a.odact[((long long)s_begin * a.N + n) * a.ldo + d];
@@ -711,8 +705,8 @@ int launch_grad_c(const GradArgs& a, hipStream_t st) {
     if constexpr (A_MEM) {
         hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 1, true, PER_SAMPLE, 32>), dim3(grid), dim3(256), 0, st, a);
     } else {                          // CQ = MFMA K steps (4 classes each) of the dA product
-        // (64-unit stages — template parameter HSTG — halve the per-stage overhead but need 16 more mask registers: measured
-        //  256 VGPR + 164 B scratch and 7.82 ms vs 6.88 ms at C2, so only the 32-unit stage is dispatched.)
+        // (64-unit stages — template parameter HSTG — halve the per-stage overhead but spill: 256 VGPR + 124 B scratch,
+        //  7.31 ms vs 6.79 ms at C2, so only the 32-unit stage is dispatched.)
 #ifdef RBNN_GRAD_STAGE64
         if (!PER_SAMPLE && TD == 7 && a.C > 4 && a.C <= 12 && a.H % 64 == 0) {
             hipLaunchKernelGGL((fc_grad_kernel<ACT, TD, 3, false, PER_SAMPLE, 64>), dim3(grid), dim3(256), 0, st, a);
@@ -783,7 +777,7 @@ int rbnn_workspace_query(const rbnn_posterior* net, int32_t N, int32_t S, int32_
     if (chunk > S) chunk = S;
     rbnn_workspace_sizes z = {};
     z.P = z.dZ = SN * RBNN_CPAD * sizeof(float);
-    z.mask1 = bm ? SN * (H / 32) * sizeof(uint32_t) : 0;
+    z.mask1 = bm ? (size_t)S * (H / 32) * mask_ld(N) * sizeof(uint32_t) : 0;
     z.dact1 = bm ? 0 : SN * H * sizeof(float);
     if (fc2) {
         z.hid1 = z.dhid1 = SN * H * sizeof(float);

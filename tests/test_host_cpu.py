@@ -45,7 +45,7 @@ def test_workspace_query_sizes():
     out = _hip.WorkspaceSizes()
     assert lib.rbnn_workspace_query(C.byref(_net()), 10000, 100, 0, C.byref(out)) == 0
     assert out.P == out.dZ == 100 * 10000 * 16 * 4
-    assert out.mask1 == 100 * 10000 * (512 // 32) * 4 and out.dact1 == 0 and out.hid1 == 0
+    assert out.mask1 == 100 * (512 // 32) * 10240 * 4 and out.dact1 == 0 and out.hid1 == 0    # rows padded to 256 points
     assert 1 <= out.chunk <= 8 and out.n_slabs == -(-100 // out.chunk)
     assert out.slabs == out.n_slabs * 10000 * 784 * 4
     assert lib.rbnn_workspace_query(C.byref(_net(activation=2, arch=1)), 64, 3, 2, C.byref(out)) == 0

@@ -36,7 +36,8 @@ def check(arch, act, shape, C, H, S, N, std, seed=0):
         layers = O.mlp_layers(p64, arch)
         _, pre = O._mlp_forward_cache(xd.reshape(N, -1), layers, act)
         Hp = sp.Hp
-        m = ws["mask1"].view(S, Hp // 32, N).permute(0, 2, 1).contiguous().cpu()
+        Npad = (N + 255) // 256 * 256
+        m = ws["mask1"].view(S, Hp // 32, Npad)[:, :, :N].permute(0, 2, 1).contiguous().cpu()
         bits = ((m.unsqueeze(-1) >> torch.arange(32, dtype=torch.int32)) & 1).reshape(S, N, Hp)[:, :, :H].bool()
         ref = pre[0] > 0
         near = pre[0].abs() < 1e-6
