@@ -218,6 +218,33 @@ int rbnn_conv_input_grad(const rbnn_conv_posterior *net, const int32_t *sample_i
 int rbnn_svi_materialize(const float *loc, const float *scale_raw, const float *eps, int64_t n_elem,
                          int32_t n_samples, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Split-half precision mode ("f16x3") of the fc forward / input-gradient contractions.  No counterpart in the
+ * reference (it computes in fp32): every fp32 operand v is carried as v * 2^e = hi + lo with hi, lo fp16, products
+ * are hi*hi' + hi*lo' + lo*hi' on the f16 matrix pipe with fp32 accumulation (2^-22 per product; the parity tests
+ * hold this mode to the same 1e-5 bar as the exact mode).  arch fc only, hidden % 128 == 0.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct rbnn_split_images {
+    const void *W1_rows;           /* rbnn_split_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/8,2,8] halves */
+    const void *W1_cols;           /* rbnn_split_cols image of W1 (backward B operand): [S_total,H/32,4,2,ld_cols,8] halves        */
+    int32_t ld_rows;               /* columns per row of W1_rows, multiple of 32, >= D                                            */
+    int32_t ld_cols;               /* columns of W1_cols, multiple of 16, >= D                                                    */
+    int32_t w1_exp;                /* both images hold W1 * 2^w1_exp                                                              */
+    int32_t reserved;
+} rbnn_split_images;
+
+/* dst[r, g, 0, :] = fp16(v), dst[r, g, 1, :] = fp16(v - hi) for v = src[r, 8g..8g+7] * 2^scale_exp (0 past `cols`):
+ * the split-rows image [rows, ld_dst/8, 2, 8] halves of a row-major fp32 matrix.  ld_dst % 32 == 0.
+ * The caller picks scale_exp so that max|v| * 2^scale_exp <= 2^14. */
+int rbnn_split_rows(const float *src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp, void *dst,
+                    int32_t ld_dst, void *stream);
+
+/* rbnn_fc_forward in split precision: same outputs (ws->P, ws->mask1 / ws->dact1), inputs as split-rows images:
+ * X_split = rbnn_split_rows(X, N, D, ldx_src, x_exp, ., ldx) with ldx == sp->ld_rows. */
+int rbnn_fc_forward_split(const rbnn_posterior *net, const rbnn_split_images *sp, const void *X_split, int32_t ldx,
+                          int32_t x_exp, int32_t n_points, const int32_t *sample_idx, int32_t n_samples,
+                          int32_t out_kind, const rbnn_workspace *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

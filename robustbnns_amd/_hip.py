@@ -55,6 +55,11 @@ class ConvWorkspaceSizes(C.Structure):
     _fields_ = [(k, C.c_size_t) for k in CONV_WS_KEYS]
 
 
+class SplitImages(C.Structure):
+    _fields_ = [("W1_rows", _fp), ("W1_cols", _fp), ("ld_rows", C.c_int32), ("ld_cols", C.c_int32),
+                ("w1_exp", C.c_int32), ("reserved", C.c_int32)]
+
+
 WS_KEYS = ("P", "dZ", "mask1", "dact1", "hid1", "mask2", "dact2", "dhid1", "slabs")
 
 _i32, _f32, _sz, _i64 = C.c_int32, C.c_float, C.c_size_t, C.c_int64
@@ -78,6 +83,8 @@ SIGNATURES = {
     "rbnn_conv_input_grad": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "rbnn_split_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _i32, _fp]),
+    "rbnn_fc_forward_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _i32, _fp, _i32, _i32, _PW, _fp]),
 }
 
 _lib = None
@@ -198,6 +205,19 @@ class HipKernels:
         require_gpu(W, "W")
         cols = W.shape[-1]
         check(self.lib.rbnn_pack_rows4(ptr(W), W.numel() // cols, cols, ptr(out), stream_of(W)), "rbnn_pack_rows4")
+
+    # -- split-half ("f16x3") precision mode ---------------------------------------------------------
+    def split_rows(self, src, cols, scale_exp, out, ld_dst):
+        """src: [..., ld_src] fp32 rows -> out: split-rows image (int16 storage [rows, ld_dst*2])."""
+        require_gpu(src, "src")
+        ld_src = src.shape[-1]
+        check(self.lib.rbnn_split_rows(ptr(src), src.numel() // ld_src, cols, ld_src, scale_exp, ptr(out), ld_dst,
+                                       stream_of(src)), "rbnn_split_rows")
+
+    def fc_forward_split(self, net, images, Xs, ld, x_exp, N, sidx, S, out_kind, ws):
+        w = self._ws(ws)
+        check(self.lib.rbnn_fc_forward_split(C.byref(net.descriptor()), C.byref(images), ptr(Xs), ld, x_exp, N, ptr(sidx), S,
+                                             out_kind, C.byref(w), stream_of(Xs)), "rbnn_fc_forward_split")
 
     # -- conv architecture ---------------------------------------------------------------------------
     def conv_workspace_sizes(self, net, N, S):

@@ -68,7 +68,19 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
 
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.S, id)) return;
+    // item -> (point tile, sample), 2-D blocked: panels of 8 samples, inside a panel the sample index runs fastest, so
+    // the ~64 blocks resident on an XCD are 8 point tiles x 8 samples: each X tile and each W1 slice is fetched into that
+    // XCD's L2 once per 8 users instead of once per user.
+#ifndef RBNN_FWD_ITEM_1D
+    int ntile, s;
+    {
+        const int full = a.S / 8, per = 8 * a.NT;
+        if (id < full * per) { ntile = (id % per) / 8; s = (id / per) * 8 + id % 8; }
+        else { const int rem = id - full * per, cnt = a.S - full * 8; ntile = rem / cnt; s = full * 8 + rem % cnt; }
+    }
+#else
     const int ntile = id % a.NT, s = id / a.NT;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int wave_h = wave % WH, wave_n = wave / WH;
     const int sw = a.sidx ? a.sidx[s] : s;

@@ -1,0 +1,81 @@
+"""GPU check of the split-half (f16x3) kernels against the exact-fp32 kernels and an fp64 torch reference.
+usage: python tools/gpu_check_split.py [N] [S] [H]"""
+import math
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as G
+G.build()
+from oracle import bnn_oracle as O
+from robustbnns_amd import AttackEngine, StackedPosterior
+from robustbnns_amd import _hip
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+D, C = 784, 10
+dev = "cuda:0"
+post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
+x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=0)
+sp = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, dev)
+eng = AttackEngine(sp)
+K = eng.k
+Xp = eng.pad_inputs(x)
+sidx, _ = eng.sample_index(S)
+ws = eng.workspace(N, S)
+
+def exp_for(t, target=14):
+    m = float(t.abs().max())
+    return target - math.ceil(math.log2(m)) if m > 0 else 0
+
+ld = (D + 31) // 32 * 32
+w1_exp = exp_for(sp.W1)
+x_exp = exp_for(Xp)
+W1s = torch.empty(sp.W1.shape[0] * H, ld * 2, dtype=torch.int16, device=dev)
+K.split_rows(sp.W1, D, w1_exp, W1s, ld)
+Xs = torch.empty(N, ld * 2, dtype=torch.int16, device=dev)
+K.split_rows(Xp, D, x_exp, Xs, ld)
+img = _hip.SplitImages()
+img.W1_rows = W1s.data_ptr(); img.W1_cols = None; img.ld_rows = ld; img.ld_cols = 0; img.w1_exp = w1_exp
+print("w1_exp", w1_exp, "x_exp", x_exp, "ld", ld)
+
+# check the split image itself
+v = (sp.W1[:, :, :D].reshape(-1, D) * 2.0 ** w1_exp)
+hl = W1s.view(torch.float16).reshape(-1, ld // 8, 2, 8)
+rec = (hl[:, :, 0].float() + hl[:, :, 1].float()).reshape(-1, ld)[:, :D]
+print("split image rel err", float(((rec.double() - v.double()).abs().max()) / v.abs().max()))
+
+K.fc_forward(sp, Xp, sidx, S, _hip.OUT_PROBS, ws)
+P_exact = ws["P"].reshape(S, N, 16).clone(); m_exact = ws["mask1"].clone()
+ws["P"].zero_(); ws["mask1"].zero_()
+K.fc_forward_split(sp, img, Xs, ld, x_exp, N, sidx, S, _hip.OUT_PROBS, ws)
+torch.cuda.synchronize()
+P_split = ws["P"].reshape(S, N, 16).clone(); m_split = ws["mask1"].clone()
+# fp64 reference on the GPU (check tool only)
+W1 = sp.W1[:, :, :D].double(); Xd = Xp[:, :D].double()
+errs_e, errs_s = 0.0, 0.0
+for s in range(min(S, 8)):
+    a = Xd @ W1[s].T + sp.b1[s].double()
+    h = torch.where(a > 0, a, 0.01 * a)
+    z = h @ sp.W2[s].double().T + sp.b2[s].double()
+    p = torch.softmax(z, -1)
+    errs_e = max(errs_e, float((P_exact[s, :, :C].double() - p).abs().max()))
+    errs_s = max(errs_s, float((P_split[s, :, :C].double() - p).abs().max()))
+print(f"max |P - P64|: exact {errs_e:.3e}  split {errs_s:.3e}   max|P_split - P_exact| {float((P_split - P_exact).abs().max()):.3e}")
+diffbits = (m_exact ^ m_split)
+nb = sum(int(((diffbits >> b) & 1).sum()) for b in range(32))
+print("mask bits differing:", nb, "of", S * H * N)
+
+def timeit(f, n=10):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+te = timeit(lambda: K.fc_forward(sp, Xp, sidx, S, _hip.OUT_PROBS, ws))
+tsp = timeit(lambda: K.fc_forward_split(sp, img, Xs, ld, x_exp, N, sidx, S, _hip.OUT_PROBS, ws))
+tx = timeit(lambda: K.split_rows(Xp, D, x_exp, Xs, ld))
+fl = 2.0 * N * S * H * (D + 16)
+print(f"forward exact {te:.3f} ms ({fl/te/1e9:.1f} TF)   split {tsp:.3f} ms ({fl/tsp/1e9:.1f} TF fp32-equivalent, {3*fl/tsp/1e9:.0f} TF f16)   split_rows(X) {tx:.3f} ms")
