@@ -227,11 +227,23 @@ int rbnn_svi_materialize(const float *loc, const float *scale_raw, const float *
 typedef struct rbnn_split_images {
     const void *W1_rows;           /* rbnn_split_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/8,2,8] halves */
     const void *W1_cols;           /* rbnn_split_cols image of W1 (backward B operand): [S_total,H/32,4,2,ld_cols,8] halves        */
+    const void *W2_gen;            /* rbnn_split_w2gen image of W2 (backward dA generator): [S_total,H/16,64,8] halves             */
     int32_t ld_rows;               /* columns per row of W1_rows, multiple of 32, >= D                                            */
-    int32_t ld_cols;               /* columns of W1_cols, multiple of 16, >= D                                                    */
-    int32_t w1_exp;                /* both images hold W1 * 2^w1_exp                                                              */
-    int32_t reserved;
+    int32_t ld_cols;               /* columns of W1_cols = in_stride (D_pad)                                                      */
+    int32_t w1_exp;                /* W1_rows and W1_cols hold W1 * 2^w1_exp                                                      */
+    int32_t w2_exp;                /* W2_gen holds W2 * 2^w2_exp                                                                  */
 } rbnn_split_images;
+
+/* per-problem scratch of the split mode */
+typedef struct rbnn_split_workspace {
+    void  *X_split;                /* [N, ld_rows] split-rows image of the current inputs (caller fills it with rbnn_split_rows) */
+    void  *dZ_gen;                 /* [S, N_pad, 64 B] dA-generator image of dZ, written by rbnn_fc_input_grad_split              */
+    float *g_scale;                /* [N_pad] per-point 2^-e(n) of that image                                                     */
+} rbnn_split_workspace;
+typedef struct rbnn_split_workspace_sizes { size_t X_split, dZ_gen, g_scale; } rbnn_split_workspace_sizes;
+
+int rbnn_split_workspace_query(const rbnn_posterior *net, const rbnn_split_images *sp, int32_t n_points,
+                               int32_t n_samples, rbnn_split_workspace_sizes *out);
 
 /* dst[r, g, 0, :] = fp16(v), dst[r, g, 1, :] = fp16(v - hi) for v = src[r, 8g..8g+7] * 2^scale_exp (0 past `cols`):
  * the split-rows image [rows, ld_dst/8, 2, 8] halves of a row-major fp32 matrix.  ld_dst % 32 == 0.
@@ -239,11 +251,28 @@ typedef struct rbnn_split_images {
 int rbnn_split_rows(const float *src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp, void *dst,
                     int32_t ld_dst, void *stream);
 
+/* Split-cols image of n_mats row-major [rows, ld_src] matrices (rows % 32 == 0):
+ * dst[m, hb, lg, p, d, j] = (p ? lo : hi) of W[m, 32*hb + 16*(j>>2) + 4*lg + (j&3), d] * 2^scale_exp, 8 halves j per
+ * 16-byte unit, ld_dst columns (% 16 == 0, zero past `cols`).  One-off at posterior load. */
+int rbnn_split_cols(const float *W, int64_t n_mats, int32_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                    void *dst, int32_t ld_dst, void *stream);
+
+/* dA-generator image of the output layer W2 [n_mats, C, H] (C <= 10): per 16 hidden units one 1-KiB tile holding,
+ * per MFMA lane, the W2 side (hi, lo, hi) of the 30 K slots 10*p + c.  One-off at posterior load. */
+int rbnn_split_w2gen(const float *W2, int32_t n_mats, int32_t n_classes, int32_t hidden, int32_t scale_exp, void *dst,
+                     void *stream);
+
 /* rbnn_fc_forward in split precision: same outputs (ws->P, ws->mask1 / ws->dact1), inputs as split-rows images:
  * X_split = rbnn_split_rows(X, N, D, ldx_src, x_exp, ., ldx) with ldx == sp->ld_rows. */
 int rbnn_fc_forward_split(const rbnn_posterior *net, const rbnn_split_images *sp, const void *X_split, int32_t ldx,
                           int32_t x_exp, int32_t n_points, const int32_t *sample_idx, int32_t n_samples,
                           int32_t out_kind, const rbnn_workspace *ws, void *stream);
+
+/* rbnn_fc_input_grad in split precision: same slabs (ws->slabs, already un-scaled), from ws->dZ and ws->mask1.
+ * relu / leaky, n_classes <= 10.  Re-scales dZ per point (2^e(n), so vanishing gradients keep their 22 bits). */
+int rbnn_fc_input_grad_split(const rbnn_posterior *net, const rbnn_split_images *sp, const int32_t *sample_idx,
+                             int32_t n_samples, int32_t n_points, int32_t chunk, const rbnn_workspace *ws,
+                             const rbnn_split_workspace *sws, int32_t *n_slabs_out, void *stream);
 
 #ifdef __cplusplus
 }

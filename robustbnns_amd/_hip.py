@@ -56,8 +56,19 @@ class ConvWorkspaceSizes(C.Structure):
 
 
 class SplitImages(C.Structure):
-    _fields_ = [("W1_rows", _fp), ("W1_cols", _fp), ("ld_rows", C.c_int32), ("ld_cols", C.c_int32),
-                ("w1_exp", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("W1_rows", _fp), ("W1_cols", _fp), ("W2_gen", _fp), ("ld_rows", C.c_int32), ("ld_cols", C.c_int32),
+                ("w1_exp", C.c_int32), ("w2_exp", C.c_int32)]
+
+
+SPLIT_WS_KEYS = ("X_split", "dZ_gen", "g_scale")
+
+
+class SplitWorkspace(C.Structure):
+    _fields_ = [(k, _fp) for k in SPLIT_WS_KEYS]
+
+
+class SplitWorkspaceSizes(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in SPLIT_WS_KEYS]
 
 
 WS_KEYS = ("P", "dZ", "mask1", "dact1", "hid1", "mask2", "dact2", "dhid1", "slabs")
@@ -85,6 +96,11 @@ SIGNATURES = {
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "rbnn_split_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _i32, _fp]),
     "rbnn_fc_forward_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _i32, _fp, _i32, _i32, _PW, _fp]),
+    "rbnn_split_cols": (_i32, [_fp, _i64, _i32, _i32, _i32, _i32, _fp, _i32, _fp]),
+    "rbnn_split_w2gen": (_i32, [_fp, _i32, _i32, _i32, _i32, _fp, _fp]),
+    "rbnn_split_workspace_query": (_i32, [_PP, C.POINTER(SplitImages), _i32, _i32, C.POINTER(SplitWorkspaceSizes)]),
+    "rbnn_fc_input_grad_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(SplitWorkspace),
+                                        C.POINTER(_i32), _fp]),
 }
 
 _lib = None
@@ -218,6 +234,32 @@ class HipKernels:
         w = self._ws(ws)
         check(self.lib.rbnn_fc_forward_split(C.byref(net.descriptor()), C.byref(images), ptr(Xs), ld, x_exp, N, ptr(sidx), S,
                                              out_kind, C.byref(w), stream_of(Xs)), "rbnn_fc_forward_split")
+
+    def split_cols(self, W, rows, cols, scale_exp, out, ld_dst):
+        """W: [n_mats, rows, ld_src] fp32 -> out: split-cols image."""
+        require_gpu(W, "W")
+        check(self.lib.rbnn_split_cols(ptr(W), W.numel() // (rows * W.shape[-1]), rows, cols, W.shape[-1], scale_exp, ptr(out),
+                                       ld_dst, stream_of(W)), "rbnn_split_cols")
+
+    def split_w2gen(self, W2, Cn, H, scale_exp, out):
+        require_gpu(W2, "W2")
+        check(self.lib.rbnn_split_w2gen(ptr(W2), W2.numel() // (Cn * H), Cn, H, scale_exp, ptr(out), stream_of(W2)), "rbnn_split_w2gen")
+
+    def split_workspace_sizes(self, net, images, N, S):
+        out = SplitWorkspaceSizes()
+        check(self.lib.rbnn_split_workspace_query(C.byref(net.descriptor()), C.byref(images), N, S, C.byref(out)),
+              "rbnn_split_workspace_query")
+        return {k: getattr(out, k) for k in SPLIT_WS_KEYS}
+
+    def fc_input_grad_split(self, net, images, sidx, S, N, chunk, ws, sws):
+        w = self._ws(ws)
+        sw = SplitWorkspace()
+        for k in SPLIT_WS_KEYS:
+            setattr(sw, k, ptr(sws.get(k)))
+        n = C.c_int32(0)
+        check(self.lib.rbnn_fc_input_grad_split(C.byref(net.descriptor()), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
+                                                C.byref(sw), C.byref(n), stream_of(ws["dZ"])), "rbnn_fc_input_grad_split")
+        return n.value
 
     # -- conv architecture ---------------------------------------------------------------------------
     def conv_workspace_sizes(self, net, N, S):

@@ -276,6 +276,289 @@ int launch_forward_split_act(const FwdSplitArgs& a, hipStream_t st) {
     return RBNN_ERR_UNSUPPORTED;
 }
 
+
+// ===================================================================================================
+// Image builders of the backward.
+// ===================================================================================================
+// W1 "split cols" image, the backward's B operand: out[m][hb][lg][p][d][j] (p = 0 hi, 1 lo; 8 halves j) =
+// split(W[m][32*hb + 16*(j>>2) + 4*lg + (j&3)][d] * scale): lane (d = li, lg) of the main MFMA reads its 8 K values
+// (K slot 8*lg + j  <->  hidden unit 32*hb + 16*(j>>2) + 4*lg + (j&3), the order the dA generator leaves them in)
+// as one 16-byte hi and one 16-byte lo read.  One thread per (m, hb, lg, d).
+__global__ void split_cols_kernel(const float* __restrict__ W, long long n_mats, int rows, int cols, int ld_src, float scale,
+                                  uint4* __restrict__ dst, int ld_dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int HB = rows / 32;
+    if (i >= n_mats * HB * 4 * ld_dst) return;
+    const int d = (int)(i % ld_dst);
+    const int lg = (int)((i / ld_dst) % 4);
+    const long long mh = i / (4LL * ld_dst);                   // m * HB + hb
+    const long long m = mh / HB;
+    const int hb = (int)(mh % HB);
+    union { f16x8 v; uint4 u; } hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int h = 32 * hb + 16 * (j >> 2) + 4 * lg + (j & 3);
+        const float v = (d < cols) ? W[(m * rows + h) * ld_src + d] * scale : 0.f;
+        const _Float16 x = (_Float16)v;
+        hi.v[j] = x;
+        lo.v[j] = (_Float16)(v - (float)x);
+    }
+    const long long base = ((mh * 4 + lg) * 2) * ld_dst;       // 16-byte units
+    dst[base + d] = hi.u;
+    dst[base + ld_dst + d] = lo.u;
+}
+
+// K-slot plan of the dA generator MFMA (one v_mfma_f32_16x16x32_f16 forms all three products of the C <= 10 classes):
+//   slot sigma = 10*p + c (p = 0,1,2; c < 10):   W2 side  hi, lo, hi      dZ side  hi, hi, lo      slots 30, 31 zero.
+// W2 generator image: out[m][t][lane][j] = W2 side of slot 8*lg + j for hidden unit 16*t + li (li = lane & 15,
+// lg = lane >> 4): 1 KiB per 16-unit tile, each lane's A operand at lane*16.  One thread per (m, t, lane).
+__global__ void split_w2gen_kernel(const float* __restrict__ W2, int n_mats, int C, int H, float scale, uint4* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_mats * (H / 16) * 64) return;
+    const int lane = (int)(i & 63), li = lane & 15, lg = lane >> 4;
+    const int t = (int)((i >> 6) % (H / 16));
+    const long long m = (i >> 6) / (H / 16);
+    union { f16x8 v; uint4 u; } o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int sg = 8 * lg + j, p = sg / 10, c = sg % 10;
+        _Float16 r = (_Float16)0.f;
+        if (sg < 30 && c < C) {
+            const float v = W2[(m * C + c) * H + 16 * t + li] * scale;
+            const _Float16 x = (_Float16)v;
+            r = (p == 1) ? (_Float16)(v - (float)x) : x;
+        }
+        o.v[j] = r;
+    }
+    dst[i] = o.u;
+}
+
+// dZ generator image + per-point scale.  One thread per point n < N_pad: e(n) = 13 - ilogb(max_{s,c} |dZ[s][n][c]|),
+// so max |dZ| * 2^e(n) lies in [2^13, 2^14); out[s][n][chunk ^ ((n >> 2) & 3)][j] = dZ side of slot 8*chunk + j of
+// dZ[s][n][:] * 2^e(n) (the chunk swizzle makes the 16-lane ds_read_b128 groups of the generator conflict-free: a
+// point is 64 B); gscale[n] = 2^-e(n).  Points n >= N get zeros.
+__global__ void split_dz_kernel(const float* __restrict__ dZ, int S, int N, long long N_pad, int C,
+                                uint4* __restrict__ dst, float* __restrict__ gscale) {
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N_pad) return;
+    float m = 0.f;
+    if (n < N)
+        for (int s = 0; s < S; ++s) {
+            const float* const p = dZ + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *(const f32x4*)(p + 4 * q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * q + r < C) m = fmaxf(m, fabsf(v[r]));
+            }
+        }
+    int e = 0;
+    if (m > 0.f && m < INFINITY) e = min(13 - ilogbf(m), 120);
+    gscale[n] = ldexpf(1.f, -e);
+    const int sw = (int)((n >> 2) & 3);
+    for (int s = 0; s < S; ++s) {
+        _Float16 hi[10], lo[10];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            float v = 0.f;
+            if (n < N && c < C) v = ldexpf(dZ[((long long)s * N + n) * RBNN_CPAD + c], e);
+            hi[c] = (_Float16)v;
+            lo[c] = (_Float16)(v - (float)hi[c]);
+        }
+        uint4* const o = dst + ((long long)s * N_pad + n) * 4;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            union { f16x8 v; uint4 u; } w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int sg = 8 * ch + j, p = sg / 10, c = sg % 10;
+                w.v[j] = (sg >= 30) ? (_Float16)0.f : (p == 2 ? lo[c] : hi[c]);
+            }
+            o[ch ^ sw] = w.u;
+        }
+    }
+}
+
+// ===================================================================================================
+// S2: input gradient, split precision.  One block = one (256-point tile, TD*16-column group, chunk of samples) item,
+// 4 waves of 64 points (NTW = 4 point tiles each):
+//   acc[n][d] += sum_h dA[n][h] * W1[s][h][d],   dA[n][h] = act'(A_s[n][h]) * sum_c dZ[s][n][c] * W2[s][c][h]
+// A stage is 32 hidden units of one sample = ONE K step of the f16 MFMA:
+//   generator  (dA^T)[h][n] for the stage's two 16-unit tiles: one f16 MFMA per (tile, point tile) whose 32 K slots
+//              hold the three split products of the <= 10 classes (slot plan above), fp32 result;
+//   split      x act' (1-bit stash) x 2^GEN_Q on the VALU, then hi/lo halves: the accumulator layout
+//              (register r of tile t on lane (n = li, lg) is unit 16*t + 4*lg + r) IS the A-operand layout of the
+//              main MFMA with K slot 8*lg + 4*t + r — the map the split-cols image of W1 is built for;
+//   main       3 f16 MFMAs per (point tile, column tile), B operand (W1 hi / lo) from the stage's LDS tile.
+// Everything a stage needs arrives by LDS-DMA one stage ahead (W1 tile, W2 generator tiles, stash words); the next
+// sample's dZ generator image (16 KiB per block) rides along, one 1-KiB piece per stage.
+// ===================================================================================================
+#define GEN_Q (-17)                                           // |generator| <= 16 * 2^14 * 2^14 = 2^32  ->  |dA| <= 2^15 < fp16 max
+
+struct GradSplitArgs {
+    const char* dzg;  long long n_pad;  const float* gscale;  const uint32_t* mask;
+    const char* W1c;  int ldc;                                  // split-cols image, ldc columns
+    const char* W2g;                                            // generator image [S_total][H/16][1 KiB]
+    int H;  int HW;  const int* sidx;  int S;  int chunk;  int nchunks;
+    int N;  int NT;  int ND;  int Dt;
+    float* out;  int ldo;  float out_scale;                     // slabs [nchunks][N][ldo]; out_scale = 2^-(e_w2 + GEN_Q + e_w1)
+};
+
+template <int ACT, int TD>
+__global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitArgs a) {
+    static_assert(ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY, "1-bit stash activations only");
+    constexpr int NTW = 4, BM = 256, LD = TD * 16;
+    constexpr int W1B = 8 * LD * 16;                           // bytes: [4 lg][2 hi/lo][LD columns][16 B]
+    constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + 3) / 4;
+    constexpr int BUFB = W1B + 2048 + 1024;                    // + 2 generator tiles + 256 stash words
+    constexpr int DZB = BM * 64;                               // dZ generator image of the block's points, one sample
+    static_assert(W1B % 1024 == 0, "whole DMA pieces");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * BUFB + 2 * DZB bytes
+    char* const ldsb = (char*)lds;
+    char* const dzl = ldsb + 2 * BUFB;
+
+    int id;
+    if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
+    const int ntile = id % a.NT, dg = (id / a.NT) % a.ND, ch = id / (a.NT * a.ND);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int nb = ntile * BM + wave * (NTW * 16);
+    const int dc0 = dg * LD;
+    const int Dp = a.Dt * 16;
+    const int s_begin = ch * a.chunk, s_end = min(a.S, s_begin + a.chunk);
+    const int HS = a.H / 32, nst = (s_end - s_begin) * HS;
+    // dZ-image pieces of the NEXT sample ride on the stages hb >= 1 of a sample (16 pieces per sample).  Stage hb = 0 is
+    // issued while the previous sample's last stage still reads the buffer they would land in.
+    const int DZPS = (16 + HS - 2) / (HS - 1);
+
+    // per-lane source offsets (bytes, relative to the stage's image base) of this wave's W1 pieces
+    int goff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int f = (wave + 4 * i) * 1024 + lane * 16, seg = f / (LD * 16), d = (f % (LD * 16)) >> 4;
+        goff[i] = (seg * a.ldc + min(dc0 + d, a.ldc - 1)) * 16;   // columns past the image: any valid address, never stored
+    }
+
+    f32x4 acc[NTW][TD];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto dz_issue = [&](int s, int piece, int dzbuf) {          // 16 points x 64 B of sample s -> dzl[dzbuf]
+        glds16((const float*)(a.dzg + (((long long)s * a.n_pad + ntile * BM + piece * 16) * 64) + lane * 16),
+               (float*)(dzl + dzbuf * DZB + piece * 1024));
+    };
+    auto stage_issue = [&](int st, int buf) {
+        const int si = st / HS, hb = st % HS, s = s_begin + si;
+        const int sw = a.sidx ? a.sidx[s] : s;
+        const char* const Wb = a.W1c + ((long long)sw * HS + hb) * 8 * a.ldc * 16;
+        char* const B = ldsb + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            if (wave + 4 * i < NPIECE) glds16((const float*)(Wb + goff[i]), (float*)(B + (wave + 4 * i) * 1024));
+        if (wave >= 2)                                          // generator tiles 2*hb, 2*hb + 1 of this sample
+            glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb + (wave - 2)) * 1024) + lane * 16),
+                   (float*)(B + W1B + (wave - 2) * 1024));
+        if (wave == 1)                                          // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
+            glds16((const float*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM + 4 * lane), (float*)(B + W1B + 2048));
+        if (s + 1 < s_end) {                                    // next sample's dZ image, spread over this sample's stages
+            for (int j = 0; j < DZPS && hb >= 1; ++j) {
+                const int piece = (hb - 1) * DZPS + j;
+                if (piece < 16 && (piece & 3) == wave) dz_issue(s + 1, piece, (si + 1) & 1);
+            }
+        }
+    };
+
+    for (int piece = wave; piece < 16; piece += 4) dz_issue(s_begin, piece, 0);
+    stage_issue(0, 0);
+    ring_wait_barrier<0>();
+    const float c_pos = ldexpf(1.f, GEN_Q), c_neg = (ACT == RBNN_ACT_RELU) ? 0.f : LEAKY_SLOPE * ldexpf(1.f, GEN_Q);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1, dzbuf = (st / HS) & 1;
+        if (st + 1 < nst) stage_issue(st + 1, buf ^ 1);
+        const char* const B = ldsb + buf * BUFB;
+
+        // ---- generator + split: da_hi / da_lo[nt] = A operand of the main MFMA for this wave's 4 point tiles ----
+        f16x8 da_hi[NTW], da_lo[NTW];
+        {
+            const f16x8 w2g0 = *(const f16x8*)(B + W1B + lane * 16);
+            const f16x8 w2g1 = *(const f16x8*)(B + W1B + 1024 + lane * 16);
+            const unsigned* const Mk = (const unsigned*)(B + W1B + 2048) + wave * 64 + li;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const f16x8 dz = *(const f16x8*)(dzl + dzbuf * DZB + (wave * 64 + nt * 16 + li) * 64 + ((lg ^ ((li >> 2) & 3)) * 16));
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 g0 = MFMA_H(w2g0, dz, z), g1 = MFMA_H(w2g1, dz, z);
+                const unsigned mw = Mk[nt * 16] >> (4 * lg);    // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = g0[r] * (((mw >> r) & 1u) ? c_pos : c_neg);
+                    const float v1 = g1[r] * (((mw >> (16 + r)) & 1u) ? c_pos : c_neg);
+                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                    da_hi[nt][r] = h0;      da_lo[nt][r] = (_Float16)(v0 - (float)h0);
+                    da_hi[nt][4 + r] = h1;  da_lo[nt][4 + r] = (_Float16)(v1 - (float)h1);
+                }
+            }
+        }
+        // ---- main: column-tile major, B operand double-buffered one column tile ahead ----
+        const char* const Bw = B + (lg * 2 * LD + li) * 16;
+        f16x8 bh = *(const f16x8*)(Bw), bl = *(const f16x8*)(Bw + LD * 16), bh_n = bh, bl_n = bl;
+#pragma unroll
+        for (int dt = 0; dt < TD; ++dt) {
+            if (dt + 1 < TD) {
+                bh_n = *(const f16x8*)(Bw + (dt + 1) * 256);
+                bl_n = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_lo[nt], bh, acc[nt][dt]);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_hi[nt], bl, acc[nt][dt]);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_hi[nt], bh, acc[nt][dt]);
+            bh = bh_n; bl = bl_n;
+        }
+        ring_wait_barrier<0>();                                // next stage landed; everyone is done with this one
+    }
+
+    // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li], un-scaled per point ----
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nb + nt * 16 + 4 * lg + r;
+            if (n >= a.N) continue;
+            const float gs = a.gscale[n];
+            float* const dst = a.out + ((long long)ch * a.N + n) * a.ldo;
+#pragma unroll
+            for (int dt = 0; dt < TD; ++dt) {
+                const int d = dc0 + dt * 16 + li;
+                if (d < Dp) dst[d] = acc[nt][dt][r] * a.out_scale * gs;
+            }
+        }
+}
+
+template <int ACT, int TD>
+int launch_grad_split_td(GradSplitArgs a, hipStream_t st) {
+    constexpr int LDSB = 2 * (8 * TD * 16 * 16 + 3072) + 2 * 256 * 64;
+    a.NT = (a.N + 255) / 256;
+    a.ND = (a.Dt + TD - 1) / TD;
+    auto kern = fc_grad_split_kernel<ACT, TD>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return RBNN_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, st, a);
+    return launch_status();
+}
+
+template <int ACT>
+int launch_grad_split(const GradSplitArgs& a, hipStream_t st) {
+    if (a.Dt % 7 == 0) return launch_grad_split_td<ACT, 7>(a, st);
+    return launch_grad_split_td<ACT, 4>(a, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -323,6 +606,78 @@ int rbnn_fc_forward_split(const rbnn_posterior* net, const rbnn_split_images* sp
 #endif
     }
     return RBNN_ERR_UNSUPPORTED;
+}
+
+int rbnn_split_cols(const float* W, int64_t n_mats, int32_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                    void* dst, int32_t ld_dst, void* stream) {
+    if (!W || !dst) return RBNN_ERR_NULL;
+    if (n_mats < 1 || rows < 32 || (rows & 31) || cols < 1 || ld_src < cols || ld_dst < cols || (ld_dst & 15)) return RBNN_ERR_SHAPE;
+    if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(dst)) return RBNN_ERR_ALIGN;
+    const long long total = (long long)n_mats * (rows / 32) * 4 * ld_dst;
+    hipLaunchKernelGGL(split_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W, (long long)n_mats, rows, cols, ld_src, ldexpf(1.f, scale_exp), (uint4*)dst, ld_dst);
+    return launch_status();
+}
+
+int rbnn_split_w2gen(const float* W2, int32_t n_mats, int32_t C, int32_t H, int32_t scale_exp, void* dst, void* stream) {
+    if (!W2 || !dst) return RBNN_ERR_NULL;
+    if (n_mats < 1 || C < 1 || C > 10 || H < 16 || (H & 15)) return RBNN_ERR_SHAPE;
+    if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(dst)) return RBNN_ERR_ALIGN;
+    const long long total = (long long)n_mats * (H / 16) * 64;
+    hipLaunchKernelGGL(split_w2gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W2, n_mats, C, H, ldexpf(1.f, scale_exp), (uint4*)dst);
+    return launch_status();
+}
+
+int rbnn_split_workspace_query(const rbnn_posterior* net, const rbnn_split_images* sp, int32_t N, int32_t S,
+                               rbnn_split_workspace_sizes* out) {
+    if (!net || !sp || !out) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || sp->ld_rows < net->in_features || (sp->ld_rows & 31)) return RBNN_ERR_SHAPE;
+    rbnn_split_workspace_sizes z = {};
+    z.X_split = (size_t)N * sp->ld_rows * 4;
+    z.dZ_gen = (size_t)S * mask_ld(N) * 64;
+    z.g_scale = (size_t)mask_ld(N) * sizeof(float);
+    *out = z;
+    return RBNN_OK;
+}
+
+int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images* sp, const int32_t* sidx, int32_t S,
+                             int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_split_workspace* sws,
+                             int32_t* n_slabs_out, void* stream) {
+    if (!net || !sp || !ws || !sws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
+    if (!sp->W1_cols || !sp->W2_gen || !sws->dZ_gen || !sws->g_scale) return RBNN_ERR_NULL;
+    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
+    if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
+    if (sp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
+    if (!aligned16(sp->W1_cols) || !aligned16(sp->W2_gen) || !aligned16(sws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (chunk <= 0) {                                           // the exact mode's slab plan (same workspace)
+        rbnn_workspace_sizes q;
+        const int rc = rbnn_workspace_query(net, N, S, 0, &q);
+        if (rc) return rc;
+        chunk = q.chunk;
+    }
+    if (chunk > S) chunk = S;
+    const int nchunks = (S + chunk - 1) / chunk;
+    if (n_slabs_out) *n_slabs_out = nchunks;
+    const long long n_pad = mask_ld(N);
+    hipLaunchKernelGGL(split_dz_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st,
+                       ws->dZ, S, N, n_pad, C, (uint4*)sws->dZ_gen, sws->g_scale);
+    if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
+    GradSplitArgs g = {};
+    g.dzg = (const char*)sws->dZ_gen; g.n_pad = n_pad; g.gscale = sws->g_scale; g.mask = ws->mask1;
+    g.W1c = (const char*)sp->W1_cols; g.ldc = sp->ld_cols; g.W2g = (const char*)sp->W2_gen;
+    g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.chunk = chunk; g.nchunks = nchunks;
+    g.N = N; g.Dt = Dp / 16; g.out = ws->slabs; g.ldo = Dp;
+    g.out_scale = ldexpf(1.f, -(sp->w2_exp + GEN_Q + sp->w1_exp));
+#ifndef RBNN_FAST_BUILD
+    if (net->activation == RBNN_ACT_RELU) return launch_grad_split<RBNN_ACT_RELU>(g, st);
+#endif
+    return launch_grad_split<RBNN_ACT_LEAKY>(g, st);
 }
 
 }  // extern "C"
