@@ -16,8 +16,13 @@ job has 100*N samples: weak scaling) and each step all-reduces sum_s p_s [N,16] 
 [N,784] over RCCL/xGMI (north star).  `--shard points` replicates the samples and
 splits points instead (no collective).
 
-The JSON line carries `roofline` for the dominant kernel (fc_grad_kernel; fc_forward_kernel is listed beside it
-under roofline.kernels), timed with HIP events on the launch stream inside the timed region, and
+Precision (`--precision`, default auto): the two GEMMs run either on the fp32 MFMA ("exact") or as error-compensated
+half pairs on the f16 MFMA pipe ("split": three f16 products per fp32 product, fp32 accumulation, 2^-22 per product;
+parity-tested to the same 1e-5 bar).  auto = split for this workload.  The line's top level is the mode that ran;
+at N=1 the other mode is timed afterwards and reported under `exact_fp32_mode` for reference.
+
+The JSON line carries `roofline` for the dominant kernel (the input-gradient kernel; the forward kernel is listed
+beside it under roofline.kernels), timed with HIP events on the launch stream inside the timed region, and
 `cpu_baseline`: the loop-structured oracle port (oracle/bnn_oracle.py::loop_attack — the reference's batch-1
 autograd nest) timed on this host's cores on a bounded sample of the same workload.
 """
@@ -33,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense, = fp32 vector peak
+F16_MFMA_PEAK_TFLOPS = 2516.6          # v_mfma_f32_16x16x32_f16: 16 cyc/SIMD -> 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz ("~2.5 PF dense")
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -99,6 +105,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--points", type=int, default=0, help="override N (debug)")
     ap.add_argument("--samples", type=int, default=0, help="override S per GPU (debug)")
+    ap.add_argument("--precision", default="auto", choices=["auto", "exact", "split"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,83 +157,120 @@ def main():
         def fc_input_grad(self, *a):
             return self._timed("fc_input_grad", super().fc_input_grad, *a)
 
+        def fc_forward_split(self, *a):
+            return self._timed("fc_forward", super().fc_forward_split, *a)
+
+        def fc_input_grad_split(self, *a):                               # includes the small dZ re-scaling kernel
+            return self._timed("fc_input_grad", super().fc_input_grad_split, *a)
+
         def conv_forward(self, *a):
             return self._timed("conv_forward", super().conv_forward, *a)
 
         def conv_input_grad(self, *a):
             return self._timed("conv_input_grad", super().conv_input_grad, *a)
 
-    kern = TimedKernels()
     if args.shard == "samples":
-        eng = make_engine(sp, kernels=kern, group=group, total_samples=w["S"] * world)
-        eng._S_total = w["S"] * world
         xs, ys, S_job, N_job = x, y, w["S"] * world, w["N"]
     else:
-        eng = make_engine(sp, kernels=kern)
         g = torch.Generator().manual_seed(4321 + rank)                # weak scaling: every rank its own N points
         xs = torch.rand((w["N"],) + w["shape"], generator=g, dtype=torch.float32) if rank else x
         ys, S_job, N_job = y, w["S"], w["N"] * world
     xs = xs.to(device)
     labels = ys.to(device=device, dtype=torch.int32)
 
-    def step():
-        if w["method"] == "fgsm":
-            return eng.fgsm(xs, labels, w["S"], w["eps"])
-        return eng.pgd(xs, labels, w["S"], w["eps"], alpha=None, iters=w["iters"])
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    kern.on = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    kern.on = False
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def run(precision):
+        """warmup, then EXACTLY --steps timed steps between barrier + synchronize; returns (engine precision, seconds, kernel events)."""
+        kern = TimedKernels()
+        if args.shard == "samples":
+            eng = make_engine(sp, kernels=kern, group=group, total_samples=w["S"] * world, precision=precision)
+            eng._S_total = w["S"] * world
+        else:
+            eng = make_engine(sp, kernels=kern, precision=precision)
 
-    if rank == 0:
-        units = N_job * S_job * w["iters"] * args.steps
-        # per-launch algorithmic flops of each GEMM kernel: half of SURVEY 8(d)'s 4*(D*H + H*C) per attack-sample
-        per_launch = 2.0 * (D * w["H"] + w["H"] * w["C"]) * w["N"] * w["S"]
-        if w["arch"] == "conv":       # 2*(460800 + 26214400*H/512 + 49*H*C) flop per (point, sample) per direction
-            per_launch = 2.0 * (460800 + 51200.0 * w["H"] + 49 * w["H"] * w["C"]) * w["N"] * w["S"]
+        def step():
+            if w["method"] == "fgsm":
+                return eng.fgsm(xs, labels, w["S"], w["eps"])
+            return eng.pgd(xs, labels, w["S"], w["eps"], alpha=None, iters=w["iters"])
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        kern.on = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kern.on = False
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return getattr(eng, "precision", "exact"), dt, kern.ev
+
+    # per-launch algorithmic flops of each GEMM kernel: half of SURVEY 8(d)'s 4*(D*H + H*C) per attack-sample
+    per_launch = 2.0 * (D * w["H"] + w["H"] * w["C"]) * w["N"] * w["S"]
+    if w["arch"] == "conv":       # SURVEY 8(d): 2*(460800 + 26214400*H/512 + 49*H*C) flop per (point, sample) per direction
+        per_launch = 2.0 * (460800 + 51200.0 * w["H"] + 49 * w["H"] * w["C"]) * w["N"] * w["S"]
+    KNAMES = {"exact": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel",
+                        "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel"},
+              "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel"}}
+
+    def roofline(mode, evs_by_name, ms_per_step):
         kernels = {}
-        for name, evs in kern.ev.items():
+        for name, evs in evs_by_name.items():
             ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
             kernels[name] = {"launches": len(evs), "avg_ms": ms, "tflops": per_launch / (ms * 1e-3) / 1e12 if ms else None}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and args.workload == "c2" and not args.points and not args.samples:
-            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(dom + ("_split" if mode == "split" else ""), {}).get("hbm_bytes_per_launch")
+        fp32_eq = kernels[dom]["tflops"]
+        r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
+             "flop_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
+        if mode == "split":
+            # matrix-pipe work of the split mode: 3 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
+            r.update({"achieved": 3.0 * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": 3.0 * fp32_eq / F16_MFMA_PEAK_TFLOPS,
+                      "pipe": "v_mfma_f32_16x16x32_f16, 3 products per fp32 MAC", "fp32_equivalent_tflops": fp32_eq,
+                      "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS})
+        else:
+            r.update({"achieved": fp32_eq, "peak": FP32_MFMA_PEAK_TFLOPS, "frac": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
+                      "pipe": "v_mfma_f32_16x16x4_f32"})
+        r["whole_step_tflops"] = 2 * per_launch / (1e-3 * ms_per_step / w["iters"]) / 1e12
+        return r
+
+    mode, dt, evs = run(args.precision)
+    other = None
+    if world == 1 and w["arch"] != "conv" and mode == "split" and args.precision == "auto":
+        other = run("exact")                                              # reference line: the exact-fp32 kernels on the same workload
+
+    if rank == 0:
+        units = N_job * S_job * w["iters"] * args.steps
+        ms_per_step = 1e3 * dt / args.steps
         out = {
             "metric": "attack-samples/sec (test_pts x posterior_samples x PGD_iters)",
             "value": units / dt, "unit": "attack-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 carried as f16 hi+lo pairs: 3 f16 MFMA products per fp32 product, f32 accumulate (2^-22 per product)" if mode == "split" else "f32",
+            "precision_mode": mode, "data": "synthetic",
             "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job,
                        "iters": w["iters"], "shard": args.shard if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel", "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel"}[dom],
-                         "achieved": kernels[dom]["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": kernels[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "flop_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels},
+            "roofline": roofline(mode, evs, ms_per_step),
         }
-        out["roofline"]["whole_step_tflops"] = 2 * per_launch / (1e-3 * out["ms_per_step"] / w["iters"]) / 1e12
+        if other is not None:
+            o_ms = 1e3 * other[1] / args.steps
+            out["exact_fp32_mode"] = {"value": units / other[1], "ms_per_step": o_ms, "roofline": roofline("exact", other[2], o_ms)}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -11,6 +11,11 @@ Reference loop nest (adversarialAttacks.py:118 -> :95 -> model_bnn.py:251, batch
                            (sharded: rbnn_sum_slabs -> all-reduce -> rbnn_attack_step)
 
 x, x0, the posterior and every intermediate stay resident in HBM for the whole attack.
+
+Precision modes of the two GEMMs (`precision=` / RBNN_PRECISION): "exact" = fp32 MFMA (rbnn_fc_forward /
+rbnn_fc_input_grad); "split" = error-compensated half pairs on the f16 MFMA pipe (rbnn_fc_forward_split /
+rbnn_fc_input_grad_split: 2^-22 per product, ~2.5x faster, same 1e-5 parity bar); "auto" (default) = split
+where the split kernels cover the posterior (fc, relu / leaky, hidden % 128 == 0, classes <= 10), else exact.
 torch supplies device memory, the current HIP stream and torch.distributed (RCCL); all arithmetic is
 in the HIP kernels behind `kernels` (robustbnns_amd._hip.HipKernels — there is no other backend in
 this package; tests inject a CPU fake to exercise the multi-process orchestration under gloo).
@@ -20,6 +25,7 @@ import os
 import torch
 
 from . import _hip
+from .posterior import scale_exp
 from ._hip import (LOSS_MEAN_LOGIT, LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_UPSTREAM, OUT_LOGITS, OUT_PROBS)
 
 _WS_DTYPE = {"mask1": torch.int32, "mask2": torch.int32}
@@ -51,7 +57,7 @@ class _DifferentiableForward(torch.autograd.Function):
 
 
 class AttackEngine:
-    def __init__(self, posterior, kernels=None, group=None, total_samples=None):
+    def __init__(self, posterior, kernels=None, group=None, total_samples=None, precision=None):
         """posterior: StackedPosterior holding THIS rank's samples.  group: a torch.distributed process
         group when the posterior is sample-sharded across ranks; total_samples: samples over
         all ranks (default: all-reduced once)."""
@@ -66,6 +72,17 @@ class AttackEngine:
                 self.world = max(self.world, 2)    # diagnostics: run the all-reduce path even in a 1-rank group
         self._S_total = total_samples
         self._ws_cache = {}
+        self.precision = self._resolve_precision(precision)
+        self._x_bound = None                    # max |x| over an attack's iterates, set by the attack loops (saves a sync per step)
+
+    def _resolve_precision(self, precision):
+        want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
+        if want not in ("auto", "exact", "split"):
+            raise ValueError(f"precision={want!r}: expected 'auto', 'exact' or 'split'")
+        ok = bool(getattr(self.post, "split_supported", lambda: False)()) and hasattr(self.k, "fc_forward_split")
+        if want == "split" and not ok:
+            raise _hip.HipError("precision='split' covers fc posteriors with relu/leaky, hidden % 128 == 0, classes <= 10 on the GPU")
+        return "split" if (want != "exact" and ok) else "exact"
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -128,6 +145,11 @@ class AttackEngine:
                     ws[name] = torch.empty(sizes[name] // 4, dtype=_WS_DTYPE.get(name, torch.float32), device=self.device)
             ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
             ws["G"] = torch.empty(N, self.post.Dp, dtype=torch.float32, device=self.device)
+            if self.precision == "split":
+                ssz = self.k.split_workspace_sizes(self.post, self.post.split_images(), N, S)
+                ws["split"] = {"X_split": torch.empty(ssz["X_split"] // 2, dtype=torch.int16, device=self.device),
+                               "dZ_gen": torch.empty(ssz["dZ_gen"] // 2, dtype=torch.int16, device=self.device),
+                               "g_scale": torch.empty(ssz["g_scale"] // 4, dtype=torch.float32, device=self.device)}
             if len(self._ws_cache) > 4:
                 self._ws_cache.clear()
             self._ws_cache[key] = ws
@@ -135,10 +157,28 @@ class AttackEngine:
 
     # ------------------------------------------------------------------ kernel hooks (overridden for the conv architecture)
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
-        self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
+        if self.precision != "split":
+            return self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
+        img = self.post.split_images()
+        bound = self._x_bound if self._x_bound is not None else float(Xp.abs().max())
+        x_exp = scale_exp(bound)
+        self.k.split_rows(Xp, self.post.D, x_exp, ws["split"]["X_split"], img.ld_rows)
+        self.k.fc_forward_split(self.post, img, ws["split"]["X_split"], img.ld_rows, x_exp, Xp.shape[0], sidx, S, out_kind, ws)
 
     def _grad_kernels(self, sidx, S, N, ws):
-        return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
+        if self.precision != "split":
+            return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
+        return self.k.fc_input_grad_split(self.post, self.post.split_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
+
+    def _bound_inputs(self, X0, iterates):
+        """Magnitude bound of the inputs an attack will feed the forward (the split images' power-of-two scale), taken
+        once per attack instead of once per step: FGSM differentiates at x0 itself; every later PGD iterate is
+        clamp(., 0, 1) of something (adversarialAttacks.py:105), so |x| <= max(|x0|, 1)."""
+        if self.precision != "split":
+            self._x_bound = None
+            return
+        m = float(X0.abs().max())
+        self._x_bound = max(1.0, m) if iterates else m
 
     # ------------------------------------------------------------------ forward
     def forward_padded(self, Xp, sidx, S, out_kind=OUT_PROBS, out=None):
@@ -234,7 +274,11 @@ class AttackEngine:
         """adversarialAttacks.fgsm_attack on every row of x (adversarialAttacks.py:69-83)."""
         sidx, S = self.sample_index(n_samples, seeds)
         X = self.pad_inputs(x, clone=True)
-        self._step(X, None, to_labels(y, self.device), sidx, S, mode, None, float(epsilon), 0.0, False)
+        self._bound_inputs(X, iterates=False)
+        try:
+            self._step(X, None, to_labels(y, self.device), sidx, S, mode, None, float(epsilon), 0.0, False)
+        finally:
+            self._x_bound = None
         return self.unpad(X, x)
 
     def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=LOSS_MEAN_PROB):
@@ -248,8 +292,12 @@ class AttackEngine:
         if alpha is None:
             alpha_t = torch.empty(X.shape[0], dtype=torch.float32, device=self.device)
             self.k.pgd_alpha(X0, self.post.D, alpha_t)
-        for _ in range(iters):
-            self._step(X, X0, labels, sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
+        self._bound_inputs(X0, iterates=True)
+        try:
+            for _ in range(iters):
+                self._step(X, X0, labels, sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
+        finally:
+            self._x_bound = None
         return self.unpad(X, x)
 
     def pgd_continue(self, x, x0, y, n_samples, epsilon, alpha=None, mode=LOSS_MEAN_PROB):

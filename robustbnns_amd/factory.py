@@ -22,6 +22,7 @@ def posterior_from_modules(nets, device):
                                       n0.output_size, n0.hidden_size, device)
 
 
-def make_engine(post, kernels=None, group=None, total_samples=None):
-    cls = ConvEngine if getattr(post, "arch", None) == "conv" else AttackEngine
-    return cls(post, kernels=kernels, group=group, total_samples=total_samples)
+def make_engine(post, kernels=None, group=None, total_samples=None, precision=None):
+    if getattr(post, "arch", None) == "conv":
+        return ConvEngine(post, kernels=kernels, group=group, total_samples=total_samples)
+    return AttackEngine(post, kernels=kernels, group=group, total_samples=total_samples, precision=precision)

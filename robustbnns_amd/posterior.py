@@ -12,6 +12,7 @@ At MNIST fc-512 one sample is 1.63 MB, so S=2000 is 3.3 GB of the 288 GB HBM3E: 
 stays resident and every kernel indexes it by sample.
 """
 import ctypes as C
+import math
 
 import torch
 
@@ -27,6 +28,13 @@ def round_up(v, m):
 
 def padded_hidden(H):
     return max(32, H)
+
+
+def scale_exp(max_abs, target=14):
+    """e with max_abs * 2^e <= 2^target: the power-of-two scale of a split-half image (rbnn_split_rows & co)."""
+    if not (max_abs > 0.0) or math.isinf(max_abs):
+        return 0
+    return max(-100, min(100, target - math.ceil(math.log2(max_abs))))
 
 
 class StackedPosterior:
@@ -65,6 +73,34 @@ class StackedPosterior:
         self.b2 = pad(w(keys[-1] + ".bias"), (self.C,))
         self._pack()
         self._desc = None
+        self._split = None
+
+    # ------------------------------------------------------------------ split-half ("f16x3") precision mode
+    def split_supported(self):
+        """The split kernels cover the headline family: fc, relu / leaky, hidden % 128 == 0, classes <= 10."""
+        return (self.arch == "fc" and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
+                and self.device.type == "cuda")
+
+    def split_images(self):
+        """rbnn_split_images of this posterior (built once, resident): W1 as split rows (forward A operand), W1 as
+        split cols (backward B operand), W2 as the dA-generator image.  Same footprint as W1 each."""
+        if self._split is None:
+            k = _hip.HipKernels()
+            S, H, Dp, D, Cn = self.S, self.Hp, self.Dp, self.D, self.C
+            ld = round_up(D, 32)
+            w1_exp = scale_exp(float(self.W1.abs().max()))
+            w2_exp = scale_exp(float(self.W2.abs().max()))
+            rows = torch.empty(S * H, ld * 2, dtype=torch.int16, device=self.device)
+            cols = torch.empty(S * (H // 32) * 8 * Dp * 8, dtype=torch.int16, device=self.device)
+            gen = torch.empty(S * (H // 16) * 512, dtype=torch.int16, device=self.device)
+            k.split_rows(self.W1, D, w1_exp, rows, ld)
+            k.split_cols(self.W1, H, D, w1_exp, cols, Dp)
+            k.split_w2gen(self.W2, Cn, H, w2_exp, gen)
+            img = _hip.SplitImages()
+            img.W1_rows, img.W1_cols, img.W2_gen = rows.data_ptr(), cols.data_ptr(), gen.data_ptr()
+            img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = ld, Dp, w1_exp, w2_exp
+            self._split = (img, rows, cols, gen)                # the tensors keep the device memory alive
+        return self._split[0]
 
     def _pack(self):
         """rbnn_pack_rows4 images [S, H/4, cols, 4] of W1 (and Wm): the backward GEMM's B-operand layout."""
@@ -128,6 +164,6 @@ class StackedPosterior:
         for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
             t = getattr(self, name)
             setattr(out, name, None if t is None else t[lo:hi].contiguous())
-        out.S, out._desc = hi - lo, None
+        out.S, out._desc, out._split = hi - lo, None, None
         out._pack()
         return out

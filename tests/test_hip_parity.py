@@ -2,7 +2,9 @@
   (1) the golden vectors produced by the reference's own functions (tests/golden/*.npz),
   (2) the fp64 oracle on seeded inputs at sizes it finishes in seconds (ragged N, every H config),
   (3) size-independent properties at BASELINE.json's full size (N=10 000, S=100).
-Tolerance: 1e-5 relative to each point's largest component (north star), fp32 arithmetic throughout.
+Tolerance: 1e-5 relative to each point's largest component (north star).  Both precision modes of the two GEMMs
+are held to it: "exact" (fp32 MFMA) and "split" (error-compensated half pairs on the f16 MFMA pipe, what "auto"
+picks for fc / relu|leaky / hidden % 128 == 0 / classes <= 10) — every case the split kernels cover runs in both.
 Adversarial images: equal except where |g| < tau * max|g| (a sign flip there is within fp32 noise)."""
 import numpy as np
 import pytest
@@ -28,6 +30,22 @@ def _need_gpu():
     _hip.load()
 
 
+def split_covers(arch, act, H, C):
+    return arch == "fc" and act in ("relu", "leaky") and max(32, H) % 128 == 0 and C <= 10
+
+
+def exact_covers(H):
+    H = max(32, H)
+    return (H % 512 == 0) or (H <= 256 and H & (H - 1) == 0)          # include/robustbnns_hip.h: 32..256 powers of two, or k*512
+
+
+def modes_for(arch, act, H, C):
+    return ["auto", "exact"] if split_covers(arch, act, H, C) and exact_covers(H) else ["auto"]
+
+
+GOLDEN_MODES = [(n, m) for n in FC_CASES for m in (["auto", "exact"] if "_fc_h512_" in n else ["auto"])]
+
+
 def make_bnn(g):
     from robustbnns_amd.model_bnn import BNN
     m = g.meta
@@ -44,10 +62,12 @@ def adv_equal(adv, ref, grad):
 
 
 # ------------------------------------------------------------------ (1) golden vectors, through the reference's call surface
-@pytest.mark.parametrize("name", FC_CASES)
-def test_golden_forward_and_gradients(golden, name):
+@pytest.mark.parametrize("name,precision", GOLDEN_MODES)
+def test_golden_forward_and_gradients(golden, name, precision, monkeypatch):
     from robustbnns_amd import lossGradients
+    monkeypatch.setenv("RBNN_PRECISION", precision)
     g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
+    assert bnn._engine.precision == ("split" if precision == "auto" and "_fc_h512_" in name else "exact")
     assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
     seeds = [int(s) for s in g.arr["forward_seeds"]]
     assert rel_err(bnn.forward(x.to(DEV), n_samples=len(seeds), seeds=seeds).cpu(), g.t("forward_probs_seeds")) < TOL
@@ -66,9 +86,10 @@ def test_golden_forward_and_gradients(golden, name):
     assert rel_err(G[:, :eng.post.D].cpu().reshape(x.shape), g.t("meanprob_grad")) < TOL
 
 
-@pytest.mark.parametrize("name", FC_CASES)
-def test_golden_attacks_and_evaluation(golden, name):
+@pytest.mark.parametrize("name,precision", GOLDEN_MODES)
+def test_golden_attacks_and_evaluation(golden, name, precision, monkeypatch):
     from robustbnns_amd import adversarialAttacks as A
+    monkeypatch.setenv("RBNN_PRECISION", precision)
     g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
     lab = y.argmax(-1)
     hyper = {"epsilon": m["eps"]}
@@ -140,15 +161,23 @@ ORACLE_CASES = [  # arch, act, shape, C, H, S, N, std
 ]
 
 
-@pytest.mark.parametrize("arch,act,shape,C,H,S,N,std", ORACLE_CASES)
-def test_against_fp64_oracle(arch, act, shape, C, H, S, N, std):
+ORACLE_CASES += [  # split-mode shapes: 4-column-tile grouping with a partial group, 2 and 10 classes, big / tiny weights and inputs
+    ("fc", "leaky", (1, 10, 10), 2, 128, 3, 300, 0.1), ("fc", "relu", (3, 8, 8), 7, 384, 2, 77, 0.1),
+    ("fc", "leaky", (1, 28, 28), 10, 640, 2, 513, 0.02), ("fc", "leaky", (1, 28, 28), 10, 128, 17, 30, 0.05),
+]
+ORACLE_MODES = [c + (m,) for c in ORACLE_CASES for m in modes_for(c[0], c[1], c[4], c[3])]
+
+
+@pytest.mark.parametrize("arch,act,shape,C,H,S,N,std,precision", ORACLE_MODES)
+def test_against_fp64_oracle(arch, act, shape, C, H, S, N, std, precision):
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
     D = int(np.prod(shape))
     post = O.synthetic_posterior(arch, D, H, C, S, std)
     x, y = O.synthetic_inputs(N, shape, C, seed=H + N)
     lab = y.argmax(-1)
     p64 = O.cast(post, torch.float64)
-    eng = AttackEngine(StackedPosterior(arch, act, shape, C, H, post, DEV))
+    eng = AttackEngine(StackedPosterior(arch, act, shape, C, H, post, DEV), precision=precision)
+    assert eng.precision == ("split" if precision == "auto" and split_covers(arch, act, H, C) else "exact")
     assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, arch, act, S)) < TOL
     assert rel_err(eng.forward(x, S, logits=True).cpu(), O.ensemble_forward(x.double(), p64, arch, act, S)) < TOL
     ok = O.kink_margin(x.double(), p64, arch, act, S) > KINK                  # gradients: away from activation kinks
@@ -167,6 +196,47 @@ def test_against_fp64_oracle(arch, act, shape, C, H, S, N, std):
         assert rel_err(eng.forward(x, 3, seeds=sub).cpu(), O.bnn_forward(x.double(), p64, arch, act, 3, seeds=sub)) < TOL
 
 
+@pytest.mark.parametrize("k", [-9, 7])
+def test_split_mode_operand_scales(k):
+    """Split precision carries every operand with a power-of-two scale taken from its largest magnitude: weights
+    2^k larger and inputs 2^k smaller (same products) must give the same parity, and so must vanishing gradients
+    (confident predictions: |dZ| down to 1e-12 — lossGradients.compute_vanishing_norms_idxs lives on those)."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    D, H, C, S, N = 784, 256, 10, 4, 150
+    post = O.synthetic_posterior("fc", D, H, C, 1, 0.05)
+    g = torch.Generator().manual_seed(9)                            # a tight posterior (samples agree) with a sharp output layer:
+    post = {k_: v.repeat(S, *([1] * (v.dim() - 1))) + 1e-3 * torch.randn((S,) + tuple(v.shape[1:]), generator=g) for k_, v in post.items()}
+    post["model.3.weight"] = post["model.3.weight"] * 40.0          # confident on ~half of the points: gradients from 1e-10 to 1
+    post["model.1.weight"] = post["model.1.weight"] * 2.0 ** k
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=5)
+    x = x * 2.0 ** (-k)
+    p64 = O.cast(post, torch.float64)
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision="split")
+    ref_p = O.bnn_forward(x.double(), p64, "fc", "leaky", S)
+    assert rel_err(eng.forward(x, S).cpu(), ref_p) < TOL
+    # use the predicted class as the label: p - y is then tiny wherever the net is confident (no fp32 cancellation noise in it)
+    lab = ref_p.argmax(-1)
+    ok = O.kink_margin(x.double(), p64, "fc", "leaky", S) > KINK * 2.0 ** 0
+    G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().reshape(x.shape)
+    ref = O.meanprob_gradients(x.double(), lab, p64, "fc", "leaky", S)
+    mags = ref.reshape(N, -1).abs().max(1)[0]
+    assert float(mags.min()) < 1e-3 * float(mags.max())           # the batch does span vanishing and ordinary gradients
+    # fp32 softmax: p - y carries ~6e-8 absolute noise, so points are compared where that is below the tolerance
+    cond = (1.0 - ref_p.max(-1)[0]) > 1e-2
+    assert int((ok & cond).sum()) >= 20
+    exact = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision="exact")
+    Ge = exact.gradient(exact.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().reshape(x.shape)
+    e_split = (G - ref).reshape(N, -1).abs().max(1)[0] / mags
+    e_exact = (Ge - ref).reshape(N, -1).abs().max(1)[0] / mags
+    # the sharp output layer (logits up to ~30) puts fp32 itself at the edge of the bar here: hold the split mode to the
+    # bar or to the exact fp32 kernels' own error, whichever is larger ...
+    assert float(e_split[ok & cond].max()) < max(TOL, 1.5 * float(e_exact[ok & cond].max()))
+    # ... and on the saturated points, where the fp32 dZ noise feeds both modes alike, to the same error as the exact mode
+    assert float(e_split[ok].max()) <= 2.0 * float(e_exact[ok].max()) + 1e-6
+    print(f"k={k}: cond points split {float(e_split[ok & cond].max()):.2e} exact {float(e_exact[ok & cond].max()):.2e}; "
+          f"all points split {float(e_split[ok].max()):.2e} exact {float(e_exact[ok].max()):.2e}")
+
+
 def test_upstream_gradient_mode_matches_autograd():
     """RBNN_LOSS_UPSTREAM: vector-Jacobian product of the mean-probability forward for an arbitrary dL/dp."""
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
@@ -183,15 +253,16 @@ def test_upstream_gradient_mode_matches_autograd():
 
 
 # ------------------------------------------------------------------ (3) properties at BASELINE.json's full size
-@pytest.fixture(scope="module")
-def full_size():
+@pytest.fixture(scope="module", params=["auto", "exact"])
+def full_size(request):
     from robustbnns_amd import AttackEngine, StackedPosterior
     D, H, C, S, N = 784, 512, 10, 100, 10000
     g = torch.Generator().manual_seed(7)
     post = {"model.1.weight": torch.randn(S, H, D, generator=g) * 0.05, "model.1.bias": torch.randn(S, H, generator=g) * 0.05,
             "model.3.weight": torch.randn(S, C, H, generator=g) * 0.05, "model.3.bias": torch.randn(S, C, generator=g) * 0.05}
     x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=11)
-    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV))
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision=request.param)
+    assert eng.precision == ("split" if request.param == "auto" else "exact")
     return eng, post, x, y
 
 

@@ -9,14 +9,14 @@ def rows(pattern):
             yield from csv.DictReader(fh)
 
 def short(name):
-    for k in ("fc_forward_kernel", "fc_grad_kernel", "reduce_samples", "loss_dlogits", "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"):
+    for k in ("fc_forward_split_kernel", "fc_grad_split_kernel", "split_dz_kernel", "split_rows_kernel", "fc_forward_kernel", "fc_grad_kernel", "reduce_samples", "loss_dlogits", "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"):
         if k in name:
             return k
     return name[:60]
 
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for r in sorted(rows("trace/**/*kernel_stats.csv"), key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))[:12]:
-    print(f"{short(r['Name']):22s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}")
+    print(f"{short(r['Name']):26s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}")
 
 print("\n== kernel trace: per-kernel duration + resources ==")
 agg = collections.defaultdict(list)
@@ -27,7 +27,11 @@ for r in rows("trace/**/*kernel_trace.csv"):
     res[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     v2 = sorted(v)
-    print(f"{k:22s} n={len(v):4d} avg_us={sum(v)/len(v):10.2f} med_us={v2[len(v)//2]:10.2f} min_us={v2[0]:10.2f}  vgpr/agpr/sgpr/lds/scratch/grid/wg={res[k]}")
+    print(f"{k:26s} n={len(v):4d} avg_us={sum(v)/len(v):10.2f} med_us={v2[len(v)//2]:10.2f} min_us={v2[0]:10.2f}  vgpr/agpr/sgpr/lds/scratch/grid/wg={res[k]}")
+
+MAIN = {"fc_forward_kernel": "fc_forward", "fc_grad_kernel": "fc_input_grad",
+        "fc_forward_split_kernel": "fc_forward_split", "fc_grad_split_kernel": "fc_input_grad_split"}   # -> bench.py's traffic keys
+
 
 def pmc(dirname, title):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -36,9 +40,9 @@ def pmc(dirname, title):
     if acc:
         print(f"\n== PMC: {title} (mean per launch) ==")
     for k, d in acc.items():
-        if k not in ("fc_forward_kernel", "fc_grad_kernel"):
+        if k not in MAIN:
             continue
-        print(f"{k:22s} " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())))
+        print(f"{k:26s} " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())))
     return acc
 
 f = pmc("pmc_fetch", "FETCH_SIZE (KB; gfx950 reads x2 for wide streaming loads)")
@@ -47,11 +51,13 @@ pmc("pmc_sq", "SQ")
 pmc("pmc_lds", "LDS / clock")
 import json
 tr = {}
-for k in ("fc_forward_kernel", "fc_grad_kernel"):
+for k in MAIN:
     if k in f and k in w:
         fs = sum(f[k]["FETCH_SIZE"]) / len(f[k]["FETCH_SIZE"]); wsz = sum(w[k]["WRITE_SIZE"]) / len(w[k]["WRITE_SIZE"])
-        tr[k] = {"fetch_size_kb_raw": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": (2 * fs + wsz) * 1024,
+        tr[MAIN[k]] = {"fetch_size_kb_raw": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": (2 * fs + wsz) * 1024,
                  "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"}
 if tr:
     print("\n== traffic json ==")
     print(json.dumps(tr))
+    tr["source"] = f"{out}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, c2 workload)"
+    json.dump(tr, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
