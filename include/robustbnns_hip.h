@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 2
+#define RBNN_ABI_VERSION 3
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {

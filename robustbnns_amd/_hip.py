@@ -121,7 +121,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 2:
+        if lib.rbnn_abi_version() != 3:
             raise HipError("librbnn_hip.so ABI version mismatch")
         _lib = lib
     return _lib

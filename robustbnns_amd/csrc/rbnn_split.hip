@@ -52,11 +52,19 @@ __global__ void split_rows_kernel(const float* __restrict__ src, long long rows,
 //   acc[h][n] = sum_d W[s][h][d] * X[n][d]        (A operand = W rows, B operand = X rows; D = [h][n])
 // K runs in stages of 32 columns: a stage tile is (BH + BN) rows of 128 B (hi/lo chunks of the 4 column groups),
 // brought in by LDS-DMA in 1-KiB pieces of 8 rows into a linear LDS image.  Physical 16-B chunk of logical chunk c
-// in row r is c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group (rows li = 0..15, same chunk) then cover
-// 16 distinct 16-B slots of a 256-B bank row.  The swizzle is applied on the SOURCE address of the DMA.
+// in row r is c ^ row_swz(r).  A ds_read_b128 is served in four 16-lane groups that are NOT contiguous —
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32 — i.e. rows {0-3,12-15} of chunk pair lg with rows {4-11} of
+// chunk pair lg+1; row_swz makes each group cover 16 distinct 16-B slots of the 256-B bank row (measured: the plain
+// (r >> 1) & 7 swizzle left 48 % conflict cycles).  The swizzle is applied on the SOURCE address of the DMA.
 // The epilogue (bias, activation, 1-bit stash, skinny H->C layer on the fp32 MFMA taking the accumulators as its
 // B operand, softmax) is the exact-mode kernel's (rbnn_kernels.hip, fc_forward_kernel).
 // ===================================================================================================
+#ifndef RBNN_OLD_SWZ
+__device__ __forceinline__ int row_swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
+#else
+__device__ __forceinline__ int row_swz(int r) { return (r >> 1) & 7; }
+#endif
+
 struct FwdSplitArgs {
     const char* X;  int ldx;  int N;                           // split-rows image of the inputs [N][ldx] (ldx elements, % 32 == 0)
     const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // split-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
@@ -96,11 +104,11 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
     const int n0 = ntile * BN;
     const int HW = a.H >> 5;
     // DMA piece q = tile rows 8q..8q+7; lane p lands at row 8q + (p >> 3), physical chunk p & 7, so it fetches
-    // logical chunk (p & 7) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4*(q & 1) + (p >> 4)) & 7 and q = wave (mod NW, even).
+    // logical chunk (p & 7) ^ row_swz(row); row mod 16 = 8*(q & 1) + (p >> 3) and q = wave (mod NW, even).
     const int prow = lane >> 3;
-    const int src_off = (((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7))) * 16;
+    const int src_off = ((lane & 7) ^ row_swz(8 * (wave & 1) + prow)) * 16;
     // fragment read of row li (any 16-row tile): hi = logical chunk 2*lg, lo = 2*lg + 1 (= physical chunk ^ 1)
-    const int foff = li * ROWB + (((2 * lg) ^ ((li >> 1) & 7)) * 16), foff_lo = foff ^ 16;
+    const int foff = li * ROWB + (((2 * lg) ^ row_swz(li)) * 16), foff_lo = foff ^ 16;
 
     f32x4 zacc[NTW];
 #pragma unroll
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
         ring_wait_barrier<0>();
         for (int kt = 0; kt < a.KT; ++kt) {
             const int buf = kt & 1;
-            if (kt + 1 < a.KT) stage(kt + 1, buf ^ 1);         // lands while this stage is multiplied
+            if (!(RBNN_ABL & 1) && kt + 1 < a.KT) stage(kt + 1, buf ^ 1);   // lands while this stage is multiplied
             const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 16 * ROWB;
             const char* const Xt = ldsb + buf * TILEB + BH * ROWB + (wave_n * NTW) * 16 * ROWB;
             f16x8 bh[NTW], bl[NTW], ah, al, ah_n, al_n;
@@ -167,8 +175,9 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
                 if (ht + 1 < HTW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW - (NTW + NTW / 2), 0);
             }
-            ring_wait_barrier<0>();                            // stage kt+1 landed; everyone is done with stage kt
+            if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();       // stage kt+1 landed; everyone is done with stage kt
         }
+        if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
         // ---- epilogue of this h chunk: scale, bias, activation, derivative stash, skinny output layer ----
         const int hw0 = hc0 + (wave_h * HTW) * 16;
@@ -333,37 +342,55 @@ __global__ void split_w2gen_kernel(const float* __restrict__ W2, int n_mats, int
     dst[i] = o.u;
 }
 
-// dZ generator image + per-point scale.  One thread per point n < N_pad: e(n) = 13 - ilogb(max_{s,c} |dZ[s][n][c]|),
-// so max |dZ| * 2^e(n) lies in [2^13, 2^14); out[s][n][chunk ^ ((n >> 2) & 3)][j] = dZ side of slot 8*chunk + j of
-// dZ[s][n][:] * 2^e(n) (the chunk swizzle makes the 16-lane ds_read_b128 groups of the generator conflict-free: a
-// point is 64 B); gscale[n] = 2^-e(n).  Points n >= N get zeros.
-__global__ void split_dz_kernel(const float* __restrict__ dZ, int S, int N, long long N_pad, int C,
-                                uint4* __restrict__ dst, float* __restrict__ gscale) {
-    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N_pad) return;
+// dZ generator image + per-point scale.  16 threads per point n < N_pad (sample-strided, LDS max-reduce): e(n) = 13 - ilogb(max_{s,c} |dZ[s][n][c]|),
+// so max |dZ| * 2^e(n) lies in [2^13, 2^14); out[s][n][chunk ^ dz_swz(n)][j] = dZ side of slot 8*chunk + j of
+// dZ[s][n][:] * 2^e(n) (a point is 64 B; the chunk swizzle makes the generator's ds_read_b128 lane groups — points
+// {0-3,12-15} of chunk lg with points {4-11} of chunk lg+1 — conflict-free); gscale[n] = 2^-e(n).  Points n >= N get zeros.
+__host__ __device__ __forceinline__ int dz_swz(long long n) { return (int)((0 - (n >> 2)) & 3); }
+
+__global__ void __launch_bounds__(256) split_dz_kernel(const float* __restrict__ dZ, int S, int N, long long N_pad, int C,
+                                                       uint4* __restrict__ dst, float* __restrict__ gscale) {
+    // block = 16 consecutive points x 16 sample lanes: thread (p = tid & 15, q = tid >> 4) handles samples q, q+16, ...
+    __shared__ float red[16][17];
+    const int p = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long long n = (long long)blockIdx.x * 16 + p;
     float m = 0.f;
     if (n < N)
-        for (int s = 0; s < S; ++s) {
-            const float* const p = dZ + ((long long)s * N + n) * RBNN_CPAD;
+        for (int s = q; s < S; s += 16) {
+            const float* const src = dZ + ((long long)s * N + n) * RBNN_CPAD;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *(const f32x4*)(p + 4 * q);
+            for (int k = 0; k < 3; ++k) {                       // classes 0..11 cover C <= 10
+                const f32x4 v = *(const f32x4*)(src + 4 * k);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * q + r < C) m = fmaxf(m, fabsf(v[r]));
+                for (int r = 0; r < 4; ++r) if (4 * k + r < C) m = fmaxf(m, fabsf(v[r]));
             }
         }
+    red[q][p] = m;
+    __syncthreads();
+    m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i][p]);
     int e = 0;
     if (m > 0.f && m < INFINITY) e = min(13 - ilogbf(m), 120);
-    gscale[n] = ldexpf(1.f, -e);
-    const int sw = (int)((n >> 2) & 3);
-    for (int s = 0; s < S; ++s) {
+    if (q == 0) gscale[n] = ldexpf(1.f, -e);
+    const int sw = dz_swz(n);
+    for (int s = q; s < S; s += 16) {
         _Float16 hi[10], lo[10];
+        float v[12];
+        if (n < N) {
+            const float* const src = dZ + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 t = *(const f32x4*)(src + 4 * k);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * k + r] = t[r];
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 10; ++c) {
-            float v = 0.f;
-            if (n < N && c < C) v = ldexpf(dZ[((long long)s * N + n) * RBNN_CPAD + c], e);
-            hi[c] = (_Float16)v;
-            lo[c] = (_Float16)(v - (float)hi[c]);
+            const float x = (n < N && c < C) ? ldexpf(v[c], e) : 0.f;
+            hi[c] = (_Float16)x;
+            lo[c] = (_Float16)(x - (float)hi[c]);
         }
         uint4* const o = dst + ((long long)s * N_pad + n) * 4;
 #pragma unroll
@@ -371,8 +398,8 @@ __global__ void split_dz_kernel(const float* __restrict__ dZ, int S, int N, long
             union { f16x8 v; uint4 u; } w;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int sg = 8 * ch + j, p = sg / 10, c = sg % 10;
-                w.v[j] = (sg >= 30) ? (_Float16)0.f : (p == 2 ? lo[c] : hi[c]);
+                const int sg = 8 * ch + j, pp = sg / 10, c = sg % 10;
+                w.v[j] = (sg >= 30) ? (_Float16)0.f : (pp == 2 ? lo[c] : hi[c]);
             }
             o[ch ^ sw] = w.u;
         }
@@ -404,12 +431,13 @@ struct GradSplitArgs {
     float* out;  int ldo;  float out_scale;                     // slabs [nchunks][N][ldo]; out_scale = 2^-(e_w2 + GEN_Q + e_w1)
 };
 
-template <int ACT, int TD>
-__global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitArgs a) {
+template <int ACT, int TD, int NTW, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSplitArgs a) {
     static_assert(ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY, "1-bit stash activations only");
-    constexpr int NTW = 4, BM = 256, LD = TD * 16;
+    constexpr int BM = NW * NTW * 16, LD = TD * 16;            // NW waves x NTW point tiles = 256 points per block
+    static_assert(BM == 256, "the dZ image and the stash rows are laid out for 256-point blocks");
     constexpr int W1B = 8 * LD * 16;                           // bytes: [4 lg][2 hi/lo][LD columns][16 B]
-    constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + 3) / 4;
+    constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + NW - 1) / NW;
     constexpr int BUFB = W1B + 2048 + 1024;                    // + 2 generator tiles + 256 stash words
     constexpr int DZB = BM * 64;                               // dZ generator image of the block's points, one sample
     static_assert(W1B % 1024 == 0, "whole DMA pieces");
@@ -424,6 +452,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitAr
     const int nb = ntile * BM + wave * (NTW * 16);
     const int dc0 = dg * LD;
     const int Dp = a.Dt * 16;
+    const int ntd = min(TD, a.Dt - dg * TD);                   // valid column tiles of this group (the last group may be partial)
     const int s_begin = ch * a.chunk, s_end = min(a.S, s_begin + a.chunk);
     const int HS = a.H / 32, nst = (s_end - s_begin) * HS;
     // dZ-image pieces of the NEXT sample ride on the stages hb >= 1 of a sample (16 pieces per sample).  Stage hb = 0 is
@@ -434,7 +463,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitAr
     int goff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int f = (wave + 4 * i) * 1024 + lane * 16, seg = f / (LD * 16), d = (f % (LD * 16)) >> 4;
+        const int f = (wave + NW * i) * 1024 + lane * 16, seg = f / (LD * 16), d = (f % (LD * 16)) >> 4;
         goff[i] = (seg * a.ldc + min(dc0 + d, a.ldc - 1)) * 16;   // columns past the image: any valid address, never stored
     }
 
@@ -455,38 +484,38 @@ __global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitAr
         char* const B = ldsb + buf * BUFB;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
-            if (wave + 4 * i < NPIECE) glds16((const float*)(Wb + goff[i]), (float*)(B + (wave + 4 * i) * 1024));
-        if (wave >= 2)                                          // generator tiles 2*hb, 2*hb + 1 of this sample
-            glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb + (wave - 2)) * 1024) + lane * 16),
-                   (float*)(B + W1B + (wave - 2) * 1024));
-        if (wave == 1)                                          // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
+            if (wave + NW * i < NPIECE) glds16((const float*)(Wb + goff[i]), (float*)(B + (wave + NW * i) * 1024));
+        if (wave >= NW - 2)                                     // generator tiles 2*hb, 2*hb + 1 of this sample
+            glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb + (wave - (NW - 2))) * 1024) + lane * 16),
+                   (float*)(B + W1B + (wave - (NW - 2)) * 1024));
+        if (wave == NW - 3)                                     // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
             glds16((const float*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM + 4 * lane), (float*)(B + W1B + 2048));
         if (s + 1 < s_end) {                                    // next sample's dZ image, spread over this sample's stages
             for (int j = 0; j < DZPS && hb >= 1; ++j) {
                 const int piece = (hb - 1) * DZPS + j;
-                if (piece < 16 && (piece & 3) == wave) dz_issue(s + 1, piece, (si + 1) & 1);
+                if (piece < 16 && piece % NW == wave) dz_issue(s + 1, piece, (si + 1) & 1);
             }
         }
     };
 
-    for (int piece = wave; piece < 16; piece += 4) dz_issue(s_begin, piece, 0);
+    for (int piece = wave; piece < 16; piece += NW) dz_issue(s_begin, piece, 0);
     stage_issue(0, 0);
     ring_wait_barrier<0>();
     const float c_pos = ldexpf(1.f, GEN_Q), c_neg = (ACT == RBNN_ACT_RELU) ? 0.f : LEAKY_SLOPE * ldexpf(1.f, GEN_Q);
+    f16x8 da_hi[NTW], da_lo[NTW];                              // A operand of the main MFMA: this wave's 4 point tiles, one stage
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, dzbuf = (st / HS) & 1;
-        if (st + 1 < nst) stage_issue(st + 1, buf ^ 1);
+        if (!(RBNN_ABL & 1) && st + 1 < nst) stage_issue(st + 1, buf ^ 1);
         const char* const B = ldsb + buf * BUFB;
 
         // ---- generator + split: da_hi / da_lo[nt] = A operand of the main MFMA for this wave's 4 point tiles ----
-        f16x8 da_hi[NTW], da_lo[NTW];
-        {
+        if (!(RBNN_ABL & 16) || st == 0) {
             const f16x8 w2g0 = *(const f16x8*)(B + W1B + lane * 16);
             const f16x8 w2g1 = *(const f16x8*)(B + W1B + 1024 + lane * 16);
-            const unsigned* const Mk = (const unsigned*)(B + W1B + 2048) + wave * 64 + li;
+            const unsigned* const Mk = (const unsigned*)(B + W1B + 2048) + wave * (NTW * 16) + li;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
-                const f16x8 dz = *(const f16x8*)(dzl + dzbuf * DZB + (wave * 64 + nt * 16 + li) * 64 + ((lg ^ ((li >> 2) & 3)) * 16));
+                const f16x8 dz = *(const f16x8*)(dzl + dzbuf * DZB + (wave * (NTW * 16) + nt * 16 + li) * 64 + ((lg ^ dz_swz(li)) * 16));
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const f32x4 g0 = MFMA_H(w2g0, dz, z), g1 = MFMA_H(w2g1, dz, z);
                 const unsigned mw = Mk[nt * 16] >> (4 * lg);    // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
@@ -505,20 +534,23 @@ __global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitAr
         f16x8 bh = *(const f16x8*)(Bw), bl = *(const f16x8*)(Bw + LD * 16), bh_n = bh, bl_n = bl;
 #pragma unroll
         for (int dt = 0; dt < TD; ++dt) {
-            if (dt + 1 < TD) {
-                bh_n = *(const f16x8*)(Bw + (dt + 1) * 256);
-                bl_n = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
+            if (dt < ntd) {                                     // block-uniform; the loop stays fully unrolled (acc in registers)
+                if (dt + 1 < TD) {
+                    bh_n = *(const f16x8*)(Bw + (dt + 1) * 256);
+                    bl_n = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_lo[nt], bh, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_hi[nt], bl, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_hi[nt], bh, acc[nt][dt]);
+                bh = bh_n; bl = bl_n;
             }
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_lo[nt], bh, acc[nt][dt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_hi[nt], bl, acc[nt][dt]);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da_hi[nt], bh, acc[nt][dt]);
-            bh = bh_n; bl = bl_n;
         }
-        ring_wait_barrier<0>();                                // next stage landed; everyone is done with this one
+        if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();           // next stage landed; everyone is done with this one
     }
+    if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
     // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li], un-scaled per point ----
 #pragma unroll
@@ -537,26 +569,36 @@ __global__ void __launch_bounds__(256, 2) fc_grad_split_kernel(const GradSplitAr
         }
 }
 
-template <int ACT, int TD>
-int launch_grad_split_td(GradSplitArgs a, hipStream_t st) {
+template <int ACT, int TD, int NTW, int NW>
+int launch_grad_split_cfg(GradSplitArgs a, hipStream_t st) {
     constexpr int LDSB = 2 * (8 * TD * 16 * 16 + 3072) + 2 * 256 * 64;
     a.NT = (a.N + 255) / 256;
     a.ND = (a.Dt + TD - 1) / TD;
-    auto kern = fc_grad_split_kernel<ACT, TD>;
+    auto kern = fc_grad_split_kernel<ACT, TD, NTW, NW>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return RBNN_ERR_LAUNCH;
         attr_done = true;
     }
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, st, a);
     return launch_status();
 }
 
+// Block shape.  Every block re-derives the split dA tiles of its points, so fewer, wider column groups would save
+// generator work (ablation at C2: the generator + split is 0.6 of 2.4 ms, the LDS-DMA instructions 0.37 ms) — but the
+// variants that do it need 8-wave blocks (one per CU) and measured SLOWER than two independent 4-wave blocks per CU:
+// 8 waves x 2 point tiles x 14 column tiles 2.74 ms vs 2.50 ms; producer/consumer wave specialisation 3.08 vs 2.43 ms.
+// RBNN_GRAD_SPLIT_TD14 keeps the first of those selectable for experiments.
 template <int ACT>
 int launch_grad_split(const GradSplitArgs& a, hipStream_t st) {
-    if (a.Dt % 7 == 0) return launch_grad_split_td<ACT, 7>(a, st);
-    return launch_grad_split_td<ACT, 4>(a, st);
+#ifdef RBNN_GRAD_SPLIT_TD14
+    if (a.Dt > 7) return launch_grad_split_cfg<ACT, 14, 2, 8>(a, st);
+#endif
+    // 7 or 4 column tiles per block: whichever pads the Dt tiles less (a partial last group skips its missing tiles'
+    // MFMAs but still pays the generator)
+    if ((a.Dt + 6) / 7 * 7 <= (a.Dt + 3) / 4 * 4) return launch_grad_split_cfg<ACT, 7, 4, 4>(a, st);
+    return launch_grad_split_cfg<ACT, 4, 4, 4>(a, st);
 }
 
 }  // namespace
@@ -665,7 +707,7 @@ int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images*
     const int nchunks = (S + chunk - 1) / chunk;
     if (n_slabs_out) *n_slabs_out = nchunks;
     const long long n_pad = mask_ld(N);
-    hipLaunchKernelGGL(split_dz_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(split_dz_kernel, dim3((unsigned)(n_pad / 16)), dim3(256), 0, st,
                        ws->dZ, S, N, n_pad, C, (uint4*)sws->dZ_gen, sws->g_scale);
     if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
     GradSplitArgs g = {};

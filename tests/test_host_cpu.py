@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rbnn_abi_version() == 2
+    assert lib.rbnn_abi_version() == 3
     assert lib.rbnn_strerror(0) == b"ok" and b"NULL" in lib.rbnn_strerror(-1)
 
 
@@ -69,6 +69,49 @@ def test_argument_validation_without_gpu():
     assert lib.rbnn_pgd_alpha(C.c_void_p(16), 1, 4, 2, C.c_void_p(16), None) == -2                  # ldx < D
     assert lib.rbnn_svi_materialize(None, None, None, 4, 1, None, None) == -1
     assert lib.rbnn_pack_rows4(C.c_void_p(16), 6, 8, C.c_void_p(16), None) == -2                    # rows % 4
+
+
+def test_split_mode_validation_without_gpu():
+    """Split-half (f16x3) entry points: argument checks and workspace sizes, no launch."""
+    lib = _hip.load()
+    ws, sws, img = _hip.Workspace(), _hip.SplitWorkspace(), _hip.SplitImages()
+    img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = 800, 784, 15, 14
+    out = _hip.SplitWorkspaceSizes()
+    assert lib.rbnn_split_workspace_query(C.byref(_net()), C.byref(img), 10000, 100, C.byref(out)) == 0
+    assert out.X_split == 10000 * 800 * 4 and out.dZ_gen == 100 * 10240 * 64 and out.g_scale == 10240 * 4
+    img.ld_rows = 784                                                                              # not a multiple of 32
+    assert lib.rbnn_split_workspace_query(C.byref(_net()), C.byref(img), 8, 2, C.byref(out)) == -2
+    img.ld_rows = 800
+    assert lib.rbnn_split_rows(None, 4, 8, 8, 0, C.c_void_p(16), 32, None) == -1
+    assert lib.rbnn_split_rows(C.c_void_p(16), 4, 8, 8, 0, C.c_void_p(16), 24, None) == -2          # ld_dst % 32
+    assert lib.rbnn_split_rows(C.c_void_p(16), 4, 8, 8, 0, C.c_void_p(8), 32, None) == -5           # alignment
+    assert lib.rbnn_split_cols(C.c_void_p(16), 1, 48, 8, 8, 0, C.c_void_p(16), 16, None) == -2      # rows % 32
+    assert lib.rbnn_split_w2gen(C.c_void_p(16), 1, 11, 128, 0, C.c_void_p(16), None) == -2         # classes > 10
+    assert lib.rbnn_fc_forward_split(C.byref(_net()), C.byref(img), None, 800, 14, 8, None, 2, 0, C.byref(ws), None) == -1
+    ws.P = C.c_void_p(16); img.W1_rows = C.c_void_p(16)
+    w = dict(W1=C.c_void_p(16), b1=C.c_void_p(16), W2=C.c_void_p(16), b2=C.c_void_p(16))
+    assert lib.rbnn_fc_forward_split(C.byref(_net(arch=1, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -3   # fc2
+    assert lib.rbnn_fc_forward_split(C.byref(_net(hidden=64, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -2  # hidden % 128
+    assert lib.rbnn_fc_forward_split(C.byref(_net(**w)), C.byref(img), C.c_void_p(16), 784, 14, 8, None, 2, 0, C.byref(ws), None) == -2             # ldx != ld_rows
+    assert lib.rbnn_fc_input_grad_split(C.byref(_net(**w)), C.byref(img), None, 2, 8, 0, C.byref(ws), C.byref(sws), None, None) == -1
+
+
+def test_precision_resolution_and_scale_exponent(monkeypatch):
+    from robustbnns_amd.posterior import scale_exp
+    assert scale_exp(1.0) == 14 and scale_exp(0.999) == 14 and scale_exp(1.001) == 13 and scale_exp(3.0e-3) == 22
+    assert scale_exp(0.0) == 0 and scale_exp(float("inf")) == 0 and scale_exp(1e-40) == 100
+    for v in (1e-6, 0.3, 1.0, 7.5, 4096.0):
+        assert v * 2.0 ** scale_exp(v) <= 2.0 ** 14 < v * 2.0 ** (scale_exp(v) + 1) * (1 + 1e-12)
+    post = O.synthetic_posterior("fc", 784, 128, 10, 2, 0.05)
+    sp = StackedPosterior("fc", "leaky", (1, 28, 28), 10, 128, post, "cpu")
+    assert not sp.split_supported()                                # CPU tensors: nothing to build images from
+    assert AttackEngine(sp, kernels=FakeKernels()).precision == "exact"      # injected test kernels never take the split path
+    monkeypatch.setenv("RBNN_PRECISION", "exact")
+    assert AttackEngine(sp, kernels=FakeKernels()).precision == "exact"
+    with pytest.raises(_hip.HipError):
+        AttackEngine(sp, kernels=FakeKernels(), precision="split")
+    with pytest.raises(ValueError):
+        AttackEngine(sp, kernels=FakeKernels(), precision="fp8")
 
 
 def test_compute_refuses_cpu_tensors():

@@ -127,3 +127,5 @@ if bad.numel():
     print("point", n, "bad cols", (dd > 1e-4).nonzero().flatten()[:40].tolist(), "gscale", float(sws["g_scale"][n]), "max|Ge|", float(mx[n]))
     print("hist n%256:", torch.bincount(bad % 256, minlength=256).nonzero().flatten()[:64].tolist())
     print("hist n//256:", torch.bincount(bad // 256).tolist())
+bad = (rel > 1e-4).nonzero().flatten()
+print("bad points:", bad.numel(), bad[:40].tolist())
