@@ -139,23 +139,25 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
         };
         stage(0, 0);
         ring_wait_barrier<0>();
+        f16x8 bh[NTW], bl[NTW], ah, al, ah_n, al_n;
         for (int kt = 0; kt < a.KT; ++kt) {
             const int buf = kt & 1;
             if (!(RBNN_ABL & 1) && kt + 1 < a.KT) stage(kt + 1, buf ^ 1);   // lands while this stage is multiplied
             const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 16 * ROWB;
             const char* const Xt = ldsb + buf * TILEB + BH * ROWB + (wave_n * NTW) * 16 * ROWB;
-            f16x8 bh[NTW], bl[NTW], ah, al, ah_n, al_n;
+            if (!(RBNN_ABL & 4) || kt == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                bh[nt] = *(const f16x8*)(Xt + nt * 16 * ROWB + foff);
-                bl[nt] = *(const f16x8*)(Xt + nt * 16 * ROWB + foff_lo);
+                for (int nt = 0; nt < NTW; ++nt) {
+                    bh[nt] = *(const f16x8*)(Xt + nt * 16 * ROWB + foff);
+                    bl[nt] = *(const f16x8*)(Xt + nt * 16 * ROWB + foff_lo);
+                }
+                ah = *(const f16x8*)(Wt + foff);
+                al = *(const f16x8*)(Wt + foff_lo);
+                ah_n = ah; al_n = al;
             }
-            ah = *(const f16x8*)(Wt + foff);
-            al = *(const f16x8*)(Wt + foff_lo);
-            ah_n = ah; al_n = al;
 #pragma unroll
             for (int ht = 0; ht < HTW; ++ht) {
-                if (ht + 1 < HTW) {
+                if (!(RBNN_ABL & 4) && ht + 1 < HTW) {
                     ah_n = *(const f16x8*)(Wt + (ht + 1) * 16 * ROWB + foff);
                     al_n = *(const f16x8*)(Wt + (ht + 1) * 16 * ROWB + foff_lo);
                 }
@@ -168,17 +170,28 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
                 ah = ah_n; al = al_n;
             }
             // pin the order: B fragments + A(0) first, then per h tile half its MFMAs, the next tile's two reads, the rest
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * NTW + 2, 0);
+            if (!(RBNN_ABL & 4)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NTW + 2, 0);
 #pragma unroll
-            for (int ht = 0; ht < HTW; ++ht) {
-                __builtin_amdgcn_sched_group_barrier(0x008, NTW + NTW / 2, 0);
-                if (ht + 1 < HTW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW - (NTW + NTW / 2), 0);
+                for (int ht = 0; ht < HTW; ++ht) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, NTW + NTW / 2, 0);
+                    if (ht + 1 < HTW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW - (NTW + NTW / 2), 0);
+                }
             }
             if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();       // stage kt+1 landed; everyone is done with stage kt
         }
         if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
+        if (RBNN_ABL & 8) {                                    // diagnostic: keep the accumulators live, skip the epilogue
+            float t = 0.f;
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) t += acc[ht][nt][0] + acc[ht][nt][1] + acc[ht][nt][2] + acc[ht][nt][3];
+            if (t == 12345.678f) a.P[tid] = t;
+            continue;
+        }
         // ---- epilogue of this h chunk: scale, bias, activation, derivative stash, skinny output layer ----
         const int hw0 = hc0 + (wave_h * HTW) * 16;
         unsigned mine[NTW];

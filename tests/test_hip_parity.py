@@ -165,6 +165,10 @@ ORACLE_CASES += [  # split-mode shapes: 4-column-tile grouping with a partial gr
     ("fc", "leaky", (1, 10, 10), 2, 128, 3, 300, 0.1), ("fc", "relu", (3, 8, 8), 7, 384, 2, 77, 0.1),
     ("fc", "leaky", (1, 28, 28), 10, 640, 2, 513, 0.02), ("fc", "leaky", (1, 28, 28), 10, 128, 17, 30, 0.05),
 ]
+ORACLE_CASES += [  # point-tile boundaries of the 256-point blocks and single-sample / single-point jobs in the split kernels
+    ("fc", "leaky", (1, 28, 28), 10, 256, 1, 1, 0.05), ("fc", "relu", (1, 28, 28), 10, 128, 2, 255, 0.05),
+    ("fc", "leaky", (1, 28, 28), 10, 128, 9, 256, 0.05), ("fc", "leaky", (1, 14, 14), 4, 256, 11, 257, 0.08),
+]
 ORACLE_MODES = [c + (m,) for c in ORACLE_CASES for m in modes_for(c[0], c[1], c[4], c[3])]
 
 
