@@ -274,6 +274,10 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        # RCCL writes its version banner through C stdio (block-buffered when stdout is a file or pipe): flush it first so
+        # that the JSON line is the LAST line of the output
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if group is not None:
         import torch.distributed as dist
