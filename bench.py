@@ -255,6 +255,9 @@ def main():
     if world == 1 and w["arch"] != "conv" and mode == "split" and args.precision == "auto":
         other = run("exact")                                              # reference line: the exact-fp32 kernels on the same workload
 
+    import ctypes
+    ctypes.CDLL(None).fflush(None)          # every rank: anything RCCL left in C stdio goes out before rank 0's JSON line
+    barrier()
     if rank == 0:
         units = N_job * S_job * w["iters"] * args.steps
         ms_per_step = 1e3 * dt / args.steps
@@ -276,7 +279,6 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         # RCCL writes its version banner through C stdio (block-buffered when stdout is a file or pipe): flush it first so
         # that the JSON line is the LAST line of the output
-        import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if group is not None:
