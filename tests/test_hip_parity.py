@@ -6,6 +6,8 @@ Tolerance: 1e-5 relative to each point's largest component (north star).  Both p
 are held to it: "exact" (fp32 MFMA) and "split" (error-compensated half pairs on the f16 MFMA pipe, what "auto"
 picks for fc / relu|leaky / hidden % 128 == 0 / classes <= 10) — every case the split kernels cover runs in both.
 Adversarial images: equal except where |g| < tau * max|g| (a sign flip there is within fp32 noise)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -147,6 +149,45 @@ def test_golden_deterministic_and_ensemble(golden):
     oa, aa, rob = A.attack_evaluation(nn0, x, g.t("nn0_fgsm"), y, DEV, n_samples=None)
     assert (oa, aa) == (float(g.arr["nn0_eval_orig_acc"]), float(g.arr["nn0_eval_adv_acc"]))
     assert float((rob.cpu() - g.t("nn0_eval_softmax_rob")).abs().max()) < 1e-6
+
+
+def test_baseline_attacks_driver(golden, tmp_path, monkeypatch):
+    """plot_baseline_attacks.build_baseline_attacks_df: NN / BNN / ensemble sections, the reference's schema and CSV path;
+    every cell equals the (golden-pinned) attack + attack_evaluation calls it is made of."""
+    from robustbnns_amd import adversarialAttacks as A, plot_baseline_attacks as PB, savedir
+    from robustbnns_amd.model_ensemble import Ensemble_NN
+    from robustbnns_amd.model_nn import NN
+    g = golden("mnist_det_ens_fc_h32_m4_n6"); m = g.meta; post = g.posterior(); M = m["M"]
+    x, y = g.t("x"), g.t("y")
+    ens = Ensemble_NN("mnist", m["hidden"], m["act"], m["arch"], 1, 0.01, tuple(m["shape"]), m["n_classes"], M)
+    ens.device = DEV
+    for i in range(M):
+        net = NN("mnist", tuple(m["shape"]), m["n_classes"], m["hidden"], m["act"], m["arch"], 0.01, 1)
+        net.load_state_dict({k: v[i] for k, v in post.items()})
+        net.device = DEV
+        ens.ensemble_models[str(i)] = net
+    nn0 = ens.ensemble_models["0"]
+    gb = golden("mnist_fc_h32_s8_n8_leaky"); bnn = make_bnn(gb)
+    monkeypatch.chdir(tmp_path)
+    df = PB.build_baseline_attacks_df(nn0, bnn, ens, "mnist", DEV, "fgsm", x, y, bayesian_attack_samples=(1, 4),
+                                      bayesian_defence_samples=(1, 8), n_samples_list=(1, M))
+    N = len(x)
+    assert list(df.columns) == ["attack_method", "epsilon", "test_acc", "adv_acc", "softmax_rob", "attack_samples",
+                                "defence_samples", "model_type"]
+    assert len(df) == N * (1 + 2 * 2 + 2) and set(df["attack_method"]) == {"fgsm"} and set(df["epsilon"]) == {0.3}
+    assert list(df["model_type"].unique()) == ["nn", "bnn", "ensemble"]
+    nn_rows = df[df["model_type"] == "nn"]
+    assert float(nn_rows["test_acc"].iloc[0]) == float(g.arr["nn0_eval_orig_acc"])       # the reference's own numbers (eps 0.3 default)
+    cell = df[(df["model_type"] == "bnn") & (df["attack_samples"] == 4) & (df["defence_samples"] == 8)]
+    adv = A.attack(net=bnn, x_test=x, y_test=y, dataset_name="mnist", device=DEV, method="fgsm", filename=bnn.name, n_samples=4)
+    oa, aa, rob = A.attack_evaluation(net=bnn, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=8)
+    assert (float(cell["test_acc"].iloc[0]), float(cell["adv_acc"].iloc[0])) == (oa, aa)
+    assert np.abs(cell["softmax_rob"].to_numpy() - rob.cpu().numpy()).max() < 1e-6
+    e_rows = df[(df["model_type"] == "ensemble") & (df["attack_samples"] == M)]
+    assert float(e_rows["test_acc"].iloc[0]) == float(g.arr["ens_eval_orig_acc"]) and (e_rows["defence_samples"] == M).all()
+    back = PB.load_baseline_attacks_df("mnist", "fgsm", "")
+    assert len(back) == len(df) and list(back.columns) == list(df.columns)
+    assert os.path.exists(savedir.TESTS + "/mnist_baseline_attacks_fgsm.csv")
 
 
 # ------------------------------------------------------------------ (2) fp64 oracle, every tile configuration, ragged sizes
