@@ -602,6 +602,9 @@ int launch_grad_split_cfg(GradSplitArgs a, hipStream_t st) {
 // generator work (ablation at C2: the generator + split is 0.6 of 2.4 ms, the LDS-DMA instructions 0.37 ms) — but the
 // variants that do it need 8-wave blocks (one per CU) and measured SLOWER than two independent 4-wave blocks per CU:
 // 8 waves x 2 point tiles x 14 column tiles 2.74 ms vs 2.50 ms; producer/consumer wave specialisation 3.08 vs 2.43 ms.
+// Building stage st+1's dA tiles inside stage st's MFMA stream (in-wave software pipelining, dA registers double-buffered,
+// slices fenced between groups of 12 MFMAs) was also slower, 2.73 vs 2.49 ms: a wave issues in order, and the dependent
+// VALU chains stall the independent MFMAs queued behind them.  (profiles/r01f/ablation_split.txt)
 // RBNN_GRAD_SPLIT_TD14 keeps the first of those selectable for experiments.
 template <int ACT>
 int launch_grad_split(const GradSplitArgs& a, hipStream_t st) {
