@@ -67,6 +67,8 @@ class ConvEngine(AttackEngine):
     """AttackEngine whose forward / gradient calls go to the conv kernels; the attack loops, the reductions over
     samples, the loss kernels and the evaluation are inherited unchanged."""
 
+    graph_safe = False                      # large jobs are cut into point blocks per call: no fixed launch sequence to capture
+
     def workspace(self, N, S, chunk=0):
         key = (N, S)
         ws = self._ws_cache.get(key)

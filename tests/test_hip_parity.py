@@ -282,6 +282,29 @@ def test_split_mode_operand_scales(k):
           f"all points split {float(e_split[ok].max()):.2e} exact {float(e_exact[ok].max()):.2e}")
 
 
+@pytest.mark.parametrize("arch,shape,C,H,S,N,precision", [("fc", (1, 28, 28), 10, 512, 6, 300, "split"), ("fc", (1, 28, 28), 10, 512, 6, 300, "exact"),
+                                                          ("fc", (1, 2, 1), 2, 64, 10, 100, "exact"), ("fc2", (1, 28, 28), 10, 64, 3, 70, "exact")])
+def test_pgd_hip_graph_replay_is_bit_identical(arch, shape, C, H, S, N, precision, monkeypatch):
+    """PGD runs iteration 1 eagerly and replays a captured HIP graph for the rest: same launches, same bits as the eager loop."""
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    D = int(np.prod(shape))
+    post = O.synthetic_posterior(arch, D, H, C, S, 0.05 if D > 16 else 0.5)
+    x, y = O.synthetic_inputs(N, shape, C, seed=21)
+    eng = AttackEngine(StackedPosterior(arch, "leaky", shape, C, H, post, DEV), precision=precision)
+    monkeypatch.setenv("RBNN_HIPGRAPH", "0")
+    eager = eng.pgd(x, y, S, 0.2, iters=6).cpu()
+    monkeypatch.setenv("RBNN_HIPGRAPH", "1")
+    captured = []
+    orig = eng._capture
+    eng._capture = lambda fn: captured.append(orig(fn)) or captured[-1]
+    graphed = eng.pgd(x, y, S, 0.2, iters=6).cpu()
+    assert captured and captured[0] is not None, "the iteration was not captured"
+    assert torch.equal(eager, graphed)
+    again = eng.pgd(x, y, S, 0.2, alpha=2 / 225, iters=4).cpu()          # scalar step size, fresh capture
+    monkeypatch.setenv("RBNN_HIPGRAPH", "0")
+    assert torch.equal(again, eng.pgd(x, y, S, 0.2, alpha=2 / 225, iters=4).cpu())
+
+
 def test_upstream_gradient_mode_matches_autograd():
     """RBNN_LOSS_UPSTREAM: vector-Jacobian product of the mean-probability forward for an arbitrary dL/dp."""
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
