@@ -68,6 +68,7 @@ class ConvEngine(AttackEngine):
     samples, the loss kernels and the evaluation are inherited unchanged."""
 
     graph_safe = False                      # large jobs are cut into point blocks per call: no fixed launch sequence to capture
+    pipelined_comm = False                  # one cached workspace: the sample-sharded step keeps the plain sequence
 
     def workspace(self, N, S, chunk=0):
         key = (N, S)

@@ -94,6 +94,12 @@ class AttackEngine:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _allreduce_async(self, t):
+        """Start the all-reduce (RCCL runs it on its own stream) and return the work handle; .wait() orders the current
+        stream after it.  Kernels launched in between overlap the exchange."""
+        import torch.distributed as dist
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def total_samples(self, S_local):
         """Samples over all ranks taking part in this call."""
         if self.world == 1:
@@ -134,8 +140,8 @@ class AttackEngine:
             return None, len(idx)                               # prefix: identity map, no index buffer
         return torch.tensor([i % self.post.S for i in idx], dtype=torch.int32, device=self.device), len(idx)
 
-    def workspace(self, N, S, chunk=0):
-        key = (N, S, chunk)
+    def workspace(self, N, S, chunk=0, tag=0):
+        key = (N, S, chunk, tag)
         ws = self._ws_cache.get(key)
         if ws is None:
             sizes = self.k.workspace_sizes(self.post, N, S, chunk)
@@ -150,7 +156,7 @@ class AttackEngine:
                 ws["split"] = {"X_split": torch.empty(ssz["X_split"] // 2, dtype=torch.int16, device=self.device),
                                "dZ_gen": torch.empty(ssz["dZ_gen"] // 2, dtype=torch.int16, device=self.device),
                                "g_scale": torch.empty(ssz["g_scale"] // 4, dtype=torch.float32, device=self.device)}
-            if len(self._ws_cache) > 4:
+            if len(self._ws_cache) > 6:
                 self._ws_cache.clear()
             self._ws_cache[key] = ws
         return ws
@@ -261,6 +267,8 @@ class AttackEngine:
     # ------------------------------------------------------------------ attacks
     def _step(self, X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project):
         p = self.post
+        if self.world > 1 and self.pipelined_comm:
+            return self._step_sharded(X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project)
         ws, n_slabs, _ = self.gradient_slabs(X, labels, sidx, S, mode)
         if self.world == 1:
             self.k.attack_step(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D)
@@ -269,6 +277,46 @@ class AttackEngine:
             self.k.sum_slabs(ws["slabs"], n_slabs, X.shape[0], p.Dp, 1.0, G)
             self._allreduce(G)
             self.k.attack_step(X, X0, G, 1, 0, p.Dp, alpha, alpha_scalar, eps, project, p.D)
+
+    pipelined_comm = True                   # ConvEngine (one cached workspace) keeps the plain sequence
+
+    def _comm_blocks(self, N):
+        want = int(os.environ.get("RBNN_COMM_BLOCKS", "2"))
+        return max(1, min(want, N // max(1, int(os.environ.get("RBNN_COMM_MIN_POINTS", "512")))))
+
+    def _step_sharded(self, X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project):
+        """One attack step with the posterior sample-sharded over the ranks, pipelined over point blocks: the
+        points are independent, so block b's two exchanges (sum_s p_s [n,16] before the loss, the summed gradients
+        [n,D_pad] before the step) run on RCCL's stream while block b+1's forward / backward kernels run on ours.
+        Every rank does the same blocks in the same order; each block has its own workspace."""
+        p, N, C = self.post, X.shape[0], self.post.C
+        nb = self._comm_blocks(N)
+        bounds = [N * i // nb for i in range(nb + 1)]
+        S_tot = self.total_samples(S)
+        need_psum = mode in (LOSS_MEAN_PROB, LOSS_MEAN_LOGIT)
+        inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
+        blocks = []
+        for b in range(nb):                                     # forward + local sum over samples; start the small exchange
+            lo, hi = bounds[b], bounds[b + 1]
+            ws = self.workspace(hi - lo, S, 0, tag=b)
+            self._forward_kernels(X[lo:hi], sidx, S, OUT_LOGITS if mode == LOSS_MEAN_LOGIT else OUT_PROBS, ws)
+            h = None
+            if need_psum:
+                self.k.reduce_samples(ws["P"], S, hi - lo, C, 1.0, ws["Psum"])
+                h = self._allreduce_async(ws["Psum"])
+            blocks.append((lo, hi, ws, h))
+        pending = []
+        for lo, hi, ws, h in blocks:                            # loss + backward; start the large exchange
+            if h is not None:
+                h.wait()
+            self.k.loss_dlogits(mode, ws["P"], ws["Psum"] if need_psum else None, None, labels[lo:hi], S, inv_S, hi - lo, C, ws["dZ"])
+            n_slabs = self._grad_kernels(sidx, S, hi - lo, ws)
+            self.k.sum_slabs(ws["slabs"], n_slabs, hi - lo, p.Dp, 1.0, ws["G"])
+            pending.append(self._allreduce_async(ws["G"]))
+        for (lo, hi, ws, _), h in zip(blocks, pending):         # identical sign / project / clamp on every rank's replica of x
+            h.wait()
+            self.k.attack_step(X[lo:hi], None if X0 is None else X0[lo:hi], ws["G"], 1, 0, p.Dp,
+                               None if alpha is None else alpha[lo:hi], alpha_scalar, eps, project, p.D)
 
     def fgsm(self, x, y, n_samples, epsilon=0.3, seeds=None, mode=LOSS_MEAN_PROB):
         """adversarialAttacks.fgsm_attack on every row of x (adversarialAttacks.py:69-83)."""

@@ -15,7 +15,6 @@ class FakeKernels:
 
     def __init__(self):
         self._real = _hip.HipKernels()          # host-only entry points (workspace sizes) come from the real library
-        self._cache = None
 
     def workspace_sizes(self, net, N, S, chunk=0):
         return self._real.workspace_sizes(net, N, S, chunk)
@@ -36,7 +35,7 @@ class FakeKernels:
         P = ws["P"].view(S, X.shape[0], _hip.CPAD)
         P.zero_()
         P[:, :, :net.C] = out
-        self._cache = (layers, pre, net.activation)
+        ws["_fake_stash"] = (layers, pre, net.activation)      # like the HIP kernels: the backward state lives in the workspace
 
     def reduce_samples(self, P, S, N, C, scale, out):
         out[:, :C] = P.view(S, N, _hip.CPAD)[:, :, :C].sum(0) * scale
@@ -56,7 +55,7 @@ class FakeKernels:
         d[:, :, :C] = out
 
     def fc_input_grad(self, net, sidx, S, N, chunk, ws):
-        layers, pre, act = self._cache
+        layers, pre, act = ws["_fake_stash"]
         dz = ws["dZ"].view(S, N, _hip.CPAD)[:, :, :net.C]
         g = O._mlp_input_grad(dz, layers, pre, act)                   # [S, N, Dp]
         n_slabs = (S + chunk - 1) // chunk

@@ -21,9 +21,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, arch, q):
+def _worker(rank, world, port, arch, q, comm_blocks=2):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    # the attack step is pipelined over point blocks with asynchronous all-reduces: force 2 (or 3, ragged) blocks on 12 points
+    os.environ["RBNN_COMM_BLOCKS"], os.environ["RBNN_COMM_MIN_POINTS"] = str(comm_blocks), "2"
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -62,12 +64,12 @@ def _worker(rank, world, port, arch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch", ["fc", "fc2"])
-def test_sample_sharded_world2_matches_single(arch):
+@pytest.mark.parametrize("arch,comm_blocks", [("fc", 2), ("fc2", 1), ("fc", 5)])
+def test_sample_sharded_world2_matches_single(arch, comm_blocks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, arch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, arch, q, comm_blocks)) for r in range(2)]
     for p in procs:
         p.start()
     errs = q.get(timeout=300)
