@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Stage-by-stage check of the HIP path against the fp64 oracle + a first timing.  GPU box only.
-usage: python tools/gpu_check.py [--big]"""
+usage: python tests/tools/gpu_check.py [--big]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from oracle import bnn_oracle as O

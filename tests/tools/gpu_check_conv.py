@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage-by-stage check of the conv HIP path against the fp64 oracle.  GPU box only."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F

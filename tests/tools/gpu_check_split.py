@@ -1,9 +1,9 @@
 """GPU check of the split-half (f16x3) kernels against the exact-fp32 kernels and an fp64 torch reference.
-usage: python tools/gpu_check_split.py [N] [S] [H]"""
+usage: python tests/tools/gpu_check_split.py [N] [S] [H]"""
 import math
 import sys
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import __graft_entry__ as G
 G.build()
