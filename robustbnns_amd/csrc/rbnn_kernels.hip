@@ -22,6 +22,7 @@
 // The k <-> memory-index map of a K step is free as long as A and B agree; both kernels use
 // "step r of a 16-wide k block: k = lg  <->  index 4*lg + r", so one 16-byte load feeds four K steps.
 #include "rbnn_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -646,6 +647,10 @@ inline int pick_td(int Dt) { return (Dt % 7 == 0) ? 7 : (Dt < 4 ? 1 : 4); }
 
 // samples per slab: fill the 2-blocks-per-CU slots evenly, keep fp32 chains short, count slab traffic
 int pick_chunk(int N, int Dt, int S) {
+    if (const char* e = getenv("RBNN_CHUNK")) {                 // experiments only
+        const int c = atoi(e);
+        if (c >= 1) return c < S ? c : S;
+    }
     const int NT = (N + 255) / 256, TD = pick_td(Dt), ND = (Dt + TD - 1) / TD;
     const long long base = (long long)NT * ND;
     int cus = 256;

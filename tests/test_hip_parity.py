@@ -305,6 +305,39 @@ def test_pgd_hip_graph_replay_is_bit_identical(arch, shape, C, H, S, N, precisio
     assert torch.equal(again, eng.pgd(x, y, S, 0.2, alpha=2 / 225, iters=4).cpu())
 
 
+@pytest.mark.parametrize("precision,blocks", [("split", 2), ("exact", 3), ("split", 1)])
+def test_sharded_step_with_real_kernels_and_rccl(precision, blocks, monkeypatch):
+    """AttackEngine._step_sharded (async all-reduces, point-block pipeline) on the GPU kernels over a 1-rank RCCL group with the
+    collectives forced on: same adversarial images as the plain single-GPU step (slab partitioning differs per block, so
+    pixels with a vanishing gradient component are excluded as everywhere else)."""
+    import socket
+    import torch.distributed as dist
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    D, H, C, S, N = 784, 256, 10, 6, 1100
+    post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=13)
+    sp = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV)
+    plain = AttackEngine(sp, precision=precision)
+    ref_f = plain.fgsm(x, y, S, 0.25).cpu()
+    ref_p = plain.pgd(x, y, S, 0.25, iters=3).cpu()
+    G = plain.gradient(plain.pad_inputs(x), y.argmax(-1).int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1"); monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.setenv("RBNN_FORCE_COLLECTIVES", "1"); monkeypatch.setenv("RBNN_COMM_BLOCKS", str(blocks))
+    monkeypatch.setenv("RBNN_COMM_MIN_POINTS", "256")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        eng = AttackEngine(sp, group=dist.group.WORLD, total_samples=S, precision=precision)
+        assert eng.world == 2 and eng._comm_blocks(N) == blocks          # world forced to 2: every exchange runs
+        adv_equal(eng.fgsm(x, y, S, 0.25).cpu(), ref_f, G)
+        pg = eng.pgd(x, y, S, 0.25, iters=3).cpu()
+        assert float(((pg - ref_p).abs() > 1e-6).double().mean()) < 0.01
+        assert rel_err(eng.forward(x, S).cpu(), plain.forward(x, S).cpu()) < 1e-6
+    finally:
+        dist.destroy_process_group()
+
+
 def test_upstream_gradient_mode_matches_autograd():
     """RBNN_LOSS_UPSTREAM: vector-Jacobian product of the mean-probability forward for an arbitrary dL/dp."""
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
