@@ -305,6 +305,40 @@ def test_pgd_hip_graph_replay_is_bit_identical(arch, shape, C, H, S, N, precisio
     assert torch.equal(again, eng.pgd(x, y, S, 0.2, alpha=2 / 225, iters=4).cpu())
 
 
+def test_split_mode_heavy_tails_and_sparse_inputs():
+    """Split precision takes ONE power-of-two scale per tensor from its largest magnitude: outlier weights (x100), MNIST-like
+    inputs (80 % exact zeros, saturated ones) and a few all-zero images must still meet the bar against the fp64 oracle."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    D, H, C, S, N = 784, 256, 10, 5, 200
+    post = O.synthetic_posterior("fc", D, H, C, S, 0.03)
+    g = torch.Generator().manual_seed(17)
+    for k in ("model.1.weight", "model.3.weight"):                  # 0.1 % outliers, 100x the bulk
+        m = torch.rand(post[k].shape, generator=g) < 1e-3
+        post[k] = torch.where(m, post[k] * 100.0, post[k])
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=8)
+    x = torch.where(torch.rand(x.shape, generator=g) < 0.8, torch.zeros_like(x), x)
+    x = torch.where(torch.rand(x.shape, generator=g) < 0.05, torch.ones_like(x), x)
+    x[:3] = 0.0
+    p64 = O.cast(post, torch.float64)
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision="split")
+    assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, "fc", "leaky", S)) < TOL
+    ok = O.kink_margin(x.double(), p64, "fc", "leaky", S) > KINK
+    ok[:3] = True                                                    # all-zero images: pre-activation = bias, no kink issue expected
+    ok &= O.kink_margin(x.double(), p64, "fc", "leaky", S) > KINK
+    assert int(ok.sum()) >= N - max(3, N // 20) - 3
+    lab = y.argmax(-1)
+    G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().reshape(x.shape)
+    ref = O.meanprob_gradients(x.double(), lab, p64, "fc", "leaky", S)
+    exact = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision="exact")
+    Ge = exact.gradient(exact.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().reshape(x.shape)
+    e_split, e_exact = rel_err(G[ok], ref[ok]), rel_err(Ge[ok], ref[ok])
+    print(f"heavy tails: split {e_split:.2e}  exact fp32 {e_exact:.2e}")
+    assert e_split < max(TOL, 1.5 * e_exact)                         # outlier weights make the logits large: fp32 itself is the yardstick
+    assert rel_err(eng.loss_gradients(x, y, S).cpu()[ok], O.loss_gradients(x.double(), y, p64, "fc", "leaky", S)[ok]) < max(TOL, 1.5 * e_exact)
+    adv = eng.fgsm(x, y, S, 0.1).cpu()
+    adv_equal(adv[ok], torch.clamp(x + 0.1 * ref.sign().float(), 0, 1)[ok], ref[ok])
+
+
 @pytest.mark.parametrize("precision,blocks", [("split", 2), ("exact", 3), ("split", 1)])
 def test_sharded_step_with_real_kernels_and_rccl(precision, blocks, monkeypatch):
     """AttackEngine._step_sharded (async all-reduces, point-block pipeline) on the GPU kernels over a 1-rank RCCL group with the
