@@ -574,6 +574,31 @@ __global__ void attack_step_kernel(float* __restrict__ X, const float* __restric
     X[n * ldx + d] = fminf(fmaxf(pert, 0.f), 1.f);
 }
 
+// four pixels per thread (16-byte loads of every slab, of x and of x0): D, ldx, ldg multiples of 4 and 16-byte aligned bases
+__global__ void attack_step4_kernel(float* __restrict__ X, const float* __restrict__ X0, int ldx,
+                                    const float* __restrict__ G, int K, long long slab_stride, int ldg,
+                                    const float* __restrict__ alpha, float alpha_scalar, float eps, int project,
+                                    int N, int D4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * D4) return;
+    const long long n = i / D4;
+    const int d = 4 * (int)(i % D4);
+    f32x4 g = *(const f32x4*)(G + n * ldg + d);
+    for (int k = 1; k < K; ++k) g += *(const f32x4*)(G + k * slab_stride + n * ldg + d);
+    const float step = alpha ? alpha[n] : alpha_scalar;
+    const f32x4 x = *(const f32x4*)(X + n * ldx + d);
+    f32x4 x0 = x, out;
+    if (project) x0 = *(const f32x4*)(X0 + n * ldx + d);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float sgn = (g[r] > 0.f) ? 1.f : ((g[r] < 0.f) ? -1.f : 0.f);
+        float pert = x[r] + step * sgn;
+        if (project) pert = x0[r] + fminf(fmaxf(pert - x0[r], -eps), eps);
+        out[r] = fminf(fmaxf(pert, 0.f), 1.f);
+    }
+    *(f32x4*)(X + n * ldx + d) = out;
+}
+
 __global__ void eval_metrics_kernel(const float* __restrict__ A, const float* __restrict__ B, int ldp,
                                     const int* __restrict__ labels, int N, int C, int* __restrict__ counts,
                                     float* __restrict__ rob) {
@@ -921,6 +946,12 @@ int rbnn_attack_step(float* X, const float* X0, int32_t ldx, const float* G, int
                      const float* alpha, float alpha_scalar, float eps, int32_t project, int32_t N, int32_t D, void* stream) {
     if (!X || !G || (project && !X0)) return RBNN_ERR_NULL;
     if (N < 1 || D < 1 || ldx < D || ldg < D || K < 1) return RBNN_ERR_SHAPE;
+    if (!(D & 3) && !(ldx & 3) && !(ldg & 3) && !(slab_stride & 3) && aligned16(X) && aligned16(G) && (!project || aligned16(X0))) {
+        const long long total4 = (long long)N * (D / 4);
+        hipLaunchKernelGGL(attack_step4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           X, X0, ldx, G, K, (long long)slab_stride, ldg, alpha, alpha_scalar, eps, project, N, D / 4);
+        return launch_status();
+    }
     const long long total = (long long)N * D;
     hipLaunchKernelGGL(attack_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        X, X0, ldx, G, K, (long long)slab_stride, ldg, alpha, alpha_scalar, eps, project, N, D);
