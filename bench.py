@@ -166,6 +166,9 @@ def main():
         def conv_forward(self, *a):
             return self._timed("conv_forward", super().conv_forward, *a)
 
+        def conv_forward_split(self, *a):
+            return self._timed("conv_forward", super().conv_forward_split, *a)
+
         def conv_input_grad(self, *a):
             return self._timed("conv_input_grad", super().conv_input_grad, *a)
 
@@ -224,7 +227,9 @@ def main():
         per_launch = 2.0 * (460800 + 51200.0 * w["H"] + 49 * w["H"] * w["C"]) * w["N"] * w["S"]
     KNAMES = {"exact": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel",
                         "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel"},
-              "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel"}}
+              "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
+                        "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_kernel"}}
+    SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward"}        # the conv backward runs on the fp32 MFMA in either mode
 
     def roofline(mode, evs_by_name, ms_per_step):
         kernels = {}
@@ -235,11 +240,11 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and args.workload == "c2" and not args.points and not args.samples:
-            traffic = json.load(open(pmc)).get(dom + ("_split" if mode == "split" else ""), {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(dom + ("_split" if mode == "split" and dom in SPLIT_KERNELS else ""), {}).get("hbm_bytes_per_launch")
         fp32_eq = kernels[dom]["tflops"]
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
              "flop_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
-        if mode == "split":
+        if mode == "split" and dom in SPLIT_KERNELS:
             # matrix-pipe work of the split mode: 3 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
             r.update({"achieved": 3.0 * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": 3.0 * fp32_eq / F16_MFMA_PEAK_TFLOPS,
                       "pipe": "v_mfma_f32_16x16x32_f16, 3 products per fp32 MAC", "fp32_equivalent_tflops": fp32_eq,
@@ -252,7 +257,7 @@ def main():
 
     mode, dt, evs = run(args.precision)
     other = None
-    if world == 1 and w["arch"] != "conv" and mode == "split" and args.precision == "auto":
+    if world == 1 and mode == "split" and args.precision == "auto":
         other = run("exact")                                              # reference line: the exact-fp32 kernels on the same workload
 
     import ctypes

@@ -188,7 +188,7 @@ typedef struct rbnn_conv_posterior {
 
 typedef struct rbnn_conv_workspace {
     float   *P, *dZ;               /* [S,N,16]                                                     */
-    float   *P1;                   /* [S,N,32*12*12]  pooled+activated conv1 output                */
+    float   *P1;                   /* [S,N,24 KiB]    pooled+activated conv1 output: fp32 [32,12,12] (18 KiB) or the split image  */
     uint8_t *st1;                  /* [S,N,32*12*12]  pool-1 stash: argmax (bits 0-1) | pre-activation > 0 (bit 2) */
     float   *Q2;                   /* [S,N,Hc*49]     pooled+activated conv2 output (the Linear's input) */
     uint8_t *st2;                  /* [S,N,Hc*49]     pool-2 stash, same encoding                  */
@@ -210,6 +210,15 @@ int rbnn_conv_forward(const rbnn_conv_posterior *net, const float *X, int32_t ld
  * (sum them with rbnn_sum_slabs(G, S, N, 784, ...)).  Replaces loss.backward() through model_nn.py:98-106. */
 int rbnn_conv_input_grad(const rbnn_conv_posterior *net, const int32_t *sample_idx, int32_t n_samples,
                          int32_t n_points, const rbnn_conv_workspace *ws, void *stream);
+
+/* rbnn_conv_forward in split-half precision (the technique of the fc split mode applied to conv2, 98 % of the MACs):
+ * K2_rows = rbnn_split_rows image of model.3.weight regrouped [S_total*Hc, 25 taps * 32 ci] (K tap-major) holding W * 2^k2_exp;
+ * the pooled conv1 activations are carried as value * 2^p1_exp = hi + lo (the caller bounds them: |P1| <= max_c(sum|K1w_c| *
+ * max|x| + |K1b_c|)).  ws->P1 holds the 24 KiB split image per (sample, point) (rbnn_conv_workspace_query sizes it);
+ * same outputs as rbnn_conv_forward, and rbnn_conv_input_grad follows it unchanged. */
+int rbnn_conv_forward_split(const rbnn_conv_posterior *net, const void *K2_rows, int32_t k2_exp, int32_t p1_exp, const float *X,
+                            int32_t ldx, int32_t n_points, const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
+                            const rbnn_conv_workspace *ws, void *stream);
 
 /* W[s,i] = loc[i] + softplus(scale_raw[i]) * eps[s,i]   — the SVI guide's draw, model_bnn.py:124-130
  * (Normal(loc, softplus(scale)).rsample()).  PARITY UNPINNED: pyro-ppl 1.3.0 is not available;

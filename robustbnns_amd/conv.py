@@ -11,6 +11,7 @@ import torch
 
 from . import _hip
 from .engine import AttackEngine, to_labels
+from .posterior import scale_exp
 from ._hip import OUT_LOGITS, OUT_PROBS
 
 CONV_KEYS = ("model.0", "model.3", "model.7")
@@ -39,6 +40,25 @@ class ConvStackedPosterior:
         # with one K tile = one tap x 16 channels
         self.K2ci = self.K2w.view(S, self.H // 16, 16, 32, 25).permute(0, 3, 1, 4, 2).reshape(S, 32, self.H * 25).contiguous()
         self._desc = None
+        self._split = None
+
+    # ------------------------------------------------------------------ split-half precision mode (forward conv2)
+    def split_supported(self):
+        return self.device.type == "cuda"
+
+    def split_images(self):
+        """(K2 split-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32], its exponent, per-unit bound of the pooled
+        conv1 activations |P1| <= max_c(sum_taps |K1w_c|) * max|x| + max|K1b|) — built once, resident."""
+        if self._split is None:
+            S, H = self.S, self.H
+            k2 = self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2).reshape(S * H, 800).contiguous()      # k = tap*32 + ci
+            k2_exp = scale_exp(float(k2.abs().max()))
+            rows = torch.empty(S * H, 800 * 2, dtype=torch.int16, device=self.device)
+            _hip.HipKernels().split_rows(k2, 800, k2_exp, rows, 800)
+            w_l1 = float(self.K1w.abs().sum(-1).max())
+            b_max = float(self.K1b.abs().max())
+            self._split = (rows, k2_exp, w_l1, b_max)
+        return self._split
 
     @classmethod
     def from_state_dicts(cls, sds, activation, input_shape, n_classes, hidden, device):
@@ -136,7 +156,12 @@ class ConvEngine(AttackEngine):
         return oa, aa, torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts]), torch.cat([p[4] for p in parts])
 
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
-        self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)
+        if self.precision != "split":
+            return self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)
+        rows, k2_exp, w_l1, b_max = self.post.split_images()
+        xmax = self._x_bound if self._x_bound is not None else float(Xp.abs().max())
+        p1_exp = scale_exp(w_l1 * xmax + b_max)
+        self.k.conv_forward_split(self.post, rows, k2_exp, p1_exp, Xp, sidx, S, out_kind, ws)
 
     def _grad_kernels(self, sidx, S, N, ws):
         return self.k.conv_input_grad(self.post, sidx, S, N, ws)

@@ -8,8 +8,10 @@
 #include "../../include/robustbnns_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)   // split-half mode (rbnn_split.hip, rbnn_conv.hip)
 // Diagnostic ablation bits (tools/ablate.hip builds this file with RBNN_ABL != 0 to price each part of the K loops;
 // results are then wrong by construction).  1: no LDS-DMA in the loop  2: no barrier in the loop
 // 4: operands not re-read from LDS  8: skip the epilogue  16: grad: no dA generation in the loop
@@ -48,6 +50,16 @@ __host__ __device__ __forceinline__ long long mask_ld(int N) { return ((long lon
 // 16-float (64 B) LDS rows read with ds_read_b128 by lane (row li, 16-B chunk lg): physical chunk =
 // lg ^ swz(row) with swz = [0,2,3,1][(row>>2)&3] makes every 16-lane b128 group hit 16 distinct slots.
 __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+// Split-half stage tiles: rows of 128 B = [hi8 | lo8] x 4 column groups, read with ds_read_b128 (row li, chunk 2*lg / 2*lg+1).
+// ds_read_b128 is served in four NON-contiguous 16-lane groups — {0-3,12-15,20-27}, {4-11,16-19,28-31}, same +32 — i.e. rows
+// {0-3,12-15} of chunk pair lg together with rows {4-11} of chunk pair lg+1; physical chunk = c ^ row_swz(row) makes every group
+// cover 16 distinct 16-B slots of the 256-B bank row (the plain (r>>1)&7 swizzle measured 48 % conflict cycles).
+#ifndef RBNN_OLD_SWZ
+__device__ __forceinline__ int row_swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
+#else
+__device__ __forceinline__ int row_swz(int r) { return (r >> 1) & 7; }
+#endif
 
 // Asynchronous 16-B-per-lane global -> LDS copy (global_load_lds_dwordx4): per-lane source, LDS destination =
 // wave-uniform base + lane*16.  Completion is tracked by vmcnt; __syncthreads() drains it before the barrier.

@@ -199,6 +199,190 @@ __global__ void __launch_bounds__(256) conv_fc_kernel(const ConvArgs a) {
     if (n0 + li < a.N) *(f32x4*)(a.P + ((long long)s * a.N + n0 + li) * RBNN_CPAD + 4 * lg) = z;
 }
 
+// =====================================================================================================
+// Split-half precision forward (the technique of rbnn_split.hip applied to conv2, 98 % of the MACs).
+//   conv1_pool_split_kernel  as conv1_pool_kernel, but one thread per pooled POSITION computing all 32 channels, so that it
+//                            can write the point's image channel-last as fp16 hi / lo:
+//                              P1s[s][n][plane hi|lo][y 0..11][x pitch 16][ci 32]   (2 x 12 KiB; value * 2^p1_exp = hi + lo)
+//                            with 16-byte channel octet o stored at o ^ (((16y + x) >> 2 & 1) << 1)  (bank swizzle, below).
+//   conv2_pool_split_kernel  K runs tap-major: k = tap*32 + ci, so ONE v_mfma_f32_16x16x32_f16 K step is one tap over the 32
+//                            input channels and the gathered B operand of a lane (position li, channel octet lg) is ONE
+//                            ds_read_b128 of the image (hi) and one of the lo plane — no k -> offset table, no scalar gathers.
+//                            A = model.3.weight regrouped [hc][tap][ci] as a split-rows image (rbnn_split_rows), staged per
+//                            tap through the same swizzled 128-B-row LDS-DMA ring as fc_forward_split_kernel.
+//                            Block = 8 waves = 4 channel quarters (64 hc) x 2 points of one sample; channels in chunks of
+//                            256; both points' images stay resident in LDS (48 KiB) and share every weight tile.
+//                            Bank rule: a ds_read_b128 group is lanes {0-3,12-15} of octet lg with lanes {4-11} of octet
+//                            lg^1; with the x pitch of 16 those two lane sets sit on 8 distinct positions mod 8 each, and
+//                            the octet swizzle above separates (p mod 4) twins: conflict-free for every tap.
+// =====================================================================================================
+constexpr int P1PITCH = 16, P1PLANE = P1W * P1PITCH * C1 * 2;            // bytes of one (hi or lo) plane: 12 x 16 x 32 halves
+constexpr int P1SPLIT = 2 * P1PLANE;                                     // 24 KiB per (sample, point)
+static_assert(P1SPLIT == 24576, "split image size");
+
+struct ConvSplitArgs {
+    const char* K2r; int k2_exp; int p1_exp;                             // split-rows image of [S_total*Hc][25*32]
+    char* P1s;                                                           // [S][N][P1SPLIT]
+};
+
+template <int ACT>
+__global__ void __launch_bounds__(256) conv1_pool_split_kernel(const ConvArgs a, const ConvSplitArgs sp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per pooled position (s, n, py, px)
+    if (i >= (long long)a.S * a.N * (P1W * P1W)) return;
+    const int pp = (int)(i % (P1W * P1W)), py = pp / P1W, px = pp % P1W;
+    const long long sn = i / (P1W * P1W);
+    const int n = (int)(sn % a.N), s = (int)(sn / a.N);
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const float* const x = a.X + (long long)n * a.ldx + (2 * py) * 28 + 2 * px;
+    float patch[6][6];
+#pragma unroll
+    for (int y = 0; y < 6; ++y)
+#pragma unroll
+        for (int xx = 0; xx < 6; ++xx) patch[y][xx] = x[y * 28 + xx];
+    const float scale = ldexpf(1.f, sp.p1_exp);
+    const int p = py * P1PITCH + px, osw = ((p >> 2) & 1) << 1;
+    char* const dst = sp.P1s + sn * P1SPLIT + (long long)p * 64;
+    for (int o = 0; o < 4; ++o) {                                         // 8 channels -> one 16-byte octet of hi and of lo
+        union { f16x8 v; uint4 u; } hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * o + j;
+            const float* const w = a.K1w + ((long long)sw * C1 + c) * 25;
+            const float b = a.K1b[(long long)sw * C1 + c];
+            float best = 0.f;
+            int arg = 0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx) v = fmaf(w[ky * 5 + kx], patch[dy + ky][dx + kx], v);
+                    v += b;
+                    if ((dy == 0 && dx == 0) || v > best) { best = v; arg = dy * 2 + dx; }
+                }
+            a.st1[sn * P1SZ + c * (P1W * P1W) + pp] = (uint8_t)(arg | (best > 0.f ? 4 : 0));
+            const float v = act_fwd<ACT>(best) * scale;
+            const _Float16 h = (_Float16)v;
+            hi.v[j] = h;
+            lo.v[j] = (_Float16)(v - (float)h);
+        }
+        *(uint4*)(dst + ((o ^ osw) * 16)) = hi.u;
+        *(uint4*)(dst + P1PLANE + ((o ^ osw) * 16)) = lo.u;
+    }
+}
+
+template <int ACT>
+__global__ void __launch_bounds__(512, 2) conv2_pool_split_kernel(const ConvArgs a, const ConvSplitArgs sp) {
+    constexpr int WROWS = 256, ROWB = 128, TILEB = WROWS * ROWB;          // weight stage tile: 256 channels x one tap (32 ci, hi + lo)
+    constexpr int NW = 8, WP = WROWS / 8 / NW;                            // DMA pieces (8 rows each) per wave per stage
+    constexpr int OFF_IMG = 2 * TILEB;                                    // two weight buffers, then the two points' images
+    extern __shared__ __attribute__((aligned(16))) float lds[];           // OFF_IMG + 2 * P1SPLIT bytes
+    char* const ldsb = (char*)lds;
+
+    const int NB = (a.N + 1) / 2;                                         // blocks per sample
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, nb0 = (id % NB) * 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int wq = wave & 3, wp = wave >> 2;                              // channel quarter, point of the pair
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const int n = min(nb0 + wp, a.N - 1);                                 // a ragged last block computes its first point twice, stores once
+    const bool live = nb0 + wp < a.N;
+    const long long sn = (long long)s * a.N + n;
+    const char* const Ws = sp.K2r + (long long)sw * a.Hc * (K2 * 4);
+    const int F = a.Hc * NP2;
+    const float out_scale = ldexpf(1.f, -(sp.k2_exp + sp.p1_exp));
+
+    // both points' images -> LDS: 2 x 24 pieces of 1 KiB, linear
+    for (int q = wave; q < 2 * (P1SPLIT / 1024); q += NW) {
+        const int pt2 = q / (P1SPLIT / 1024), piece = q % (P1SPLIT / 1024);
+        const long long src_sn = (long long)s * a.N + min(nb0 + pt2, a.N - 1);
+        glds16((const float*)(sp.P1s + src_sn * P1SPLIT + piece * 1024 + lane * 16), (float*)(ldsb + OFF_IMG + pt2 * P1SPLIT + piece * 1024));
+    }
+    const int prow = lane >> 3;
+    const int src_off = ((lane & 7) ^ row_swz(8 * (wave & 1) + prow)) * 16;
+    const int foff = li * ROWB + (((2 * lg) ^ row_swz(li)) * 16), foff_lo = foff ^ 16;
+    // image position of lane li in position tile pt: (y, x) = (2pt + li/8, li%8); per tap add ky*16 + kx
+    int pbase[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) pbase[pt] = (2 * pt + (li >> 3)) * P1PITCH + (li & 7);
+    const char* const img = ldsb + OFF_IMG + wp * P1SPLIT;
+
+    for (int hc0 = 0; hc0 < a.Hc; hc0 += WROWS) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto stage = [&](int tap, int buf) {
+#pragma unroll
+            for (int i = 0; i < WP; ++i) {
+                const int q = wave + NW * i, row = min(hc0 + 8 * q + prow, a.Hc - 1);   // rows past Hc repeat the last channel; never stored
+                glds16((const float*)(Ws + (long long)row * (K2 * 4) + tap * ROWB + src_off), (float*)(ldsb + buf * TILEB + q * 1024));
+            }
+        };
+        stage(0, 0);
+        ring_wait_barrier<0>();
+        for (int tap = 0; tap < 25; ++tap) {
+            const int buf = tap & 1;
+            if (tap + 1 < 25) stage(tap + 1, buf ^ 1);
+            const char* const Wt = ldsb + buf * TILEB + (wq * 4) * 16 * ROWB;
+            const int toff = (tap / 5) * P1PITCH + (tap % 5);
+            f16x8 bh[4], bl[4], ah[4], al[4];
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) {
+                const int p = pbase[pt] + toff;
+                const int off = p * 64 + ((lg ^ (((p >> 2) & 1) << 1)) * 16);
+                bh[pt] = *(const f16x8*)(img + off);
+                bl[pt] = *(const f16x8*)(img + P1PLANE + off);
+            }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                ah[ht] = *(const f16x8*)(Wt + ht * 16 * ROWB + foff);
+                al[ht] = *(const f16x8*)(Wt + ht * 16 * ROWB + foff_lo);
+            }
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ht][pt] = MFMA_H(al[ht], bh[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ht][pt] = MFMA_H(ah[ht], bl[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) acc[ht][pt] = MFMA_H(ah[ht], bh[pt], acc[ht][pt]);
+            }
+            ring_wait_barrier<0>();                                      // tap+1's weights landed; everyone is done with this tile
+        }
+        // epilogue (as conv2_pool_kernel): scale, bias, 2x2 / stride-1 max-pool of the pre-activations through a per-wave LDS
+        // tile (aliases weight buffer 0: every wave passed the barrier above), activation, stash
+        float* const my = (float*)ldsb + wave * 16 * NPOS;
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            const int hcb = hc0 + (wq * 4 + ht) * 16;                      // wave-uniform
+            if (hcb >= a.Hc) break;
+            const f32x4 bias = *(const f32x4*)(a.K2b + (long long)sw * a.Hc + hcb + 4 * lg);
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) my[(4 * lg + r) * NPOS + pt * 16 + li] = acc[ht][pt][r] * out_scale + bias[r];
+            for (int idx = lane; idx < 16 * NP2 && live; idx += 64) {
+                const int hl = idx / NP2, p = idx % NP2, base = hl * NPOS + (p / P2W) * O2W + (p % P2W);
+                float best = my[base];
+                int arg = 0;
+                if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
+                if (my[base + O2W] > best) { best = my[base + O2W]; arg = 2; }
+                if (my[base + O2W + 1] > best) { best = my[base + O2W + 1]; arg = 3; }
+                const long long o = sn * F + (long long)(hcb + hl) * NP2 + p;
+                a.Q2[o] = act_fwd<ACT>(best);
+                a.st2[o] = (uint8_t)(arg | (best > 0.f ? 4 : 0));
+            }
+        }
+        __syncthreads();                                                 // the scratch aliases weight buffer 0 of the next chunk
+    }
+}
+
 int validate_conv(const rbnn_conv_posterior* net) {
     if (!net || !net->K1w || !net->K1b || !net->K2w || !net->K2b || !net->Fw || !net->Fb) return RBNN_ERR_NULL;
     if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
@@ -217,7 +401,7 @@ int rbnn_conv_workspace_query(const rbnn_conv_posterior* net, int32_t N, int32_t
     const size_t SN = (size_t)S * N, F = (size_t)net->hidden * NP2;
     rbnn_conv_workspace_sizes z = {};
     z.P = z.dZ = SN * RBNN_CPAD * sizeof(float);
-    z.P1 = SN * P1SZ * sizeof(float);
+    z.P1 = SN * (size_t)P1SPLIT;                                  // fp32 image [32][12][12] (18 KiB) or the split image (24 KiB); the backward reuses it for dP1
     z.st1 = SN * P1SZ;
     z.Q2 = SN * F * sizeof(float);
     z.st2 = SN * F;
@@ -248,6 +432,45 @@ int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ld
     const int grid = grid_for_items((long long)N * S);
     if (leaky) hipLaunchKernelGGL(conv2_pool_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL(conv2_pool_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
+    if ((rc = launch_status())) return rc;
+    const int items = ((N + 15) / 16) * S;
+    hipLaunchKernelGGL(conv_fc_kernel, dim3((items + 3) / 4), dim3(256), 0, st, a);
+    return launch_status();
+}
+
+int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows, int32_t k2_exp, int32_t p1_exp, const float* X,
+                            int32_t ldx, int32_t N, const int32_t* sidx, int32_t S, int32_t out_kind,
+                            const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (!K2_rows || !X || !ws || !ws->P || !ws->P1 || !ws->st1 || !ws->Q2 || !ws->st2) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || ldx < 784 || k2_exp < -100 || k2_exp > 100 || p1_exp < -100 || p1_exp > 100) return RBNN_ERR_SHAPE;
+    if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
+    if (!aligned16(K2_rows) || !aligned16(ws->P) || !aligned16(ws->P1) || !aligned16(ws->Q2)) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a = {};
+    a.X = X; a.ldx = ldx; a.N = N;
+    a.K1w = net->K1w; a.K1b = net->K1b; a.K2w = net->K2w; a.K2b = net->K2b; a.Fw = net->Fw; a.Fb = net->Fb;
+    a.Hc = net->hidden; a.C = net->n_classes; a.sidx = sidx; a.S = S;
+    a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind;
+    ConvSplitArgs sp = {};
+    sp.K2r = (const char*)K2_rows; sp.k2_exp = k2_exp; sp.p1_exp = p1_exp; sp.P1s = (char*)ws->P1;   // ws->P1 holds 24 KiB per (s, n)
+    const long long t1 = (long long)S * N * (P1W * P1W);
+    const bool leaky = net->activation == RBNN_ACT_LEAKY;
+    if (leaky) hipLaunchKernelGGL(conv1_pool_split_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a, sp);
+    else       hipLaunchKernelGGL(conv1_pool_split_kernel<RBNN_ACT_RELU>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a, sp);
+    if ((rc = launch_status())) return rc;
+    constexpr int LDSB = 2 * 256 * 128 + 2 * P1SPLIT;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)conv2_pool_split_kernel<RBNN_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv2_pool_split_kernel<RBNN_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
+            return RBNN_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int grid = grid_for_items((long long)((N + 1) / 2) * S);
+    if (leaky) hipLaunchKernelGGL(conv2_pool_split_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(512), LDSB, st, a, sp);
+    else       hipLaunchKernelGGL(conv2_pool_split_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(512), LDSB, st, a, sp);
     if ((rc = launch_status())) return rc;
     const int items = ((N + 15) / 16) * S;
     hipLaunchKernelGGL(conv_fc_kernel, dim3((items + 3) / 4), dim3(256), 0, st, a);

@@ -20,8 +20,6 @@
 //   A operand  a[j] = A[i = li][k = 8*lg + j]    B operand  b[j] = B[k = 8*lg + j][j' = li]    acc[r] = D[4*lg + r][li]
 #include "rbnn_common.hpp"
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 
 namespace {
 
@@ -59,11 +57,6 @@ __global__ void split_rows_kernel(const float* __restrict__ src, long long rows,
 // The epilogue (bias, activation, 1-bit stash, skinny H->C layer on the fp32 MFMA taking the accumulators as its
 // B operand, softmax) is the exact-mode kernel's (rbnn_kernels.hip, fc_forward_kernel).
 // ===================================================================================================
-#ifndef RBNN_OLD_SWZ
-__device__ __forceinline__ int row_swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
-#else
-__device__ __forceinline__ int row_swz(int r) { return (r >> 1) & 7; }
-#endif
 
 struct FwdSplitArgs {
     const char* X;  int ldx;  int N;                           // split-rows image of the inputs [N][ldx] (ldx elements, % 32 == 0)

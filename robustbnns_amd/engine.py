@@ -79,9 +79,10 @@ class AttackEngine:
         want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
         if want not in ("auto", "exact", "split"):
             raise ValueError(f"precision={want!r}: expected 'auto', 'exact' or 'split'")
-        ok = bool(getattr(self.post, "split_supported", lambda: False)()) and hasattr(self.k, "fc_forward_split")
+        ok = bool(getattr(self.post, "split_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
         if want == "split" and not ok:
-            raise _hip.HipError("precision='split' covers fc posteriors with relu/leaky, hidden % 128 == 0, classes <= 10 on the GPU")
+            raise _hip.HipError("precision='split' covers fc posteriors with relu/leaky, hidden % 128 == 0, classes <= 10 (and the "
+                                "conv forward) on the GPU")
         return "split" if (want != "exact" and ok) else "exact"
 
     # ------------------------------------------------------------------ plumbing

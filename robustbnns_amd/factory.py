@@ -24,5 +24,5 @@ def posterior_from_modules(nets, device):
 
 def make_engine(post, kernels=None, group=None, total_samples=None, precision=None):
     if getattr(post, "arch", None) == "conv":
-        return ConvEngine(post, kernels=kernels, group=group, total_samples=total_samples)
+        return ConvEngine(post, kernels=kernels, group=group, total_samples=total_samples, precision=precision)
     return AttackEngine(post, kernels=kernels, group=group, total_samples=total_samples, precision=precision)

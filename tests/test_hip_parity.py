@@ -510,15 +510,17 @@ def test_conv_golden(golden):
     assert all(torch.equal(sd[k], g.posterior()[k][1]) for k in sd)
 
 
+@pytest.mark.parametrize("precision", ["auto", "exact"])
 @pytest.mark.parametrize("act,C,Hc,S,N", [("leaky", 10, 16, 2, 5), ("relu", 10, 32, 2, 19), ("leaky", 10, 64, 3, 33),
                                           ("leaky", 10, 512, 2, 12), ("leaky", 3, 272, 1, 5)])
-def test_conv_against_fp64_oracle(act, C, Hc, S, N):
+def test_conv_against_fp64_oracle(act, C, Hc, S, N, precision):
     from robustbnns_amd import _hip
     from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
     post = O.synthetic_posterior("conv", 784, Hc, C, S, 0.05 if Hc < 512 else 0.03)
     x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=Hc + N)
     lab = y.argmax(-1); p64 = O.cast(post, torch.float64)
-    eng = ConvEngine(ConvStackedPosterior(act, (1, 28, 28), C, Hc, post, DEV))
+    eng = ConvEngine(ConvStackedPosterior(act, (1, 28, 28), C, Hc, post, DEV), precision=precision)
+    assert eng.precision == ("split" if precision == "auto" else "exact")       # split: conv2 forward on the f16 pipe (hi/lo pairs)
     assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, "conv", act, S)) < TOL
     assert rel_err(eng.forward(x, S, logits=True).cpu(), O.ensemble_forward(x.double(), p64, "conv", act, S)) < TOL
     ok = O.kink_margin(x.double(), p64, "conv", act, S) > KINK_CONV

@@ -372,7 +372,7 @@ def test_conv_posterior_layout_and_roundtrip(golden):
     lib = _hip.load()
     out = _hip.ConvWorkspaceSizes()
     assert lib.rbnn_conv_workspace_query(C.byref(d), 100, 3, C.byref(out)) == 0
-    assert out.P1 == 3 * 100 * 4608 * 4 and out.st1 == 3 * 100 * 4608 and out.Q2 == 3 * 100 * 16 * 49 * 4 and out.G == 3 * 100 * 784 * 4
+    assert out.P1 == 3 * 100 * 24576 and out.st1 == 3 * 100 * 4608 and out.Q2 == 3 * 100 * 16 * 49 * 4 and out.G == 3 * 100 * 784 * 4
     assert lib.rbnn_conv_forward(C.byref(d), None, 784, 4, None, 2, 0, None, None) == -1
     bnn = model_bnn.BNN("mnist", 16, "leaky", "conv", "hmc", None, None, 2, 0, (1, 28, 28), 10)
     bnn.set_posterior_samples(post, "cpu")
