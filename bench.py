@@ -172,6 +172,9 @@ def main():
         def conv_input_grad(self, *a):
             return self._timed("conv_input_grad", super().conv_input_grad, *a)
 
+        def conv_input_grad_split(self, *a):
+            return self._timed("conv_input_grad", super().conv_input_grad_split, *a)
+
     if args.shard == "samples":
         xs, ys, S_job, N_job = x, y, w["S"] * world, w["N"]
     else:
@@ -228,8 +231,8 @@ def main():
     KNAMES = {"exact": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel",
                         "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel"},
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
-                        "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_kernel"}}
-    SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward"}        # the conv backward runs on the fp32 MFMA in either mode
+                        "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
+    SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}
 
     def roofline(mode, evs_by_name, ms_per_step):
         kernels = {}

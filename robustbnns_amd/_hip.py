@@ -94,6 +94,7 @@ SIGNATURES = {
     "rbnn_conv_input_grad": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
+    "rbnn_conv_input_grad_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, _fp, _i32, _i32,
                                        C.POINTER(ConvWorkspace), _fp]),
     "rbnn_split_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _i32, _fp]),
@@ -287,6 +288,12 @@ class HipKernels:
         w = self._conv_ws(ws)
         check(self.lib.rbnn_conv_forward_split(C.byref(net.descriptor()), ptr(K2_rows), k2_exp, p1_exp, ptr(X), X.stride(0), X.shape[0],
                                                ptr(sidx), S, out_kind, C.byref(w), stream_of(X)), "rbnn_conv_forward_split")
+
+    def conv_input_grad_split(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):
+        w = self._conv_ws(ws)
+        check(self.lib.rbnn_conv_input_grad_split(C.byref(net.descriptor()), ptr(K2_bwd), k2_exp, fw_l1, ptr(sidx), S, N, C.byref(w),
+                                                  stream_of(ws["dZ"])), "rbnn_conv_input_grad_split")
+        return S
 
     def conv_input_grad(self, net, sidx, S, N, ws):
         w = self._conv_ws(ws)

@@ -57,7 +57,14 @@ class ConvStackedPosterior:
             _hip.HipKernels().split_rows(k2, 800, k2_exp, rows, 800)
             w_l1 = float(self.K1w.abs().sum(-1).max())
             b_max = float(self.K1b.abs().max())
-            self._split = (rows, k2_exp, w_l1, b_max)
+            # backward image: [S*32 ci, chunk(Hc/16) x 13 tap pairs x lg(4 = tap parity*2 + channel octet) x 8 channels]
+            w26 = torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device)
+            w26[..., :25] = self.K2w.view(S, H, 32, 25)
+            kb = w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3).reshape(S * 32, (H // 16) * 13 * 32).contiguous()
+            bwd = torch.empty(kb.shape[0], kb.shape[1] * 2, dtype=torch.int16, device=self.device)
+            _hip.HipKernels().split_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
+            fw_l1 = float(self.Fw.abs().sum(1).max())
+            self._split = (rows, k2_exp, w_l1, b_max, bwd, fw_l1)
         return self._split
 
     @classmethod
@@ -158,10 +165,13 @@ class ConvEngine(AttackEngine):
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
         if self.precision != "split":
             return self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)
-        rows, k2_exp, w_l1, b_max = self.post.split_images()
+        rows, k2_exp, w_l1, b_max = self.post.split_images()[:4]
         xmax = self._x_bound if self._x_bound is not None else float(Xp.abs().max())
         p1_exp = scale_exp(w_l1 * xmax + b_max)
         self.k.conv_forward_split(self.post, rows, k2_exp, p1_exp, Xp, sidx, S, out_kind, ws)
 
     def _grad_kernels(self, sidx, S, N, ws):
-        return self.k.conv_input_grad(self.post, sidx, S, N, ws)
+        if self.precision != "split" or os.environ.get("RBNN_CONV_BWD_EXACT") == "1":
+            return self.k.conv_input_grad(self.post, sidx, S, N, ws)
+        _, k2_exp, _, _, bwd, fw_l1 = self.post.split_images()
+        return self.k.conv_input_grad_split(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)

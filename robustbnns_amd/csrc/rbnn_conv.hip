@@ -637,6 +637,132 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
             for (int r = 0; r < 4; ++r) a.dP1[sn * P1SZ + (16 * ct + 4 * lg + r) * (P1W * P1W) + 16 * pt + li] = acc[ct][pt][r];
 }
 
+// conv2^T in split-half precision: conv_bwd_kernel's structure (one wave = one (sample, point), no block barriers, the whole
+// dP1^T[32 ci][144 pos] in 18 accumulator tiles), with the chunk's zero-padded gradient image stored CHANNEL-LAST as fp16
+// hi / lo — img[plane][16 x 16 positions][16 hc] — so that the gathered B operand of v_mfma_f32_16x16x32_f16 is one
+// ds_read_b128 per plane: a K step is TWO taps x 16 channels (lanes lg = 0,1: tap 2t, channel octets 0,1; lg = 2,3: tap 2t+1),
+// 13 steps per chunk (the 26th tap is zero weight).  A = model.3.weight regrouped [ci][chunk][step][lg][8] as a split-rows
+// image (rbnn_split_rows), read straight from memory.  The gradients are scaled per (sample, point) by a power of two taken
+// from max|dZ| * max_f sum_c |Fw[c][f]| (x4 for the overlapping pool windows), divided out in the epilogue.
+template <int ACT>
+__global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp, float fw_l1) {
+    constexpr int HCH = 16, NPT = 9, PLANE = 256 * 32, NSTEP = 13;        // bytes of one image plane: 256 positions x 16 halves
+    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    char* const img = lds + wave * 2 * PLANE;
+
+    const int NB = (a.N + 3) / 4;
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, n = (id % NB) * 4 + wave;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    if (n >= a.N) return;
+    const long long sn = (long long)s * a.N + n;
+    const int F = a.Hc * NP2, NCH = a.Hc / HCH;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+
+    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1
+    float dzmax = fabsf(a.dZ[sn * RBNN_CPAD + li]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
+    const float bound = 4.f * dzmax * fw_l1;
+    int e = 0;
+    if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 11 - ilogbf(bound)));
+    const float in_scale = ldexpf(1.f, e), out_scale = ldexpf(1.f, -(e + k2_exp));
+
+    int poff[NPT];                                                        // image position index of output position 16pt + li (tap 0,0)
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) { const int pos = pt * 16 + li; poff[pt] = (pos / P1W + 4) * 16 + pos % P1W + 4; }
+    // weight rows: row = sw*32 + ci, one 32-byte group (hi8 | lo8) per (chunk, step, lg)
+    const long long rowb = (long long)NCH * NSTEP * 4 * 32;
+    const char* const Wr0 = K2b + ((long long)sw * C1 + li) * rowb + lg * 32;
+    const char* const Wr1 = Wr0 + 16 * rowb;
+
+    f32x4 acc[2][NPT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int i = lane; i < 2 * PLANE / 16; i += 64) *(uint4*)(img + 16 * i) = make_uint4(0, 0, 0, 0);   // the border stays zero
+    const int gy = lane >> 3, gx = lane & 7;
+    int woff[4];
+    bool wok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int py = gy - (q >> 1), px = gx - (q & 1);
+        wok[q] = py >= 0 && py < P2W && px >= 0 && px < P2W;
+        woff[q] = wok[q] ? py * P2W + px : 0;
+    }
+    char* const mine = img + ((gy + 4) * 16 + gx + 4) * 32;               // this lane's interior position record
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int hc0 = ch * HCH;
+        // 1. interior of the image for channels hc0 .. hc0+15: pool-2 routing + activation derivative (gather form), scaled, split
+        f16x8 hv[2], lv[2];
+#pragma unroll
+        for (int h4 = 0; h4 < HCH; h4 += 4) {
+            int st[4][4];
+            float dq[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long fb = sn * F + (long long)(hc0 + h4 + j) * NP2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { st[j][q] = a.st2[fb + woff[q]]; dq[j][q] = a.dQ2[fb + woff[q]]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (wok[q] && (st[j][q] & 3) == q) v += (st[j][q] & 4) ? dq[j][q] : dq[j][q] * slope;
+                v *= in_scale;
+                const _Float16 h = (_Float16)v;
+                hv[h4 >> 3][(h4 & 4) + j] = h;
+                lv[h4 >> 3][(h4 & 4) + j] = (_Float16)(v - (float)h);
+            }
+        }
+        *(f16x8*)(mine) = hv[0];
+        *(f16x8*)(mine + 16) = hv[1];
+        *(f16x8*)(mine + PLANE) = lv[0];
+        *(f16x8*)(mine + PLANE + 16) = lv[1];
+        // 2. 13 K steps = tap pairs x 16 channels; a position tile whose rows no tap row of the pair can reach multiplies pure
+        //    padding and is skipped
+        const char* const w0 = Wr0 + (long long)ch * NSTEP * 128;
+        const char* const w1 = Wr1 + (long long)ch * NSTEP * 128;
+        f16x8 a0h = *(const f16x8*)w0, a0l = *(const f16x8*)(w0 + 16), a1h = *(const f16x8*)w1, a1l = *(const f16x8*)(w1 + 16);
+#pragma unroll 1
+        for (int t = 0; t < NSTEP; ++t) {
+            const f16x8 c0h = a0h, c0l = a0l, c1h = a1h, c1l = a1l;
+            if (t + 1 < NSTEP) {
+                a0h = *(const f16x8*)(w0 + 128 * (t + 1)); a0l = *(const f16x8*)(w0 + 128 * (t + 1) + 16);
+                a1h = *(const f16x8*)(w1 + 128 * (t + 1)); a1l = *(const f16x8*)(w1 + 128 * (t + 1) + 16);
+            }
+            const int tA = 2 * t, tB = min(2 * t + 1, 24);               // the padded 26th tap has zero weights: any image offset will do
+            const int kyA = tA / 5, kyB = tB / 5;
+            const int tap = (lg >> 1) ? tB : tA;                          // this lane's tap
+            const char* const src = img + (lg & 1) * 16 - ((tap / 5) * 16 + tap % 5) * 32;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int Ya = (16 * pt) / P1W, Yb = (16 * pt + 15) / P1W;
+                if ((kyA < Ya - 7 || kyA > Yb) && (kyB < Ya - 7 || kyB > Yb)) continue;   // wave-uniform
+                const f16x8 bh = *(const f16x8*)(src + poff[pt] * 32), bl = *(const f16x8*)(src + PLANE + poff[pt] * 32);
+                acc[0][pt] = MFMA_H(c0l, bh, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c1l, bh, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c0h, bl, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c1h, bl, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c0h, bh, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c1h, bh, acc[1][pt]);
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.dP1[sn * P1SZ + (16 * ct + 4 * lg + r) * (P1W * P1W) + 16 * pt + li] = acc[ct][pt][r] * out_scale;
+}
+
 // pool-1 routing + activation derivative + conv1^T (in_channels = 1), gather form: one thread per input pixel (Yo, Xo).
 // A pooled cell (c, py, px) routes its gradient to ONE conv1 output (Ya, Xa) = (2py + arg/2, 2px + arg%2); that output
 // touches pixel (Yo, Xo) through tap (Yo - Ya, Xo - Xa) if it lies in the 5x5 kernel.  Only cells with
@@ -696,6 +822,32 @@ extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_
     }
     if (leaky) hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
+    if ((rc = launch_status())) return rc;
+    if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
+    return launch_status();
+}
+
+extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const void* K2_bwd, int32_t k2_exp, float fw_l1,
+                                          const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (!K2_bwd || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
+    if (!aligned16(K2_bwd) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
+    ConvBwdArgs a = {};
+    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = nullptr; a.Fw = net->Fw;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
+    const int grid = grid_for_items((long long)((N + 3) / 4) * S);
+    const bool leaky = net->activation == RBNN_ACT_LEAKY;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const long long F = (long long)net->hidden * NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+        hipLaunchKernelGGL(conv_fc_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+        if ((rc = launch_status())) return rc;
+    }
+    if (leaky) hipLaunchKernelGGL(conv_bwd_split_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
+    else       hipLaunchKernelGGL(conv_bwd_split_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
     if ((rc = launch_status())) return rc;
     if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
