@@ -647,9 +647,14 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
 template <int ACT>
 __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp, float fw_l1) {
     constexpr int HCH = 16, NPT = 9, PLANE = 256 * 32, NSTEP = 13;        // bytes of one image plane: 256 positions x 16 halves
-    __shared__ __attribute__((aligned(16))) char lds[4 * 2 * PLANE];
+    constexpr int NFL = HCH * NP2;                                        // 784 pooled cells per chunk
+    constexpr int STG = NFL * 4 + NFL;                                    // staging: 784 dQ2 floats + 784 stash bytes, packed (2 blocks per CU need <= 80 KiB each)
+    static_assert(STG % 16 == 0 && 4 * (2 * PLANE + STG) <= 81920, "two blocks per CU");
+    __shared__ __attribute__((aligned(16))) char lds[4 * (2 * PLANE + STG)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    char* const img = lds + wave * 2 * PLANE;
+    char* const img = lds + wave * (2 * PLANE + STG);
+    float* const sdq = (float*)(img + 2 * PLANE);                          // [16 hc][49] pooled gradients of the chunk
+    unsigned char* const sst = (unsigned char*)(img + 2 * PLANE + NFL * 4);   // [16 hc][49] stash bytes
 
     const int NB = (a.N + 3) / 4;
     int id;
@@ -695,8 +700,27 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
         woff[q] = wok[q] ? py * P2W + px : 0;
     }
     char* const mine = img + ((gy + 4) * 16 + gx + 4) * 32;               // this lane's interior position record
+    // The chunk's 16 x 49 pooled gradients and stash bytes are contiguous in memory: they come in by 4-byte-per-lane LDS-DMA
+    // (13 + 4 wave instructions, coalesced, no registers), issued right after the previous chunk's routing has read the
+    // staging area, so they land under that chunk's MFMAs; the routing then gathers from LDS instead of from memory
+    // (128 scattered global loads per lane per chunk made the routing 3/4 of this kernel's time).
+    auto dma4 = [&](const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)l, 4, 0, 0);
+    };
+    auto stage_chunk = [&](int ch) {                                       // lane p of instruction q lands at byte 256q + 4p of its region
+        const long long fb = sn * F + (long long)ch * NFL;                 // a multiple of 4: the stash dwords are aligned
+#pragma unroll
+        for (int q = 0; q < 12; ++q) dma4(a.dQ2 + fb + q * 64 + lane, sdq + q * 64);
+        if (lane < NFL - 12 * 64) dma4(a.dQ2 + fb + 12 * 64 + lane, sdq + 12 * 64);          // the last 16 floats
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dma4(a.st2 + fb + q * 256 + 4 * lane, sst + q * 256);
+        if (lane < (NFL - 3 * 256) / 4) dma4(a.st2 + fb + 3 * 256 + 4 * lane, sst + 3 * 256);    // the last 16 bytes
+    };
+    stage_chunk(0);
     for (int ch = 0; ch < NCH; ++ch) {
         const int hc0 = ch * HCH;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): this chunk's staging has landed (wave-local, no barrier)
+        asm volatile("" ::: "memory");
         // 1. interior of the image for channels hc0 .. hc0+15: pool-2 routing + activation derivative (gather form), scaled, split
         f16x8 hv[2], lv[2];
 #pragma unroll
@@ -705,9 +729,9 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
             float dq[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const long long fb = sn * F + (long long)(hc0 + h4 + j) * NP2;
+                const int fb = (h4 + j) * NP2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { st[j][q] = a.st2[fb + woff[q]]; dq[j][q] = a.dQ2[fb + woff[q]]; }
+                for (int q = 0; q < 4; ++q) { st[j][q] = sst[fb + woff[q]]; dq[j][q] = sdq[fb + woff[q]]; }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -725,6 +749,8 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
         *(f16x8*)(mine + 16) = hv[1];
         *(f16x8*)(mine + PLANE) = lv[0];
         *(f16x8*)(mine + PLANE + 16) = lv[1];
+        asm volatile("" ::: "memory");
+        if (ch + 1 < NCH) stage_chunk(ch + 1);                             // the staging area is free again: next chunk's rows fly under the MFMAs
         // 2. 13 K steps = tap pairs x 16 channels; a position tile whose rows no tap row of the pair can reach multiplies pure
         //    padding and is skipped
         const char* const w0 = Wr0 + (long long)ch * NSTEP * 128;
