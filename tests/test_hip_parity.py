@@ -190,6 +190,46 @@ def test_baseline_attacks_driver(golden, tmp_path, monkeypatch):
     assert os.path.exists(savedir.TESTS + "/mnist_baseline_attacks_fgsm.csv")
 
 
+def test_half_moons_grid_driver(tmp_path, monkeypatch):
+    """grid_search_halfMoons.serial_compute_grads / grid_attack over a 2 x 2 model grid stored in the reference's on-disk HMC
+    format (<name>/<name>_weights_<i>.pt): every cell equals the direct loss_gradients / attack call and the fp64 oracle."""
+    from robustbnns_amd import adversarialAttacks as A, grid_search_halfMoons as GS, savedir
+    monkeypatch.chdir(tmp_path)
+    shape, C, S = (1, 2, 1), 2, 6
+    x, y = O.synthetic_inputs(40, shape, C, seed=3)
+    rel = str(tmp_path) + "/models/"
+    posts = {}
+    for arch, hid in (("fc2", 32), ("fc2", 128)):
+        for n_inp in (100, 200):
+            bnn = GS.MoonsBNN(hid, "leaky", arch, "hmc", None, None, S, 10, n_inp, shape, C)
+            assert bnn.name == f"half_moons_bnn_hmc_hid={hid}_act=leaky_arch={arch}_inp={n_inp}_samp={S}_warm=10_stepsize=0.001_numsteps=10"
+            post = O.synthetic_posterior(arch, 2, hid, C, S, 1.5 / hid ** 0.5)     # O(1) pre-activations: fp32 itself stays well inside the bar
+            post = {k: v + 0.01 * n_inp / 100 for k, v in post.items()}            # different weights per grid cell
+            bnn.set_posterior_samples(post, "cpu")
+            bnn.save(rel_path=rel)
+            posts[bnn.name] = post
+    grid = dict(hidden_size=[32, 128], activation=["leaky"], architecture=["fc2"], inference=["hmc"], epochs=[None], lr=[None],
+                n_samples=[S], warmup=[10], n_inputs=[100, 200])
+    grads = GS.serial_compute_grads(**grid, posterior_samples=[S], rel_path=rel, x_test=x, y_test=y, device=DEV)
+    assert len(grads) == 4
+    for (name, s_), g in grads.items():
+        arch, hid = "fc2", int(name.split("hid=")[1].split("_")[0])
+        p64 = O.cast(posts[name], torch.float64)
+        ref = O.loss_gradients(x.double(), y, p64, arch, "leaky", s_)
+        ok = O.kink_margin(x.double(), p64, arch, "leaky", s_) > KINK
+        assert g.shape == (40, 2) and int(ok.sum()) >= 36 and rel_err(torch.from_numpy(g).reshape(ref.shape)[ok], ref[ok]) < TOL
+        assert os.path.exists(savedir.DATA + name + "/" + name + "_samp=" + str(s_) + "_lossGrads.pkl")
+    advs = GS.grid_attack("fgsm", **grid, posterior_samples=[2, S], x_test=x, y_test=y, device=DEV, rel_path=rel)
+    assert len(advs) == 8
+    for (name, s_), adv in advs.items():
+        hid = int(name.split("hid=")[1].split("_")[0])
+        p64 = O.cast(posts[name], torch.float64)
+        gm = O.meanprob_gradients(x.double(), y.argmax(-1), p64, "fc2", "leaky", s_)
+        ok = O.kink_margin(x.double(), p64, "fc2", "leaky", s_) > KINK
+        adv_equal(adv[ok], torch.clamp(x + 0.3 * gm.sign().float(), 0, 1)[ok], gm[ok])
+        assert torch.equal(A.load_attack("fgsm", name, n_samples=s_).cpu(), adv.cpu())
+
+
 # ------------------------------------------------------------------ (2) fp64 oracle, every tile configuration, ragged sizes
 ORACLE_CASES = [  # arch, act, shape, C, H, S, N, std
     ("fc", "leaky", (1, 28, 28), 10, 512, 7, 333, 0.05), ("fc", "relu", (1, 28, 28), 10, 512, 5, 257, 0.05),
