@@ -49,6 +49,8 @@ WORKLOADS = {
                desc="F-MNIST fc-BNN 784->512->10 (leaky), PGD T=40 eps=0.3, N=10000 points, S=500 samples/GPU"),
     "conv": dict(shape=(1, 28, 28), H=512, C=10, arch="conv", act="leaky", S=16, N=2048, method="fgsm", iters=1, eps=0.3,
                  desc="MNIST conv-BNN (conv5x5x32 - pool - conv5x5x512 - pool - fc, leaky), FGSM eps=0.3, N=2048 points, S=16 samples/GPU"),
+    "fc2": dict(shape=(1, 28, 28), H=512, C=10, arch="fc2", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
+                desc="MNIST fc2-BNN 784->512->512->10 (leaky; the reference's saved model_1), FGSM eps=0.3, N=10000 points, S=100 samples/GPU"),
     "c1": dict(shape=(1, 2, 1), H=64, C=2, arch="fc", act="leaky", S=10, N=100, method="fgsm", iters=1, eps=0.3,
                desc="half-moons fc-BNN 2->64->2 (leaky), FGSM eps=0.3, N=100 points, S=10 samples/GPU"),
 }
@@ -67,6 +69,11 @@ def make_problem(w, rank, device):
         r = lambda *shape: torch.randn(S, *shape, generator=gw) * 0.03
         post = {"model.0.weight": r(32, 1, 5, 5), "model.0.bias": r(32), "model.3.weight": r(H, 32, 5, 5), "model.3.bias": r(H),
                 "model.7.weight": r(C, 49 * H), "model.7.bias": r(C)}
+        return x, y, post
+    if w["arch"] == "fc2":
+        post = {"model.1.weight": torch.randn(S, H, D, generator=gw) * std, "model.1.bias": torch.randn(S, H, generator=gw) * std,
+                "model.3.weight": torch.randn(S, H, H, generator=gw) * std, "model.3.bias": torch.randn(S, H, generator=gw) * std,
+                "model.5.weight": torch.randn(S, C, H, generator=gw) * std, "model.5.bias": torch.randn(S, C, generator=gw) * std}
         return x, y, post
     post = {"model.1.weight": torch.randn(S, H, D, generator=gw) * std, "model.1.bias": torch.randn(S, H, generator=gw) * std,
             "model.3.weight": torch.randn(S, C, H, generator=gw) * std, "model.3.bias": torch.randn(S, C, generator=gw) * std}
@@ -226,6 +233,8 @@ def main():
 
     # per-launch algorithmic flops of each GEMM kernel: half of SURVEY 8(d)'s 4*(D*H + H*C) per attack-sample
     per_launch = 2.0 * (D * w["H"] + w["H"] * w["C"]) * w["N"] * w["S"]
+    if w["arch"] == "fc2":        # F_fc2 = 4*(D*H + H^2 + H*C), half per direction
+        per_launch = 2.0 * (D * w["H"] + w["H"] ** 2 + w["H"] * w["C"]) * w["N"] * w["S"]
     if w["arch"] == "conv":       # 2*(460800 + 26214400*H/512 + 49*H*C) flop per (point, sample) per direction
         per_launch = 2.0 * (460800 + 51200.0 * w["H"] + 49 * w["H"] * w["C"]) * w["N"] * w["S"]
     KNAMES = {"exact": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel",
@@ -233,6 +242,10 @@ def main():
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
     SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}
+    if w["arch"] == "fc2":
+        KNAMES["split"].update({"fc_forward": "fc_forward_split_kernel (x2: layer 1 -> split image, layer 2)",
+                                "fc_input_grad": "fc_grad_split_kernel (x2: per-sample step through Wm, then W1; + split_dz)"})
+        KNAMES["exact"].update({"fc_forward": "fc_forward_kernel (x2)", "fc_input_grad": "fc_grad_kernel (x2)"})
 
     def roofline(mode, evs_by_name, ms_per_step):
         kernels = {}

@@ -239,7 +239,7 @@ int rbnn_svi_materialize(const float *loc, const float *scale_raw, const float *
  * Split-half precision mode ("f16x3") of the fc forward / input-gradient contractions.  No counterpart in the
  * reference (it computes in fp32): every fp32 operand v is carried as v * 2^e = hi + lo with hi, lo fp16, products
  * are hi*hi' + hi*lo' + lo*hi' on the f16 matrix pipe with fp32 accumulation (2^-22 per product; the parity tests
- * hold this mode to the same 1e-5 bar as the exact mode).  arch fc only, hidden % 128 == 0.
+ * hold this mode to the same 1e-5 bar as the exact mode).  hidden % 128 == 0, relu / leaky backward, <= 10 classes; arch fc and fc2.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct rbnn_split_images {
     const void *W1_rows;           /* rbnn_split_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/8,2,8] halves */
@@ -249,6 +249,13 @@ typedef struct rbnn_split_images {
     int32_t ld_cols;               /* columns of W1_cols = in_stride (D_pad)                                                      */
     int32_t w1_exp;                /* W1_rows and W1_cols hold W1 * 2^w1_exp                                                      */
     int32_t w2_exp;                /* W2_gen holds W2 * 2^w2_exp                                                                  */
+    /* fc2: */
+    const void *Wm_rows;           /* rbnn_split_rows image of Wm viewed as [S_total*H, H] rows, holding Wm * 2^wm_exp (forward)   */
+    const void *Wm_cols;           /* rbnn_split_cols image of Wm [S_total,H/32,4,2,H,8] (backward step 1); W2_gen is then built    */
+                                   /* from the OUTPUT layer (model.5), w2_exp its exponent                                        */
+    int32_t wm_exp;
+    int32_t h1_exp;                /* layer-1 activations are carried as h * 2^h1_exp = hi + lo in ws->hid1; set per call from the  */
+                                   /* bound max_h sum_d |W1[h,d]| * max|x| + max|b1|                                              */
 } rbnn_split_images;
 
 /* per-problem scratch of the split mode */

@@ -57,7 +57,8 @@ class ConvWorkspaceSizes(C.Structure):
 
 class SplitImages(C.Structure):
     _fields_ = [("W1_rows", _fp), ("W1_cols", _fp), ("W2_gen", _fp), ("ld_rows", C.c_int32), ("ld_cols", C.c_int32),
-                ("w1_exp", C.c_int32), ("w2_exp", C.c_int32)]
+                ("w1_exp", C.c_int32), ("w2_exp", C.c_int32), ("Wm_rows", _fp), ("Wm_cols", _fp), ("wm_exp", C.c_int32),
+                ("h1_exp", C.c_int32)]
 
 
 SPLIT_WS_KEYS = ("X_split", "dZ_gen", "g_scale")

@@ -60,13 +60,15 @@ __global__ void split_rows_kernel(const float* __restrict__ src, long long rows,
 
 struct FwdSplitArgs {
     const char* X;  int ldx;  int N;                           // split-rows image of the inputs [N][ldx] (ldx elements, % 32 == 0)
+    long long x_sample_bytes;                                  // 0: shared inputs; fc2 layer 2: the per-sample hidden image [S][N][ldx]
     const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // split-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
     const float* b;  const float* W2;  const float* b2;  int C;  int H;
     const int* sidx;  int S;  int NT;  float out_scale;        // out_scale = 2^-(e_x + e_w)
     float* P;  uint32_t* mask;  float* dact;  int out_kind;
+    char* hid;  float hid_scale;                               // !LAYER2 (fc2 layer 1): activations out as a split-rows image [S][N][H], value * hid_scale = hi + lo
 };
 
-template <int ACT, int WH, int HTW, int WN, int NTW>
+template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
 __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const FwdSplitArgs a) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int ROWB = 128;                                  // bytes per tile row: 32 columns x (hi + lo)
@@ -94,6 +96,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
     const int wave_h = wave % WH, wave_n = wave / WH;
     const int sw = a.sidx ? a.sidx[s] : s;
     const char* const Ws = a.W + (long long)sw * a.w_sample_bytes;
+    const char* const Xs = a.X + (long long)s * a.x_sample_bytes;
     const int n0 = ntile * BN;
     const int HW = a.H >> 5;
     // DMA piece q = tile rows 8q..8q+7; lane p lands at row 8q + (p >> 3), physical chunk p & 7, so it fetches
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
             for (int i = 0; i < XP; ++i) {
                 const int q = wave + NW * i;
                 const int n = min(n0 + 8 * q + prow, a.N - 1);  // rows past N repeat the last point; never stored
-                glds16((const float*)(a.X + (long long)n * a.ldx * 4 + koff), (float*)(Xt + q * 1024));
+                glds16((const float*)(Xs + (long long)n * a.ldx * 4 + koff), (float*)(Xt + q * 1024));
             }
         };
         stage(0, 0);
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
             const int hrow = hw0 + ht * 16 + 4 * lg;           // acc[ht][nt][r] is hidden unit hrow + r
             const f32x4 bias = *(const f32x4*)(a.b + (long long)sw * a.H + hrow);
             f32x4 w2f = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (li < a.C) w2f = *(const f32x4*)(a.W2 + ((long long)sw * a.C + li) * a.H + hrow);
+            if (LAYER2 && li < a.C) w2f = *(const f32x4*)(a.W2 + ((long long)sw * a.C + li) * a.H + hrow);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int n = n0 + (wave_n * NTW + nt) * 16 + li;
@@ -218,8 +221,22 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
                     for (int r = 0; r < 4; ++r) dv[r] = act_grad_from_value<ACT>(hv[r]);
                     *(f32x4*)(a.dact + ((long long)s * a.N + n) * a.H + hrow) = dv;
                 }
+                if (LAYER2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
+                    for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
+                } else if (n < a.N) {
+                    // hidden units hrow..hrow+3 of point n -> half of a group of 8 of the split-rows image (8 B of hi, 8 B of lo)
+                    union { _Float16 h[4]; unsigned long long u; } hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = hv[r] * a.hid_scale;
+                        hi.h[r] = (_Float16)x;
+                        lo.h[r] = (_Float16)(x - (float)hi.h[r]);
+                    }
+                    char* const g = a.hid + (((long long)s * a.N + n) * a.H + (hrow & ~7)) * 4 + (hrow & 4) * 2;
+                    *(unsigned long long*)g = hi.u;
+                    *(unsigned long long*)(g + 16) = lo.u;
+                }
             }
         }
         if (BITMASK && a.mask) {
@@ -231,6 +248,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
         }
     }
 
+    if (!LAYER2) return;
     // Z^T partials of the WH waves that split h -> LDS -> one thread per point finishes the softmax.
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -268,12 +286,12 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
     }
 }
 
-template <int ACT, int WH, int HTW, int WN, int NTW>
+template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
 int launch_forward_split_cfg(FwdSplitArgs a, hipStream_t st) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int LDSB = 2 * (BH + BN) * 128;
     a.NT = (a.N + BN - 1) / BN;
-    auto kern = fc_forward_split_kernel<ACT, WH, HTW, WN, NTW>;
+    auto kern = fc_forward_split_kernel<ACT, WH, HTW, WN, NTW, LAYER2>;
     static bool attr_done = false;                              // per instantiation; idempotent, so a race is harmless
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return RBNN_ERR_LAUNCH;
@@ -284,10 +302,25 @@ int launch_forward_split_cfg(FwdSplitArgs a, hipStream_t st) {
     return launch_status();
 }
 
-template <int ACT>
+template <int ACT, bool LAYER2>
 int launch_forward_split_act(const FwdSplitArgs& a, hipStream_t st) {
-    if (a.H % 256 == 0) return launch_forward_split_cfg<ACT, 2, 8, 4, 4>(a, st);   // 256 h x 256 n, 8 waves of 128 h x 64 n
-    if (a.H % 128 == 0) return launch_forward_split_cfg<ACT, 1, 8, 4, 4>(a, st);   // 128 h x 256 n, 4 waves
+    if (a.H % 256 == 0) return launch_forward_split_cfg<ACT, 2, 8, 4, 4, LAYER2>(a, st);   // 256 h x 256 n, 8 waves of 128 h x 64 n
+    if (a.H % 128 == 0) return launch_forward_split_cfg<ACT, 1, 8, 4, 4, LAYER2>(a, st);   // 128 h x 256 n, 4 waves
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+template <bool LAYER2>
+int launch_forward_split(int act, const FwdSplitArgs& a, hipStream_t st) {
+    switch (act) {
+#ifndef RBNN_FAST_BUILD
+        case RBNN_ACT_RELU:  return launch_forward_split_act<RBNN_ACT_RELU, LAYER2>(a, st);
+#endif
+        case RBNN_ACT_LEAKY: return launch_forward_split_act<RBNN_ACT_LEAKY, LAYER2>(a, st);
+#ifndef RBNN_FAST_BUILD
+        case RBNN_ACT_SIGM:  return launch_forward_split_act<RBNN_ACT_SIGM, LAYER2>(a, st);
+        case RBNN_ACT_TANH:  return launch_forward_split_act<RBNN_ACT_TANH, LAYER2>(a, st);
+#endif
+    }
     return RBNN_ERR_UNSUPPORTED;
 }
 
@@ -435,10 +468,16 @@ struct GradSplitArgs {
     int H;  int HW;  const int* sidx;  int S;  int chunk;  int nchunks;
     int N;  int NT;  int ND;  int Dt;
     float* out;  int ldo;  float out_scale;                     // slabs [nchunks][N][ldo]; out_scale = 2^-(e_w2 + GEN_Q + e_w1)
+    // fc2.  MODE 1 (step 1, one sample per block): out = [S][N][H] = act'(A1) * (dA2 . Wm), KEPT SCALED (x out_scale, no per-point
+    // un-scaling): it is the fp32 source of step 2's A operand.  MODE 2 (step 2): A operand read from `amem` and split in registers.
+    const uint32_t* omask;  int OHW;                            // MODE 1: stash of the layer below [S][H/32][N_pad]
+    const float* amem;                                          // MODE 2: [S][N][H]
 };
+enum { GRAD_FC = 0, GRAD_FC2_STEP1 = 1, GRAD_FC2_STEP2 = 2 };
 
-template <int ACT, int TD, int NTW, int NW>
+template <int ACT, int TD, int NTW, int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSplitArgs a) {
+    constexpr bool GEN = MODE != GRAD_FC2_STEP2;               // dA generated from dZ, or read from memory
     static_assert(ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY, "1-bit stash activations only");
     constexpr int BM = NW * NTW * 16, LD = TD * 16;            // NW waves x NTW point tiles = 256 points per block
     static_assert(BM == 256, "the dZ image and the stash rows are laid out for 256-point blocks");
@@ -491,12 +530,12 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             if (wave + NW * i < NPIECE) glds16((const float*)(Wb + goff[i]), (float*)(B + (wave + NW * i) * 1024));
-        if (wave >= NW - 2)                                     // generator tiles 2*hb, 2*hb + 1 of this sample
+        if (GEN && wave >= NW - 2)                              // generator tiles 2*hb, 2*hb + 1 of this sample
             glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb + (wave - (NW - 2))) * 1024) + lane * 16),
                    (float*)(B + W1B + (wave - (NW - 2)) * 1024));
-        if (wave == NW - 3)                                     // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
+        if (GEN && wave == NW - 3)                              // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
             glds16((const float*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM + 4 * lane), (float*)(B + W1B + 2048));
-        if (s + 1 < s_end) {                                    // next sample's dZ image, spread over this sample's stages
+        if (GEN && s + 1 < s_end) {                             // next sample's dZ image, spread over this sample's stages
             for (int j = 0; j < DZPS && hb >= 1; ++j) {
                 const int piece = (hb - 1) * DZPS + j;
                 if (piece < 16 && piece % NW == wave) dz_issue(s + 1, piece, (si + 1) & 1);
@@ -504,18 +543,44 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
         }
     };
 
-    for (int piece = wave; piece < 16; piece += NW) dz_issue(s_begin, piece, 0);
+    if (GEN) for (int piece = wave; piece < 16; piece += NW) dz_issue(s_begin, piece, 0);
     stage_issue(0, 0);
+    // MODE 2: the A operand of stage st (this lane: point li of each tile, units 16t + 4lg + r of the stage's 32) is loaded from
+    // memory one stage ahead, AFTER the next stage's LDS-DMA has been issued, so the barrier's vmcnt(0) covers both
+    f32x4 am[GEN ? 1 : NTW][2];
+    auto load_a = [&](int st) {
+        const int s = s_begin + st / HS, h0 = (st % HS) * 32;
+#pragma unroll
+        for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt) {
+            const int n = min(nb + nt * 16 + li, a.N - 1);     // rows past N: any valid row, never stored
+            const float* const src = a.amem + ((long long)s * a.N + n) * a.H + h0 + 4 * lg;
+            am[nt][0] = *(const f32x4*)src;
+            am[nt][1] = *(const f32x4*)(src + 16);
+        }
+    };
+    if (!GEN) load_a(0);
     ring_wait_barrier<0>();
     const float c_pos = ldexpf(1.f, GEN_Q), c_neg = (ACT == RBNN_ACT_RELU) ? 0.f : LEAKY_SLOPE * ldexpf(1.f, GEN_Q);
     f16x8 da_hi[NTW], da_lo[NTW];                              // A operand of the main MFMA: this wave's 4 point tiles, one stage
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, dzbuf = (st / HS) & 1;
+        if (!GEN) {                                            // split this stage's A (already in registers), then fetch the next one
+#pragma unroll
+            for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = am[nt][0][r], v1 = am[nt][1][r];
+                    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+                    da_hi[nt][r] = h0;      da_lo[nt][r] = (_Float16)(v0 - (float)h0);
+                    da_hi[nt][4 + r] = h1;  da_lo[nt][4 + r] = (_Float16)(v1 - (float)h1);
+                }
+        }
         if (!(RBNN_ABL & 1) && st + 1 < nst) stage_issue(st + 1, buf ^ 1);
+        if (!GEN && st + 1 < nst) load_a(st + 1);
         const char* const B = ldsb + buf * BUFB;
 
         // ---- generator + split: da_hi / da_lo[nt] = A operand of the main MFMA for this wave's 4 point tiles ----
-        if (!(RBNN_ABL & 16) || st == 0) {
+        if (GEN && (!(RBNN_ABL & 16) || st == 0)) {
             const f16x8 w2g0 = *(const f16x8*)(B + W1B + lane * 16);
             const f16x8 w2g1 = *(const f16x8*)(B + W1B + 1024 + lane * 16);
             const unsigned* const Mk = (const unsigned*)(B + W1B + 2048) + wave * (NTW * 16) + li;
@@ -565,22 +630,28 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
         for (int r = 0; r < 4; ++r) {
             const int n = nb + nt * 16 + 4 * lg + r;
             if (n >= a.N) continue;
-            const float gs = a.gscale[n];
+            const float gs = (MODE == GRAD_FC2_STEP1) ? 1.f : a.gscale[n];
             float* const dst = a.out + ((long long)ch * a.N + n) * a.ldo;
 #pragma unroll
             for (int dt = 0; dt < TD; ++dt) {
                 const int d = dc0 + dt * 16 + li;
-                if (d < Dp) dst[d] = acc[nt][dt][r] * a.out_scale * gs;
+                if (d >= Dp) continue;
+                float v = acc[nt][dt][r] * a.out_scale * gs;
+                if (MODE == GRAD_FC2_STEP1) {                   // derivative of the layer below: unit d of point n, sample ch
+                    const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n];
+                    v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
+                }
+                dst[d] = v;
             }
         }
 }
 
-template <int ACT, int TD, int NTW, int NW>
+template <int ACT, int TD, int NTW, int NW, int MODE>
 int launch_grad_split_cfg(GradSplitArgs a, hipStream_t st) {
     constexpr int LDSB = 2 * (8 * TD * 16 * 16 + 3072) + 2 * 256 * 64;
     a.NT = (a.N + 255) / 256;
     a.ND = (a.Dt + TD - 1) / TD;
-    auto kern = fc_grad_split_kernel<ACT, TD, NTW, NW>;
+    auto kern = fc_grad_split_kernel<ACT, TD, NTW, NW, MODE>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return RBNN_ERR_LAUNCH;
@@ -599,15 +670,23 @@ int launch_grad_split_cfg(GradSplitArgs a, hipStream_t st) {
 // slices fenced between groups of 12 MFMAs) was also slower, 2.73 vs 2.49 ms: a wave issues in order, and the dependent
 // VALU chains stall the independent MFMAs queued behind them.  (profiles/r01f/ablation_split.txt)
 // RBNN_GRAD_SPLIT_TD14 keeps the first of those selectable for experiments.
-template <int ACT>
+template <int ACT, int MODE>
 int launch_grad_split(const GradSplitArgs& a, hipStream_t st) {
 #ifdef RBNN_GRAD_SPLIT_TD14
-    if (a.Dt > 7) return launch_grad_split_cfg<ACT, 14, 2, 8>(a, st);
+    if (MODE == GRAD_FC && a.Dt > 7) return launch_grad_split_cfg<ACT, 14, 2, 8, MODE>(a, st);
 #endif
     // 7 or 4 column tiles per block: whichever pads the Dt tiles less (a partial last group skips its missing tiles'
     // MFMAs but still pays the generator)
-    if ((a.Dt + 6) / 7 * 7 <= (a.Dt + 3) / 4 * 4) return launch_grad_split_cfg<ACT, 7, 4, 4>(a, st);
-    return launch_grad_split_cfg<ACT, 4, 4, 4>(a, st);
+    if ((a.Dt + 6) / 7 * 7 <= (a.Dt + 3) / 4 * 4) return launch_grad_split_cfg<ACT, 7, 4, 4, MODE>(a, st);
+    return launch_grad_split_cfg<ACT, 4, 4, 4, MODE>(a, st);
+}
+
+template <int MODE>
+int launch_grad_split_act(int act, const GradSplitArgs& a, hipStream_t st) {
+#ifndef RBNN_FAST_BUILD
+    if (act == RBNN_ACT_RELU) return launch_grad_split<RBNN_ACT_RELU, MODE>(a, st);
+#endif
+    return launch_grad_split<RBNN_ACT_LEAKY, MODE>(a, st);
 }
 
 }  // namespace
@@ -632,31 +711,35 @@ int rbnn_fc_forward_split(const rbnn_posterior* net, const rbnn_split_images* sp
                           const rbnn_workspace* ws, void* stream) {
     if (!net || !sp || !X_split || !ws || !ws->P || !sp->W1_rows) return RBNN_ERR_NULL;
     if (!net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
-    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
     if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2, bm = net->activation == RBNN_ACT_RELU || net->activation == RBNN_ACT_LEAKY;
     const int H = net->hidden, ld = sp->ld_rows;
     if (H < 128 || (H % 128) || ld < net->in_features || (ld & 31) || ldx != ld) return RBNN_ERR_SHAPE;
     if (net->n_classes < 1 || net->n_classes > RBNN_CPAD || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
     if (!aligned16(X_split) || !aligned16(sp->W1_rows) || !aligned16(ws->P) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
+    if (fc2 && (!sp->Wm_rows || !net->bm || !ws->hid1 || (bm ? !ws->mask2 : !ws->dact2))) return RBNN_ERR_NULL;
+    if (fc2 && (!aligned16(sp->Wm_rows) || !aligned16(ws->hid1) || !aligned16(net->bm))) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
     FwdSplitArgs a = {};
-    a.X = (const char*)X_split; a.ldx = ldx; a.N = N;
+    a.X = (const char*)X_split; a.ldx = ldx; a.N = N; a.x_sample_bytes = 0;
     a.W = (const char*)sp->W1_rows; a.w_sample_bytes = (long long)H * ld * 4; a.ldw = ld; a.KT = ld / 32;
     a.b = net->b1; a.W2 = net->W2; a.b2 = net->b2; a.C = net->n_classes; a.H = H;
     a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -(x_exp + sp->w1_exp));
     a.P = ws->P; a.mask = ws->mask1; a.dact = ws->dact1; a.out_kind = out_kind;
-    hipStream_t st = (hipStream_t)stream;
-    switch (net->activation) {
-#ifndef RBNN_FAST_BUILD
-        case RBNN_ACT_RELU:  return launch_forward_split_act<RBNN_ACT_RELU>(a, st);
-#endif
-        case RBNN_ACT_LEAKY: return launch_forward_split_act<RBNN_ACT_LEAKY>(a, st);
-#ifndef RBNN_FAST_BUILD
-        case RBNN_ACT_SIGM:  return launch_forward_split_act<RBNN_ACT_SIGM>(a, st);
-        case RBNN_ACT_TANH:  return launch_forward_split_act<RBNN_ACT_TANH>(a, st);
-#endif
-    }
-    return RBNN_ERR_UNSUPPORTED;
+    if (!fc2) return launch_forward_split<true>(net->activation, a, st);
+    // fc2: layer 1 -> hidden activations as a split-rows image in ws->hid1 (same bytes as the fp32 [S,N,H] buffer), scaled by
+    // 2^h1_exp (the caller bounds |h|: max_h sum_d |W1[h,d]| * max|x| + max|b1|); layer 2 reads it per sample
+    a.hid = (char*)ws->hid1; a.hid_scale = ldexpf(1.f, sp->h1_exp);
+    int rc = launch_forward_split<false>(net->activation, a, st);
+    if (rc) return rc;
+    FwdSplitArgs b = a;
+    b.X = (const char*)ws->hid1; b.ldx = H; b.x_sample_bytes = (long long)N * H * 4;
+    b.W = (const char*)sp->Wm_rows; b.w_sample_bytes = (long long)H * H * 4; b.ldw = H; b.KT = H / 32;
+    b.b = net->bm; b.out_scale = ldexpf(1.f, -(sp->h1_exp + sp->wm_exp));
+    b.mask = ws->mask2; b.dact = ws->dact2; b.hid = nullptr;
+    return launch_forward_split<true>(net->activation, b, st);
 }
 
 int rbnn_split_cols(const float* W, int64_t n_mats, int32_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
@@ -699,12 +782,15 @@ int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images*
                              int32_t* n_slabs_out, void* stream) {
     if (!net || !sp || !ws || !sws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
     if (!sp->W1_cols || !sp->W2_gen || !sws->dZ_gen || !sws->g_scale) return RBNN_ERR_NULL;
-    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
     if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2;
     const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
     if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     if (sp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
     if (!aligned16(sp->W1_cols) || !aligned16(sp->W2_gen) || !aligned16(sws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
+    if (fc2 && (!sp->Wm_cols || !ws->mask2 || !ws->dhid1)) return RBNN_ERR_NULL;
+    if (fc2 && (!aligned16(sp->Wm_cols) || !aligned16(ws->dhid1))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (chunk <= 0) {                                           // the exact mode's slab plan (same workspace)
         rbnn_workspace_sizes q;
@@ -720,15 +806,31 @@ int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images*
                        ws->dZ, S, N, n_pad, C, (uint4*)sws->dZ_gen, sws->g_scale);
     if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
     GradSplitArgs g = {};
-    g.dzg = (const char*)sws->dZ_gen; g.n_pad = n_pad; g.gscale = sws->g_scale; g.mask = ws->mask1;
-    g.W1c = (const char*)sp->W1_cols; g.ldc = sp->ld_cols; g.W2g = (const char*)sp->W2_gen;
-    g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.chunk = chunk; g.nchunks = nchunks;
-    g.N = N; g.Dt = Dp / 16; g.out = ws->slabs; g.ldo = Dp;
-    g.out_scale = ldexpf(1.f, -(sp->w2_exp + GEN_Q + sp->w1_exp));
-#ifndef RBNN_FAST_BUILD
-    if (net->activation == RBNN_ACT_RELU) return launch_grad_split<RBNN_ACT_RELU>(g, st);
-#endif
-    return launch_grad_split<RBNN_ACT_LEAKY>(g, st);
+    g.dzg = (const char*)sws->dZ_gen; g.n_pad = n_pad; g.gscale = sws->g_scale;
+    g.W2g = (const char*)sp->W2_gen;
+    g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N;
+    if (!fc2) {
+        g.mask = ws->mask1; g.W1c = (const char*)sp->W1_cols; g.ldc = sp->ld_cols; g.Dt = Dp / 16;
+        g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
+        g.out_scale = ldexpf(1.f, -(sp->w2_exp + GEN_Q + sp->w1_exp));
+        return launch_grad_split_act<GRAD_FC>(net->activation, g, st);
+    }
+    // fc2 step 1, one sample per block: dhid1[s] = act'(A1_s) * ((act'(A2_s) * (dZ_s . W3_s)) . Wm_s), kept scaled:
+    //   stored = dhid1 * 2^(e(n) + e_w3 + GEN_Q + e_wm - Q2),  Q2 = 14 + ceil(log2 H): |dA2 scaled| <= 2^15, |Wm scaled| <= 2^14, K = H
+    //   => |stored| <= 2^15, fp16 range, ready to be split as step 2's A operand
+    int q2 = 14;
+    while ((1 << (q2 - 14)) < H) ++q2;
+    g.mask = ws->mask2; g.W1c = (const char*)sp->Wm_cols; g.ldc = H; g.Dt = H / 16;
+    g.chunk = 1; g.nchunks = S; g.out = ws->dhid1; g.ldo = H; g.out_scale = ldexpf(1.f, -q2);
+    g.omask = ws->mask1; g.OHW = H / 32;
+    int rc = launch_grad_split_act<GRAD_FC2_STEP1>(net->activation, g, st);
+    if (rc) return rc;
+    // fc2 step 2: slabs[k] = sum_{s in chunk k} dhid1[s] . W1_s; acc = g * 2^(e(n) + e_w3 + GEN_Q + e_wm - Q2 + e_w1)
+    GradSplitArgs h = g;
+    h.amem = ws->dhid1; h.W1c = (const char*)sp->W1_cols; h.ldc = sp->ld_cols; h.Dt = Dp / 16;
+    h.chunk = chunk; h.nchunks = nchunks; h.out = ws->slabs; h.ldo = Dp;
+    h.out_scale = ldexpf(1.f, -(sp->w2_exp + GEN_Q + sp->wm_exp - q2 + sp->w1_exp));
+    return launch_grad_split_act<GRAD_FC2_STEP2>(net->activation, h, st);
 }
 
 }  // extern "C"

@@ -169,11 +169,13 @@ class AttackEngine:
         img = self.post.split_images()
         bound = self._x_bound if self._x_bound is not None else float(Xp.abs().max())
         x_exp = scale_exp(bound)
+        if self.post.arch == "fc2":
+            img.h1_exp = self.post.hidden_exp(bound)
         self.k.split_rows(Xp, self.post.D, x_exp, ws["split"]["X_split"], img.ld_rows)
         self.k.fc_forward_split(self.post, img, ws["split"]["X_split"], img.ld_rows, x_exp, Xp.shape[0], sidx, S, out_kind, ws)
 
     def _grad_kernels(self, sidx, S, N, ws):
-        if self.precision != "split":
+        if self.precision != "split" or (self.post.arch == "fc2" and os.environ.get("RBNN_FC2_BWD_EXACT") == "1"):
             return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
         return self.k.fc_input_grad_split(self.post, self.post.split_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
 

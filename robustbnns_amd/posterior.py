@@ -77,8 +77,8 @@ class StackedPosterior:
 
     # ------------------------------------------------------------------ split-half ("f16x3") precision mode
     def split_supported(self):
-        """The split kernels cover the headline family: fc, relu / leaky, hidden % 128 == 0, classes <= 10."""
-        return (self.arch == "fc" and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
+        """The split kernels cover fc and fc2 with relu / leaky, hidden % 128 == 0 and <= 10 classes."""
+        return (self.arch in ("fc", "fc2") and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
                 and self.device.type == "cuda")
 
     def split_images(self):
@@ -99,8 +99,24 @@ class StackedPosterior:
             img = _hip.SplitImages()
             img.W1_rows, img.W1_cols, img.W2_gen = rows.data_ptr(), cols.data_ptr(), gen.data_ptr()
             img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = ld, Dp, w1_exp, w2_exp
-            self._split = (img, rows, cols, gen)                # the tensors keep the device memory alive
+            keep = [rows, cols, gen]
+            if self.arch == "fc2":                               # forward of the middle layer: Wm as split rows [S*H, H]
+                wm_exp = scale_exp(float(self.Wm.abs().max()))
+                wm_rows = torch.empty(S * H, H * 2, dtype=torch.int16, device=self.device)
+                k.split_rows(self.Wm, H, wm_exp, wm_rows, H)
+                wm_cols = torch.empty(S * (H // 32) * 8 * H * 8, dtype=torch.int16, device=self.device)
+                k.split_cols(self.Wm, H, H, wm_exp, wm_cols, H)
+                img.Wm_rows, img.Wm_cols, img.wm_exp = wm_rows.data_ptr(), wm_cols.data_ptr(), wm_exp
+                keep += [wm_rows, wm_cols]
+                # |h1| <= max_h sum_d |W1[h,d]| * max|x| + max|b1|: the per-call exponent of the hidden image
+                self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
+            self._split = (img, keep)                            # the tensors keep the device memory alive
         return self._split[0]
+
+    def hidden_exp(self, x_max):
+        """Exponent of the fc2 hidden-activation image for inputs bounded by x_max (relu / leaky: |act(a)| <= |a|)."""
+        w_l1, b_max = self._h1_bound
+        return scale_exp(w_l1 * x_max + b_max)
 
     def _pack(self):
         """rbnn_pack_rows4 images [S, H/4, cols, 4] of W1 (and Wm): the backward GEMM's B-operand layout."""

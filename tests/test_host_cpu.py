@@ -90,7 +90,8 @@ def test_split_mode_validation_without_gpu():
     assert lib.rbnn_fc_forward_split(C.byref(_net()), C.byref(img), None, 800, 14, 8, None, 2, 0, C.byref(ws), None) == -1
     ws.P = C.c_void_p(16); img.W1_rows = C.c_void_p(16)
     w = dict(W1=C.c_void_p(16), b1=C.c_void_p(16), W2=C.c_void_p(16), b2=C.c_void_p(16))
-    assert lib.rbnn_fc_forward_split(C.byref(_net(arch=1, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -3   # fc2
+    assert lib.rbnn_fc_forward_split(C.byref(_net(arch=1, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -1   # fc2 without Wm_rows / bm / hid1
+    assert lib.rbnn_fc_input_grad_split(C.byref(_net(arch=1, **w)), C.byref(img), None, 2, 8, 0, C.byref(ws), C.byref(sws), None, None) == -1   # fc2 without Wm_cols / mask2 / dhid1
     assert lib.rbnn_fc_forward_split(C.byref(_net(hidden=64, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -2  # hidden % 128
     assert lib.rbnn_fc_forward_split(C.byref(_net(**w)), C.byref(img), C.c_void_p(16), 784, 14, 8, None, 2, 0, C.byref(ws), None) == -2             # ldx != ld_rows
     assert lib.rbnn_fc_input_grad_split(C.byref(_net(**w)), C.byref(img), None, 2, 8, 0, C.byref(ws), C.byref(sws), None, None) == -1
