@@ -224,18 +224,23 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
                 if (LAYER2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
-                } else if (n < a.N) {
-                    // hidden units hrow..hrow+3 of point n -> half of a group of 8 of the split-rows image (8 B of hi, 8 B of lo)
-                    union { _Float16 h[4]; unsigned long long u; } hi, lo;
+                }
+                if (!LAYER2) {
+                    // lanes lg (even) and lg+1 hold the two halves of a group of 8 units: swap so that the even lane owns the whole
+                    // 16-byte hi block and the odd lane the whole lo block — one 16-byte store per lane instead of two 8-byte ones
+                    union { _Float16 h[4]; unsigned long long u; unsigned w[2]; } hi, lo;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = hv[r] * a.hid_scale;
                         hi.h[r] = (_Float16)x;
                         lo.h[r] = (_Float16)(x - (float)hi.h[r]);
                     }
-                    char* const g = a.hid + (((long long)s * a.N + n) * a.H + (hrow & ~7)) * 4 + (hrow & 4) * 2;
-                    *(unsigned long long*)g = hi.u;
-                    *(unsigned long long*)(g + 16) = lo.u;
+                    const bool odd = lg & 1;
+                    const unsigned s0 = odd ? hi.w[0] : lo.w[0], s1 = odd ? hi.w[1] : lo.w[1];
+                    const unsigned r0 = __shfl_xor(s0, 16), r1 = __shfl_xor(s1, 16);
+                    const uint4 blk = odd ? make_uint4(r0, r1, lo.w[0], lo.w[1]) : make_uint4(hi.w[0], hi.w[1], r0, r1);
+                    if (n < a.N)
+                        *(uint4*)(a.hid + (((long long)s * a.N + n) * a.H + (hrow & ~7)) * 4 + (odd ? 16 : 0)) = blk;
                 }
             }
         }
@@ -675,9 +680,10 @@ int launch_grad_split(const GradSplitArgs& a, hipStream_t st) {
 #ifdef RBNN_GRAD_SPLIT_TD14
     if (MODE == GRAD_FC && a.Dt > 7) return launch_grad_split_cfg<ACT, 14, 2, 8, MODE>(a, st);
 #endif
-    // 7 or 4 column tiles per block: whichever pads the Dt tiles less (a partial last group skips its missing tiles'
-    // MFMAs but still pays the generator)
-    if ((a.Dt + 6) / 7 * 7 <= (a.Dt + 3) / 4 * 4) return launch_grad_split_cfg<ACT, 7, 4, 4, MODE>(a, st);
+    // 7 or 4 column tiles per block.  A partial last group skips its missing tiles' MFMAs, so padding costs little; every
+    // group pays the dA generator (or the A-operand reads) again, so FEWER groups win: 7 wherever that saves a group
+    // (fc2 step 1 at H = 512: 32 tiles = 5 groups of 7 instead of 8 of 4 — 2.72 -> see profiles)
+    if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_split_cfg<ACT, 7, 4, 4, MODE>(a, st);
     return launch_grad_split_cfg<ACT, 4, 4, 4, MODE>(a, st);
 }
 
