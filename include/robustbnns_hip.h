@@ -239,7 +239,7 @@ int rbnn_svi_materialize(const float *loc, const float *scale_raw, const float *
  * Split-half precision mode ("f16x3") of the fc forward / input-gradient contractions.  No counterpart in the
  * reference (it computes in fp32): every fp32 operand v is carried as v * 2^e = hi + lo with hi, lo fp16, products
  * are hi*hi' + hi*lo' + lo*hi' on the f16 matrix pipe with fp32 accumulation (2^-22 per product; the parity tests
- * hold this mode to the same 1e-5 bar as the exact mode).  hidden % 128 == 0, relu / leaky backward, <= 10 classes; arch fc and fc2.
+ * hold this mode to the same 1e-5 bar as the exact mode).  hidden % 128 == 0, <= 10 classes; arch fc and fc2, all four activations.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct rbnn_split_images {
     const void *W1_rows;           /* rbnn_split_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/8,2,8] halves */
@@ -293,7 +293,7 @@ int rbnn_fc_forward_split(const rbnn_posterior *net, const rbnn_split_images *sp
                           int32_t out_kind, const rbnn_workspace *ws, void *stream);
 
 /* rbnn_fc_input_grad in split precision: same slabs (ws->slabs, already un-scaled), from ws->dZ and ws->mask1.
- * relu / leaky, n_classes <= 10.  Re-scales dZ per point (2^e(n), so vanishing gradients keep their 22 bits). */
+ * n_classes <= 10 (fc2: two steps through ws->dhid1).  Re-scales dZ per point (2^e(n), so vanishing gradients keep their 22 bits). */
 int rbnn_fc_input_grad_split(const rbnn_posterior *net, const rbnn_split_images *sp, const int32_t *sample_idx,
                              int32_t n_samples, int32_t n_points, int32_t chunk, const rbnn_workspace *ws,
                              const rbnn_split_workspace *sws, int32_t *n_slabs_out, void *stream);

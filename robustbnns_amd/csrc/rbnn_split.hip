@@ -477,13 +477,15 @@ struct GradSplitArgs {
     // un-scaling): it is the fp32 source of step 2's A operand.  MODE 2 (step 2): A operand read from `amem` and split in registers.
     const uint32_t* omask;  int OHW;                            // MODE 1: stash of the layer below [S][H/32][N_pad]
     const float* amem;                                          // MODE 2: [S][N][H]
+    const float* dact;  const float* odact;                     // sigmoid / tanh: act' as fp32 [S][N][H] (this layer / the layer below)
 };
 enum { GRAD_FC = 0, GRAD_FC2_STEP1 = 1, GRAD_FC2_STEP2 = 2 };
 
 template <int ACT, int TD, int NTW, int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSplitArgs a) {
     constexpr bool GEN = MODE != GRAD_FC2_STEP2;               // dA generated from dZ, or read from memory
-    static_assert(ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY, "1-bit stash activations only");
+    constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);   // act' from the 1-bit stash, or an fp32 stream
+    constexpr bool STREAM = !GEN || !BITMASK;                  // a per-lane fp32 operand (A itself, or act') is prefetched from memory
     constexpr int BM = NW * NTW * 16, LD = TD * 16;            // NW waves x NTW point tiles = 256 points per block
     static_assert(BM == 256, "the dZ image and the stash rows are laid out for 256-point blocks");
     constexpr int W1B = 8 * LD * 16;                           // bytes: [4 lg][2 hi/lo][LD columns][16 B]
@@ -538,7 +540,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
         if (GEN && wave >= NW - 2)                              // generator tiles 2*hb, 2*hb + 1 of this sample
             glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb + (wave - (NW - 2))) * 1024) + lane * 16),
                    (float*)(B + W1B + (wave - (NW - 2)) * 1024));
-        if (GEN && wave == NW - 3)                              // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
+        if (GEN && BITMASK && wave == NW - 3)                   // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
             glds16((const float*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM + 4 * lane), (float*)(B + W1B + 2048));
         if (GEN && s + 1 < s_end) {                             // next sample's dZ image, spread over this sample's stages
             for (int j = 0; j < DZPS && hb >= 1; ++j) {
@@ -552,23 +554,30 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
     stage_issue(0, 0);
     // MODE 2: the A operand of stage st (this lane: point li of each tile, units 16t + 4lg + r of the stage's 32) is loaded from
     // memory one stage ahead, AFTER the next stage's LDS-DMA has been issued, so the barrier's vmcnt(0) covers both
-    f32x4 am[GEN ? 1 : NTW][2];
+    // (sigmoid / tanh in the generator modes: the same prefetch carries act' of the stage's units instead)
+    f32x4 am[STREAM ? NTW : 1][2];
     auto load_a = [&](int st) {
         const int s = s_begin + st / HS, h0 = (st % HS) * 32;
+        const float* const base = GEN ? a.dact : a.amem;
 #pragma unroll
-        for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt) {
+        for (int nt = 0; nt < (STREAM ? NTW : 0); ++nt) {
             const int n = min(nb + nt * 16 + li, a.N - 1);     // rows past N: any valid row, never stored
-            const float* const src = a.amem + ((long long)s * a.N + n) * a.H + h0 + 4 * lg;
+            const float* const src = base + ((long long)s * a.N + n) * a.H + h0 + 4 * lg;
             am[nt][0] = *(const f32x4*)src;
             am[nt][1] = *(const f32x4*)(src + 16);
         }
     };
-    if (!GEN) load_a(0);
+    if (STREAM) load_a(0);
     ring_wait_barrier<0>();
     const float c_pos = ldexpf(1.f, GEN_Q), c_neg = (ACT == RBNN_ACT_RELU) ? 0.f : LEAKY_SLOPE * ldexpf(1.f, GEN_Q);
     f16x8 da_hi[NTW], da_lo[NTW];                              // A operand of the main MFMA: this wave's 4 point tiles, one stage
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, dzbuf = (st / HS) & 1;
+        f32x4 dm[(GEN && STREAM) ? NTW : 1][2];                // sigmoid / tanh: this stage's act' (copied before the next prefetch)
+        if (GEN && STREAM) {
+#pragma unroll
+            for (int nt = 0; nt < ((GEN && STREAM) ? NTW : 0); ++nt) { dm[nt][0] = am[nt][0]; dm[nt][1] = am[nt][1]; }
+        }
         if (!GEN) {                                            // split this stage's A (already in registers), then fetch the next one
 #pragma unroll
             for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt)
@@ -581,7 +590,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
                 }
         }
         if (!(RBNN_ABL & 1) && st + 1 < nst) stage_issue(st + 1, buf ^ 1);
-        if (!GEN && st + 1 < nst) load_a(st + 1);
+        if (STREAM && st + 1 < nst) load_a(st + 1);
         const char* const B = ldsb + buf * BUFB;
 
         // ---- generator + split: da_hi / da_lo[nt] = A operand of the main MFMA for this wave's 4 point tiles ----
@@ -594,11 +603,11 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
                 const f16x8 dz = *(const f16x8*)(dzl + dzbuf * DZB + (wave * (NTW * 16) + nt * 16 + li) * 64 + ((lg ^ dz_swz(li)) * 16));
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const f32x4 g0 = MFMA_H(w2g0, dz, z), g1 = MFMA_H(w2g1, dz, z);
-                const unsigned mw = Mk[nt * 16] >> (4 * lg);    // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
+                const unsigned mw = BITMASK ? Mk[nt * 16] >> (4 * lg) : 0u;    // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v0 = g0[r] * (((mw >> r) & 1u) ? c_pos : c_neg);
-                    const float v1 = g1[r] * (((mw >> (16 + r)) & 1u) ? c_pos : c_neg);
+                    const float v0 = g0[r] * (BITMASK ? (((mw >> r) & 1u) ? c_pos : c_neg) : dm[BITMASK ? 0 : nt][0][r] * c_pos);
+                    const float v1 = g1[r] * (BITMASK ? (((mw >> (16 + r)) & 1u) ? c_pos : c_neg) : dm[BITMASK ? 0 : nt][1][r] * c_pos);
                     const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
                     da_hi[nt][r] = h0;      da_lo[nt][r] = (_Float16)(v0 - (float)h0);
                     da_hi[nt][4 + r] = h1;  da_lo[nt][4 + r] = (_Float16)(v1 - (float)h1);
@@ -643,8 +652,12 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSpl
                 if (d >= Dp) continue;
                 float v = acc[nt][dt][r] * a.out_scale * gs;
                 if (MODE == GRAD_FC2_STEP1) {                   // derivative of the layer below: unit d of point n, sample ch
-                    const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n];
-                    v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
+                    if (BITMASK) {
+                        const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n];
+                        v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
+                    } else {
+                        v *= a.odact[((long long)ch * a.N + n) * a.ldo + d];
+                    }
                 }
                 dst[d] = v;
             }
@@ -691,6 +704,8 @@ template <int MODE>
 int launch_grad_split_act(int act, const GradSplitArgs& a, hipStream_t st) {
 #ifndef RBNN_FAST_BUILD
     if (act == RBNN_ACT_RELU) return launch_grad_split<RBNN_ACT_RELU, MODE>(a, st);
+    if (act == RBNN_ACT_SIGM || act == RBNN_ACT_TANH)          // both read act' from the stream: one instantiation serves them
+        return launch_grad_split<RBNN_ACT_SIGM, (MODE == GRAD_FC2_STEP2 ? GRAD_FC2_STEP2 : MODE)>(a, st);
 #endif
     return launch_grad_split<RBNN_ACT_LEAKY, MODE>(a, st);
 }
@@ -786,16 +801,18 @@ int rbnn_split_workspace_query(const rbnn_posterior* net, const rbnn_split_image
 int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images* sp, const int32_t* sidx, int32_t S,
                              int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_split_workspace* sws,
                              int32_t* n_slabs_out, void* stream) {
-    if (!net || !sp || !ws || !sws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
+    if (!net || !sp || !ws || !sws || !ws->dZ || !ws->slabs) return RBNN_ERR_NULL;
     if (!sp->W1_cols || !sp->W2_gen || !sws->dZ_gen || !sws->g_scale) return RBNN_ERR_NULL;
     if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
-    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
-    const bool fc2 = net->arch == RBNN_ARCH_FC2;
+    if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2, bm = net->activation == RBNN_ACT_RELU || net->activation == RBNN_ACT_LEAKY;
+    if (bm ? !ws->mask1 : !ws->dact1) return RBNN_ERR_NULL;
+    if (fc2 && (bm ? !ws->mask2 : !ws->dact2)) return RBNN_ERR_NULL;
     const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
     if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     if (sp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
     if (!aligned16(sp->W1_cols) || !aligned16(sp->W2_gen) || !aligned16(sws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
-    if (fc2 && (!sp->Wm_cols || !ws->mask2 || !ws->dhid1)) return RBNN_ERR_NULL;
+    if (fc2 && (!sp->Wm_cols || !ws->dhid1)) return RBNN_ERR_NULL;
     if (fc2 && (!aligned16(sp->Wm_cols) || !aligned16(ws->dhid1))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (chunk <= 0) {                                           // the exact mode's slab plan (same workspace)
@@ -816,7 +833,7 @@ int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images*
     g.W2g = (const char*)sp->W2_gen;
     g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N;
     if (!fc2) {
-        g.mask = ws->mask1; g.W1c = (const char*)sp->W1_cols; g.ldc = sp->ld_cols; g.Dt = Dp / 16;
+        g.mask = ws->mask1; g.dact = ws->dact1; g.W1c = (const char*)sp->W1_cols; g.ldc = sp->ld_cols; g.Dt = Dp / 16;
         g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
         g.out_scale = ldexpf(1.f, -(sp->w2_exp + GEN_Q + sp->w1_exp));
         return launch_grad_split_act<GRAD_FC>(net->activation, g, st);
@@ -826,7 +843,7 @@ int rbnn_fc_input_grad_split(const rbnn_posterior* net, const rbnn_split_images*
     //   => |stored| <= 2^15, fp16 range, ready to be split as step 2's A operand
     int q2 = 14;
     while ((1 << (q2 - 14)) < H) ++q2;
-    g.mask = ws->mask2; g.W1c = (const char*)sp->Wm_cols; g.ldc = H; g.Dt = H / 16;
+    g.mask = ws->mask2; g.dact = ws->dact2; g.odact = ws->dact1; g.W1c = (const char*)sp->Wm_cols; g.ldc = H; g.Dt = H / 16;
     g.chunk = 1; g.nchunks = S; g.out = ws->dhid1; g.ldo = H; g.out_scale = ldexpf(1.f, -q2);
     g.omask = ws->mask1; g.OHW = H / 32;
     int rc = launch_grad_split_act<GRAD_FC2_STEP1>(net->activation, g, st);

@@ -77,9 +77,8 @@ class StackedPosterior:
 
     # ------------------------------------------------------------------ split-half ("f16x3") precision mode
     def split_supported(self):
-        """The split kernels cover fc and fc2 with relu / leaky, hidden % 128 == 0 and <= 10 classes."""
-        return (self.arch in ("fc", "fc2") and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
-                and self.device.type == "cuda")
+        """The split kernels cover fc and fc2 (all four activations) with hidden % 128 == 0 and <= 10 classes."""
+        return self.arch in ("fc", "fc2") and self.Hp % 128 == 0 and self.C <= 10 and self.device.type == "cuda"
 
     def split_images(self):
         """rbnn_split_images of this posterior (built once, resident): W1 as split rows (forward A operand), W1 as
@@ -114,9 +113,15 @@ class StackedPosterior:
         return self._split[0]
 
     def hidden_exp(self, x_max):
-        """Exponent of the fc2 hidden-activation image for inputs bounded by x_max (relu / leaky: |act(a)| <= |a|)."""
+        """Exponent of the fc2 hidden-activation image for inputs bounded by x_max (relu / leaky: |act(a)| <= |a|; sigmoid <= 1;
+        |tanh(a)| <= min(|a|, 1))."""
         w_l1, b_max = self._h1_bound
-        return scale_exp(w_l1 * x_max + b_max)
+        bound = w_l1 * x_max + b_max
+        if self.activation == "sigm":
+            bound = 1.0
+        elif self.activation == "tanh":
+            bound = min(bound, 1.0)
+        return scale_exp(bound)
 
     def _pack(self):
         """rbnn_pack_rows4 images [S, H/4, cols, 4] of W1 (and Wm): the backward GEMM's B-operand layout."""
