@@ -65,7 +65,7 @@ __device__ __forceinline__ int row_swz(int r) { return (r >> 1) & 7; }
 // wave-uniform base + lane*16.  Completion is tracked by vmcnt; __syncthreads() drains it before the barrier.
 __device__ __forceinline__ void glds16(const float* g, float* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)l, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 16, 0, 0);
 }
 
 // Ring hand-off: this wave's DMA pieces except the N youngest have landed and its LDS reads are done (counted

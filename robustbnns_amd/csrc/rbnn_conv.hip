@@ -705,7 +705,7 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
     // staging area, so they land under that chunk's MFMAs; the routing then gathers from LDS instead of from memory
     // (128 scattered global loads per lane per chunk made the routing 3/4 of this kernel's time).
     auto dma4 = [&](const void* g, void* l) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)l, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
     };
     auto stage_chunk = [&](int ch) {                                       // lane p of instruction q lands at byte 256q + 4p of its region
         const long long fb = sn * F + (long long)ch * NFL;                 // a multiple of 4: the stash dwords are aligned
