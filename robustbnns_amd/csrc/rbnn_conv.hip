@@ -826,6 +826,109 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
     }
 }
 
+// pool-1 routing + conv1^T on the matrix pipe (the dispatched version; conv1_bwd_kernel above is its VALU gather form:
+// 3.32 ms at the conv-512 bench against 1.24 ms for this one).  One WAVE = one (sample, point), no barriers.
+//   dX[Y][X] = sum_{c, ky, kx} w[c][ky][kx] * R[c][Y - ky][X - kx],   R = the pooled gradient routed to its argmax position (24x24, one
+//   non-zero per 2x2 cell) times the activation derivative.
+// Per position row Ya the wave forms  T[tap][Xa] = sum_c w[c][tap] * R[c][Ya][Xa]  — a 32(taps, 25 used) x 32(c) x 32(Xa, 24 used)
+// fp32 MFMA product whose B operand is built in registers from the stash bytes and pooled gradients of pooled row Ya/2 — keeps the
+// last five rows of T in an LDS ring, and emits output row Y = Ya as a 25-term gather  dX[Y][X] = sum_tap T[tap][Y - ky][X - kx].
+template <int ACT>
+__global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
+    constexpr int RING = 5, TROW = 25 * 32;                              // floats per ring row: [25 taps][32 Xa]
+    __shared__ float lds[4 * RING * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int NB = (a.N + 3) / 4;
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, n = (id % NB) * 4 + wave;
+    if (n >= a.N) return;                                                // whole wave idle; no block barrier anywhere
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const long long sn = (long long)s * a.N + n;
+    float* const T = lds + wave * RING * TROW;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+
+    // A operand: A[i = tap][k = c], K step r of channel block kb is c = 16kb + 4lg + r (one f32x4 per (tap tile, channel block))
+    f32x4 aw[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tap = 16 * mt + li, c = 16 * kb + 4 * lg + r;
+                aw[mt][kb][r] = tap < 25 ? a.K1w[((long long)sw * C1 + c) * 25 + tap] : 0.f;
+            }
+    auto emit_row = [&](int Y) {                                         // output row Y from the ring (rows Y-4 .. Y of T)
+        if (lane < 28) {
+            float g = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int Yp = Y - ky;
+                if (Yp < 0 || Yp > 23) continue;                         // wave-uniform
+                const float* const row = T + (Yp % RING) * TROW + ky * 5 * 32;
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int Xp = lane - kx;
+                    if (Xp >= 0 && Xp <= 23) g += row[kx * 32 + Xp];
+                }
+            }
+            a.G[sn * 784 + Y * 28 + lane] = g;
+        }
+    };
+    for (int py = 0; py < P1W; ++py) {
+        // this lane's 16 (channel, position) elements of pooled row py: pt = position tile (Xa = 16pt + li), kb, r as above
+        float gv[2][2][4];
+        int ar[2][2][4];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int Xa = 16 * pt + li, c = 16 * kb + 4 * lg + r;
+                    const long long e = sn * P1SZ + c * (P1W * P1W) + py * P1W + min(Xa >> 1, P1W - 1);
+                    const int st = a.st1[e];
+                    const float d = a.dP1[e];
+                    gv[pt][kb][r] = (Xa < 24) ? ((st & 4) ? d : d * slope) : 0.f;
+                    ar[pt][kb][r] = (st & 3) ^ (Xa & 1);                 // == 2*half for the row half that owns the argmax, with the right column parity
+                }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int Ya = 2 * py + half;
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float b[2];
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) b[pt] = (ar[pt][kb][r] == 2 * half) ? gv[pt][kb][r] : 0.f;   // arg = 2*dy + dx
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = MFMA16(aw[mt][kb][r], b[pt], acc[mt][pt]);
+                }
+            float* const row = T + (Ya % RING) * TROW;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int tap = 16 * mt + 4 * lg + r;            // acc[mt][pt][r] = T[tap][Xa = 16pt + li]
+                        if (tap < 25) row[tap * 32 + 16 * pt + li] = acc[mt][pt][r];
+                    }
+            emit_row(Ya);
+        }
+    }
+    for (int Y = 24; Y < 28; ++Y) emit_row(Y);
+}
+
 }  // namespace
 
 extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_t* sidx, int32_t S, int32_t N,
@@ -849,8 +952,13 @@ extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_
     if (leaky) hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
     if ((rc = launch_status())) return rc;
+#ifdef RBNN_CONV1_BWD_VALU
     if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
+#else
+    if (leaky) hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
+#endif
     return launch_status();
 }
 
@@ -875,7 +983,12 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
     if (leaky) hipLaunchKernelGGL(conv_bwd_split_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
     else       hipLaunchKernelGGL(conv_bwd_split_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
     if ((rc = launch_status())) return rc;
+#ifdef RBNN_CONV1_BWD_VALU
     if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
+#else
+    if (leaky) hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
+#endif
     return launch_status();
 }
