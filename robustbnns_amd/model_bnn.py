@@ -60,7 +60,12 @@ class BNN(nn.Module):
         self.name = self.get_name()
         self.posterior = None                 # hmc: StackedPosterior of the chain
         self.svi_loc = self.svi_scale = None  # svi: dict key -> tensor (raw scale, softplus applied at draw)
-        self.svi_rng = "host"                 # "host": CPU generator in the guide's draw order; "device": on-GPU randn
+        # SVI draws.  "device" (default): eps comes from the GPU generator — fresh from the live generator without seeds (the
+        # reference draws from the live global RNG too), one generator re-seeded per seed otherwise (same seed -> same weights,
+        # whatever the other seeds are).  "host": a CPU restatement of the guide's draw order (2 discarded tensors per key, then
+        # one per parameter) — same-seed parity with pyro is unpinned either way, and at MNIST fc-512 the
+        # host loop costs 3.7 s per 100 draws against 2.4 ms for the whole forward.
+        self.svi_rng = os.environ.get("RBNN_SVI_RNG", "device")
         self._engine = None
 
     def get_name(self, n_inputs=None):
@@ -148,8 +153,15 @@ class BNN(nn.Module):
         model_bnn.py:125-126), then one standard normal per parameter in named_parameters() order."""
         shapes = [(k, tuple(v.shape)) for k, v in self.basenet.state_dict().items()]
         total = sum(int(np.prod(s)) for _, s in shapes)
-        if self.svi_rng == "device" and not seeds:
-            return torch.randn(n_samples, total, device=self.device, dtype=torch.float32)
+        if self.svi_rng == "device" and torch.device(self.device).type == "cuda":
+            if not seeds:
+                return torch.randn(n_samples, total, device=self.device, dtype=torch.float32)
+            eps = torch.empty(n_samples, total, device=self.device, dtype=torch.float32)
+            gen = torch.Generator(device=self.device)
+            for i in range(n_samples):
+                gen.manual_seed(int(seeds[i]))
+                torch.randn(total, generator=gen, device=self.device, dtype=torch.float32, out=eps[i])
+            return eps
         eps = torch.empty(n_samples, total, dtype=torch.float32)
         for i in range(n_samples):
             if seeds:
