@@ -21,3 +21,8 @@ for inf in ("hmc","svi"):
         for _ in range(5): fn()
         torch.cuda.synchronize(); dt=(time.perf_counter()-t0)/5
         print(inf, name, "%.2f ms" % (dt*1e3))
+    t0=time.perf_counter(); A.pgd_attack(bnn, xd, lab, {"epsilon":0.3}, n_samples=S); torch.cuda.synchronize(); print(inf, "pgd_attack T=40 (all points): %.1f ms" % ((time.perf_counter()-t0)*1e3))
+    onehot = torch.nn.functional.one_hot(lab, C).float()
+    t0=time.perf_counter(); r = A.attack_evaluation(bnn, xd, xd, onehot, "cuda:0", n_samples=S); torch.cuda.synchronize(); print(inf, "attack_evaluation: %.1f ms" % ((time.perf_counter()-t0)*1e3))
+    from robustbnns_amd import lossGradients as LG
+    t0=time.perf_counter(); g_ = LG.loss_gradient(bnn, xd[0], onehot[0], n_samples=S); torch.cuda.synchronize(); print(inf, "loss_gradient (one point): %.2f ms" % ((time.perf_counter()-t0)*1e3))
