@@ -252,6 +252,7 @@ ORACLE_CASES += [  # point-tile boundaries of the 256-point blocks and single-sa
 ]
 ORACLE_CASES += [("fc2", "leaky", (1, 28, 28), 10, 256, 5, 300, 0.05), ("fc2", "relu", (1, 14, 14), 4, 128, 9, 257, 0.1),
                  ("fc2", "leaky", (1, 2, 1), 2, 128, 6, 70, 0.15)]
+ORACLE_CASES += [("fc2", "leaky", (1, 28, 28), 10, 1024, 2, 70, 0.03)]       # the reference's saved model_3 / model_7 shape
 ORACLE_CASES += [("fc", "sigm", (1, 28, 28), 10, 256, 3, 140, 0.05), ("fc", "tanh", (1, 14, 14), 5, 128, 4, 90, 0.1),
                  ("fc2", "tanh", (1, 28, 28), 10, 256, 3, 130, 0.05), ("fc2", "sigm", (1, 8, 8), 3, 128, 2, 50, 0.2)]
 ORACLE_MODES = [c + (m,) for c in ORACLE_CASES for m in modes_for(c[0], c[1], c[4], c[3])]
