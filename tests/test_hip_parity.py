@@ -557,11 +557,11 @@ def test_conv_golden(golden):
 
 @pytest.mark.parametrize("precision", ["auto", "exact"])
 @pytest.mark.parametrize("act,C,Hc,S,N", [("leaky", 10, 16, 2, 5), ("relu", 10, 32, 2, 19), ("leaky", 10, 64, 3, 33),
-                                          ("leaky", 10, 512, 2, 12), ("leaky", 3, 272, 1, 5)])
+                                          ("leaky", 10, 512, 2, 12), ("leaky", 3, 272, 1, 5), ("leaky", 10, 1024, 1, 40)])
 def test_conv_against_fp64_oracle(act, C, Hc, S, N, precision):
     from robustbnns_amd import _hip
     from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
-    post = O.synthetic_posterior("conv", 784, Hc, C, S, 0.05 if Hc < 512 else 0.03)
+    post = O.synthetic_posterior("conv", 784, Hc, C, S, 0.05 if Hc < 512 else (0.03 if Hc < 1024 else 0.02))
     x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=Hc + N)
     lab = y.argmax(-1); p64 = O.cast(post, torch.float64)
     eng = ConvEngine(ConvStackedPosterior(act, (1, 28, 28), C, Hc, post, DEV), precision=precision)
