@@ -74,7 +74,7 @@ class AttackEngine:
         self._ws_cache = {}
         self.precision = self._resolve_precision(precision)
         self._x_bound = None                    # max |x| over an attack's iterates, set by the attack loops (saves a sync per step)
-        self._absmax_cache = (None, 0.0)
+        self._absmax_cache = (None, None, 0.0)
 
     def _resolve_precision(self, precision):
         want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
@@ -183,12 +183,13 @@ class AttackEngine:
     def _absmax(self, X, src=None):
         """max |X| on the host (one device->host sync).  `src` = the caller's tensor X was padded from: when the same unmodified
         tensor comes back (an attack repeated on the same inputs), the previous value is reused instead of syncing again."""
-        key = None if src is None or not torch.is_tensor(src) else (src.data_ptr(), src._version, tuple(src.shape), src.device)
-        if key is not None and self._absmax_cache[0] == key:
-            return self._absmax_cache[1]
+        ref, ver, val = self._absmax_cache
+        if torch.is_tensor(src) and ref is not None and ref() is src and ver == (src._version, src.data_ptr()):
+            return val                          # the very same tensor object, not written to since (a recycled address cannot match)
         m = float(X.abs().max())
-        if key is not None:
-            self._absmax_cache = (key, m)
+        if torch.is_tensor(src):
+            import weakref
+            self._absmax_cache = (weakref.ref(src), (src._version, src.data_ptr()), m)
         return m
 
     def _bound_inputs(self, X0, iterates, src=None):
