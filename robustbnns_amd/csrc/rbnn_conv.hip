@@ -367,16 +367,25 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_split_kernel(const ConvArgs
             for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) my[(4 * lg + r) * NPOS + pt * 16 + li] = acc[ht][pt][r] * out_scale + bias[r];
-            for (int idx = lane; idx < 16 * NP2 && live; idx += 64) {
-                const int hl = idx / NP2, p = idx % NP2, base = hl * NPOS + (p / P2W) * O2W + (p % P2W);
-                float best = my[base];
-                int arg = 0;
-                if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
-                if (my[base + O2W] > best) { best = my[base + O2W]; arg = 2; }
-                if (my[base + O2W + 1] > best) { best = my[base + O2W + 1]; arg = 3; }
-                const long long o = sn * F + (long long)(hcb + hl) * NP2 + p;
-                a.Q2[o] = act_fwd<ACT>(best);
-                a.st2[o] = (uint8_t)(arg | (best > 0.f ? 4 : 0));
+            // four consecutive pooled cells per lane: one 16-byte store of Q2 and one 4-byte store of the stash (the tile's 16 x 49
+            // cells are contiguous in both); 196 lane-items per tile
+            for (int i4 = lane; i4 < 16 * NP2 / 4 && live; i4 += 64) {
+                f32x4 q;
+                unsigned stw = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = 4 * i4 + j, hl = idx / NP2, p = idx % NP2, base = hl * NPOS + (p / P2W) * O2W + (p % P2W);
+                    float best = my[base];
+                    int arg = 0;
+                    if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
+                    if (my[base + O2W] > best) { best = my[base + O2W]; arg = 2; }
+                    if (my[base + O2W + 1] > best) { best = my[base + O2W + 1]; arg = 3; }
+                    q[j] = act_fwd<ACT>(best);
+                    stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
+                }
+                const long long o = sn * F + (long long)hcb * NP2 + 4 * i4;           // a multiple of 4
+                *(f32x4*)(a.Q2 + o) = q;
+                *(unsigned*)(a.st2 + o) = stw;
             }
         }
         __syncthreads();                                                 // the scratch aliases weight buffer 0 of the next chunk
