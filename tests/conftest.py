@@ -16,6 +16,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is a build artefact (git-ignored): compile it for gfx950 if it is missing or older than its sources
+    (hipcc cross-compiles without a GPU; ~45 s), so that a fresh checkout can run either test tier directly."""
+    import __graft_entry__ as G
+    G.build()
+
+
 class Golden:
     """One tests/golden/*.npz fixture: inputs, stacked posterior weights, reference outputs."""
 
