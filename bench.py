@@ -1,30 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — attack-samples/s of the Bayesian FGSM hot path on MI355X (BASELINE.json metric).
+"""bench.py — attack-samples/s of the Bayesian attack hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...           # N > 1 without a torchrun environment: spawns the N ranks itself (child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): MNIST-shaped fc-BNN 784->512->10 (leaky), FGSM eps=0.3 on
+Default workload (BASELINE.json configs[1], "C2"): MNIST-shaped fc-BNN 784->512->10 (leaky), FGSM eps=0.3 on
 N=10 000 test points with S=100 posterior samples PER GPU, synthetic data (X ~ U[0,1), weights ~ N(0,0.05^2)),
 everything resident in HBM before the timed region.  One step = one pass of the hot path over the batch:
 forward over all (point, sample) pairs, CE on the mean probabilities, hand-rolled input gradient, sign/clamp.
-attack-samples = points x posterior samples x iterations (1 for FGSM).
+attack-samples = points x posterior samples x iterations (1 for FGSM).  Other workloads (--workload): c1, c3 (PGD T=40,
+S=500), c4 (the per-GPU share of S=2000 sharded 8-way: loss_gradients + FGSM per step), c5 (CIFAR-shaped conv-BNN, PGD
+T=100 over eps in {2,4,8}/255; build-defined shapes, parity unpinned), conv, fc2.
 
-N GPUs: one process per GPU; the posterior is SAMPLE-sharded (each rank holds its own S=100 samples, so the
-job has 100*N samples: weak scaling) and each step all-reduces sum_s p_s [N,16] and the summed gradients
-[N,784] over RCCL/xGMI (north star).  `--shard points` replicates the samples and
-splits points instead (no collective).
+N GPUs: one process per GPU; the posterior is SAMPLE-sharded (each rank holds its own S samples, so the job has S*N
+samples: weak scaling) and each step all-reduces sum_s p_s [N,16] and the summed gradients [N,784] over RCCL/xGMI
+(north star).  `--shard points` replicates the samples and splits points instead (no collective).
 
-Precision (`--precision`, default auto): the two GEMMs run either on the fp32 MFMA ("exact") or as error-compensated
-half pairs on the f16 MFMA pipe ("split": three f16 products per fp32 product, fp32 accumulation, 2^-22 per product;
-parity-tested to the same 1e-5 bar).  auto = split for this workload.  The line's top level is the mode that ran;
-at N=1 the other mode is timed afterwards and reported under `exact_fp32_mode` for reference.
+Precision (`--precision`, default exact).  The line's TOP LEVEL is IEEE-fp32 arithmetic: both GEMMs on
+v_mfma_f32_16x16x4_f32 ("exact", dtype f32) — the reference's arithmetic.  The faster split-half mode (every fp32 operand
+an fp16 hi+lo pair, 3 f16 MFMA products per fp32 product, fp32 accumulation; operands ~22-23 bits wide, i.e. narrower than
+fp32, parity-tested to the same 1e-5 bar) is timed afterwards at N=1 and reported as the sub-record `split_f16x3_mode`;
+`--precision split` puts it on top instead, labelled as such.
 
-The JSON line carries `roofline` for the dominant kernel (the input-gradient kernel; the forward kernel is listed
-beside it under roofline.kernels), timed with HIP events on the launch stream inside the timed region, and
-`cpu_baseline`: the loop-structured oracle port (oracle/bnn_oracle.py::loop_attack — the reference's batch-1
-autograd nest) timed on this host's cores on a bounded sample of the same workload.
+The JSON line carries `roofline` for the dominant kernel (the other GEMM kernel is listed beside it under roofline.kernels),
+timed with HIP events on the launch stream inside the timed region, and `cpu_baseline`: the loop-structured oracle port
+(oracle/bnn_oracle.py::loop_attack — the reference's batch-1 autograd nest) timed on this host's cores on a bounded sample
+of the same workload.
 """
 import argparse
 import json
@@ -42,11 +45,16 @@ F16_MFMA_PEAK_TFLOPS = 2516.6          # v_mfma_f32_16x16x32_f16: 16 cyc/SIMD ->
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
-    # name: (input shape, hidden, classes, arch, act, S per GPU, N, method, iters, eps)
+    # name: input shape, hidden, classes, arch, act, S per GPU, N, method(s) of one step, iters, eps
     "c2": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
                desc="MNIST fc-BNN 784->512->10 (leaky), FGSM eps=0.3, N=10000 points, S=100 samples/GPU"),
     "c3": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=500, N=10000, method="pgd", iters=40, eps=0.3,
                desc="F-MNIST fc-BNN 784->512->10 (leaky), PGD T=40 eps=0.3, N=10000 points, S=500 samples/GPU"),
+    # BASELINE.json configs[3]: S=2000 sharded 8-way = 250 samples per GPU; one step = loss_gradients (per-sample loss) + FGSM
+    # (mean-probability loss) over all points, i.e. 2 x N x S attack-samples
+    "c4": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=250, N=10000, method="lossgrad+fgsm", iters=1, eps=0.3,
+               passes=2, desc="MNIST fc-BNN 784->512->10 (leaky), expected_loss_gradients + FGSM eps=0.3, N=10000 points, "
+                              "S=250 samples/GPU (S=2000 sharded 8-way at 8 GPUs)"),
     "conv": dict(shape=(1, 28, 28), H=512, C=10, arch="conv", act="leaky", S=16, N=2048, method="fgsm", iters=1, eps=0.3,
                  desc="MNIST conv-BNN (conv5x5x32 - pool - conv5x5x512 - pool - fc, leaky), FGSM eps=0.3, N=2048 points, S=16 samples/GPU"),
     "fc2": dict(shape=(1, 28, 28), H=512, C=10, arch="fc2", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
@@ -54,6 +62,12 @@ WORKLOADS = {
     "c1": dict(shape=(1, 2, 1), H=64, C=2, arch="fc", act="leaky", S=10, N=100, method="fgsm", iters=1, eps=0.3,
                desc="half-moons fc-BNN 2->64->2 (leaky), FGSM eps=0.3, N=100 points, S=10 samples/GPU"),
 }
+
+
+def conv_geometry(shape):
+    """(pooled conv1 side, pooled conv2 side) of the conv net on a CxHxW input (model_nn.py:98-106: 5x5 convs, pool 2, pool 2 stride 1)."""
+    p1 = (shape[1] - 4) // 2
+    return p1, p1 - 4 - 1
 
 
 def make_problem(w, rank, device):
@@ -67,8 +81,9 @@ def make_problem(w, rank, device):
     S, H, C = w["S"], w["H"], w["C"]
     if w["arch"] == "conv":
         r = lambda *shape: torch.randn(S, *shape, generator=gw) * 0.03
-        post = {"model.0.weight": r(32, 1, 5, 5), "model.0.bias": r(32), "model.3.weight": r(H, 32, 5, 5), "model.3.bias": r(H),
-                "model.7.weight": r(C, 49 * H), "model.7.bias": r(C)}
+        q2 = conv_geometry(w["shape"])[1]
+        post = {"model.0.weight": r(32, w["shape"][0], 5, 5), "model.0.bias": r(32), "model.3.weight": r(H, 32, 5, 5), "model.3.bias": r(H),
+                "model.7.weight": r(C, q2 * q2 * H), "model.7.bias": r(C)}
         return x, y, post
     if w["arch"] == "fc2":
         post = {"model.1.weight": torch.randn(S, H, D, generator=gw) * std, "model.1.bias": torch.randn(S, H, generator=gw) * std,
@@ -84,22 +99,68 @@ def cpu_baseline(w, x, y, post, budget_s):
     """The reference's loop nest (batch 1, autograd) on this host: bounded sample, linear in points."""
     from oracle import bnn_oracle as O
     onehot = torch.nn.functional.one_hot(y, w["C"]).float()
-    hyper = {"epsilon": w["eps"]}
-    fn = O.loop_fgsm_attack if w["method"] == "fgsm" else O.loop_pgd_attack
+    hyper = {"epsilon": w["eps"] if not isinstance(w["eps"], (list, tuple)) else w["eps"][0]}
+
+    def one_point(i):
+        if "lossgrad" in w["method"]:
+            O.loop_loss_gradient(x[i], onehot[i], post, w["arch"], w["act"], w["S"])
+        if "fgsm" in w["method"]:
+            O.loop_fgsm_attack(x[i:i + 1], y[i:i + 1], post, w["arch"], w["act"], w["S"], hyper)
+        if w["method"] == "pgd":
+            O.loop_pgd_attack(x[i:i + 1], y[i:i + 1], post, w["arch"], w["act"], w["S"], hyper, iters=w["iters"])
+
+    cut = None
+    if w["method"] == "pgd" and w["iters"] * w["S"] > 4000:
+        # one full point would take minutes (C3: 10 s, C5: longer): time a prefix of the PGD iterations of each point instead —
+        # every iteration costs the same (same S forwards + one backward), so the rate per attack-sample is unchanged
+        cut = max(2, 4000 // w["S"])
+    iters_timed = cut or w["iters"]
+    if cut:
+        def one_point(i):                                                   # noqa: F811
+            O.loop_pgd_attack(x[i:i + 1], y[i:i + 1], post, w["arch"], w["act"], w["S"], hyper, iters=cut)
+    one_point(0)                                                            # untimed warm-up (thread pool, caches)
     done, t0 = 0, time.perf_counter()
-    fn(x[0:1], y[0:1], post, w["arch"], w["act"], w["S"], hyper)           # untimed warm-up (thread pool, caches)
-    t0 = time.perf_counter()
     while done < w["N"]:
-        fn(x[done:done + 1], y[done:done + 1], post, w["arch"], w["act"], w["S"], hyper)
+        one_point(done)
         done += 1
-        if time.perf_counter() - t0 > budget_s and done >= 4:
+        if time.perf_counter() - t0 > budget_s and done >= (2 if cut else 4):
             break
     dt = time.perf_counter() - t0
-    return {"value": done * w["S"] * w["iters"] / dt, "unit": "attack-samples/s", "cores": torch.get_num_threads(),
+    passes = w.get("passes", 1)
+    return {"value": done * w["S"] * iters_timed * passes / dt, "unit": "attack-samples/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"first {done} points of the workload ({w['method']}, S={w['S']}, T={w['iters']}), "
-                      f"oracle loop_attack = reference nest batch-1 autograd, {dt:.1f} s, linear in points",
-            "host_cpus": os.cpu_count(), "ms_per_point": 1e3 * dt / done}
+            "sample": f"first {done} points of the workload ({w['method']}, S={w['S']}, "
+                      f"{'first %d of T=%d iterations' % (cut, w['iters']) if cut else 'T=%d' % w['iters']}), "
+                      f"oracle loop_attack = reference nest batch-1 autograd, {dt:.1f} s, linear in points and iterations",
+            "host_cpus": os.cpu_count(), "ms_per_point": 1e3 * dt / done * (w["iters"] / iters_timed)}
+
+
+def spawn_ranks(args):
+    """`--gpus N` (N > 1) outside a torchrun environment: start the N ranks as a CHILD process (never an exec; nothing in this
+    process has touched the GPU yet) and relay the child's output, its JSON line last."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()                       # counting devices does not initialise the GPU
+    if have < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {have} GPU(s) visible on this host")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = proc.stdout.splitlines()
+    last_json = None
+    for i in range(len(lines) - 1, -1, -1):
+        if lines[i].startswith("{") and lines[i].rstrip().endswith("}"):
+            last_json = lines.pop(i)
+            break
+    for ln in lines:
+        print(ln)
+    if last_json is not None:
+        print(last_json, flush=True)
+    return proc.returncode if (proc.returncode or last_json is not None) else 1
 
 
 def main():
@@ -112,12 +173,17 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--points", type=int, default=0, help="override N (debug)")
     ap.add_argument("--samples", type=int, default=0, help="override S per GPU (debug)")
-    ap.add_argument("--precision", default="auto", choices=["auto", "exact", "split"])
+    ap.add_argument("--iters", type=int, default=0, help="override the PGD iteration count (debug)")
+    ap.add_argument("--precision", default="exact", choices=["exact", "split", "fast"],
+                    help="arithmetic of the line's top level (exact = IEEE fp32 on the fp32 MFMA; the split mode is reported as a sub-record)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision mode at N=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
@@ -129,13 +195,17 @@ def main():
         dist.init_process_group("nccl", device_id=device)           # nccl == RCCL on ROCm
         group = dist.group.WORLD
 
-    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    from robustbnns_amd import _hip
 
     w = dict(WORKLOADS[args.workload])
     if args.points:
         w["N"] = args.points
     if args.samples:
         w["S"] = args.samples
+    if args.iters:
+        w["iters"] = args.iters
+    eps_list = list(w["eps"]) if isinstance(w["eps"], (list, tuple)) else [w["eps"]]
+    passes = w.get("passes", len(eps_list))                           # hot-path passes (each N x S x iters attack-samples) per step
     x, y, post = make_problem(w, rank if args.shard == "samples" else 0, device)
     D = x[0].numel()
     from robustbnns_amd.factory import make_engine, posterior_from_stacked
@@ -148,39 +218,39 @@ def main():
             self.ev = {"fc_forward": [], "fc_input_grad": []} if w["arch"] != "conv" else {"conv_forward": [], "conv_input_grad": []}
             self.on = False
 
-        def _timed(self, name, fn, *a):
+        def _timed(self, name, fn, *a, **kw):
             if not self.on:
-                return fn(*a)
+                return fn(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = fn(*a)
+            r = fn(*a, **kw)
             e1.record()
             self.ev[name].append((e0, e1))
             return r
 
-        def fc_forward(self, *a):
-            return self._timed("fc_forward", super().fc_forward, *a)
+        def fc_forward(self, *a, **kw):
+            return self._timed("fc_forward", super().fc_forward, *a, **kw)
 
-        def fc_input_grad(self, *a):
-            return self._timed("fc_input_grad", super().fc_input_grad, *a)
+        def fc_input_grad(self, *a, **kw):
+            return self._timed("fc_input_grad", super().fc_input_grad, *a, **kw)
 
-        def fc_forward_split(self, *a):
-            return self._timed("fc_forward", super().fc_forward_split, *a)
+        def fc_forward_split(self, *a, **kw):
+            return self._timed("fc_forward", super().fc_forward_split, *a, **kw)
 
-        def fc_input_grad_split(self, *a):                               # includes the small dZ re-scaling kernel
-            return self._timed("fc_input_grad", super().fc_input_grad_split, *a)
+        def fc_input_grad_split(self, *a, **kw):                          # includes the small dZ re-scaling kernel
+            return self._timed("fc_input_grad", super().fc_input_grad_split, *a, **kw)
 
-        def conv_forward(self, *a):
-            return self._timed("conv_forward", super().conv_forward, *a)
+        def conv_forward(self, *a, **kw):
+            return self._timed("conv_forward", super().conv_forward, *a, **kw)
 
-        def conv_forward_split(self, *a):
-            return self._timed("conv_forward", super().conv_forward_split, *a)
+        def conv_forward_split(self, *a, **kw):
+            return self._timed("conv_forward", super().conv_forward_split, *a, **kw)
 
-        def conv_input_grad(self, *a):
-            return self._timed("conv_input_grad", super().conv_input_grad, *a)
+        def conv_input_grad(self, *a, **kw):
+            return self._timed("conv_input_grad", super().conv_input_grad, *a, **kw)
 
-        def conv_input_grad_split(self, *a):
-            return self._timed("conv_input_grad", super().conv_input_grad_split, *a)
+        def conv_input_grad_split(self, *a, **kw):
+            return self._timed("conv_input_grad", super().conv_input_grad_split, *a, **kw)
 
     if args.shard == "samples":
         xs, ys, S_job, N_job = x, y, w["S"] * world, w["N"]
@@ -206,9 +276,14 @@ def main():
             eng = make_engine(sp, kernels=kern, precision=precision)
 
         def step():
-            if w["method"] == "fgsm":
-                return eng.fgsm(xs, labels, w["S"], w["eps"])
-            return eng.pgd(xs, labels, w["S"], w["eps"], alpha=None, iters=w["iters"])
+            if "lossgrad" in w["method"]:
+                eng.loss_gradients(xs, labels, w["S"])
+            if "fgsm" in w["method"]:
+                for e in eps_list:
+                    eng.fgsm(xs, labels, w["S"], e)
+            if w["method"] == "pgd":
+                for e in eps_list:
+                    eng.pgd(xs, labels, w["S"], e, alpha=None, iters=w["iters"])
 
         for _ in range(args.warmup):
             step()
@@ -235,10 +310,18 @@ def main():
     per_launch = 2.0 * (D * w["H"] + w["H"] * w["C"]) * w["N"] * w["S"]
     if w["arch"] == "fc2":        # F_fc2 = 4*(D*H + H^2 + H*C), half per direction
         per_launch = 2.0 * (D * w["H"] + w["H"] ** 2 + w["H"] * w["C"]) * w["N"] * w["S"]
-    if w["arch"] == "conv":       # 2*(460800 + 26214400*H/512 + 49*H*C) flop per (point, sample) per direction
-        per_launch = 2.0 * (460800 + 51200.0 * w["H"] + 49 * w["H"] * w["C"]) * w["N"] * w["S"]
+    if w["arch"] == "conv":
+        # SURVEY 8(d) generalised to a Cin x Hin x Win input: conv1 25*Cin*32 MACs per output pixel, conv2 800*Hc per output
+        # pixel, Linear q2^2*Hc*C; 2 flop per MAC per direction.  1x28x28, Hc=512: 2*(460800 + 26214400 + 250880).
+        c1 = w["shape"][1] - 4
+        p1, q2 = conv_geometry(w["shape"])
+        macs = 25 * w["shape"][0] * 32 * c1 * c1 + 800 * w["H"] * (p1 - 4) ** 2 + q2 * q2 * w["H"] * w["C"]
+        per_launch = 2.0 * macs * w["N"] * w["S"]
+    # algorithmic HBM bytes per hot-path pass: every sample's weights once + inputs in + gradients out
+    n_params = sum(int(v[0].numel()) for v in post.values())
+    alg_bytes = 4.0 * w["S"] * n_params + 8.0 * w["N"] * D
     KNAMES = {"exact": {"fc_input_grad": "fc_grad_kernel", "fc_forward": "fc_forward_kernel",
-                        "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel"},
+                        "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel (+ conv_fc_bwd, conv1_bwd)"},
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
     SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}
@@ -253,12 +336,17 @@ def main():
             ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
             kernels[name] = {"launches": len(evs), "avg_ms": ms, "tflops": per_launch / (ms * 1e-3) / 1e12 if ms else None}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.workload == "c2" and not args.points and not args.samples:
-            traffic = json.load(open(pmc)).get(dom + ("_split" if mode == "split" and dom in SPLIT_KERNELS else ""), {}).get("hbm_bytes_per_launch")
+        if os.path.exists(pmc) and not args.points and not args.samples:
+            rec = json.load(open(pmc))
+            key = dom + ("_split" if mode == "split" and dom in SPLIT_KERNELS else "")
+            ent = rec.get(args.workload, rec if args.workload == "c2" else {}).get(key, {})
+            traffic = ent.get("hbm_bytes_per_launch")
+            traffic_src = rec.get("source") if traffic is not None else None
         fp32_eq = kernels[dom]["tflops"]
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
+             "traffic_source": traffic_src,      # PMC counters cannot be read inside this run: a committed rocprofv3 --pmc pass of the same command
              "flop_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
         if mode == "split" and dom in SPLIT_KERNELS:
             # matrix-pipe work of the split mode: 3 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
@@ -268,33 +356,47 @@ def main():
         else:
             r.update({"achieved": fp32_eq, "peak": FP32_MFMA_PEAK_TFLOPS, "frac": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
                       "pipe": "v_mfma_f32_16x16x4_f32"})
-        r["whole_step_tflops"] = 2 * per_launch / (1e-3 * ms_per_step / w["iters"]) / 1e12
+        ms_per_pass = ms_per_step / (passes * w["iters"])
+        r["whole_step_tflops"] = 2 * per_launch / (1e-3 * ms_per_pass) / 1e12
+        # HBM side (BASELINE.json configs[4] asks for per-GPU HBM GB/s): algorithmic bytes of one pass over its duration, and the
+        # PMC-counted bytes of the two GEMM kernels (when a committed pass covers this workload) over the same time
+        r["hbm"] = {"algorithmic_bytes_per_pass": alg_bytes, "algorithmic_gbs": alg_bytes / (1e-3 * ms_per_pass) / 1e9,
+                    "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes / (1e-3 * ms_per_pass) / 1e9 / HBM_PEAK_GBS}
         return r
 
+    DTYPES = {"exact": "f32",
+              "split": "f32 carried as f16 hi+lo pairs: 3 f16 MFMA products per fp32 product, f32 accumulate (2^-22 per product)"}
     mode, dt, evs = run(args.precision)
     other = None
-    if world == 1 and mode == "split" and args.precision == "auto":
-        other = run("exact")                                              # reference line: the exact-fp32 kernels on the same workload
+    if world == 1 and not args.no_other_mode:
+        want = "split" if mode == "exact" else "exact"
+        try:
+            other = run(want)                                             # the other precision mode on the same workload
+        except _hip.HipError:
+            other = None                                                  # the split kernels do not cover this posterior
+        if other is not None and other[0] != want:
+            other = None
 
     import ctypes
     ctypes.CDLL(None).fflush(None)          # every rank: anything RCCL left in C stdio goes out before rank 0's JSON line
     barrier()
     if rank == 0:
-        units = N_job * S_job * w["iters"] * args.steps
+        units = N_job * S_job * w["iters"] * passes * args.steps
         ms_per_step = 1e3 * dt / args.steps
         out = {
             "metric": "attack-samples/sec (test_pts x posterior_samples x PGD_iters)",
             "value": units / dt, "unit": "attack-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 carried as f16 hi+lo pairs: 3 f16 MFMA products per fp32 product, f32 accumulate (2^-22 per product)" if mode == "split" else "f32",
-            "precision_mode": mode, "data": "synthetic",
+            "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
             "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job,
-                       "iters": w["iters"], "shard": args.shard if world > 1 else "none"},
+                       "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none"},
             "roofline": roofline(mode, evs, ms_per_step),
         }
         if other is not None:
             o_ms = 1e3 * other[1] / args.steps
-            out["exact_fp32_mode"] = {"value": units / other[1], "ms_per_step": o_ms, "roofline": roofline("exact", other[2], o_ms)}
+            key = "split_f16x3_mode" if other[0] == "split" else "exact_fp32_mode"
+            out[key] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],
+                        "roofline": roofline(other[0], other[2], o_ms)}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 3
+#define RBNN_ABI_VERSION 4
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {
@@ -145,6 +145,13 @@ int rbnn_fc_input_grad(const rbnn_posterior *net, const int32_t *sample_idx, int
 int rbnn_sum_slabs(const float *slabs, int32_t n_slabs, int32_t n_points, int32_t d_pad, float scale,
                    float *out, int32_t ldo, void *stream);
 
+/* rbnn_sum_slabs with the norms of every point's result fused into the same pass (no second read of the gradients):
+ * linf[n] = max_{d<D} |out[n,d]|, l2[n] = sqrt(sum_{d<D} out[n,d]^2)  (fp32, fixed summation order: reproducible).
+ * Replaces np.max(np.abs(g)) / np.linalg.norm(g) per image in compute_vanishing_norms_idxs, lossGradients.py:91-94,102-105
+ * (and plot_gradients_components.py:73-79).  `out` is bit-identical to rbnn_sum_slabs'. */
+int rbnn_sum_slabs_norms(const float *slabs, int32_t n_slabs, int32_t n_points, int32_t d_pad, int32_t in_features, float scale,
+                         float *out, int32_t ldo, float *linf, float *l2, void *stream);
+
 /* alpha[n] = 2 / max_d X0[n,d]   — adversarialAttacks.py:89 (per image, from the clean image). */
 int rbnn_pgd_alpha(const float *X0, int32_t ldx, int32_t n_points, int32_t in_features,
                    float *alpha, void *stream);
@@ -169,6 +176,23 @@ int rbnn_eval_metrics(const float *out_orig, const float *out_adv, int32_t ldp, 
  * rbnn_fc_input_grad reads (rows = S_total*H of W1 [cols = D_pad] or of Wm [cols = H]).  One-off layout
  * transform at posterior-load time; no counterpart in the reference. */
 int rbnn_pack_rows4(const float *W, int64_t rows, int32_t cols, float *out, void *stream);
+
+/* A power-of-two operand scale that lives in DEVICE memory, so that the split images of data-dependent operands (the
+ * inputs, and the activations they bound) need no device->host round trip: value * scale = hi + lo, scale = 2^exp. */
+typedef struct rbnn_dev_scale {
+    uint32_t absmax_bits;          /* bit pattern of the bound the exponent was derived from                    */
+    int32_t  exp;                  /* 14 - ceil(log2(bound)), clamped to [-100, 100]; 0 for a zero / non-finite bound */
+    float    scale;                /* 2^exp                                                                     */
+    float    inv_scale;            /* 2^-exp                                                                    */
+} rbnn_dev_scale;
+
+/* out[0] <- scale of the inputs:        bound0 = max(floor_abs, max_{r,c<cols} |X[r,c]|)
+ * out[1] <- scale of what they bound:   bound1 = min(cap, mul * bound0 + add)
+ * (fc2: the layer-1 activations, mul = max_h sum_d |W1[h,d]|, add = max|b1|, cap = 1 for sigmoid / tanh else +inf;
+ * conv: the pooled conv1 activations).  floor_abs = 1 when later iterates are clamp(., 0, 1) of something
+ * (adversarialAttacks.py:105), else 0.  No counterpart in the reference (it computes in fp32).  Asynchronous on `stream`. */
+int rbnn_input_scales(const float *X, int64_t rows, int32_t cols, int32_t ld, float floor_abs, float mul, float add,
+                      float cap, rbnn_dev_scale *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * `conv` architecture (model_nn.py:93-106) on 1x28x28 inputs (mnist / fashion_mnist only, as the reference guards,
@@ -215,9 +239,11 @@ int rbnn_conv_input_grad(const rbnn_conv_posterior *net, const int32_t *sample_i
  * K2_rows = rbnn_split_rows image of model.3.weight regrouped [S_total*Hc, 25 taps * 32 ci] (K tap-major) holding W * 2^k2_exp;
  * the pooled conv1 activations are carried as value * 2^p1_exp = hi + lo (the caller bounds them: |P1| <= max_c(sum|K1w_c| *
  * max|x| + |K1b_c|)).  ws->P1 holds the 24 KiB split image per (sample, point) (rbnn_conv_workspace_query sizes it);
- * same outputs as rbnn_conv_forward, and rbnn_conv_input_grad follows it unchanged. */
-int rbnn_conv_forward_split(const rbnn_conv_posterior *net, const void *K2_rows, int32_t k2_exp, int32_t p1_exp, const float *X,
-                            int32_t ldx, int32_t n_points, const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
+ * same outputs as rbnn_conv_forward, and rbnn_conv_input_grad follows it unchanged.  p1_dev_scale != NULL: record [1] of
+ * rbnn_input_scales, read on the device instead of p1_exp. */
+int rbnn_conv_forward_split(const rbnn_conv_posterior *net, const void *K2_rows, int32_t k2_exp, int32_t p1_exp,
+                            const rbnn_dev_scale *p1_dev_scale, const float *X, int32_t ldx,
+                            int32_t n_points, const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                             const rbnn_conv_workspace *ws, void *stream);
 
 /* rbnn_conv_input_grad with conv2^T in split-half precision.  K2_bwd = rbnn_split_rows image of model.3.weight regrouped
@@ -269,11 +295,13 @@ typedef struct rbnn_split_workspace_sizes { size_t X_split, dZ_gen, g_scale; } r
 int rbnn_split_workspace_query(const rbnn_posterior *net, const rbnn_split_images *sp, int32_t n_points,
                                int32_t n_samples, rbnn_split_workspace_sizes *out);
 
+
 /* dst[r, g, 0, :] = fp16(v), dst[r, g, 1, :] = fp16(v - hi) for v = src[r, 8g..8g+7] * 2^scale_exp (0 past `cols`):
  * the split-rows image [rows, ld_dst/8, 2, 8] halves of a row-major fp32 matrix.  ld_dst % 32 == 0.
- * The caller picks scale_exp so that max|v| * 2^scale_exp <= 2^14. */
-int rbnn_split_rows(const float *src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp, void *dst,
-                    int32_t ld_dst, void *stream);
+ * The caller picks scale_exp so that max|v| * 2^scale_exp <= 2^14; with dev_scale != NULL the scale is read from that device
+ * record instead (rbnn_input_scales) and scale_exp is ignored. */
+int rbnn_split_rows(const float *src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                    const rbnn_dev_scale *dev_scale, void *dst, int32_t ld_dst, void *stream);
 
 /* Split-cols image of n_mats row-major [rows, ld_src] matrices (rows % 32 == 0):
  * dst[m, hb, lg, p, d, j] = (p ? lo : hi) of W[m, 32*hb + 16*(j>>2) + 4*lg + (j&3), d] * 2^scale_exp, 8 halves j per
@@ -287,10 +315,11 @@ int rbnn_split_w2gen(const float *W2, int32_t n_mats, int32_t n_classes, int32_t
                      void *stream);
 
 /* rbnn_fc_forward in split precision: same outputs (ws->P, ws->mask1 / ws->dact1), inputs as split-rows images:
- * X_split = rbnn_split_rows(X, N, D, ldx_src, x_exp, ., ldx) with ldx == sp->ld_rows. */
+ * X_split = rbnn_split_rows(X, N, D, ldx_src, x_exp, ., ldx) with ldx == sp->ld_rows.  dev_scales != NULL: the two records
+ * of rbnn_input_scales — [0] replaces x_exp, [1] replaces sp->h1_exp (fc2) — read on the device. */
 int rbnn_fc_forward_split(const rbnn_posterior *net, const rbnn_split_images *sp, const void *X_split, int32_t ldx,
-                          int32_t x_exp, int32_t n_points, const int32_t *sample_idx, int32_t n_samples,
-                          int32_t out_kind, const rbnn_workspace *ws, void *stream);
+                          int32_t x_exp, const rbnn_dev_scale *dev_scales, int32_t n_points, const int32_t *sample_idx,
+                          int32_t n_samples, int32_t out_kind, const rbnn_workspace *ws, void *stream);
 
 /* rbnn_fc_input_grad in split precision: same slabs (ws->slabs, already un-scaled), from ws->dZ and ws->mask1.
  * n_classes <= 10 (fc2: two steps through ws->dhid1).  Re-scales dZ per point (2^e(n), so vanishing gradients keep their 22 bits). */

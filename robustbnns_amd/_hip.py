@@ -87,6 +87,7 @@ SIGNATURES = {
     "rbnn_loss_dlogits": (_i32, [_i32, _fp, _fp, _i32, _fp, _fp, _i32, _f32, _i32, _i32, _fp, _fp]),
     "rbnn_fc_input_grad": (_i32, [_PP, _fp, _i32, _i32, _i32, _PW, C.POINTER(_i32), _fp]),
     "rbnn_sum_slabs": (_i32, [_fp, _i32, _i32, _i32, _f32, _fp, _i32, _fp]),
+    "rbnn_sum_slabs_norms": (_i32, [_fp, _i32, _i32, _i32, _i32, _f32, _fp, _i32, _fp, _fp, _fp]),
     "rbnn_pgd_alpha": (_i32, [_fp, _i32, _i32, _i32, _fp, _fp]),
     "rbnn_attack_step": (_i32, [_fp, _fp, _i32, _fp, _i32, _sz, _i32, _fp, _f32, _f32, _i32, _i32, _i32, _fp]),
     "rbnn_eval_metrics": (_i32, [_fp, _fp, _i32, _fp, _i32, _i32, _fp, _fp, _fp]),
@@ -96,10 +97,11 @@ SIGNATURES = {
     "rbnn_conv_forward": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_svi_materialize": (_i32, [_fp, _fp, _fp, _i64, _i32, _fp, _fp]),
     "rbnn_conv_input_grad_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
-    "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _i32, _i32, _fp, _i32, _i32,
+    "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                        C.POINTER(ConvWorkspace), _fp]),
-    "rbnn_split_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _i32, _fp]),
-    "rbnn_fc_forward_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _i32, _fp, _i32, _i32, _PW, _fp]),
+    "rbnn_input_scales": (_i32, [_fp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _fp, _fp]),
+    "rbnn_split_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
+    "rbnn_fc_forward_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
     "rbnn_split_cols": (_i32, [_fp, _i64, _i32, _i32, _i32, _i32, _fp, _i32, _fp]),
     "rbnn_split_w2gen": (_i32, [_fp, _i32, _i32, _i32, _i32, _fp, _fp]),
     "rbnn_split_workspace_query": (_i32, [_PP, C.POINTER(SplitImages), _i32, _i32, C.POINTER(SplitWorkspaceSizes)]),
@@ -125,7 +127,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 3:
+        if lib.rbnn_abi_version() != 4:
             raise HipError("librbnn_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -206,6 +208,12 @@ class HipKernels:
         require_gpu(slabs, "slabs")
         check(self.lib.rbnn_sum_slabs(ptr(slabs), K, N, Dp, scale, ptr(out), out.stride(0), stream_of(slabs)), "rbnn_sum_slabs")
 
+    def sum_slabs_norms(self, slabs, K, N, Dp, D, scale, out, linf, l2):
+        """sum_slabs + per-point Linf / L2 norms of the result over the D real columns, one pass."""
+        require_gpu(slabs, "slabs")
+        check(self.lib.rbnn_sum_slabs_norms(ptr(slabs), K, N, Dp, D, scale, ptr(out), out.stride(0), ptr(linf), ptr(l2),
+                                            stream_of(slabs)), "rbnn_sum_slabs_norms")
+
     def pgd_alpha(self, X0, D, alpha):
         require_gpu(X0, "X0")
         check(self.lib.rbnn_pgd_alpha(ptr(X0), X0.stride(0), X0.shape[0], D, ptr(alpha), stream_of(X0)), "rbnn_pgd_alpha")
@@ -227,17 +235,26 @@ class HipKernels:
         check(self.lib.rbnn_pack_rows4(ptr(W), W.numel() // cols, cols, ptr(out), stream_of(W)), "rbnn_pack_rows4")
 
     # -- split-half ("f16x3") precision mode ---------------------------------------------------------
-    def split_rows(self, src, cols, scale_exp, out, ld_dst):
-        """src: [..., ld_src] fp32 rows -> out: split-rows image (int16 storage [rows, ld_dst*2])."""
+    def input_scales(self, X, cols, floor_abs, mul, add, cap, out):
+        """Device-resident operand scales of the inputs X [N, ld] (record 0) and of the activations they bound (record 1):
+        out = int32[8] on the device (two rbnn_dev_scale records).  No host sync."""
+        require_gpu(X, "X")
+        check(self.lib.rbnn_input_scales(ptr(X), X.shape[0], cols, X.stride(0), floor_abs, mul, add, cap, ptr(out), stream_of(X)),
+              "rbnn_input_scales")
+        return out
+
+    def split_rows(self, src, cols, scale_exp, out, ld_dst, dev_scale=None):
+        """src: [..., ld_src] fp32 rows -> out: split-rows image (int16 storage [rows, ld_dst*2]).  dev_scale: an
+        rbnn_dev_scale record on the device that replaces scale_exp."""
         require_gpu(src, "src")
         ld_src = src.shape[-1]
-        check(self.lib.rbnn_split_rows(ptr(src), src.numel() // ld_src, cols, ld_src, scale_exp, ptr(out), ld_dst,
+        check(self.lib.rbnn_split_rows(ptr(src), src.numel() // ld_src, cols, ld_src, scale_exp, ptr(dev_scale), ptr(out), ld_dst,
                                        stream_of(src)), "rbnn_split_rows")
 
-    def fc_forward_split(self, net, images, Xs, ld, x_exp, N, sidx, S, out_kind, ws):
+    def fc_forward_split(self, net, images, Xs, ld, x_exp, N, sidx, S, out_kind, ws, dev_scales=None):
         w = self._ws(ws)
-        check(self.lib.rbnn_fc_forward_split(C.byref(net.descriptor()), C.byref(images), ptr(Xs), ld, x_exp, N, ptr(sidx), S,
-                                             out_kind, C.byref(w), stream_of(Xs)), "rbnn_fc_forward_split")
+        check(self.lib.rbnn_fc_forward_split(C.byref(net.descriptor()), C.byref(images), ptr(Xs), ld, x_exp, ptr(dev_scales), N,
+                                             ptr(sidx), S, out_kind, C.byref(w), stream_of(Xs)), "rbnn_fc_forward_split")
 
     def split_cols(self, W, rows, cols, scale_exp, out, ld_dst):
         """W: [n_mats, rows, ld_src] fp32 -> out: split-cols image."""
@@ -284,10 +301,11 @@ class HipKernels:
         check(self.lib.rbnn_conv_forward(C.byref(net.descriptor()), ptr(X), X.stride(0), X.shape[0], ptr(sidx), S, out_kind,
                                          C.byref(w), stream_of(X)), "rbnn_conv_forward")
 
-    def conv_forward_split(self, net, K2_rows, k2_exp, p1_exp, X, sidx, S, out_kind, ws):
+    def conv_forward_split(self, net, K2_rows, k2_exp, p1_exp, X, sidx, S, out_kind, ws, p1_dev_scale=None):
         require_gpu(X, "X")
         w = self._conv_ws(ws)
-        check(self.lib.rbnn_conv_forward_split(C.byref(net.descriptor()), ptr(K2_rows), k2_exp, p1_exp, ptr(X), X.stride(0), X.shape[0],
+        check(self.lib.rbnn_conv_forward_split(C.byref(net.descriptor()), ptr(K2_rows), k2_exp, p1_exp, ptr(p1_dev_scale), ptr(X),
+                                               X.stride(0), X.shape[0],
                                                ptr(sidx), S, out_kind, C.byref(w), stream_of(X)), "rbnn_conv_forward_split")
 
     def conv_input_grad_split(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):

@@ -73,6 +73,12 @@ class ConvStackedPosterior:
         stacked = {k: torch.stack([sd[k].detach().to("cpu", torch.float32) for sd in sds]) for k in keys}
         return cls(activation, input_shape, n_classes, hidden, stacked, device)
 
+    def scale_bounds(self):
+        """(mul, add, cap) of rbnn_input_scales' record 1: |P1| <= max_c(sum_taps |K1w_c|) * max|x| + max|K1b| bounds the pooled
+        conv1 activations (relu / leaky: |act(a)| <= |a|)."""
+        _, _, w_l1, b_max = self.split_images()[:4]
+        return w_l1, b_max, float("inf")
+
     def descriptor(self):
         if self._desc is None:
             d = _hip.ConvPosterior()
@@ -97,7 +103,10 @@ class ConvEngine(AttackEngine):
     graph_safe = False                      # large jobs are cut into point blocks per call: no fixed launch sequence to capture
     pipelined_comm = False                  # one cached workspace: the sample-sharded step keeps the plain sequence
 
-    def workspace(self, N, S, chunk=0):
+    def workspace(self, N, S, chunk=0, tag=0):
+        """One workspace per (N, S); `chunk` / `tag` are the fc engine's knobs (slab plan, pipelined point blocks) and do not
+        apply here.  Two entries stay cached — the full point block and a ragged tail block — so that a blocked job does not
+        re-allocate its multi-GB buffers on every call."""
         key = (N, S)
         ws = self._ws_cache.get(key)
         if ws is None:
@@ -111,7 +120,8 @@ class ConvEngine(AttackEngine):
             ws["slabs"] = ws["G"]                                          # per-sample gradients play the role of the slabs
             ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
             ws["Gsum"] = torch.empty(N, 784, dtype=torch.float32, device=self.device)
-            self._ws_cache.clear()
+            while len(self._ws_cache) >= 2:
+                self._ws_cache.pop(next(iter(self._ws_cache)))             # oldest entry out
             self._ws_cache[key] = ws
         return ws
 
@@ -137,9 +147,13 @@ class ConvEngine(AttackEngine):
             return super().forward(x, n_samples, seeds, logits)
         return self._blocked(lambda xb: AttackEngine.forward(self, xb, n_samples, seeds, logits), x, n_samples=n_samples)
 
-    def loss_gradients(self, x, y, n_samples):
+    def loss_gradients(self, x, y, n_samples, seeds=None, norms=False):
         y = torch.as_tensor(y)
-        return self._blocked(lambda xb, yb: AttackEngine.loss_gradients(self, xb, yb, n_samples), x, y, n_samples=n_samples)
+        parts = self._blocked(lambda xb, yb: AttackEngine.loss_gradients(self, xb, yb, n_samples, seeds, norms), x, y,
+                              n_samples=n_samples, cat=not norms)
+        if not norms or isinstance(parts, tuple):
+            return parts
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
     def fgsm(self, x, y, n_samples, epsilon=0.3, seeds=None, mode=_hip.LOSS_MEAN_PROB):
         y = torch.as_tensor(y)
@@ -165,10 +179,9 @@ class ConvEngine(AttackEngine):
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
         if self.precision != "split":
             return self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)
-        rows, k2_exp, w_l1, b_max = self.post.split_images()[:4]
-        xmax = self._x_bound if self._x_bound is not None else float(Xp.abs().max())
-        p1_exp = scale_exp(w_l1 * xmax + b_max)
-        self.k.conv_forward_split(self.post, rows, k2_exp, p1_exp, Xp, sidx, S, out_kind, ws)
+        rows, k2_exp = self.post.split_images()[:2]
+        ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
+        self.k.conv_forward_split(self.post, rows, k2_exp, 0, Xp, sidx, S, out_kind, ws, p1_dev_scale=ds[4:])
 
     def _grad_kernels(self, sidx, S, N, ws):
         if self.precision != "split" or os.environ.get("RBNN_CONV_BWD_EXACT") == "1":

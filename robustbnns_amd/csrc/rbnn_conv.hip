@@ -222,6 +222,7 @@ static_assert(P1SPLIT == 24576, "split image size");
 
 struct ConvSplitArgs {
     const char* K2r; int k2_exp; int p1_exp;                             // split-rows image of [S_total*Hc][25*32]
+    const rbnn_dev_scale* p1_ds;                                         // != NULL: the P1 scale lives on the device (rbnn_input_scales record [1])
     char* P1s;                                                           // [S][N][P1SPLIT]
 };
 
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256) conv1_pool_split_kernel(const ConvArgs a,
     for (int y = 0; y < 6; ++y)
 #pragma unroll
         for (int xx = 0; xx < 6; ++xx) patch[y][xx] = x[y * 28 + xx];
-    const float scale = ldexpf(1.f, sp.p1_exp);
+    const float scale = sp.p1_ds ? sp.p1_ds->scale : ldexpf(1.f, sp.p1_exp);
     const int p = py * P1PITCH + px, osw = ((p >> 2) & 1) << 1;
     char* const dst = sp.P1s + sn * P1SPLIT + (long long)p * 64;
     for (int o = 0; o < 4; ++o) {                                         // 8 channels -> one 16-byte octet of hi and of lo
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_split_kernel(const ConvArgs
     const long long sn = (long long)s * a.N + n;
     const char* const Ws = sp.K2r + (long long)sw * a.Hc * (K2 * 4);
     const int F = a.Hc * NP2;
-    const float out_scale = ldexpf(1.f, -(sp.k2_exp + sp.p1_exp));
+    const float out_scale = sp.p1_ds ? ldexpf(1.f, -sp.k2_exp) * sp.p1_ds->inv_scale : ldexpf(1.f, -(sp.k2_exp + sp.p1_exp));
 
     // both points' images -> LDS: 2 x 24 pieces of 1 KiB, linear
     for (int q = wave; q < 2 * (P1SPLIT / 1024); q += NW) {
@@ -447,7 +448,8 @@ int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ld
     return launch_status();
 }
 
-int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows, int32_t k2_exp, int32_t p1_exp, const float* X,
+int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows, int32_t k2_exp, int32_t p1_exp,
+                            const rbnn_dev_scale* p1_dev_scale, const float* X,
                             int32_t ldx, int32_t N, const int32_t* sidx, int32_t S, int32_t out_kind,
                             const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);
@@ -463,20 +465,16 @@ int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows,
     a.Hc = net->hidden; a.C = net->n_classes; a.sidx = sidx; a.S = S;
     a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind;
     ConvSplitArgs sp = {};
-    sp.K2r = (const char*)K2_rows; sp.k2_exp = k2_exp; sp.p1_exp = p1_exp; sp.P1s = (char*)ws->P1;   // ws->P1 holds 24 KiB per (s, n)
+    sp.K2r = (const char*)K2_rows; sp.k2_exp = k2_exp; sp.p1_exp = p1_exp; sp.p1_ds = p1_dev_scale; sp.P1s = (char*)ws->P1;   // ws->P1 holds 24 KiB per (s, n)
     const long long t1 = (long long)S * N * (P1W * P1W);
     const bool leaky = net->activation == RBNN_ACT_LEAKY;
     if (leaky) hipLaunchKernelGGL(conv1_pool_split_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a, sp);
     else       hipLaunchKernelGGL(conv1_pool_split_kernel<RBNN_ACT_RELU>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a, sp);
     if ((rc = launch_status())) return rc;
     constexpr int LDSB = 2 * 256 * 128 + 2 * P1SPLIT;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)conv2_pool_split_kernel<RBNN_ACT_LEAKY>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv2_pool_split_kernel<RBNN_ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess)
-            return RBNN_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static unsigned long long attr_leaky = 0, attr_relu = 0;              // one bit per device
+    if (!ensure_dynamic_lds((const void*)conv2_pool_split_kernel<RBNN_ACT_LEAKY>, LDSB, attr_leaky) ||
+        !ensure_dynamic_lds((const void*)conv2_pool_split_kernel<RBNN_ACT_RELU>, LDSB, attr_relu)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)((N + 1) / 2) * S);
     if (leaky) hipLaunchKernelGGL(conv2_pool_split_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(512), LDSB, st, a, sp);
     else       hipLaunchKernelGGL(conv2_pool_split_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(512), LDSB, st, a, sp);

@@ -542,6 +542,30 @@ __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int K, long lo
     *(f32x4*)(out + n * ldo + 4 * c4) = sum * scale;
 }
 
+// sum_slabs with the per-point norms of the result fused in: one wave per point row, lanes stride over the row's float4s,
+// slabs summed in index order (the same fixed order as sum_slabs_kernel: bit-identical `out`), then max |g| and sum g^2 over the
+// row's d < D by a fixed butterfly (deterministic).  lossGradients.py:78-127 takes these norms of every expected gradient.
+__global__ void __launch_bounds__(256) sum_slabs_norms_kernel(const float* __restrict__ slabs, int K, long long slab_stride, int N,
+                                                               int d_pad, int D, float scale, float* __restrict__ out, int ldo,
+                                                               float* __restrict__ linf, float* __restrict__ l2) {
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float m = 0.f, ss = 0.f;
+    for (int c = 4 * lane; c < d_pad; c += 256) {
+        const long long off = (long long)n * d_pad + c;
+        f32x4 sum = *(const f32x4*)(slabs + off);
+        for (int k = 1; k < K; ++k) sum += *(const f32x4*)(slabs + k * slab_stride + off);
+        sum = sum * scale;
+        *(f32x4*)(out + (long long)n * ldo + c) = sum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (c + r < D) { m = fmaxf(m, fabsf(sum[r])); ss = fmaf(sum[r], sum[r], ss); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); ss += __shfl_xor(ss, o); }
+    if (lane == 0) { linf[n] = m; l2[n] = sqrtf(ss); }
+}
+
 __global__ void pgd_alpha_kernel(const float* __restrict__ X0, int ldx, int N, int D, float* __restrict__ alpha) {
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per image
     if (n >= N) return;
@@ -932,6 +956,16 @@ int rbnn_sum_slabs(const float* slabs, int32_t K, int32_t N, int32_t d_pad, floa
     const long long total4 = (long long)N * d_pad / 4;
     hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        slabs, K, (long long)N * d_pad, total4, d_pad / 4, scale, out, ldo);
+    return launch_status();
+}
+
+int rbnn_sum_slabs_norms(const float* slabs, int32_t K, int32_t N, int32_t d_pad, int32_t D, float scale, float* out, int32_t ldo,
+                         float* linf, float* l2, void* stream) {
+    if (!slabs || !out || !linf || !l2) return RBNN_ERR_NULL;
+    if (K < 1 || N < 1 || d_pad < 4 || (d_pad & 3) || ldo < d_pad || (ldo & 3) || D < 1 || D > d_pad) return RBNN_ERR_SHAPE;
+    if (!aligned16(slabs) || !aligned16(out)) return RBNN_ERR_ALIGN;
+    hipLaunchKernelGGL(sum_slabs_norms_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       slabs, K, (long long)N * d_pad, N, d_pad, D, scale, out, ldo, linf, l2);
     return launch_status();
 }
 

@@ -19,17 +19,69 @@
 // Lane maps (v_mfma_f32_16x16x32_f16, wave64, li = lane & 15, lg = lane >> 4):
 //   A operand  a[j] = A[i = li][k = 8*lg + j]    B operand  b[j] = B[k = 8*lg + j][j' = li]    acc[r] = D[4*lg + r][li]
 #include "rbnn_common.hpp"
+#include <algorithm>
 
 
 namespace {
 
 // ===================================================================================================
+// Device-resident operand scales (rbnn_input_scales): max |X| by a grid-stride pass (wave max by DPP shuffles, one
+// atomicMax on the bit pattern per wave — non-negative floats order like unsigned ints), then one thread turns the
+// bound(s) into exponents.  No host round trip: the consumers (split_rows_kernel, the forward kernels) read the record.
+// ===================================================================================================
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ X, long long rows, int cols, int ld,
+                                                      unsigned* __restrict__ out_bits) {
+    const int c4 = cols >> 2;                                   // whole float4s per row (ld % 4 == 0 checked by the host)
+    const long long total = rows * c4;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c4;
+        const int c = (int)(i % c4) * 4;
+        const f32x4 v = *(const f32x4*)(X + r * ld + c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) m = INFINITY;    // NaN inputs: non-finite bound -> exponent 0
+    }
+    const int tail = cols & 3;
+    if (tail)
+        for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x)
+            for (int c = cols - tail; c < cols; ++c) {
+                const float v = X[r * ld + c];
+                m = (v != v) ? INFINITY : fmaxf(m, fabsf(v));
+            }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out_bits, __float_as_uint(m));
+}
+
+__device__ __forceinline__ void scale_record(rbnn_dev_scale* r, float bound) {
+    int e = 0;
+    if (bound > 0.f && bound < INFINITY) {
+        int k;
+        const float mant = frexpf(bound, &k);                   // bound = mant * 2^k, mant in [0.5, 1): ceil(log2 bound) = k, or k-1 for a power of two
+        e = 14 - (mant == 0.5f ? k - 1 : k);
+        e = max(-100, min(100, e));
+    }
+    r->absmax_bits = __float_as_uint(bound);
+    r->exp = e;
+    r->scale = ldexpf(1.f, e);
+    r->inv_scale = ldexpf(1.f, -e);
+}
+
+__global__ void scale_finalize_kernel(rbnn_dev_scale* out, float floor_abs, float mul, float add, float cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float m = fmaxf(floor_abs, __uint_as_float(out[0].absmax_bits));
+    scale_record(out, m);
+    scale_record(out + 1, fminf(cap, mul * m + add));
+}
+
+// ===================================================================================================
 // fp32 rows -> split-rows image.  One thread per (row, group of 8 columns): 32-B store.
 // ===================================================================================================
 __global__ void split_rows_kernel(const float* __restrict__ src, long long rows, int cols, int ld_src, float scale,
-                                  uint4* __restrict__ dst, int groups) {
+                                  const rbnn_dev_scale* __restrict__ ds, uint4* __restrict__ dst, int groups) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * groups) return;
+    if (ds) scale = ds->scale;
     const long long r = i / groups;
     const int g = (int)(i % groups);
     const float* const p = src + r * ld_src + 8 * g;
@@ -66,6 +118,8 @@ struct FwdSplitArgs {
     const int* sidx;  int S;  int NT;  float out_scale;        // out_scale = 2^-(e_x + e_w)
     float* P;  uint32_t* mask;  float* dact;  int out_kind;
     char* hid;  float hid_scale;                               // !LAYER2 (fc2 layer 1): activations out as a split-rows image [S][N][H], value * hid_scale = hi + lo
+    const rbnn_dev_scale* x_ds;                                // != NULL: out_scale *= x_ds->inv_scale (the X operand's scale lives on the device)
+    const rbnn_dev_scale* hid_ds;                              // != NULL: hid_scale = hid_ds->scale
 };
 
 template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
@@ -95,6 +149,8 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int wave_h = wave % WH, wave_n = wave / WH;
     const int sw = a.sidx ? a.sidx[s] : s;
+    const float out_scale = a.x_ds ? a.out_scale * a.x_ds->inv_scale : a.out_scale;
+    const float hid_scale = (!LAYER2 && a.hid_ds) ? a.hid_ds->scale : a.hid_scale;
     const char* const Ws = a.W + (long long)sw * a.w_sample_bytes;
     const char* const Xs = a.X + (long long)s * a.x_sample_bytes;
     const int n0 = ntile * BN;
@@ -202,7 +258,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int n = n0 + (wave_n * NTW + nt) * 16 + li;
-                f32x4 v = acc[ht][nt] * a.out_scale + bias, hv;
+                f32x4 v = acc[ht][nt] * out_scale + bias, hv;
                 unsigned bits = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -231,7 +287,7 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
                     union { _Float16 h[4]; unsigned long long u; unsigned w[2]; } hi, lo;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float x = hv[r] * a.hid_scale;
+                        const float x = hv[r] * hid_scale;
                         hi.h[r] = (_Float16)x;
                         lo.h[r] = (_Float16)(x - (float)hi.h[r]);
                     }
@@ -297,11 +353,8 @@ int launch_forward_split_cfg(FwdSplitArgs a, hipStream_t st) {
     constexpr int LDSB = 2 * (BH + BN) * 128;
     a.NT = (a.N + BN - 1) / BN;
     auto kern = fc_forward_split_kernel<ACT, WH, HTW, WN, NTW, LAYER2>;
-    static bool attr_done = false;                              // per instantiation; idempotent, so a race is harmless
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return RBNN_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;                    // per instantiation, one bit per device
+    if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.S);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WH * WN), LDSB, st, a);
     return launch_status();
@@ -670,11 +723,8 @@ int launch_grad_split_cfg(GradSplitArgs a, hipStream_t st) {
     a.NT = (a.N + 255) / 256;
     a.ND = (a.Dt + TD - 1) / TD;
     auto kern = fc_grad_split_kernel<ACT, TD, NTW, NW, MODE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) return RBNN_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, st, a);
     return launch_status();
@@ -714,8 +764,23 @@ int launch_grad_split_act(int act, const GradSplitArgs& a, hipStream_t st) {
 
 extern "C" {
 
-int rbnn_split_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp, void* dst,
-                    int32_t ld_dst, void* stream) {
+int rbnn_input_scales(const float* X, int64_t rows, int32_t cols, int32_t ld, float floor_abs, float mul, float add, float cap,
+                      rbnn_dev_scale* out, void* stream) {
+    if (!X || !out) return RBNN_ERR_NULL;
+    if (rows < 1 || cols < 1 || ld < cols || (ld & 3)) return RBNN_ERR_SHAPE;
+    if (!(floor_abs >= 0.f) || !(mul >= 0.f) || !(add >= 0.f) || !(cap > 0.f)) return RBNN_ERR_SHAPE;
+    if (!aligned16(X) || !aligned16(out)) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, 2 * sizeof(rbnn_dev_scale), st) != hipSuccess) return RBNN_ERR_LAUNCH;
+    const long long work = (long long)rows * ((cols + 3) / 4);
+    const unsigned grid = (unsigned)std::min<long long>(2048, (work + 255) / 256);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, X, (long long)rows, cols, ld, &out->absmax_bits);
+    hipLaunchKernelGGL(scale_finalize_kernel, dim3(1), dim3(64), 0, st, out, floor_abs, mul, add, cap);
+    return launch_status();
+}
+
+int rbnn_split_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                    const rbnn_dev_scale* dev_scale, void* dst, int32_t ld_dst, void* stream) {
     if (!src || !dst) return RBNN_ERR_NULL;
     if (rows < 1 || cols < 1 || ld_src < cols || ld_dst < cols || (ld_dst & 31)) return RBNN_ERR_SHAPE;
     if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
@@ -723,13 +788,13 @@ int rbnn_split_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_src
     const int groups = ld_dst / 8;
     const long long total = (long long)rows * groups;
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       src, (long long)rows, cols, ld_src, ldexpf(1.f, scale_exp), (uint4*)dst, groups);
+                       src, (long long)rows, cols, ld_src, ldexpf(1.f, scale_exp), dev_scale, (uint4*)dst, groups);
     return launch_status();
 }
 
 int rbnn_fc_forward_split(const rbnn_posterior* net, const rbnn_split_images* sp, const void* X_split, int32_t ldx,
-                          int32_t x_exp, int32_t N, const int32_t* sidx, int32_t S, int32_t out_kind,
-                          const rbnn_workspace* ws, void* stream) {
+                          int32_t x_exp, const rbnn_dev_scale* dev_scales, int32_t N, const int32_t* sidx, int32_t S,
+                          int32_t out_kind, const rbnn_workspace* ws, void* stream) {
     if (!net || !sp || !X_split || !ws || !ws->P || !sp->W1_rows) return RBNN_ERR_NULL;
     if (!net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
     if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
@@ -747,18 +812,19 @@ int rbnn_fc_forward_split(const rbnn_posterior* net, const rbnn_split_images* sp
     a.X = (const char*)X_split; a.ldx = ldx; a.N = N; a.x_sample_bytes = 0;
     a.W = (const char*)sp->W1_rows; a.w_sample_bytes = (long long)H * ld * 4; a.ldw = ld; a.KT = ld / 32;
     a.b = net->b1; a.W2 = net->W2; a.b2 = net->b2; a.C = net->n_classes; a.H = H;
-    a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -(x_exp + sp->w1_exp));
+    a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -((dev_scales ? 0 : x_exp) + sp->w1_exp)); a.x_ds = dev_scales;
     a.P = ws->P; a.mask = ws->mask1; a.dact = ws->dact1; a.out_kind = out_kind;
     if (!fc2) return launch_forward_split<true>(net->activation, a, st);
     // fc2: layer 1 -> hidden activations as a split-rows image in ws->hid1 (same bytes as the fp32 [S,N,H] buffer), scaled by
     // 2^h1_exp (the caller bounds |h|: max_h sum_d |W1[h,d]| * max|x| + max|b1|); layer 2 reads it per sample
-    a.hid = (char*)ws->hid1; a.hid_scale = ldexpf(1.f, sp->h1_exp);
+    a.hid = (char*)ws->hid1; a.hid_scale = ldexpf(1.f, sp->h1_exp); a.hid_ds = dev_scales ? dev_scales + 1 : nullptr;
     int rc = launch_forward_split<false>(net->activation, a, st);
     if (rc) return rc;
     FwdSplitArgs b = a;
     b.X = (const char*)ws->hid1; b.ldx = H; b.x_sample_bytes = (long long)N * H * 4;
     b.W = (const char*)sp->Wm_rows; b.w_sample_bytes = (long long)H * H * 4; b.ldw = H; b.KT = H / 32;
-    b.b = net->bm; b.out_scale = ldexpf(1.f, -(sp->h1_exp + sp->wm_exp));
+    b.b = net->bm; b.out_scale = ldexpf(1.f, -((dev_scales ? 0 : sp->h1_exp) + sp->wm_exp));
+    b.x_ds = dev_scales ? dev_scales + 1 : nullptr; b.hid_ds = nullptr;
     b.mask = ws->mask2; b.dact = ws->dact2; b.hid = nullptr;
     return launch_forward_split<true>(net->activation, b, st);
 }

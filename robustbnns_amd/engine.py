@@ -12,10 +12,10 @@ Reference loop nest (adversarialAttacks.py:118 -> :95 -> model_bnn.py:251, batch
 
 x, x0, the posterior and every intermediate stay resident in HBM for the whole attack.
 
-Precision modes of the two GEMMs (`precision=` / RBNN_PRECISION): "exact" = fp32 MFMA (rbnn_fc_forward /
-rbnn_fc_input_grad); "split" = error-compensated half pairs on the f16 MFMA pipe (rbnn_fc_forward_split /
-rbnn_fc_input_grad_split: 2^-22 per product, ~2.5x faster, same 1e-5 parity bar); "auto" (default) = split
-where the split kernels cover the posterior (fc, relu / leaky, hidden % 128 == 0, classes <= 10), else exact.
+Precision modes of the two GEMMs (`precision=` / RBNN_PRECISION): "exact" (default; "auto" resolves to it) = IEEE fp32 on
+the fp32 MFMA (rbnn_fc_forward / rbnn_fc_input_grad), the reference's arithmetic; "split" (opt-in) = error-compensated half
+pairs on the f16 MFMA pipe (rbnn_fc_forward_split / rbnn_fc_input_grad_split: 2^-22 per product, ~2.7x faster, same 1e-5
+parity bar, operands narrower than fp32); "fast" = split where the split kernels cover the posterior, else exact.
 torch supplies device memory, the current HIP stream and torch.distributed (RCCL); all arithmetic is
 in the HIP kernels behind `kernels` (robustbnns_amd._hip.HipKernels — there is no other backend in
 this package; tests inject a CPU fake to exercise the multi-process orchestration under gloo).
@@ -25,7 +25,6 @@ import os
 import torch
 
 from . import _hip
-from .posterior import scale_exp
 from ._hip import (LOSS_MEAN_LOGIT, LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_UPSTREAM, OUT_LOGITS, OUT_PROBS)
 
 _WS_DTYPE = {"mask1": torch.int32, "mask2": torch.int32}
@@ -73,18 +72,21 @@ class AttackEngine:
         self._S_total = total_samples
         self._ws_cache = {}
         self.precision = self._resolve_precision(precision)
-        self._x_bound = None                    # max |x| over an attack's iterates, set by the attack loops (saves a sync per step)
-        self._absmax_cache = (None, None, 0.0)
+        self._scales = None                     # device-resident operand scales of an attack's iterates (split mode), set by the attack loops
 
     def _resolve_precision(self, precision):
+        """exact (the default, also what "auto" resolves to): both GEMMs in IEEE fp32 on the fp32 MFMA — the reference's arithmetic.
+        split: error-compensated fp16 pairs on the f16 MFMA pipe (operands ~22-23 bits, i.e. narrower than fp32; ~2.7x faster;
+        same 1e-5 parity bar, and the same adversarial accuracy in the split-vs-exact tests) — OPT-IN, raises where the split
+        kernels do not cover the posterior.  fast: split where it applies, else exact.  RBNN_PRECISION sets the default."""
         want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
-        if want not in ("auto", "exact", "split"):
-            raise ValueError(f"precision={want!r}: expected 'auto', 'exact' or 'split'")
+        if want not in ("auto", "exact", "split", "fast"):
+            raise ValueError(f"precision={want!r}: expected 'auto', 'exact', 'split' or 'fast'")
         ok = bool(getattr(self.post, "split_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
         if want == "split" and not ok:
-            raise _hip.HipError("precision='split' covers fc posteriors with relu/leaky, hidden % 128 == 0, classes <= 10 (and the "
-                                "conv forward) on the GPU")
-        return "split" if (want != "exact" and ok) else "exact"
+            raise _hip.HipError("precision='split' covers fc / fc2 posteriors with hidden % 128 == 0 and classes <= 10, and the conv "
+                                "architecture, on the GPU")
+        return "split" if (want in ("split", "fast") and ok) else "exact"
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -168,39 +170,25 @@ class AttackEngine:
         if self.precision != "split":
             return self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
         img = self.post.split_images()
-        bound = self._x_bound if self._x_bound is not None else float(Xp.abs().max())
-        x_exp = scale_exp(bound)
-        if self.post.arch == "fc2":
-            img.h1_exp = self.post.hidden_exp(bound)
-        self.k.split_rows(Xp, self.post.D, x_exp, ws["split"]["X_split"], img.ld_rows)
-        self.k.fc_forward_split(self.post, img, ws["split"]["X_split"], img.ld_rows, x_exp, Xp.shape[0], sidx, S, out_kind, ws)
+        ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
+        self.k.split_rows(Xp, self.post.D, 0, ws["split"]["X_split"], img.ld_rows, dev_scale=ds)
+        self.k.fc_forward_split(self.post, img, ws["split"]["X_split"], img.ld_rows, 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
 
     def _grad_kernels(self, sidx, S, N, ws):
         if self.precision != "split" or (self.post.arch == "fc2" and os.environ.get("RBNN_FC2_BWD_EXACT") == "1"):
             return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
         return self.k.fc_input_grad_split(self.post, self.post.split_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
 
-    def _absmax(self, X, src=None):
-        """max |X| on the host (one device->host sync).  `src` = the caller's tensor X was padded from: when the same unmodified
-        tensor comes back (an attack repeated on the same inputs), the previous value is reused instead of syncing again."""
-        ref, ver, val = self._absmax_cache
-        if torch.is_tensor(src) and ref is not None and ref() is src and ver == (src._version, src.data_ptr()):
-            return val                          # the very same tensor object, not written to since (a recycled address cannot match)
-        m = float(X.abs().max())
-        if torch.is_tensor(src):
-            import weakref
-            self._absmax_cache = (weakref.ref(src), (src._version, src.data_ptr()), m)
-        return m
-
-    def _bound_inputs(self, X0, iterates, src=None):
-        """Magnitude bound of the inputs an attack will feed the forward (the split images' power-of-two scale), taken
-        once per attack instead of once per step: FGSM differentiates at x0 itself; every later PGD iterate is
-        clamp(., 0, 1) of something (adversarialAttacks.py:105), so |x| <= max(|x0|, 1)."""
+    def _input_scales(self, X, iterates):
+        """Split mode: the power-of-two scales of the inputs' half-pair image (and of the activations they bound: fc2 hidden
+        layer / conv1 output), computed ON THE DEVICE by rbnn_input_scales — two 16-byte records the kernels read, no
+        device->host sync.  `iterates`: later PGD iterates are clamp(., 0, 1) of something (adversarialAttacks.py:105), so
+        |x| <= max(|x0|, 1) bounds them all and one record serves the whole attack; FGSM differentiates at x0 itself."""
         if self.precision != "split":
-            self._x_bound = None
-            return
-        m = self._absmax(X0, src)
-        self._x_bound = max(1.0, m) if iterates else m
+            return None
+        mul, add, cap = self.post.scale_bounds()
+        out = torch.empty(8, dtype=torch.int32, device=self.device)
+        return self.k.input_scales(X, self.post.D, 1.0 if iterates else 0.0, mul, add, cap, out)
 
     # ------------------------------------------------------------------ forward
     def forward_padded(self, Xp, sidx, S, out_kind=OUT_PROBS, out=None):
@@ -265,20 +253,34 @@ class AttackEngine:
         n_slabs = self._grad_kernels(sidx, S, N, ws)
         return ws, n_slabs, S_tot
 
-    def gradient(self, Xp, labels, sidx, S, mode, G_up=None):
-        """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad]."""
+    def gradient(self, Xp, labels, sidx, S, mode, G_up=None, norms=None):
+        """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad].  norms = (linf [N], l2 [N]) device
+        buffers: filled with the per-point norms of that gradient in the same pass as the slab sum (rbnn_sum_slabs_norms)."""
         ws, n_slabs, S_tot = self.gradient_slabs(Xp, labels, sidx, S, mode, G_up)
         scale = 1.0 / S_tot if mode == LOSS_PER_SAMPLE else 1.0
+        N, p = Xp.shape[0], self.post
         G = ws["Gsum"] if "Gsum" in ws else ws["G"]
-        self.k.sum_slabs(ws["slabs"], n_slabs, Xp.shape[0], self.post.Dp, scale, G)
+        if norms is not None and self.world == 1:
+            self.k.sum_slabs_norms(ws["slabs"], n_slabs, N, p.Dp, p.D, scale, G, norms[0], norms[1])
+            return G
+        self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, scale, G)
         self._allreduce(G)                                      # N x D_pad fp32: the one large exchange
+        if norms is not None:                                   # sharded: the norms are those of the all-reduced gradient
+            out = torch.empty_like(G)
+            self.k.sum_slabs_norms(G, 1, N, p.Dp, p.D, 1.0, out, norms[0], norms[1])
+            return out
         return G
 
-    def loss_gradients(self, x, y, n_samples):
-        """lossGradients.loss_gradient for every row of x (lossGradients.py:20-40) -> x's shape."""
-        sidx, S = self.sample_index(n_samples)
-        G = self.gradient(self.pad_inputs(x), to_labels(y, self.device), sidx, S, LOSS_PER_SAMPLE)
-        return self.unpad(G, x)
+    def loss_gradients(self, x, y, n_samples, seeds=None, norms=False):
+        """lossGradients.loss_gradient for every row of x (lossGradients.py:20-40) -> x's shape; norms=True: also the per-point
+        Linf and L2 norms of those gradients ([N] each, device), fused into the gradient pass (lossGradients.py:91-105)."""
+        sidx, S = self.sample_index(n_samples, seeds)
+        nb = None
+        if norms:
+            nb = (torch.empty(x.shape[0], dtype=torch.float32, device=self.device),
+                  torch.empty(x.shape[0], dtype=torch.float32, device=self.device))
+        G = self.gradient(self.pad_inputs(x), to_labels(y, self.device), sidx, S, LOSS_PER_SAMPLE, norms=nb)
+        return (self.unpad(G, x), nb[0], nb[1]) if norms else self.unpad(G, x)
 
     # ------------------------------------------------------------------ attacks
     def _step(self, X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project):
@@ -338,11 +340,11 @@ class AttackEngine:
         """adversarialAttacks.fgsm_attack on every row of x (adversarialAttacks.py:69-83)."""
         sidx, S = self.sample_index(n_samples, seeds)
         X = self.pad_inputs(x, clone=True)
-        self._bound_inputs(X, iterates=False, src=x)
+        self._scales = self._input_scales(X, iterates=False)
         try:
             self._step(X, None, to_labels(y, self.device), sidx, S, mode, None, float(epsilon), 0.0, False)
         finally:
-            self._x_bound = None
+            self._scales = None
         return self.unpad(X, x)
 
     def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=LOSS_MEAN_PROB):
@@ -356,7 +358,7 @@ class AttackEngine:
         if alpha is None:
             alpha_t = torch.empty(X.shape[0], dtype=torch.float32, device=self.device)
             self.k.pgd_alpha(X0, self.post.D, alpha_t)
-        self._bound_inputs(X0, iterates=True, src=x)
+        self._scales = self._input_scales(X0, iterates=True)
         step = lambda: self._step(X, X0, labels, sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
         try:
             done = 0
@@ -376,7 +378,7 @@ class AttackEngine:
             for _ in range(iters - done):
                 step()
         finally:
-            self._x_bound = None
+            self._scales = None
         return self.unpad(X, x)
 
     graph_safe = True                       # ConvEngine (per-call point blocking) turns this off

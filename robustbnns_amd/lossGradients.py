@@ -16,8 +16,9 @@ def loss_gradient(net, image, label, n_samples=None):
     if not n_samples:
         # the reference's deterministic branch (:42-48) reads undefined names and raises NameError
         raise NameError("name 'net_copy' is not defined")
-    eng, S, _, _ = net.hot_path(n_samples)
-    return eng.loss_gradients(image.unsqueeze(0), label.unsqueeze(0), S)[0]
+    # sample i is evaluated with seeds=[i] (lossGradients.py:29-33): deterministic, and the draws for n are a prefix of those for m > n
+    eng, S, seeds, _ = net.hot_path(n_samples, seeds=list(range(n_samples)))
+    return eng.loss_gradients(image.unsqueeze(0), label.unsqueeze(0), S, seeds=seeds)[0]
 
 
 def loss_gradients(net, data_loader, device, filename, savedir, n_samples=None):
@@ -27,8 +28,8 @@ def loss_gradients(net, data_loader, device, filename, savedir, n_samples=None):
         raise NameError("name 'net_copy' is not defined")
     images = torch.cat([im for im, _ in data_loader])
     labels = torch.cat([lb for _, lb in data_loader])
-    eng, S, _, _ = net.hot_path(n_samples)
-    grads = eng.loss_gradients(images.to(device), labels, S)
+    eng, S, seeds, _ = net.hot_path(n_samples, seeds=list(range(n_samples)))       # seeds=[i] per sample, :29-33
+    grads = eng.loss_gradients(images.to(device), labels, S, seeds=seeds)
     print(f"\nmin = {grads.min():.4f} \t max = {grads.max():.4f}")
     grads = grads.cpu().detach().numpy().squeeze()
     save_loss_gradients(grads, n_samples, filename, savedir)
@@ -45,19 +46,10 @@ def load_loss_gradients(n_samples, filename, savedir, relpath=DATA):
     return load_from_pickle(path=relpath + savedir + filename + "_samp=" + str(n_samples) + "_lossGrads.pkl")
 
 
-def compute_vanishing_norms_idxs(loss_gradients, n_samples_list, norm):
-    """lossGradients.py:78-127: indices of the images whose expected-gradient norm never increases along
-    `n_samples_list`.  loss_gradients: np.ndarray [n_images, len(n_samples_list), ...] (host post-processing of the
-    pickled results; same classification rule, including the running `<=` comparison against the last accepted norm)."""
-    if loss_gradients.shape[1] != len(n_samples_list):
-        raise ValueError("Second dimension should equal the length of `n_samples_list`")
-    flat = np.asarray(loss_gradients).reshape(loss_gradients.shape[0], loss_gradients.shape[1], -1)
-    if norm == "linfty":
-        norms = np.abs(flat).max(axis=-1)
-    elif norm == "l2":
-        norms = np.stack([[np.linalg.norm(flat[i, j]) for j in range(flat.shape[1])] for i in range(flat.shape[0])])
-    else:
-        raise UnboundLocalError("local variable 'gradient_norm' referenced before assignment")
+def _vanishing_rule(norms):
+    """The classification of lossGradients.py:89-121 on a table norms[image, j] (j along n_samples_list): an image is
+    `vanishing` when its first norm is non-zero and every norm is <= the last ACCEPTED one (a running comparison, not a
+    comparison of neighbours); `null` when the first norm is exactly 0; `increasing` otherwise."""
     vanishing, count_incr, count_null = [], 0, 0
     for image_idx in range(norms.shape[0]):
         gradient_norm = norms[image_idx, 0]
@@ -79,3 +71,42 @@ def compute_vanishing_norms_idxs(loss_gradients, n_samples_list, norm):
     print(f"null gradients = {count_null/n} %")
     print("\nvanishing_gradients_idxs = ", vanishing)
     return vanishing
+
+
+def compute_vanishing_norms_idxs(loss_gradients, n_samples_list, norm):
+    """lossGradients.py:78-127: indices of the images whose expected-gradient norm never increases along
+    `n_samples_list`.  loss_gradients: np.ndarray [n_images, len(n_samples_list), ...] — host post-processing of pickled
+    results; `expected_gradient_norms` + `_vanishing_rule` is the same computation with the norms taken on the GPU."""
+    if loss_gradients.shape[1] != len(n_samples_list):
+        raise ValueError("Second dimension should equal the length of `n_samples_list`")
+    flat = np.asarray(loss_gradients).reshape(loss_gradients.shape[0], loss_gradients.shape[1], -1)
+    if norm == "linfty":
+        norms = np.abs(flat).max(axis=-1)
+    elif norm == "l2":
+        norms = np.stack([[np.linalg.norm(flat[i, j]) for j in range(flat.shape[1])] for i in range(flat.shape[0])])
+    else:
+        raise UnboundLocalError("local variable 'gradient_norm' referenced before assignment")
+    return _vanishing_rule(norms)
+
+
+def expected_gradient_norms(net, images, labels, n_samples_list, norm, device=None):
+    """norms[image, j] of the expected loss gradient at n_samples_list[j] samples, taken INSIDE the gradient pass on the GPU
+    (rbnn_sum_slabs_norms) — what compute_vanishing_norms_idxs derives from the stored gradients (lossGradients.py:91-105),
+    without the [N, len(list), D] gradients ever leaving the device.  Returns (norms np.ndarray [N, len(list)] fp32,
+    gradients list of device tensors).  Sample i is seeds=[i] as in loss_gradient, so the draws nest along the list."""
+    if norm not in ("linfty", "l2"):
+        raise UnboundLocalError("local variable 'gradient_norm' referenced before assignment")
+    device = net.device if device is None else device
+    cols, grads = [], []
+    for n_samples in n_samples_list:
+        eng, S, seeds, _ = net.hot_path(n_samples, seeds=list(range(n_samples)))
+        g, linf, l2 = eng.loss_gradients(images.to(device), labels, S, seeds=seeds, norms=True)
+        cols.append(linf if norm == "linfty" else l2)
+        grads.append(g)
+    return torch.stack(cols, dim=1).cpu().numpy(), grads
+
+
+def vanishing_gradients_idxs(net, images, labels, n_samples_list, norm, device=None):
+    """compute_vanishing_norms_idxs over a freshly computed grid, as one resident GPU job (no pickles, no host norms)."""
+    norms, _ = expected_gradient_norms(net, images, labels, n_samples_list, norm, device)
+    return _vanishing_rule(norms)

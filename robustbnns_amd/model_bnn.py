@@ -41,6 +41,41 @@ def set_rng_seed(seed):
     np.random.seed(seed)
 
 
+def param_store_state(loc, scale):
+    """The dict pyro 1.3.0's ParamStoreDict.save() pickles (pyro/params/param_store.py get_state(), [recalled]; the reference
+    writes it at model_bnn.py:148-155): {"params": {name: UNCONSTRAINED value, a leaf tensor with requires_grad},
+    "constraints": {name: torch.distributions constraint}}.  The guide's params `<key>_loc` / `<key>_scale` (:125-126) are
+    registered without a constraint, i.e. constraints.real, for which unconstrained == constrained."""
+    from torch.distributions import constraints
+    params = {}
+    for k, v in loc.items():
+        params[k + "_loc"] = v.detach().cpu().clone().requires_grad_(True)
+    for k, v in scale.items():
+        params[k + "_scale"] = v.detach().cpu().clone().requires_grad_(True)
+    return {"params": params, "constraints": {name: constraints.real for name in params}}
+
+
+def read_param_store(path):
+    """name -> CONSTRAINED fp32 tensor from a pyro param-store file (what pyro.get_param_store().load() + iteration yields,
+    model_bnn.py:177-181).  Unconstrained values go through transform_to(constraint), the identity for constraints.real.
+    Also accepts a bare {name: tensor} dict.  weights_only=False: the file pickles constraint objects."""
+    from torch.distributions import constraints, transform_to
+    store = torch.load(path, map_location="cpu", weights_only=False)
+    if not isinstance(store, dict):
+        raise TypeError(f"{path}: malformed ParamStore state ({type(store).__name__})")
+    if "params" not in store:
+        return {k: v.detach().to(torch.float32) for k, v in store.items()}
+    if set(store.keys()) != {"params", "constraints"}:
+        raise KeyError(f"{path}: malformed ParamStore keys {sorted(store.keys())}")
+    out = {}
+    for name, value in store["params"].items():
+        c = store["constraints"].get(name, constraints.real)
+        c = constraints.real if isinstance(c, type(constraints.real)) else c       # pyro's own unpickling workaround
+        value = value.detach()
+        out[name] = (value if c is constraints.real else transform_to(c)(value)).to(torch.float32)
+    return out
+
+
 class BNN(nn.Module):
 
     def __init__(self, dataset_name, hidden_size, activation, architecture, inference, epochs, lr, n_samples, warmup,
@@ -126,8 +161,7 @@ class BNN(nn.Module):
             for key, value in self.posterior_predictive.items():
                 torch.save(value.state_dict(), path + filename + "_" + str(key) + ".pt")
         else:
-            torch.save({"params": {**{k + "_loc": v.cpu() for k, v in self.svi_loc.items()},
-                                   **{k + "_scale": v.cpu() for k, v in self.svi_scale.items()}}}, path + filename + ".pt")
+            torch.save(param_store_state(self.svi_loc, self.svi_scale), path + filename + ".pt")
 
     def load(self, device, rel_path=TESTS, filename=None):
         """model_bnn.py:167-196"""
@@ -135,9 +169,12 @@ class BNN(nn.Module):
             filename = self.name + "_weights"
         path = rel_path + self.name + "/"
         if self.inference == "svi":
-            store = torch.load(path + filename + ".pt", map_location="cpu", weights_only=False)
-            params = store["params"] if "params" in store else store
+            params = read_param_store(path + filename + ".pt")
             keys = list(self.basenet.state_dict().keys())
+            missing = [k + sfx for k in keys for sfx in ("_loc", "_scale") if k + sfx not in params]
+            if missing:
+                raise KeyError(f"param store {path + filename}.pt lacks {missing[:4]}{'...' if len(missing) > 4 else ''} "
+                               f"(has {sorted(params)[:4]}...): not written by this architecture's guide (model_bnn.py:124-126)")
             self.set_variational_params({k: params[k + "_loc"] for k in keys}, {k: params[k + "_scale"] for k in keys}, device)
             print("\nLoading ", path + filename + ".pt\n")
         elif self.inference == "hmc":

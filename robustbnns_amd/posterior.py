@@ -112,28 +112,26 @@ class StackedPosterior:
             self._split = (img, keep)                            # the tensors keep the device memory alive
         return self._split[0]
 
-    def hidden_exp(self, x_max):
-        """Exponent of the fc2 hidden-activation image for inputs bounded by x_max (relu / leaky: |act(a)| <= |a|; sigmoid <= 1;
-        |tanh(a)| <= min(|a|, 1))."""
+    def scale_bounds(self):
+        """(mul, add, cap) of rbnn_input_scales' record 1 — the bound of the fc2 hidden-activation image given max|x|:
+        |h1| <= min(cap, mul * max|x| + add) with mul = max_h sum_d |W1[h,d]|, add = max|b1| (relu / leaky: |act(a)| <= |a|;
+        |tanh(a)| <= min(|a|, 1); sigmoid <= 1).  fc has no such operand: the record is unused."""
+        if self.arch != "fc2":
+            return 0.0, 0.0, math.inf
+        self.split_images()
         w_l1, b_max = self._h1_bound
-        bound = w_l1 * x_max + b_max
         if self.activation == "sigm":
-            bound = 1.0
-        elif self.activation == "tanh":
-            bound = min(bound, 1.0)
-        return scale_exp(bound)
+            return 0.0, 1.0, 1.0
+        return w_l1, b_max, (1.0 if self.activation == "tanh" else math.inf)
 
     def _pack(self):
-        """rbnn_pack_rows4 images [S, H/4, cols, 4] of W1 (and Wm): the backward GEMM's B-operand layout."""
+        """rbnn_pack_rows4 images [S, H/4, cols, 4] of W1 (and Wm): the backward GEMM's B-operand layout.  Built by the HIP
+        kernel; a posterior that is not on the GPU has no images (nothing could read them: there is no CPU compute path)."""
         def pack(W):
-            if W is None:
+            if W is None or W.device.type != "cuda":
                 return None
             out = torch.empty_like(W)
-            if W.device.type == "cuda":
-                _hip.HipKernels().pack_rows4(W, out)
-            else:       # layout-only transform for the CPU-side tests (no arithmetic): same image via a permute
-                S, H, cols = W.shape
-                out.copy_(W.view(S, H // 4, 4, cols).permute(0, 1, 3, 2).reshape(S, H, cols))
+            _hip.HipKernels().pack_rows4(W, out)
             return out
         self.W1p, self.Wmp = pack(self.W1), pack(self.Wm)
 
@@ -159,7 +157,7 @@ class StackedPosterior:
             for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
                 t = getattr(self, name)
                 setattr(d, name, None if t is None else C.c_void_p(t.data_ptr()))
-            d.W1_pack4 = C.c_void_p(self.W1p.data_ptr())
+            d.W1_pack4 = None if self.W1p is None else C.c_void_p(self.W1p.data_ptr())
             d.Wm_pack4 = None if self.Wmp is None else C.c_void_p(self.Wmp.data_ptr())
             self._desc = d
         return self._desc

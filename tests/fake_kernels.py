@@ -67,6 +67,11 @@ class FakeKernels:
     def sum_slabs(self, slabs, K, N, Dp, scale, out):
         out[:, :Dp] = slabs.view(-1)[:K * N * Dp].view(K, N, Dp).sum(0) * scale
 
+    def sum_slabs_norms(self, slabs, K, N, Dp, D, scale, out, linf, l2):
+        self.sum_slabs(slabs, K, N, Dp, scale, out)
+        linf.copy_(out[:, :D].abs().max(1)[0])
+        l2.copy_(out[:, :D].norm(dim=1))
+
     def pgd_alpha(self, X0, D, alpha):
         alpha.copy_(2 / X0[:, :D].max(dim=1)[0])
 

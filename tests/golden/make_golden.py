@@ -194,6 +194,13 @@ def run_case(name, *, dataset, shape, n_classes, hidden, act, arch, S, N, std, s
     out["eval_orig_acc"] = np.float64(oa)
     out["eval_adv_acc"] = np.float64(aa)
     out["eval_softmax_rob"] = rob.numpy()
+    # ... and of the PGD images (the points pgd_idx): the triple a HIP attack -> HIP evaluation run must reproduce
+    pg = torch.from_numpy(out["pgd"])
+    oa, aa, rob = adversarialAttacks.attack_evaluation(net=bnn, x_test=x[pidx], x_attack=pg, y_test=y[pidx],
+                                                       device="cpu", n_samples=S)
+    out["eval_pgd_orig_acc"] = np.float64(oa)
+    out["eval_pgd_adv_acc"] = np.float64(aa)
+    out["eval_pgd_softmax_rob"] = rob.numpy()
 
     if with_attack_fn:
         # the full attack()/loss_gradients() drivers incl. their file side effects
@@ -279,6 +286,11 @@ def run_det_and_ensemble(name, *, shape, n_classes, hidden, act, arch, M, N, std
                                                        device="cpu", n_samples=M)
     out["ens_eval_orig_acc"], out["ens_eval_adv_acc"] = np.float64(oa), np.float64(aa)
     out["ens_eval_softmax_rob"] = rob.numpy()
+    for tag, net, ns in (("nn0", nets[0], None), ("ens", ens, M)):          # the PGD images' evaluation triples
+        pg = torch.from_numpy(out[tag + "_pgd"])
+        oa, aa, rob = adversarialAttacks.attack_evaluation(net=net, x_test=x, x_attack=pg, y_test=y, device="cpu", n_samples=ns)
+        out[tag + "_eval_pgd_orig_acc"], out[tag + "_eval_pgd_adv_acc"] = np.float64(oa), np.float64(aa)
+        out[tag + "_eval_pgd_softmax_rob"] = rob.numpy()
     out["meta"] = np.array(repr(meta))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -350,6 +362,8 @@ def main():
     if only == "eps":
         run_eps_grid("halfmoons_eps_grid_fgsm", S=6, N=30, std=0.5, seed=12, epsilon_list=[0.1, 0.3],
                      n_samples_list=[1, 3, 6], method="fgsm")
+        run_eps_grid("halfmoons_eps_grid_pgd", S=6, N=12, std=0.5, seed=13, epsilon_list=[0.1, 0.25],
+                     n_samples_list=[2, 6], method="pgd")
         return
     mn = (1, 28, 28)
     hm = (1, 2, 1)
@@ -379,9 +393,16 @@ def main():
     # (5) conv on 1x28x28 (the only input size the reference's conv head is correct for)
     run_case("mnist_conv_h16_s2_n4_leaky", dataset="mnist", shape=mn, n_classes=10, hidden=16,
              act="leaky", arch="conv", S=2, N=4, std=0.05, seed=10, pgd_points=2)
+    # (5b) conv with the two smooth activations the reference also allows (model_nn.py:66-75)
+    run_case("mnist_conv_h16_s2_n4_sigm", dataset="mnist", shape=mn, n_classes=10, hidden=16,
+             act="sigm", arch="conv", S=2, N=4, std=0.05, seed=14, pgd_points=1)
+    run_case("mnist_conv_h16_s2_n4_tanh", dataset="mnist", shape=mn, n_classes=10, hidden=16,
+             act="tanh", arch="conv", S=2, N=4, std=0.05, seed=15, pgd_points=1)
     # (7) the eps x n_samples grid driver
     run_eps_grid("halfmoons_eps_grid_fgsm", S=6, N=30, std=0.5, seed=12, epsilon_list=[0.1, 0.3],
                  n_samples_list=[1, 3, 6], method="fgsm")
+    run_eps_grid("halfmoons_eps_grid_pgd", S=6, N=12, std=0.5, seed=13, epsilon_list=[0.1, 0.25],
+                 n_samples_list=[2, 6], method="pgd")
     # (8) vanishing-gradient classification (host post-processing)
     run_vanishing_norms("vanishing_norms")
     # (6) deterministic NN + Ensemble_NN (mean of logits)

@@ -11,6 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+pytestmark = pytest.mark.usefixtures("built_library")       # the workers' test double takes its workspace sizes from the library
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 

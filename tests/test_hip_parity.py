@@ -3,7 +3,7 @@
   (2) the fp64 oracle on seeded inputs at sizes it finishes in seconds (ragged N, every H config),
   (3) size-independent properties at BASELINE.json's full size (N=10 000, S=100).
 Tolerance: 1e-5 relative to each point's largest component (north star).  Both precision modes of the two GEMMs
-are held to it: "exact" (fp32 MFMA) and "split" (error-compensated half pairs on the f16 MFMA pipe, what "auto"
+are held to it: "exact" (fp32 MFMA) and "split" (error-compensated half pairs on the f16 MFMA pipe, what "fast"
 picks for fc / relu|leaky / hidden % 128 == 0 / classes <= 10) — every case the split kernels cover runs in both.
 Adversarial images: equal except where |g| < tau * max|g| (a sign flip there is within fp32 noise)."""
 import os
@@ -15,7 +15,7 @@ import torch
 from conftest import rel_err
 from oracle import bnn_oracle as O
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
 TOL = 1e-5
 TAU = 1e-3
 KINK = 2e-6      # points with a hidden pre-activation this close to 0 are excluded: act' jumps there (oracle.kink_margin)
@@ -42,10 +42,10 @@ def exact_covers(H):
 
 
 def modes_for(arch, act, H, C):
-    return ["auto", "exact"] if split_covers(arch, act, H, C) and exact_covers(H) else ["auto"]
+    return ["fast", "exact"] if split_covers(arch, act, H, C) and exact_covers(H) else ["fast"]
 
 
-GOLDEN_MODES = [(n, m) for n in FC_CASES for m in (["auto", "exact"] if "_fc_h512_" in n else ["auto"])]
+GOLDEN_MODES = [(n, m) for n in FC_CASES for m in (["fast", "exact"] if "_fc_h512_" in n else ["fast"])]
 
 
 def make_bnn(g):
@@ -69,7 +69,7 @@ def test_golden_forward_and_gradients(golden, name, precision, monkeypatch):
     from robustbnns_amd import lossGradients
     monkeypatch.setenv("RBNN_PRECISION", precision)
     g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
-    assert bnn._engine.precision == ("split" if precision == "auto" and "_fc_h512_" in name else "exact")
+    assert bnn._engine.precision == ("split" if precision == "fast" and "_fc_h512_" in name else "exact")
     assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
     seeds = [int(s) for s in g.arr["forward_seeds"]]
     assert rel_err(bnn.forward(x.to(DEV), n_samples=len(seeds), seeds=seeds).cpu(), g.t("forward_probs_seeds")) < TOL
@@ -267,7 +267,7 @@ def test_against_fp64_oracle(arch, act, shape, C, H, S, N, std, precision):
     lab = y.argmax(-1)
     p64 = O.cast(post, torch.float64)
     eng = AttackEngine(StackedPosterior(arch, act, shape, C, H, post, DEV), precision=precision)
-    assert eng.precision == ("split" if precision == "auto" and split_covers(arch, act, H, C) else "exact")
+    assert eng.precision == ("split" if precision == "fast" and split_covers(arch, act, H, C) else "exact")
     assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, arch, act, S)) < TOL
     assert rel_err(eng.forward(x, S, logits=True).cpu(), O.ensemble_forward(x.double(), p64, arch, act, S)) < TOL
     ok = O.kink_margin(x.double(), p64, arch, act, S) > KINK                  # gradients: away from activation kinks
@@ -433,7 +433,7 @@ def test_upstream_gradient_mode_matches_autograd():
 
 
 # ------------------------------------------------------------------ (3) properties at BASELINE.json's full size
-@pytest.fixture(scope="module", params=["auto", "exact"])
+@pytest.fixture(scope="module", params=["fast", "exact"])
 def full_size(request):
     from robustbnns_amd import AttackEngine, StackedPosterior
     D, H, C, S, N = 784, 512, 10, 100, 10000
@@ -442,7 +442,7 @@ def full_size(request):
             "model.3.weight": torch.randn(S, C, H, generator=g) * 0.05, "model.3.bias": torch.randn(S, C, generator=g) * 0.05}
     x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=11)
     eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision=request.param)
-    assert eng.precision == ("split" if request.param == "auto" else "exact")
+    assert eng.precision == ("split" if request.param == "fast" else "exact")
     return eng, post, x, y
 
 
@@ -555,7 +555,7 @@ def test_conv_golden(golden):
     assert all(torch.equal(sd[k], g.posterior()[k][1]) for k in sd)
 
 
-@pytest.mark.parametrize("precision", ["auto", "exact"])
+@pytest.mark.parametrize("precision", ["fast", "exact"])
 @pytest.mark.parametrize("act,C,Hc,S,N", [("leaky", 10, 16, 2, 5), ("relu", 10, 32, 2, 19), ("leaky", 10, 64, 3, 33),
                                           ("leaky", 10, 512, 2, 12), ("leaky", 3, 272, 1, 5), ("leaky", 10, 1024, 1, 40)])
 def test_conv_against_fp64_oracle(act, C, Hc, S, N, precision):
@@ -565,7 +565,7 @@ def test_conv_against_fp64_oracle(act, C, Hc, S, N, precision):
     x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=Hc + N)
     lab = y.argmax(-1); p64 = O.cast(post, torch.float64)
     eng = ConvEngine(ConvStackedPosterior(act, (1, 28, 28), C, Hc, post, DEV), precision=precision)
-    assert eng.precision == ("split" if precision == "auto" else "exact")       # split: conv2 forward on the f16 pipe (hi/lo pairs)
+    assert eng.precision == ("split" if precision == "fast" else "exact")       # split: conv2 forward on the f16 pipe (hi/lo pairs)
     assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, "conv", act, S)) < TOL
     assert rel_err(eng.forward(x, S, logits=True).cpu(), O.ensemble_forward(x.double(), p64, "conv", act, S)) < TOL
     ok = O.kink_margin(x.double(), p64, "conv", act, S) > KINK_CONV

@@ -1,0 +1,412 @@
+"""GPU parity tests, round 2 (-m gpu): the configurations and end-to-end chains round 1 left unexercised on hardware.
+
+  C3 at full size   S=500, N=10 000, PGD T=40: eps-ball / range / bit-determinism, iteration-1 gradient vs the fp64 oracle
+  C4's share        S=250 of 2000, N=10 000: loss_gradients + FGSM vs the fp64 oracle on rows across every 256-point tile edge
+  split vs exact    adversarial accuracy identical, softmax robustness within 1e-5, differing non-marginal pixels counted
+  end to end        HIP attack() -> HIP attack_evaluation() for every golden case, FGSM and PGD: the reference's triple
+  drivers           build_eps_attacks_df (FGSM and PGD grids) on the HIP path against the reference's rows and CSV
+  norms             per-point Linf / L2 norms fused into the slab sum; the vanishing-gradient rule fed from them
+  SVI               seeded loss_gradients are reproducible and nested along n_samples; the Pyro param-store loader
+Everything goes through the C-ABI (robustbnns_amd._hip); the oracle is the checker only.
+"""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import bnn_oracle as O
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
+TOL, TAU, KINK, DEV = 1e-5, 1e-3, 2e-6, "cuda:0"
+D, H, C = 784, 512, 10
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from robustbnns_amd import _hip
+    _hip.load()
+
+
+def big_posterior(S, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {"model.1.weight": torch.randn(S, H, D, generator=g) * 0.05, "model.1.bias": torch.randn(S, H, generator=g) * 0.05,
+            "model.3.weight": torch.randn(S, C, H, generator=g) * 0.05, "model.3.bias": torch.randn(S, C, generator=g) * 0.05}
+
+
+def oracle_gradients_fp64(x, lab, post, S, mode, chunk=50):
+    """fp64 expected input gradient of the fc net for the rows x, samples streamed in chunks (S=500 x 256 rows would not fit
+    otherwise): pass 1 = mean probabilities, pass 2 = the closed-form backward (oracle helpers).
+    Returns (gradient [n, D], smallest |pre-activation| per row)."""
+    xf = x.reshape(len(x), -1).double()
+    sel = lambda lo, hi: {k: v[lo:hi].double() for k, v in post.items()}
+    pbar = torch.zeros(len(x), C, dtype=torch.float64)
+    for lo in range(0, S, chunk):
+        z, _ = O._mlp_forward_cache(xf, O.mlp_layers(sel(lo, min(S, lo + chunk)), "fc"), "leaky")
+        pbar += torch.softmax(z, -1).sum(0)
+    pbar /= S
+    G = torch.zeros(len(x), D, dtype=torch.float64)
+    margin = torch.full((len(x),), float("inf"), dtype=torch.float64)
+    onehot = torch.nn.functional.one_hot(lab, C).double()
+    for lo in range(0, S, chunk):
+        layers = O.mlp_layers(sel(lo, min(S, lo + chunk)), "fc")
+        z, pre = O._mlp_forward_cache(xf, layers, "leaky")
+        p = torch.softmax(z, -1)
+        if mode == "mean_prob":
+            g = ((torch.softmax(pbar, -1) - onehot) / S).unsqueeze(0)
+        else:
+            g = (torch.softmax(p, -1) - onehot.unsqueeze(0)) / S
+        dz = p * (g - (g * p).sum(-1, keepdim=True))
+        G += O._mlp_input_grad(dz, layers, pre, "leaky").sum(0)
+        margin = torch.minimum(margin, pre[0].abs().amin(dim=(0, 2)))
+    return G, margin
+
+
+EDGE_ROWS = torch.cat([torch.arange(0, 64), torch.arange(224, 288), torch.arange(4960, 5024), torch.arange(5100, 5132),
+                       torch.arange(9936, 10000)])          # 288 rows on both sides of 256-point tile edges, start, middle and ragged end
+
+
+# ------------------------------------------------------------------ C3 at full size
+@pytest.fixture(scope="module")
+def c3():
+    S, N = 500, 10000
+    post = big_posterior(S, seed=21)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=22)
+    from robustbnns_amd import StackedPosterior
+    return StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), post, x, y
+
+
+@pytest.mark.parametrize("precision", ["exact", "split"])
+def test_c3_full_size_pgd(c3, precision):
+    from robustbnns_amd import AttackEngine, _hip
+    sp, post, x, y = c3
+    S, N, eps = 500, 10000, 0.3
+    eng = AttackEngine(sp, precision=precision)
+    lab = y.argmax(-1)
+    # iteration-1 gradient (the clean images) against the fp64 oracle on 288 rows
+    G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu()
+    ref, margin = oracle_gradients_fp64(x[EDGE_ROWS], lab[EDGE_ROWS], post, S, "mean_prob")
+    ok = margin > KINK
+    assert int(ok.sum()) >= len(EDGE_ROWS) - 8
+    assert rel_err(G[EDGE_ROWS][ok], ref[ok]) < TOL
+    # the whole attack: 40 iterations over 10 000 points x 500 samples
+    adv = eng.pgd(x, y, S, eps, alpha=None, iters=40)
+    assert adv.shape == x.shape
+    a = adv.cpu()
+    assert float((a - x).abs().max()) <= eps + 1e-6 and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    # alpha = 2/max(x) > eps: after iteration 1 every pixel with a non-marginal gradient sits on the eps-ball or a clamp
+    step1 = torch.clamp(x.reshape(N, -1)[EDGE_ROWS] + eps * ref.sign().float(), 0, 1)
+    it1 = eng.pgd(x[EDGE_ROWS], y[EDGE_ROWS], S, eps, alpha=None, iters=1).cpu().reshape(len(EDGE_ROWS), -1)
+    safe = (ref.abs() > TAU * ref.abs().max(1, keepdim=True)[0]) & ok[:, None]
+    assert int((((it1 - step1).abs() > 1e-6) & safe).sum()) == 0
+    # bit-determinism of the full attack
+    assert torch.equal(eng.pgd(x, y, S, eps, alpha=None, iters=40), adv)
+
+
+# ------------------------------------------------------------------ C4's per-GPU share
+@pytest.mark.parametrize("precision", ["exact", "split"])
+def test_c4_share_loss_gradients_and_fgsm(precision):
+    """BASELINE.json configs[3]: S=2000 sharded 8-way = 250 samples on this GPU, N=10 000: expected loss gradients (per-sample
+    loss) and FGSM (mean-probability loss) against the fp64 oracle on 288 rows; fused norms against host norms."""
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    S, N = 250, 10000
+    post = big_posterior(S, seed=31)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=32)
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), precision=precision)
+    lab = y.argmax(-1)
+    lg, linf, l2 = eng.loss_gradients(x, y, S, norms=True)
+    lg = lg.cpu().reshape(N, -1)
+    ref, margin = oracle_gradients_fp64(x[EDGE_ROWS], lab[EDGE_ROWS], post, S, "per_sample")
+    ok = margin > KINK
+    assert int(ok.sum()) >= len(EDGE_ROWS) - 8
+    assert rel_err(lg[EDGE_ROWS][ok], ref[ok]) < TOL
+    assert torch.equal(linf.cpu(), lg.abs().max(1)[0])                                   # Linf: exact
+    assert float(((l2.cpu().double() - lg.double().norm(dim=1)).abs() / lg.double().norm(dim=1)).max()) < 1e-6
+    adv = eng.fgsm(x, y, S, 0.3).cpu().reshape(N, -1)
+    gm, margin = oracle_gradients_fp64(x[EDGE_ROWS], lab[EDGE_ROWS], post, S, "mean_prob")
+    ok = margin > KINK
+    expect = torch.clamp(x.reshape(N, -1)[EDGE_ROWS] + 0.3 * gm.sign().float(), 0, 1)
+    safe = (gm.abs() > TAU * gm.abs().max(1, keepdim=True)[0]) & ok[:, None]
+    assert int((((adv[EDGE_ROWS] - expect).abs() > 1e-6) & safe).sum()) == 0
+    from robustbnns_amd import _hip
+    G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu()
+    assert float((adv - torch.clamp(x.reshape(N, -1) + 0.3 * G.sign(), 0, 1)).abs().max()) == 0.0     # exactly x +- eps (or x), clamped
+
+
+# ------------------------------------------------------------------ split vs exact
+@pytest.mark.parametrize("S,N,method", [(100, 10000, "fgsm"), (500, 10000, "pgd")])
+def test_split_vs_exact_accuracy_and_robustness(S, N, method):
+    """The opt-in split mode against the IEEE-fp32 kernels on the same posterior and inputs (C2: FGSM, C3: PGD T=40): the
+    adversarial accuracy must be IDENTICAL, the per-point softmax robustness within 1e-5, and the adversarial images may
+    differ only where the gradient component is within noise of zero (counted and bounded)."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    post = big_posterior(S, seed=41 + S)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=42)
+    sp = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV)
+    res = {}
+    for precision in ("exact", "split"):
+        eng = AttackEngine(sp, precision=precision)
+        adv = eng.fgsm(x, y, S, 0.3) if method == "fgsm" else eng.pgd(x, y, S, 0.3, alpha=None, iters=40)
+        res[precision] = (adv, eng)
+    exact_eng = res["exact"][1]
+    G = exact_eng.gradient(exact_eng.pad_inputs(x), y.argmax(-1).int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu()
+    a_e, a_s = res["exact"][0].cpu().reshape(N, -1), res["split"][0].cpu().reshape(N, -1)
+    diff = (a_e - a_s).abs() > 1e-6
+    if method == "fgsm":                                       # one step from the same point: only marginal components may differ
+        safe = G.abs() > TAU * G.abs().max(1, keepdim=True)[0]
+        assert int((diff & safe).sum()) == 0
+    frac = float(diff.double().mean())
+    print(f"[split vs exact] {method} S={S}: {int(diff.sum())} of {diff.numel()} pixels differ ({frac:.2e})")
+    assert frac < (1e-4 if method == "fgsm" else 2e-2)
+    # each mode evaluates its own adversarial set with its own kernels; and crosswise (exact evaluation of the split images)
+    oa_e, aa_e, rob_e, _, _ = res["exact"][1].evaluate(x, res["exact"][0], y, S)
+    oa_s, aa_s, rob_s, _, _ = res["split"][1].evaluate(x, res["split"][0], y, S)
+    oa_x, aa_x, rob_x, _, _ = res["exact"][1].evaluate(x, res["split"][0], y, S)
+    assert oa_e == oa_s == oa_x
+    assert aa_e == aa_s == aa_x, (aa_e, aa_s, aa_x)
+    assert float((rob_e - rob_s).abs().max()) < 1e-5 and float((rob_e - rob_x).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------ end to end: HIP attack -> HIP evaluation, golden triples
+E2E_CASES = ["halfmoons_fc_h64_s10_n100", "mnist_fc_h32_s8_n8_leaky", "mnist_fc_h32_s8_n8_relu", "mnist_fc_h16_s4_n6_sigm",
+             "mnist_fc_h16_s4_n6_tanh", "mnist_fc_h512_s8_n8_leaky", "mnist_fc_h512_s8_n8_relu", "mnist_fc2_h32_s4_n6_leaky",
+             "halfmoons_fc2_h32_s6_n40", "mnist_conv_h16_s2_n4_leaky"]
+
+
+def _bnn(g):
+    from robustbnns_amd.model_bnn import BNN
+    m = g.meta
+    bnn = BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], 0, tuple(m["shape"]), m["n_classes"])
+    bnn.set_posterior_samples(g.posterior(), DEV)
+    return bnn
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("name", E2E_CASES)
+def test_end_to_end_attack_then_evaluation(golden, name, precision, monkeypatch):
+    """adversarialAttacks.py:111-143 then :151-198 entirely on the HIP path: attack() produces the images, attack_evaluation()
+    scores THOSE images; (orig_acc, adv_acc) must equal the reference's and softmax_rob agree within 1e-5 — FGSM and PGD."""
+    from robustbnns_amd import adversarialAttacks as A
+    monkeypatch.setenv("RBNN_PRECISION", precision)
+    g = golden(name); m = g.meta; bnn = _bnn(g); x, y = g.t("x"), g.t("y")
+    hyper = {"epsilon": m["eps"]}
+    adv = A.attack(net=bnn, x_test=x, y_test=y, dataset_name=m["dataset"], device=DEV, method="fgsm", filename=bnn.name,
+                   hyperparams=hyper, n_samples=m["S"])
+    oa, aa, rob = A.attack_evaluation(net=bnn, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=m["S"])
+    assert (oa, aa) == (float(g.arr["eval_orig_acc"]), float(g.arr["eval_adv_acc"]))
+    assert float((rob.cpu() - g.t("eval_softmax_rob")).abs().max()) < 1e-5
+    idx = torch.from_numpy(g.arr["pgd_idx"])
+    adv = A.attack(net=bnn, x_test=x[idx], y_test=y[idx], dataset_name=m["dataset"], device=DEV, method="pgd", filename=bnn.name,
+                   hyperparams=hyper, n_samples=m["S"])
+    oa, aa, rob = A.attack_evaluation(net=bnn, x_test=x[idx], x_attack=adv, y_test=y[idx], device=DEV, n_samples=m["S"])
+    assert (oa, aa) == (float(g.arr["eval_pgd_orig_acc"]), float(g.arr["eval_pgd_adv_acc"]))
+    err = (rob.cpu() - g.t("eval_pgd_softmax_rob")).abs()
+    # PGD compounds 40 sign decisions: a pixel whose gradient component is within fp32 noise of zero at some iterate may end
+    # elsewhere in the eps-ball (tests/test_oracle_golden.py holds the oracle to the same rule); the robustness of every point
+    # must still agree to 1e-5 unless its PGD image differs from the reference's in such pixels, and then to 1e-3
+    same = ((adv.cpu() - g.t("pgd")).abs().reshape(len(idx), -1) > 1e-6).sum(1) == 0
+    assert float(err[same].max() if same.any() else 0.0) < 1e-5
+    assert float(err.max()) < 1e-3, (int((~same).sum()), float(err.max()))
+
+
+def test_end_to_end_deterministic_and_ensemble(golden):
+    from robustbnns_amd import adversarialAttacks as A
+    from robustbnns_amd.model_ensemble import Ensemble_NN
+    from robustbnns_amd.model_nn import NN
+    g = golden("mnist_det_ens_fc_h32_m4_n6"); m = g.meta; post = g.posterior()
+    x, y = g.t("x"), g.t("y"); M = m["M"]; hyper = {"epsilon": m["eps"]}
+    ens = Ensemble_NN("mnist", m["hidden"], m["act"], m["arch"], 1, 0.01, tuple(m["shape"]), m["n_classes"], M)
+    ens.device = DEV
+    for i in range(M):
+        net = NN("mnist", tuple(m["shape"]), m["n_classes"], m["hidden"], m["act"], m["arch"], 0.01, 1)
+        net.load_state_dict({k: v[i] for k, v in post.items()})
+        net.device = DEV
+        ens.ensemble_models[str(i)] = net
+    for tag, net, ns in (("nn0", ens.ensemble_models["0"], None), ("ens", ens, M)):
+        for method, key in (("fgsm", "_eval_"), ("pgd", "_eval_pgd_")):
+            adv = A.attack(net=net, x_test=x, y_test=y, dataset_name="mnist", device=DEV, method=method, filename=net.name,
+                           hyperparams=hyper, n_samples=ns)
+            oa, aa, rob = A.attack_evaluation(net=net, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=ns)
+            assert (oa, aa) == (float(g.arr[tag + key + "orig_acc"]), float(g.arr[tag + key + "adv_acc"])), (tag, method)
+            same = ((adv.cpu() - g.t(tag + "_" + method)).abs().reshape(len(x), -1) > 1e-6).sum(1) == 0
+            err = (rob.cpu() - g.t(tag + key + "softmax_rob")).abs()
+            assert float(err[same].max() if same.any() else 0.0) < 1e-5 and float(err.max()) < 1e-3, (tag, method)
+
+
+# ------------------------------------------------------------------ f1: the eps x n_samples grid driver on the HIP path
+@pytest.mark.parametrize("fixture", ["halfmoons_eps_grid_fgsm", "halfmoons_eps_grid_pgd"])
+def test_eps_grid_driver_on_hip(golden, fixture):
+    """plot_eps_attacks.build_eps_attacks_df (plot_eps_attacks.py:9-39) with every cell computed by the HIP kernels: the
+    reference's rows (test_acc, adv_acc exactly; softmax_rob to 1e-5), column order, CSV path, and the CSV read back."""
+    from robustbnns_amd import plot_eps_attacks
+    g = golden(fixture); m = g.meta; bnn = _bnn(g)
+    assert bnn.name == m["bnn_name"]
+    df = plot_eps_attacks.build_eps_attacks_df(bnn=bnn, dataset=m["dataset"], device=DEV, method=m["method"], x_test=g.t("x"),
+                                               y_test=g.t("y"), epsilon_list=m["epsilon_list"], n_samples_list=m["n_samples_list"],
+                                               savedir=bnn.name)
+    assert list(df.columns) == m["columns"] and len(df) == len(g.arr["df_epsilon"])
+    for col in ("epsilon", "test_acc", "adv_acc", "n_samples"):
+        assert np.array_equal(df[col].to_numpy().astype("float64"), g.arr["df_" + col]), col
+    err = np.abs(df["softmax_rob"].to_numpy() - g.arr["df_softmax_rob"])
+    assert err.max() < (1e-5 if m["method"] == "fgsm" else 1e-3) and np.median(err) < 1e-6
+    assert set(df["attack_method"]) == {m["method"]}
+    assert os.path.exists(m["csv_files"][0])
+    back = plot_eps_attacks.load_eps_attacks_df(m["dataset"], m["method"], bnn.name)
+    assert len(back) == len(df) and list(back.columns) == m["columns"]
+    assert np.abs(back["softmax_rob"].to_numpy() - df["softmax_rob"].to_numpy()).max() < 1e-12
+
+
+# ------------------------------------------------------------------ f4: fused gradient norms
+def test_fused_norms_feed_the_vanishing_rule(golden):
+    """rbnn_sum_slabs_norms on the fixture's crafted gradients (one slab, 160 rows of 36 columns): the norms, and the
+    classification of lossGradients.py:78-127 derived from them, equal the reference's indices for both norms."""
+    from robustbnns_amd import _hip
+    from robustbnns_amd.lossGradients import _vanishing_rule, compute_vanishing_norms_idxs
+    d = np.load(os.path.join(GOLDEN, "vanishing_norms.npz"))
+    grads = torch.from_numpy(d["grads"])                                   # [40, 4, 1, 6, 6]
+    n_img, n_list = grads.shape[:2]
+    flat = grads.reshape(n_img * n_list, -1).to(DEV).contiguous()
+    k = _hip.HipKernels()
+    out = torch.empty_like(flat)
+    linf = torch.empty(len(flat), device=DEV)
+    l2 = torch.empty(len(flat), device=DEV)
+    k.sum_slabs_norms(flat, 1, len(flat), flat.shape[1], flat.shape[1], 1.0, out, linf, l2)
+    assert torch.equal(out, flat)
+    assert torch.equal(linf.cpu(), flat.cpu().abs().max(1)[0])
+    assert float(((l2.cpu() - flat.cpu().norm(dim=1)).abs() / flat.cpu().norm(dim=1).clamp_min(1e-30)).max()) < 1e-6
+    for norm, t in (("linfty", linf), ("l2", l2)):
+        got = _vanishing_rule(t.cpu().numpy().reshape(n_img, n_list))
+        assert got == list(d[norm]) == compute_vanishing_norms_idxs(d["grads"], list(d["n_samples_list"]), norm)
+
+
+def test_vanishing_gradients_grid_on_hip(golden):
+    """expected_gradient_norms / vanishing_gradients over n_samples_list on an HMC posterior: the fused norms equal the host
+    norms of the gradients the same run returns, the indices equal compute_vanishing_norms_idxs on the stacked host arrays,
+    and plot_gradients_components._get_gradients returns the same arrays (computing, then loading its pickles)."""
+    from types import SimpleNamespace
+    from torch.utils.data import DataLoader
+    from robustbnns_amd import lossGradients as LG, plot_gradients_components as PG, savedir
+    g = golden("halfmoons_fc_h64_s10_n100"); m = g.meta; bnn = _bnn(g); x, y = g.t("x"), g.t("y")
+    n_list = [1, 5, 10]
+    loader = DataLoader(dataset=list(zip(x, y)), batch_size=32, shuffle=False)
+    for norm in ("linfty", "l2"):
+        stacked, idxs = PG.vanishing_gradients(bnn, loader, DEV, n_list, norm=norm)
+        assert stacked.shape == (len(x), len(n_list), 2)
+        assert idxs == LG.compute_vanishing_norms_idxs(stacked, n_list, norm)
+    assert rel_err(torch.from_numpy(stacked[:, 2]), g.t("loss_gradients").reshape(len(x), -1)) < TOL
+    args = SimpleNamespace(compute_grads=True, device=DEV)
+    lst = PG._get_gradients(args, bnn, loader, n_list, savedir.DATA)
+    assert len(lst) == 3 and all(np.array_equal(a, stacked[:, j]) for j, a in enumerate(lst))
+    args.compute_grads = False
+    lst2 = PG._get_gradients(args, bnn, loader, n_list, savedir.DATA)
+    assert all(np.array_equal(a, b) for a, b in zip(lst, lst2))
+
+
+# ------------------------------------------------------------------ SVI: seeded draws, param-store files
+def _svi_bnn(shape, Cn, Hn, seed):
+    from robustbnns_amd.model_bnn import BNN
+    bnn = BNN("mnist" if shape[1] == 28 else "half_moons", Hn, "leaky", "fc", "svi", 5, 0.01, None, None, shape, Cn)
+    g = torch.Generator().manual_seed(seed)
+    loc = {k: torch.randn(v.shape, generator=g) * 0.05 for k, v in bnn.basenet.state_dict().items()}
+    scale = {k: torch.full(v.shape, -3.0) for k, v in bnn.basenet.state_dict().items()}
+    bnn.set_variational_params(loc, scale, DEV)
+    return bnn
+
+
+@pytest.mark.parametrize("rng", ["device", "host"])
+def test_svi_loss_gradients_are_seeded_and_nested(rng):
+    """lossGradients.py:29-33 evaluates sample i with seeds=[i]: an SVI BNN's expected gradients are deterministic, and the
+    sample set for n is a prefix of the set for m > n (compute_vanishing_norms_idxs relies on that nesting)."""
+    from robustbnns_amd import lossGradients as LG
+    bnn = _svi_bnn((1, 28, 28), 10, 128, seed=5)
+    bnn.svi_rng = rng
+    x, y = O.synthetic_inputs(24, (1, 28, 28), 10, seed=6)
+    eng1, S1, seeds1, _ = bnn.hot_path(1, seeds=[0])
+    g1 = eng1.loss_gradients(x, y, S1)
+    torch.manual_seed(123)                                                  # the live generator must not matter
+    eng2, S2, seeds2, _ = bnn.hot_path(2, seeds=[0, 1])
+    g2 = eng2.loss_gradients(x, y, S2)
+    only1 = bnn.hot_path(1, seeds=[1])[0].loss_gradients(x, y, 1)
+    assert rel_err(((g1 + only1) / 2).cpu(), g2.cpu()) < 2e-6                # n=2 is the n=1 draw plus one more
+    for i in range(3):                                                      # public call surface: two calls agree bit for bit
+        a = LG.loss_gradient(bnn, x[i].to(DEV), y[i].to(DEV), n_samples=3)
+        torch.manual_seed(999 + i)
+        b = LG.loss_gradient(bnn, x[i].to(DEV), y[i].to(DEV), n_samples=3)
+        assert torch.equal(a, b)
+    w2 = bnn.draw_posterior(2, [0, 1])
+    w1 = bnn.draw_posterior(1, [0])
+    assert torch.equal(w2.W1[:1], w1.W1) and torch.equal(w2.W2[:1], w1.W2)
+
+
+def test_pyro_param_store_file_on_gpu(tmp_path):
+    """BNN.load(inference="svi") on a file in pyro 1.3.0's param-store layout (tests/golden/make_pyro_store.py; parity unpinned:
+    built by hand from the documented format): the variational parameters arrive bit-exact, avg_posterior returns the logits
+    of the mean weights, seeded draws follow the guide's restated RNG order, and save() writes the same layout back."""
+    from robustbnns_amd.model_bnn import BNN, read_param_store
+    bnn = BNN("half_moons", 32, "leaky", "fc", "svi", 5, 0.01, None, None, (1, 2, 1), 2)
+    rel = str(tmp_path) + "/"
+    os.makedirs(rel + bnn.name)
+    shutil.copy(os.path.join(GOLDEN, "pyro_store_halfmoons_fc_h32.pt"), rel + bnn.name + "/" + bnn.name + "_weights.pt")
+    bnn.load(device=DEV, rel_path=rel)
+    exp = np.load(os.path.join(GOLDEN, "pyro_store_halfmoons_fc_h32_expected.npz"))
+    for k in bnn.basenet.state_dict():
+        assert np.array_equal(bnn.svi_loc[k].cpu().numpy(), exp[k + "_loc"]) and np.array_equal(bnn.svi_scale[k].cpu().numpy(), exp[k + "_scale"])
+    x, _ = O.synthetic_inputs(50, (1, 2, 1), 2, seed=8)
+    loc = {k: torch.from_numpy(exp[k + "_loc"]).unsqueeze(0) for k in bnn.basenet.state_dict()}
+    z = bnn.forward(x.to(DEV), n_samples=3, avg_posterior=True).cpu()
+    assert rel_err(z, O.nn_logits(x.double(), O.cast(loc, torch.float64), "fc", "leaky")[0]) < TOL
+    bnn.svi_rng = "host"
+    seeds = [4, 9, 2]
+    eps = {}
+    for i, sd in enumerate(seeds):                                           # the restated draw order
+        torch.manual_seed(sd)
+        for k, v in bnn.basenet.state_dict().items():
+            torch.randn(v.shape); torch.randn(v.shape)
+        for k, v in bnn.basenet.state_dict().items():
+            eps.setdefault(k, []).append(torch.randn(v.shape))
+    w = O.svi_materialize({k: torch.from_numpy(exp[k + "_loc"]) for k in eps}, {k: torch.from_numpy(exp[k + "_scale"]) for k in eps},
+                          {k: torch.stack(v) for k, v in eps.items()})
+    p = bnn.forward(x.to(DEV), n_samples=3, seeds=seeds).cpu()
+    assert rel_err(p, O.bnn_forward(x.double(), O.cast(w, torch.float64), "fc", "leaky", 3)) < TOL
+    bnn.save(rel_path=rel, filename="again")
+    st = torch.load(rel + bnn.name + "/again.pt", weights_only=False)
+    assert set(st) == {"params", "constraints"} and all(t.requires_grad for t in st["params"].values())
+    back = read_param_store(rel + bnn.name + "/again.pt")
+    assert all(np.array_equal(back[k].numpy(), exp[k]) for k in exp.files)
+
+
+# ------------------------------------------------------------------ small C-ABI pieces added this round
+def test_input_scales_records_on_device():
+    """rbnn_input_scales: the exponent records the split kernels read equal the host rule scale_exp() for the same bounds."""
+    from robustbnns_amd import _hip
+    from robustbnns_amd.posterior import scale_exp
+    k = _hip.HipKernels()
+    g = torch.Generator().manual_seed(0)
+    for rows, cols, ld, mag, floor, mul, add, cap in [(7, 784, 784, 1.0, 0.0, 0.0, 0.0, float("inf")), (300, 2, 16, 37.5, 1.0, 3.0, 0.5, float("inf")),
+                                                      (1, 5, 8, 1e-6, 0.0, 2.0, 0.0, 1.0), (64, 100, 112, 4.0, 0.0, 0.0, 1.0, 1.0),
+                                                      (9, 3, 4, 0.0, 0.0, 1.0, 0.0, float("inf"))]:
+        X = torch.zeros(rows, ld)
+        X[:, :cols] = (torch.rand(rows, cols, generator=g) * 2 - 1) * mag
+        X[:, cols:] = 1e9                                                   # padding columns must not be looked at
+        rec = k.input_scales(X.to(DEV), cols, floor, mul, add, cap, torch.empty(8, dtype=torch.int32, device=DEV)).cpu()
+        m = max(floor, float(X[:, :cols].abs().max()))
+        b1 = min(cap, float(np.float32(mul) * np.float32(m) + np.float32(add)))
+        assert int(rec[1]) == scale_exp(m) and int(rec[5]) == scale_exp(b1), (rows, cols, int(rec[1]), scale_exp(m), int(rec[5]), scale_exp(b1))
+        f = rec.view(torch.float32)
+        assert float(f[2]) == 2.0 ** int(rec[1]) and float(f[3]) == 2.0 ** -int(rec[1]) and float(f[6]) == 2.0 ** int(rec[5])
+    bad = torch.full((4, 8), float("nan")).to(DEV)
+    rec = k.input_scales(bad, 8, 0.0, 0.0, 0.0, 1.0, torch.empty(8, dtype=torch.int32, device=DEV)).cpu()
+    assert int(rec[1]) == 0                                                # non-finite inputs: neutral scale, no overflow of the image
+
+
+def test_pack_rows4_image_layout():
+    from robustbnns_amd import StackedPosterior
+    post = O.synthetic_posterior("fc2", 2, 16, 2, 3, 0.5)
+    sp = StackedPosterior("fc2", "tanh", (1, 2, 1), 2, 16, post, DEV)
+    # packed image [S, H/4, cols, 4]: element (q, c, j) is row 4q+j, column c
+    assert sp.W1p.shape == sp.W1.shape and torch.equal(sp.W1p.view(3, 8, 16, 4)[1, 2, 5], sp.W1[1, 8:12, 5])
+    assert torch.equal(sp.Wmp.view(3, 8, 32, 4)[2, 7, 31], sp.Wm[2, 28:32, 31])
+    assert torch.equal(sp.W1p.view(3, 8, 16, 4).permute(0, 1, 3, 2).reshape(3, 32, 16), sp.W1)

@@ -19,6 +19,8 @@ from conftest import rel_err
 from fake_kernels import FakeKernels
 from oracle import bnn_oracle as O
 
+pytestmark = pytest.mark.usefixtures("built_library")
+
 
 # ----------------------------------------------------------------------------- C-ABI
 def test_library_exports_every_declared_symbol():
@@ -28,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rbnn_abi_version() == 3
+    assert lib.rbnn_abi_version() == 4
     assert lib.rbnn_strerror(0) == b"ok" and b"NULL" in lib.rbnn_strerror(-1)
 
 
@@ -82,18 +84,22 @@ def test_split_mode_validation_without_gpu():
     img.ld_rows = 784                                                                              # not a multiple of 32
     assert lib.rbnn_split_workspace_query(C.byref(_net()), C.byref(img), 8, 2, C.byref(out)) == -2
     img.ld_rows = 800
-    assert lib.rbnn_split_rows(None, 4, 8, 8, 0, C.c_void_p(16), 32, None) == -1
-    assert lib.rbnn_split_rows(C.c_void_p(16), 4, 8, 8, 0, C.c_void_p(16), 24, None) == -2          # ld_dst % 32
-    assert lib.rbnn_split_rows(C.c_void_p(16), 4, 8, 8, 0, C.c_void_p(8), 32, None) == -5           # alignment
+    assert lib.rbnn_split_rows(None, 4, 8, 8, 0, None, C.c_void_p(16), 32, None) == -1
+    assert lib.rbnn_split_rows(C.c_void_p(16), 4, 8, 8, 0, None, C.c_void_p(16), 24, None) == -2          # ld_dst % 32
+    assert lib.rbnn_split_rows(C.c_void_p(16), 4, 8, 8, 0, None, C.c_void_p(8), 32, None) == -5           # alignment
+    assert lib.rbnn_input_scales(None, 4, 8, 8, 0.0, 0.0, 0.0, 1.0, C.c_void_p(16), None) == -1
+    assert lib.rbnn_input_scales(C.c_void_p(16), 4, 8, 6, 0.0, 0.0, 0.0, 1.0, C.c_void_p(16), None) == -2     # ld < cols
+    assert lib.rbnn_input_scales(C.c_void_p(16), 4, 8, 8, -1.0, 0.0, 0.0, 1.0, C.c_void_p(16), None) == -2    # negative floor
+    assert lib.rbnn_input_scales(C.c_void_p(16), 4, 8, 8, 0.0, 0.0, 0.0, 1.0, C.c_void_p(8), None) == -5      # alignment
     assert lib.rbnn_split_cols(C.c_void_p(16), 1, 48, 8, 8, 0, C.c_void_p(16), 16, None) == -2      # rows % 32
     assert lib.rbnn_split_w2gen(C.c_void_p(16), 1, 11, 128, 0, C.c_void_p(16), None) == -2         # classes > 10
-    assert lib.rbnn_fc_forward_split(C.byref(_net()), C.byref(img), None, 800, 14, 8, None, 2, 0, C.byref(ws), None) == -1
+    assert lib.rbnn_fc_forward_split(C.byref(_net()), C.byref(img), None, 800, 14, None, 8, None, 2, 0, C.byref(ws), None) == -1
     ws.P = C.c_void_p(16); img.W1_rows = C.c_void_p(16)
     w = dict(W1=C.c_void_p(16), b1=C.c_void_p(16), W2=C.c_void_p(16), b2=C.c_void_p(16))
-    assert lib.rbnn_fc_forward_split(C.byref(_net(arch=1, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -1   # fc2 without Wm_rows / bm / hid1
+    assert lib.rbnn_fc_forward_split(C.byref(_net(arch=1, **w)), C.byref(img), C.c_void_p(16), 800, 14, None, 8, None, 2, 0, C.byref(ws), None) == -1   # fc2 without Wm_rows / bm / hid1
     assert lib.rbnn_fc_input_grad_split(C.byref(_net(arch=1, **w)), C.byref(img), None, 2, 8, 0, C.byref(ws), C.byref(sws), None, None) == -1   # fc2 without Wm_cols / mask2 / dhid1
-    assert lib.rbnn_fc_forward_split(C.byref(_net(hidden=64, **w)), C.byref(img), C.c_void_p(16), 800, 14, 8, None, 2, 0, C.byref(ws), None) == -2  # hidden % 128
-    assert lib.rbnn_fc_forward_split(C.byref(_net(**w)), C.byref(img), C.c_void_p(16), 784, 14, 8, None, 2, 0, C.byref(ws), None) == -2             # ldx != ld_rows
+    assert lib.rbnn_fc_forward_split(C.byref(_net(hidden=64, **w)), C.byref(img), C.c_void_p(16), 800, 14, None, 8, None, 2, 0, C.byref(ws), None) == -2  # hidden % 128
+    assert lib.rbnn_fc_forward_split(C.byref(_net(**w)), C.byref(img), C.c_void_p(16), 784, 14, None, 8, None, 2, 0, C.byref(ws), None) == -2             # ldx != ld_rows
     assert lib.rbnn_fc_input_grad_split(C.byref(_net(**w)), C.byref(img), None, 2, 8, 0, C.byref(ws), C.byref(sws), None, None) == -1
 
 
@@ -136,9 +142,8 @@ def test_stacked_posterior_padding_and_roundtrip():
         assert torch.equal(v, post[k][1])
     d = sp.descriptor()
     assert (d.arch, d.activation, d.in_features, d.in_stride, d.hidden, d.n_classes, d.n_stored) == (1, 3, 2, 16, 32, 2, 3)
-    # packed image [S, H/4, cols, 4]: element (q, c, j) is row 4q+j, column c
-    assert sp.W1p.shape == sp.W1.shape and torch.equal(sp.W1p.view(3, 8, 16, 4)[1, 2, 5], sp.W1[1, 8:12, 5])
-    assert torch.equal(sp.Wmp.view(3, 8, 32, 4)[2, 7, 31], sp.Wm[2, 28:32, 31])
+    # the packed backward images are written by the HIP kernel only: a CPU-resident posterior has none (no CPU compute path)
+    assert sp.W1p is None and sp.Wmp is None and not d.W1_pack4
     sh = sp.shard(1, 2)
     assert sh.S == 2 and torch.equal(sh.W1, sp.W1[1:3])
     with pytest.raises(NotImplementedError):
@@ -391,3 +396,80 @@ def test_conv_engine_point_blocking(monkeypatch, golden):
     assert calls == [(16, 16), (16, 16), (8, 8)] and torch.equal(out, torch.arange(40.).reshape(40, 1) * 2)
     monkeypatch.setenv("RBNN_CONV_WS_GB", "48")
     assert eng.point_block(100) >= 2048
+
+
+# ----------------------------------------------------------------------------- f2: Pyro param-store files
+def test_pyro_param_store_layout_roundtrip(tmp_path):
+    """BNN.load(inference="svi") reads a file in pyro 1.3.0's ParamStoreDict layout ({"params": unconstrained leaf tensors,
+    "constraints": constraint objects}; hand-built fixture, tests/golden/make_pyro_store.py) and BNN.save writes it back."""
+    import shutil
+    from conftest import GOLDEN
+    from torch.distributions import constraints
+    bnn = model_bnn.BNN("half_moons", 32, "leaky", "fc", "svi", 5, 0.01, None, None, (1, 2, 1), 2)
+    rel = str(tmp_path) + "/"
+    os.makedirs(rel + bnn.name)
+    shutil.copy(os.path.join(GOLDEN, "pyro_store_halfmoons_fc_h32.pt"), rel + bnn.name + "/" + bnn.name + "_weights.pt")
+    raw = torch.load(rel + bnn.name + "/" + bnn.name + "_weights.pt", weights_only=False)
+    assert set(raw) == {"params", "constraints"} and set(raw["params"]) == set(raw["constraints"])
+    assert all(t.requires_grad and t.is_leaf for t in raw["params"].values())
+    assert all(c is constraints.real or isinstance(c, type(constraints.real)) for c in raw["constraints"].values())
+    bnn.load(device="cpu", rel_path=rel)
+    exp = np.load(os.path.join(GOLDEN, "pyro_store_halfmoons_fc_h32_expected.npz"))
+    keys = list(bnn.basenet.state_dict())
+    assert sorted(exp.files) == sorted(k + s for k in keys for s in ("_loc", "_scale"))
+    for k in keys:
+        assert np.array_equal(bnn.svi_loc[k].numpy(), exp[k + "_loc"]) and np.array_equal(bnn.svi_scale[k].numpy(), exp[k + "_scale"])
+        assert not bnn.svi_loc[k].requires_grad
+    bnn.save(rel_path=rel, filename="copy")
+    back = model_bnn.read_param_store(rel + bnn.name + "/copy.pt")
+    assert all(np.array_equal(back[k].numpy(), exp[k]) for k in exp.files)
+    # a positive-constrained parameter is stored unconstrained (log): the reader applies transform_to(constraint)
+    st = model_bnn.param_store_state({"a": torch.tensor([0.5])}, {"a": torch.tensor([-1.0])})
+    st["constraints"]["a_scale"] = constraints.positive
+    torch.save(st, rel + "pos.pt")
+    assert torch.allclose(model_bnn.read_param_store(rel + "pos.pt")["a_scale"], torch.tensor([-1.0]).exp())
+    torch.save({"params": {}, "oops": {}}, rel + "bad.pt")
+    with pytest.raises(KeyError, match="malformed"):
+        model_bnn.read_param_store(rel + "bad.pt")
+    other = model_bnn.BNN("half_moons", 32, "leaky", "fc2", "svi", 5, 0.01, None, None, (1, 2, 1), 2)
+    os.makedirs(rel + other.name)
+    shutil.copy(os.path.join(GOLDEN, "pyro_store_halfmoons_fc_h32.pt"), rel + other.name + "/" + other.name + "_weights.pt")
+    with pytest.raises(KeyError, match="lacks"):
+        other.load(device="cpu", rel_path=rel)                  # written by the fc guide: no model.5.* entries
+
+
+# ----------------------------------------------------------------------------- bench.py --gpus N outside torchrun
+def test_bench_spawns_ranks_as_a_child_process(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a torchrun environment (the driver's scaling command) starts the ranks as a child
+    process before anything touches the GPU and relays the child's JSON line as its own last line."""
+    import importlib.util
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return types.SimpleNamespace(returncode=0, stdout='RCCL banner\n{"metric": "m", "value": 1.0, "n_gpus": 2}\ntrailing noise\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a: (_ for _ in ()).throw(AssertionError("the parent must not touch the GPU")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert cmd[-7].endswith("bench.py") and seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert lines[-1].startswith("{") and '"n_gpus": 2' in lines[-1] and "RCCL banner" in lines[0]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.main()

@@ -17,7 +17,7 @@ from oracle import bnn_oracle as O
 BNN_CASES = ["halfmoons_fc_h64_s10_n100", "mnist_fc_h32_s8_n8_leaky", "mnist_fc_h32_s8_n8_relu",
              "mnist_fc_h16_s4_n6_sigm", "mnist_fc_h16_s4_n6_tanh", "mnist_fc_h512_s8_n8_leaky",
              "mnist_fc_h512_s8_n8_relu", "mnist_fc2_h32_s4_n6_leaky", "halfmoons_fc2_h32_s6_n40",
-             "mnist_conv_h16_s2_n4_leaky"]
+             "mnist_conv_h16_s2_n4_leaky", "mnist_conv_h16_s2_n4_sigm", "mnist_conv_h16_s2_n4_tanh"]
 TOL = 1e-5
 TAU = 1e-3      # |g| below tau * max|g| of that point may legitimately flip sign
 
@@ -95,6 +95,11 @@ def test_attack_evaluation(golden, name):
     oa, aa, rob = O.attack_evaluation(g.t("x"), g.t("fgsm"), g.t("y"), post, m["arch"], m["act"], m["S"])
     assert oa == float(g.arr["eval_orig_acc"]) and aa == float(g.arr["eval_adv_acc"])
     assert float((rob - g.t("eval_softmax_rob")).abs().max()) < 1e-6
+    # the PGD images' triple (evaluated on the attacked subset pgd_idx)
+    idx = torch.from_numpy(g.arr["pgd_idx"])
+    oa, aa, rob = O.attack_evaluation(g.t("x")[idx], g.t("pgd"), g.t("y")[idx], post, m["arch"], m["act"], m["S"])
+    assert oa == float(g.arr["eval_pgd_orig_acc"]) and aa == float(g.arr["eval_pgd_adv_acc"])
+    assert float((rob - g.t("eval_pgd_softmax_rob")).abs().max()) < 1e-6
 
 
 def test_attack_and_loss_gradients_drivers(golden):
@@ -123,3 +128,7 @@ def test_deterministic_and_ensemble(golden):
     oa, aa, rob = O.attack_evaluation(x, g.t("nn0_fgsm"), y, post, arch, act, 1, kind="ensemble")
     assert (oa, aa) == (float(g.arr["nn0_eval_orig_acc"]), float(g.arr["nn0_eval_adv_acc"]))
     assert float((rob - g.t("nn0_eval_softmax_rob")).abs().max()) < 1e-6
+    for tag, S_ in (("nn0", 1), ("ens", M)):
+        oa, aa, rob = O.attack_evaluation(x, g.t(tag + "_pgd"), y, post, arch, act, S_, kind="ensemble")
+        assert (oa, aa) == (float(g.arr[tag + "_eval_pgd_orig_acc"]), float(g.arr[tag + "_eval_pgd_adv_acc"]))
+        assert float((rob - g.t(tag + "_eval_pgd_softmax_rob")).abs().max()) < 1e-6
