@@ -59,6 +59,14 @@ WORKLOADS = {
                  desc="MNIST conv-BNN (conv5x5x32 - pool - conv5x5x512 - pool - fc, leaky), FGSM eps=0.3, N=2048 points, S=16 samples/GPU"),
     "fc2": dict(shape=(1, 28, 28), H=512, C=10, arch="fc2", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
                 desc="MNIST fc2-BNN 784->512->512->10 (leaky; the reference's saved model_1), FGSM eps=0.3, N=10000 points, S=100 samples/GPU"),
+    # BASELINE.json configs[4]: CIFAR-shaped conv-BNN, n_samples=500 over 8 GPUs (64 per GPU, 512 at 8), PGD T=100 for each eps of
+    # the grid {2,4,8}/255, 10 000 points.  Shapes are BUILD-DEFINED (3x32x32 -> head 81*Hc; the reference's conv cannot express
+    # them, SURVEY 8a note): parity unpinned.  One step = the whole eps grid = 3 x 100 iterations (minutes): profile with
+    # --points / --iters overrides, which the line then reports.
+    "c5": dict(shape=(3, 32, 32), H=512, C=10, arch="conv", act="leaky", S=64, N=10000, method="pgd", iters=100,
+               eps=(2 / 255, 4 / 255, 8 / 255),
+               desc="CIFAR-shaped conv-BNN (3x32x32: conv5x5x32 - pool - conv5x5x512 - pool - fc 81*512, leaky; build-defined shapes, parity "
+                    "unpinned), PGD T=100 over eps in {2,4,8}/255, N=10000 points, S=64 samples/GPU (n_samples=500 sharded 8-way)"),
     "c1": dict(shape=(1, 2, 1), H=64, C=2, arch="fc", act="leaky", S=10, N=100, method="fgsm", iters=1, eps=0.3,
                desc="half-moons fc-BNN 2->64->2 (leaky), FGSM eps=0.3, N=100 points, S=10 samples/GPU"),
 }
@@ -110,15 +118,21 @@ def cpu_baseline(w, x, y, post, budget_s):
             O.loop_pgd_attack(x[i:i + 1], y[i:i + 1], post, w["arch"], w["act"], w["S"], hyper, iters=w["iters"])
 
     cut = None
-    if w["method"] == "pgd" and w["iters"] * w["S"] > 4000:
-        # one full point would take minutes (C3: 10 s, C5: longer): time a prefix of the PGD iterations of each point instead —
-        # every iteration costs the same (same S forwards + one backward), so the rate per attack-sample is unchanged
-        cut = max(2, 4000 // w["S"])
+    if w["method"] == "pgd":
+        # one full point can take minutes (C3: 10 s, C5: far longer): time a prefix of the PGD iterations of each point instead —
+        # every iteration costs the same (same S forwards + one backward), so the rate per attack-sample is unchanged.  The prefix
+        # is sized from one untimed iteration so that a point takes about a quarter of the budget.
+        t1 = time.perf_counter()
+        O.loop_pgd_attack(x[0:1], y[0:1], post, w["arch"], w["act"], w["S"], hyper, iters=1)
+        t1 = time.perf_counter() - t1
+        cut = int(min(w["iters"], max(2, budget_s / 4 / max(t1, 1e-6))))
+        cut = None if cut >= w["iters"] else cut
     iters_timed = cut or w["iters"]
     if cut:
         def one_point(i):                                                   # noqa: F811
             O.loop_pgd_attack(x[i:i + 1], y[i:i + 1], post, w["arch"], w["act"], w["S"], hyper, iters=cut)
-    one_point(0)                                                            # untimed warm-up (thread pool, caches)
+    else:
+        one_point(0)                                                        # untimed warm-up (thread pool, caches)
     done, t0 = 0, time.perf_counter()
     while done < w["N"]:
         one_point(done)
@@ -389,7 +403,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
             "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job,
-                       "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none"},
+                       "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none",
+                       "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters)) if v}},
             "roofline": roofline(mode, evs, ms_per_step),
         }
         if other is not None:

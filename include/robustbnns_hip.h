@@ -195,28 +195,35 @@ int rbnn_input_scales(const float *X, int64_t rows, int32_t cols, int32_t ld, fl
                       float cap, rbnn_dev_scale *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * `conv` architecture (model_nn.py:93-106) on 1x28x28 inputs (mnist / fashion_mnist only, as the reference guards,
- * :95-96): Conv2d(1,32,5) -> act -> MaxPool2d(2) -> Conv2d(32,Hc,5) -> act -> MaxPool2d(2, stride 1) -> Flatten ->
- * Linear(49*Hc, C).  relu / leaky only.  state_dict keys: model.0.* model.3.* model.7.* (SURVEY 8a row a1).
+ * `conv` architecture (model_nn.py:93-106): Conv2d(Cin,32,5) -> act -> MaxPool2d(2) -> Conv2d(32,Hc,5) -> act ->
+ * MaxPool2d(2, stride 1) -> Flatten -> Linear(NP2*Hc, C), all four activations (:66-75).  state_dict keys: model.0.*
+ * model.3.* model.7.* (SURVEY 8a row a1).  Two input geometries:
+ *   1x28x28  mnist / fashion_mnist — the only inputs the reference's conv accepts (:95-96) and sizes its head for (:106:
+ *            NP2 = 49); pinned by the reference-generated fixtures;
+ *   3x32x32  CIFAR-shaped (BASELINE.json configs[4]): NP2 = 81, a BUILD-DEFINED head (Hc/16 * 3072 of :106 would be wrong,
+ *            SURVEY 8a note) — parity unpinned, checked against the fp64 oracle only.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct rbnn_conv_posterior {
-    int32_t activation;            /* RBNN_ACT_RELU or RBNN_ACT_LEAKY                              */
+    int32_t activation;            /* rbnn_activation                                              */
     int32_t hidden;                /* Hc = conv2 output channels, multiple of 16                   */
     int32_t n_classes;             /* C <= 16                                                      */
     int32_t n_stored;              /* S_total                                                      */
-    const float *K1w, *K1b;        /* model.0.weight [S_total,32,1,5,5], model.0.bias [S_total,32] */
+    int32_t in_channels;           /* Cin: 1 or 3                                                  */
+    int32_t in_width;              /* square input width: 28 (Cin = 1) or 32 (Cin = 3); X rows hold Cin*W*W floats */
+    const float *K1w, *K1b;        /* model.0.weight [S_total,32,Cin,5,5], model.0.bias [S_total,32] */
     const float *K2w, *K2b;        /* model.3.weight [S_total,Hc,32,5,5], model.3.bias [S_total,Hc] */
-    const float *Fw, *Fb;          /* model.7.weight [S_total,C,49*Hc], model.7.bias [S_total,C]   */
+    const float *Fw, *Fb;          /* model.7.weight [S_total,C,NP2*Hc], model.7.bias [S_total,C]  */
     const float *K2w_ci;           /* [S_total,32,Hc/16,25,16]: model.3.weight regrouped [ci][hc block][tap][hc%16] (backward only) */
 } rbnn_conv_posterior;
 
 typedef struct rbnn_conv_workspace {
     float   *P, *dZ;               /* [S,N,16]                                                     */
-    float   *P1;                   /* [S,N,24 KiB]    pooled+activated conv1 output: fp32 [32,12,12] (18 KiB) or the split image  */
-    uint8_t *st1;                  /* [S,N,32*12*12]  pool-1 stash: argmax (bits 0-1) | pre-activation > 0 (bit 2) */
-    float   *Q2;                   /* [S,N,Hc*49]     pooled+activated conv2 output (the Linear's input) */
-    uint8_t *st2;                  /* [S,N,Hc*49]     pool-2 stash, same encoding                  */
-    float   *G;                    /* [S,N,784]       per-sample input gradients (backward)        */
+    float   *P1;                   /* pooled+activated conv1 output, dense fp32 [S,N,32,P1W,P1W] (P1W = 12 / 14), or the 24 KiB split image per
+                                      (s,n); sized by rbnn_conv_workspace_query (whole 1-KiB pieces per point)               */
+    uint8_t *st1;                  /* [S,N,32*P1W*P1W] pool-1 stash: argmax (bits 0-1) | pre-activation > 0 (bit 2) */
+    float   *Q2;                   /* [S,N,Hc*NP2]    pooled+activated conv2 output (the Linear's input) */
+    uint8_t *st2;                  /* [S,N,Hc*NP2]    pool-2 stash, same encoding                  */
+    float   *G;                    /* [S,N,Cin*W*W]   per-sample input gradients (backward)        */
 } rbnn_conv_workspace;
 
 typedef struct rbnn_conv_workspace_sizes { size_t P, dZ, P1, st1, Q2, st2, G; } rbnn_conv_workspace_sizes;
@@ -231,11 +238,12 @@ int rbnn_conv_forward(const rbnn_conv_posterior *net, const float *X, int32_t ld
                       const rbnn_conv_workspace *ws, void *stream);
 
 /* Per-sample input gradients of the conv net: G[s,n,:] = dL_s/dx_n for the dZ left in ws->dZ by rbnn_loss_dlogits
- * (sum them with rbnn_sum_slabs(G, S, N, 784, ...)).  Replaces loss.backward() through model_nn.py:98-106. */
+ * (sum them with rbnn_sum_slabs(G, S, N, Cin*W*W, ...)).  Replaces loss.backward() through model_nn.py:98-106. */
 int rbnn_conv_input_grad(const rbnn_conv_posterior *net, const int32_t *sample_idx, int32_t n_samples,
                          int32_t n_points, const rbnn_conv_workspace *ws, void *stream);
 
-/* rbnn_conv_forward in split-half precision (the technique of the fc split mode applied to conv2, 98 % of the MACs):
+/* rbnn_conv_forward in split-half precision (the technique of the fc split mode applied to conv2, 98 % of the MACs; 1x28x28
+ * inputs, relu / leaky only — RBNN_ERR_UNSUPPORTED otherwise):
  * K2_rows = rbnn_split_rows image of model.3.weight regrouped [S_total*Hc, 25 taps * 32 ci] (K tap-major) holding W * 2^k2_exp;
  * the pooled conv1 activations are carried as value * 2^p1_exp = hi + lo (the caller bounds them: |P1| <= max_c(sum|K1w_c| *
  * max|x| + |K1b_c|)).  ws->P1 holds the 24 KiB split image per (sample, point) (rbnn_conv_workspace_query sizes it);

@@ -382,7 +382,7 @@ def loop_attack(x, y_onehot, post, arch, act, method, n_samples, hyperparams=Non
 
 
 # ------------------------------------------------------------ synthetic posteriors
-def param_shapes(arch, D, H, C, in_ch=1):
+def param_shapes(arch, D, H, C, in_ch=1, head=None):
     if arch == "fc":
         return [("model.1.weight", (H, D)), ("model.1.bias", (H,)),
                 ("model.3.weight", (C, H)), ("model.3.bias", (C,))]
@@ -393,15 +393,17 @@ def param_shapes(arch, D, H, C, in_ch=1):
     if arch == "conv":
         return [("model.0.weight", (32, in_ch, 5, 5)), ("model.0.bias", (32,)),
                 ("model.3.weight", (H, 32, 5, 5)), ("model.3.bias", (H,)),
-                ("model.7.weight", (C, int(H / 16) * D)), ("model.7.bias", (C,))]
+                # model_nn.py:106 sizes the head int(H/16) * D (= 49*H, right for 1x28x28 only); `head` = the build-defined
+                # flattened conv output for other input sizes (81*H at 3x32x32, BASELINE config 5: parity unpinned)
+                ("model.7.weight", (C, int(H / 16) * D if head is None else head)), ("model.7.bias", (C,))]
     raise NotImplementedError(arch)
 
 
-def synthetic_posterior(arch, D, H, C, S, std, in_ch=1):
+def synthetic_posterior(arch, D, H, C, S, std, in_ch=1, head=None):
     """The HMC-style synthetic posterior of tests/golden/make_golden.py::fill_net:
     sample i = manual_seed(100+i), every parameter tensor ~ N(0, std^2) in
     nn.Module.parameters() order.  Bit-identical to the fixtures' weights (checked by sha256)."""
-    shapes = param_shapes(arch, D, H, C, in_ch)
+    shapes = param_shapes(arch, D, H, C, in_ch, head)
     out = {k: torch.empty((S,) + shp, dtype=torch.float32) for k, shp in shapes}
     for i in range(S):
         torch.manual_seed(100 + i)

@@ -41,6 +41,7 @@ class WorkspaceSizes(C.Structure):
 
 class ConvPosterior(C.Structure):
     _fields_ = [("activation", C.c_int32), ("hidden", C.c_int32), ("n_classes", C.c_int32), ("n_stored", C.c_int32),
+                ("in_channels", C.c_int32), ("in_width", C.c_int32),
                 ("K1w", _fp), ("K1b", _fp), ("K2w", _fp), ("K2b", _fp), ("Fw", _fp), ("Fb", _fp), ("K2w_ci", _fp)]
 
 

@@ -1,8 +1,11 @@
 """The reference's `conv` architecture (model_nn.py:93-106) on the HIP path: stacked posterior + batched engine.
 
-Layout in HBM (all S samples resident): K1w [S,32,25], K1b [S,32], K2w [S,Hc,800] (k = ci*25 + ky*5 + kx, exactly
-nn.Conv2d's [out,in,kh,kw] flattened), K2b [S,Hc], Fw [S,C,49*Hc], Fb [S,C].  Activations per (sample, point):
-P1 18 KB, Q2 196*Hc B, two byte stashes — 148 KB at Hc=512, so large jobs are run in blocks of samples.
+Layout in HBM (all S samples resident): K1w [S,32,Cin*25], K1b [S,32], K2w [S,Hc,800] (k = ci*25 + ky*5 + kx, exactly
+nn.Conv2d's [out,in,kh,kw] flattened), K2b [S,Hc], Fw [S,C,NP2*Hc], Fb [S,C].  Activations per (sample, point):
+P1 18 KB, Q2 196*Hc B, two byte stashes — 148 KB at Hc=512 on 1x28x28, so large jobs are run in blocks of points.
+
+Input geometries (include/robustbnns_hip.h): 1x28x28 — the only one the reference's conv accepts (model_nn.py:95-96) — and
+3x32x32, BASELINE.json's CIFAR-shaped config 5, whose head Linear(81*Hc, C) is build-defined (SURVEY 8a note; parity unpinned).
 """
 import ctypes as C
 import os
@@ -16,26 +19,37 @@ from ._hip import OUT_LOGITS, OUT_PROBS
 
 CONV_KEYS = ("model.0", "model.3", "model.7")
 _U8 = {"st1", "st2"}
+GEOMETRIES = {(1, 28, 28), (3, 32, 32)}
+
+
+def conv_geometry(input_shape):
+    """(pooled conv1 width, pooled conv2 width) of model_nn.py:98-106 on a Cin x W x W input: 5x5 convs, pool 2, pool 2 stride 1."""
+    p1 = (int(input_shape[1]) - 4) // 2
+    return p1, p1 - 4 - 1
 
 
 class ConvStackedPosterior:
     arch = "conv"
 
     def __init__(self, activation, input_shape, n_classes, hidden, stacked, device):
-        if tuple(int(v) for v in input_shape) != (1, 28, 28):
-            raise NotImplementedError()                                   # model_nn.py:95-96: mnist / fashion_mnist only
-        if activation not in ("relu", "leaky"):
-            raise NotImplementedError(f"conv on the HIP path supports relu/leaky, not {activation!r}")
-        self.activation, self.input_shape = activation, (1, 28, 28)
-        self.D = self.Dp = 784
+        shape = tuple(int(v) for v in input_shape)
+        if shape not in GEOMETRIES:
+            raise NotImplementedError(f"conv on the HIP path is built for inputs {sorted(GEOMETRIES)}, not {shape}")
+        if activation not in _hip.ACTIVATIONS:
+            raise AssertionError("\nWrong activation name.")                      # model_nn.py:74-75
+        self.activation, self.input_shape = activation, shape
+        self.Cin, self.W = shape[0], shape[1]
+        self.D = self.Dp = shape[0] * shape[1] * shape[2]
+        self.P1W, self.P2W = conv_geometry(shape)
+        self.NP2 = self.P2W * self.P2W
         self.H, self.C = int(hidden), int(n_classes)
         self.device = torch.device(device)
         S = stacked["model.0.weight"].shape[0]
         self.S = int(S)
-        f = lambda k, shape: stacked[k].to(self.device, torch.float32).reshape((S,) + shape).contiguous()
-        self.K1w, self.K1b = f("model.0.weight", (32, 25)), f("model.0.bias", (32,))
+        f = lambda k, shp: stacked[k].to(self.device, torch.float32).reshape((S,) + shp).contiguous()
+        self.K1w, self.K1b = f("model.0.weight", (32, self.Cin * 25)), f("model.0.bias", (32,))
         self.K2w, self.K2b = f("model.3.weight", (self.H, 800)), f("model.3.bias", (self.H,))
-        self.Fw, self.Fb = f("model.7.weight", (self.C, 49 * self.H)), f("model.7.bias", (self.C,))
+        self.Fw, self.Fb = f("model.7.weight", (self.C, self.NP2 * self.H)), f("model.7.bias", (self.C,))
         # model.3.weight regrouped [S, 32 ci, Hc/16 blocks, 25 taps, 16 hc]: the backward GEMM's A operand, K-contiguous
         # with one K tile = one tap x 16 channels
         self.K2ci = self.K2w.view(S, self.H // 16, 16, 32, 25).permute(0, 3, 1, 4, 2).reshape(S, 32, self.H * 25).contiguous()
@@ -44,7 +58,8 @@ class ConvStackedPosterior:
 
     # ------------------------------------------------------------------ split-half precision mode (forward conv2)
     def split_supported(self):
-        return self.device.type == "cuda"
+        """The split-half conv kernels are built for 1x28x28 inputs with relu / leaky (the reference's saved conv models)."""
+        return self.device.type == "cuda" and self.input_shape == (1, 28, 28) and self.activation in ("relu", "leaky")
 
     def split_images(self):
         """(K2 split-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32], its exponent, per-unit bound of the pooled
@@ -83,6 +98,7 @@ class ConvStackedPosterior:
         if self._desc is None:
             d = _hip.ConvPosterior()
             d.activation, d.hidden, d.n_classes, d.n_stored = _hip.ACTIVATIONS[self.activation], self.H, self.C, self.S
+            d.in_channels, d.in_width = self.Cin, self.W
             for name, t in (("K1w", self.K1w), ("K1b", self.K1b), ("K2w", self.K2w), ("K2b", self.K2b), ("Fw", self.Fw),
                             ("Fb", self.Fb), ("K2w_ci", self.K2ci)):
                 setattr(d, name, C.c_void_p(t.data_ptr()))
@@ -90,7 +106,7 @@ class ConvStackedPosterior:
         return self._desc
 
     def state_dict(self, i):
-        sd = {"model.0.weight": self.K1w[i].view(32, 1, 5, 5), "model.0.bias": self.K1b[i],
+        sd = {"model.0.weight": self.K1w[i].view(32, self.Cin, 5, 5), "model.0.bias": self.K1b[i],
               "model.3.weight": self.K2w[i].view(self.H, 32, 5, 5), "model.3.bias": self.K2b[i],
               "model.7.weight": self.Fw[i], "model.7.bias": self.Fb[i]}
         return {k: v.detach().cpu().clone() for k, v in sd.items()}
@@ -119,18 +135,20 @@ class ConvEngine(AttackEngine):
                     ws[name] = torch.empty(sizes[name] // 4, dtype=torch.float32, device=self.device)
             ws["slabs"] = ws["G"]                                          # per-sample gradients play the role of the slabs
             ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
-            ws["Gsum"] = torch.empty(N, 784, dtype=torch.float32, device=self.device)
+            ws["Gsum"] = torch.empty(N, self.post.D, dtype=torch.float32, device=self.device)
             while len(self._ws_cache) >= 2:
                 self._ws_cache.pop(next(iter(self._ws_cache)))             # oldest entry out
             self._ws_cache[key] = ws
         return ws
 
     # -------------------------------------------------------------- point blocking
-    # Activations cost 148 KB per (point, sample) at Hc=512 (P1 18 KB, Q2 100 KB, two byte stashes, per-sample
+    # Activations cost 148 KB per (point, sample) at Hc=512 on 1x28x28 (P1 18 KB, Q2 100 KB, two byte stashes, per-sample
     # gradients), and the mean-probability loss needs every sample's forward before any backward — so large jobs are
     # split over POINTS (independent), never over samples.  Budget: RBNN_CONV_WS_GB (default 48 GB of the 288 GB).
     def point_block(self, S):
-        per_point = S * (4608 * 5 + self.post.H * 49 * 5 + 784 * 4 + 2 * 64)
+        p = self.post
+        p1 = 32 * p.P1W * p.P1W
+        per_point = S * (max(24576, (p1 + 255) // 256 * 1024) + p1 + p.H * p.NP2 * 5 + p.D * 4 + 2 * 64)
         budget = float(os.environ.get("RBNN_CONV_WS_GB", "48")) * 2 ** 30
         return max(16, int(budget // per_point) // 16 * 16)
 

@@ -1,80 +1,112 @@
 // rbnn_conv.hip — the reference's `conv` architecture (model_nn.py:93-106) on gfx950:
-//   Conv2d(1,32,5) -> act -> MaxPool2d(2) -> Conv2d(32,Hc,5) -> act -> MaxPool2d(2, stride 1) -> Flatten -> Linear(49*Hc, C)
-// on 1x28x28 inputs (the only input size the reference's head is correct for: model_nn.py:95-96,106).
+//   Conv2d(Cin,32,5) -> act -> MaxPool2d(2) -> Conv2d(32,Hc,5) -> act -> MaxPool2d(2, stride 1) -> Flatten -> Linear(P2W^2*Hc, C)
+// Two input geometries are instantiated (struct Geo): 1x28x28 — the only one the reference's head is correct for
+// (model_nn.py:95-96,106: pinned by the reference-generated fixtures) — and 3x32x32, BASELINE.json's CIFAR-shaped config 5,
+// whose head size 81*Hc is BUILD-DEFINED (the reference cannot express it: parity unpinned, checked against the fp64 oracle).
 //
 // Per posterior sample the weights differ, so every layer is batched over (sample, point):
-//   conv1_pool_kernel   25-tap conv + 2x2 max-pool + activation on the VALU (1.7 % of the MACs)   -> P1 [S][N][32][12][12]
+//   conv1_pool_kernel   25*Cin-tap conv + 2x2 max-pool + activation on the VALU (~2 % of the MACs)  -> P1 [S][N][32][P1W][P1W]
 //   conv2_pool_kernel   the 98 % of the work: implicit GEMM on v_mfma_f32_16x16x4_f32,
 //                       O2^T[hc][pos] = sum_k W2[hc][k] * P1[ci(k)][y(pos)+ky(k)][x(pos)+kx(k)],  k = (ci,ky,kx) in 0..799;
 //                       A = W2 rows through an LDS-DMA tile ring, B gathered from the point's P1 image resident in LDS
-//                       with a k -> offset table; epilogue: bias, 2x2/stride-1 max-pool on the pre-activations,
-//                       activation, 3-bit stash (argmax, sign) for the backward                    -> Q2 [S][N][Hc*49]
-//   conv_fc_kernel      the skinny Linear(49*Hc -> C) as an MFMA with both operands K-contiguous in memory, + softmax
-// max-pool commutes with the (monotone) relu / leaky-relu, so pooling the pre-activation and activating once is exact.
+//                       with a k -> offset table; epilogue: bias, 2x2/stride-1 max-pool, activation, 3-bit stash (argmax,
+//                       sign) for the backward                                                       -> Q2 [S][N][Hc*NP2]
+//   conv_fc_kernel      the skinny Linear(NP2*Hc -> C) as an MFMA with both operands K-contiguous in memory, + softmax
+// relu / leaky: max-pool commutes with the monotone activation, so the pre-activation is pooled and activated once (exact).
+// sigmoid / tanh: the pooling compares the ACTIVATED values, as torch does (two distinct pre-activations can round to the same
+// activation, and then the first one wins); their backward takes act' from the stored activation value, no sign bit.
 #include "rbnn_common.hpp"
 
 namespace {
 
-constexpr int C1 = 32, O1 = 24, P1W = 12, P1SZ = C1 * P1W * P1W;      // conv1 channels, its output width, pooled width, floats per point
-constexpr int K2 = C1 * 25, O2W = 8, P2W = 7, NPOS = O2W * O2W, NP2 = P2W * P2W;
+constexpr int C1 = 32;                                                 // conv1 output channels (model_nn.py:99)
+template <int CIN_, int IW_> struct Geo {
+    static constexpr int CIN = CIN_, IW = IW_, DIN = CIN_ * IW_ * IW_;    // input channels, (square) width, flattened size
+    static constexpr int O1 = IW_ - 4, P1W = O1 / 2, P1SZ = C1 * P1W * P1W;   // conv1 output width, pooled width, floats per point
+    static constexpr int O2W = P1W - 4, P2W = O2W - 1, NPOS = O2W * O2W, NP2 = P2W * P2W;   // conv2 output, stride-1 pooled
+    static constexpr int NPT2 = (NPOS + 15) / 16, NPT1 = (P1W * P1W + 15) / 16;   // 16-position MFMA tiles of conv2's output / of dP1
+    static constexpr int K1 = CIN_ * 25;
+    static constexpr int P1STRIDE = (P1SZ * 4 > 24576 ? (P1SZ + 255) / 256 * 1024 : 24576);   // bytes of ws->P1 ALLOCATED per (s, n): the fp32 image rounded up to whole 1-KiB DMA pieces, >= the 24 KiB split image
+    static constexpr int PITCH = O2W + 8;                             // zero-padded conv2-gradient image: border 4 on every side
+};
+using GeoMnist = Geo<1, 28>;      // O1 24, P1W 12, O2W 8,  P2W 7, NPOS 64,  NP2 49, NPT2 4, NPT1 9
+using GeoCifar = Geo<3, 32>;      // O1 28, P1W 14, O2W 10, P2W 9, NPOS 100, NP2 81, NPT2 7, NPT1 13
+// the split-half kernels further down are built for the 1x28x28 geometry only
+constexpr int P1W = GeoMnist::P1W, P1SZ = GeoMnist::P1SZ, K2 = C1 * 25, O2W = GeoMnist::O2W, P2W = GeoMnist::P2W,
+              NPOS = GeoMnist::NPOS, NP2 = GeoMnist::NP2;
+
+template <int ACT> constexpr bool smooth_act() { return ACT == RBNN_ACT_SIGM || ACT == RBNN_ACT_TANH; }
 
 struct ConvArgs {
     const float* X; int ldx; int N;
-    const float* K1w; const float* K1b;            // [S_total][32][25], [S_total][32]
+    const float* K1w; const float* K1b;            // [S_total][32][Cin*25], [S_total][32]
     const float* K2w; const float* K2b;            // [S_total][Hc][800], [S_total][Hc]
-    const float* Fw;  const float* Fb;             // [S_total][C][49*Hc], [S_total][C]
+    const float* Fw;  const float* Fb;             // [S_total][C][NP2*Hc], [S_total][C]
     int Hc; int C; const int* sidx; int S;
-    float* P1; uint8_t* st1;                       // [S][N][4608]
-    float* Q2; uint8_t* st2;                       // [S][N][Hc*49]
+    float* P1; uint8_t* st1;                       // [S][N][P1SZ] (dense fp32 image; the buffer is allocated P1STRIDE bytes per point)
+    float* Q2; uint8_t* st2;                       // [S][N][Hc*NP2]
     float* P; int out_kind;
+    int NP2;                                       // pooled conv2 positions per channel (conv_fc / conv_fc_bwd are geometry-agnostic)
 };
 
 // ---------------------------------------------------------------------------------------------------
-template <int ACT>
+template <int ACT, class G>
 __global__ void __launch_bounds__(256) conv1_pool_kernel(const ConvArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per pooled output (s, n, c, py, px)
-    if (i >= (long long)a.S * a.N * P1SZ) return;
-    const int e = (int)(i % P1SZ), c = e / (P1W * P1W), py = (e / P1W) % P1W, px = e % P1W;
-    const long long sn = i / P1SZ;
+    if (i >= (long long)a.S * a.N * G::P1SZ) return;
+    const int e = (int)(i % G::P1SZ), c = e / (G::P1W * G::P1W), py = (e / G::P1W) % G::P1W, px = e % G::P1W;
+    const long long sn = i / G::P1SZ;
     const int n = (int)(sn % a.N), s = (int)(sn / a.N);
     const int sw = a.sidx ? a.sidx[s] : s;
-    const float* const x = a.X + (long long)n * a.ldx + (2 * py) * 28 + 2 * px;
-    const float* const w = a.K1w + ((long long)sw * C1 + c) * 25;
-    float patch[6][6];
+    const float* const w = a.K1w + ((long long)sw * C1 + c) * G::K1;
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int y = 0; y < 6; ++y)
+    for (int ci = 0; ci < G::CIN; ++ci) {                                 // channel-major accumulation, taps in (ky, kx) order
+        const float* const x = a.X + (long long)n * a.ldx + ci * (G::IW * G::IW) + (2 * py) * G::IW + 2 * px;
+        float patch[6][6];
 #pragma unroll
-        for (int xx = 0; xx < 6; ++xx) patch[y][xx] = x[y * 28 + xx];
+        for (int y = 0; y < 6; ++y)
+#pragma unroll
+            for (int xx = 0; xx < 6; ++xx) patch[y][xx] = x[y * G::IW + xx];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) v4[dy * 2 + dx] = fmaf(w[ci * 25 + ky * 5 + kx], patch[dy + ky][dx + kx], v4[dy * 2 + dx]);
+    }
     const float b = a.K1b[(long long)sw * C1 + c];
-    float best = 0.f;
+    float best = 0.f, best_pre = 0.f;
     int arg = 0;
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            float v = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 5; ++kx) v = fmaf(w[ky * 5 + kx], patch[dy + ky][dx + kx], v);
-            v += b;
-            if ((dy == 0 && dx == 0) || v > best) { best = v; arg = dy * 2 + dx; }   // first maximum wins (torch max_pool2d)
-        }
-    a.P1[i] = act_fwd<ACT>(best);
-    a.st1[i] = (uint8_t)(arg | (best > 0.f ? 4 : 0));
+    for (int q = 0; q < 4; ++q) {
+        const float pre = v4[q] + b, v = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+        if (q == 0 || v > best) { best = v; best_pre = pre; arg = q; }   // first maximum wins (torch max_pool2d)
+    }
+    a.P1[i] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);          // dense [S][N][P1SZ]
+    a.st1[i] = (uint8_t)(arg | (best_pre > 0.f ? 4 : 0));
 }
 
 // ---------------------------------------------------------------------------------------------------
-// conv2: one block = one (sample, point); 4 waves, each 64 output channels x the point's 64 output positions
-// (4 x 4 accumulator tiles), output channels in chunks of 256.
-template <int ACT>
+// conv2: one block = one (sample, point); 4 waves, each 64 output channels x the point's NPOS output positions
+// (4 x NPT2 accumulator tiles), output channels in chunks of 256.  Dynamic LDS: the point's P1 image, the k -> offset table
+// and two weight stage tiles; the per-wave pooling tiles of the epilogue alias the (then idle) weight tiles.
+// 1x28x28: 53 KiB, 3x32x32: 60 KiB — two blocks per CU either way.
+template <class G> constexpr int conv2_lds_floats() { return (G::P1SZ + 255) / 256 * 256 + 800 + 2 * 256 * 16; }
+
+template <int ACT, class G>
 __global__ void __launch_bounds__(256, 2) conv2_pool_kernel(const ConvArgs a) {
-    constexpr int WROWS = 256, TILE = WROWS * 16;
-    __shared__ __attribute__((aligned(16))) float lds[P1SZ + 800 + 2 * TILE + 4 * 16 * NPOS];
+    constexpr int WROWS = 256, TILE = WROWS * 16, NPT = G::NPT2;
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NPOS_ = G::NPOS, NP2_ = G::NP2;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int P1LDS = (G::P1SZ + 255) / 256 * 256;
+    static_assert(4 * 16 * G::NPOS <= 2 * TILE, "the four waves' pooling tiles fit in the weight stage buffers they alias");
     float* const P1s = lds;
-    int* const koff = (int*)(lds + P1SZ);
-    float* const Wt = lds + P1SZ + 800;
-    float* const scr = Wt + 2 * TILE;
+    int* const koff = (int*)(lds + P1LDS);
+    float* const Wt = lds + P1LDS + 800;
+    float* const scr = Wt;                                                // epilogue only: every wave is past the K loop's last barrier
 
     int id;
     if (!item_of_block(blockIdx.x, a.N * a.S, id)) return;
@@ -83,22 +115,27 @@ __global__ void __launch_bounds__(256, 2) conv2_pool_kernel(const ConvArgs a) {
     const int sw = a.sidx ? a.sidx[s] : s;
     const long long sn = (long long)s * a.N + n;
     const float* const Ws = a.K2w + (long long)sw * a.Hc * K2;
-    const int F = a.Hc * NP2;
+    const int F = a.Hc * NP2_;
 
-    // the point's pooled conv1 image -> LDS (18 pieces of 1 KiB), and the k -> image offset table
-    for (int q = wave; q < P1SZ / 256; q += 4) glds16(a.P1 + sn * P1SZ + q * 256 + 4 * lane, P1s + q * 256);
-    for (int k = tid; k < K2; k += 256) koff[k] = (k / 25) * (P1W * P1W) + ((k % 25) / 5) * P1W + (k % 5);
+    // the point's pooled conv1 image (dense [S][N][P1SZ] floats) -> LDS in whole 1-KiB pieces, and the k -> image offset table.
+    // A ragged last piece (3x32x32: 24.5 pieces) reads up to 512 B past the point's image — into the next point's, or into the
+    // slack of the allocation (ws->P1 is sized P1STRIDE >= P1SZ*4 + 512 bytes per point); those floats are never addressed.
+    for (int q = wave; q < (G::P1SZ + 255) / 256; q += 4) glds16(a.P1 + sn * G::P1SZ + q * 256 + 4 * lane, P1s + q * 256);
+    for (int k = tid; k < K2; k += 256) koff[k] = (k / 25) * (P1W_ * P1W_) + ((k % 25) / 5) * P1W_ + (k % 5);
     const int prow = lane >> 2, lchunk = (lane & 3) ^ swz(prow), pch = 4 * (lg ^ swz(li));
-    int poff[4];
+    int poff[NPT];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) poff[pt] = (2 * pt + (li >> 3)) * P1W + (li & 7);   // position pt*16+li = (y, x) = (2pt + li/8, li%8)
+    for (int pt = 0; pt < NPT; ++pt) {                                    // position pt*16+li = (y, x); positions past NPOS read (0,0), never stored
+        const int pos = pt * 16 + li;
+        poff[pt] = pos < NPOS_ ? (pos / O2W_) * P1W_ + pos % O2W_ : 0;
+    }
 
     for (int hc0 = 0; hc0 < a.Hc; hc0 += WROWS) {
-        f32x4 acc[4][4];
+        f32x4 acc[4][NPT];
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         auto stage = [&](int kt, int buf) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -113,9 +150,9 @@ __global__ void __launch_bounds__(256, 2) conv2_pool_kernel(const ConvArgs a) {
             if (kt + 1 < K2 / 16) stage(kt + 1, buf ^ 1);
             const float* const W = Wt + buf * TILE;
             const int kq0 = koff[kt * 16 + 4 * lg], kq1 = koff[kt * 16 + 4 * lg + 1], kq2 = koff[kt * 16 + 4 * lg + 2], kq3 = koff[kt * 16 + 4 * lg + 3];
-            f32x4 b[4], af[4];
+            f32x4 b[NPT], af[4];
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
                 b[pt] = (f32x4){P1s[kq0 + poff[pt]], P1s[kq1 + poff[pt]], P1s[kq2 + poff[pt]], P1s[kq3 + poff[pt]]};
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) af[ht] = *(const f32x4*)(W + ((wave * 4 + ht) * 16 + li) * 16 + pch);
@@ -124,37 +161,44 @@ __global__ void __launch_bounds__(256, 2) conv2_pool_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) acc[ht][pt] = MFMA16(af[ht][r], b[pt][r], acc[ht][pt]);
+                    for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA16(af[ht][r], b[pt][r], acc[ht][pt]);
             __syncthreads();
         }
-        // epilogue: bias, 2x2 / stride-1 max-pool of the pre-activations through a per-wave LDS tile, activation, stash
-        float* const my = scr + wave * 16 * NPOS;
+        // epilogue: bias, 2x2 / stride-1 max-pool through a per-wave LDS tile, activation, stash
+        float* const my = scr + wave * 16 * NPOS_;
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             const int hcb = hc0 + (wave * 4 + ht) * 16;                    // wave-uniform
             if (hcb >= a.Hc) break;
             const f32x4 bias = *(const f32x4*)(a.K2b + (long long)sw * a.Hc + hcb + 4 * lg);
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt)
+            for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) my[(4 * lg + r) * NPOS + pt * 16 + li] = acc[ht][pt][r] + bias[r];
-            for (int idx = lane; idx < 16 * NP2; idx += 64) {
-                const int hl = idx / NP2, p = idx % NP2, base = hl * NPOS + (p / P2W) * O2W + (p % P2W);
+                for (int r = 0; r < 4; ++r)
+                    if (pt * 16 + li < NPOS_) {
+                        const float pre = acc[ht][pt][r] + bias[r];
+                        // smooth activations are pooled on their VALUES (sign bit 30 of the stored float is free for them: the
+                        // pre-activation's sign rides there only for relu / leaky, which keep the pre-activation itself)
+                        my[(4 * lg + r) * NPOS_ + pt * 16 + li] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+                    }
+            for (int idx = lane; idx < 16 * NP2_; idx += 64) {
+                const int hl = idx / NP2_, p = idx % NP2_, base = hl * NPOS_ + (p / P2W_) * O2W_ + (p % P2W_);
                 float best = my[base];
                 int arg = 0;
                 if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
-                if (my[base + O2W] > best) { best = my[base + O2W]; arg = 2; }
-                if (my[base + O2W + 1] > best) { best = my[base + O2W + 1]; arg = 3; }
-                const long long o = sn * F + (long long)(hcb + hl) * NP2 + p;
-                a.Q2[o] = act_fwd<ACT>(best);
+                if (my[base + O2W_] > best) { best = my[base + O2W_]; arg = 2; }
+                if (my[base + O2W_ + 1] > best) { best = my[base + O2W_ + 1]; arg = 3; }
+                const long long o = sn * F + (long long)(hcb + hl) * NP2_ + p;
+                a.Q2[o] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
                 a.st2[o] = (uint8_t)(arg | (best > 0.f ? 4 : 0));
             }
         }
+        if (hc0 + WROWS < a.Hc) __syncthreads();                           // the pooling tiles alias the next chunk's first weight tile
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Linear(49*Hc -> C) + softmax: one wave = 16 points of one sample.  D[i = class][j = point] = sum_f Fw[c][f] * Q2[n][f];
+// Linear(NP2*Hc -> C) + softmax: one wave = 16 points of one sample.  D[i = class][j = point] = sum_f Fw[c][f] * Q2[n][f];
 // both operands are read straight from memory, 16 bytes (4 K steps) per lane per load.
 __global__ void __launch_bounds__(256) conv_fc_kernel(const ConvArgs a) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
@@ -163,13 +207,13 @@ __global__ void __launch_bounds__(256) conv_fc_kernel(const ConvArgs a) {
     if (item >= NT * a.S) return;
     const int s = item / NT, n0 = (item % NT) * 16;
     const int sw = a.sidx ? a.sidx[s] : s;
-    const int F = a.Hc * NP2;
+    const int F = a.Hc * a.NP2;
     const int n = min(n0 + li, a.N - 1), c = min(li, a.C - 1);
     const float* const fw = a.Fw + ((long long)sw * a.C + c) * F + 4 * lg;
     const float* const q2 = a.Q2 + ((long long)s * a.N + n) * F + 4 * lg;
     const float cmask = li < a.C ? 1.f : 0.f;
     f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int f = 0; f < F; f += 16) {                                      // F = 49*Hc is a multiple of 16
+    for (int f = 0; f < F; f += 16) {                                      // F = NP2*Hc is a multiple of 16 (Hc is)
         const f32x4 av = *(const f32x4*)(fw + f) * cmask, bv = *(const f32x4*)(q2 + f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) z = MFMA16(av[r], bv[r], z);
@@ -395,10 +439,51 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_split_kernel(const ConvArgs
 
 int validate_conv(const rbnn_conv_posterior* net) {
     if (!net || !net->K1w || !net->K1b || !net->K2w || !net->K2b || !net->Fw || !net->Fb) return RBNN_ERR_NULL;
-    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    if (!((net->in_channels == 1 && net->in_width == 28) || (net->in_channels == 3 && net->in_width == 32))) return RBNN_ERR_UNSUPPORTED;
     if (net->hidden < 16 || (net->hidden & 15) || net->n_classes < 1 || net->n_classes > RBNN_CPAD || net->n_stored < 1) return RBNN_ERR_SHAPE;
     if (!aligned16(net->K2w) || !aligned16(net->K2b) || !aligned16(net->Fw)) return RBNN_ERR_ALIGN;
     return RBNN_OK;
+}
+// the split-half conv kernels: 1x28x28, relu / leaky
+int validate_conv_split(const rbnn_conv_posterior* net) {
+    const int rc = validate_conv(net);
+    if (rc) return rc;
+    if (net->in_channels != 1 || net->in_width != 28) return RBNN_ERR_UNSUPPORTED;
+    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    return RBNN_OK;
+}
+
+// geometry / activation dispatch of the exact kernels: f(Geo{}) / f(integral_constant<int, ACT>{})
+template <class F> int for_geometry(const rbnn_conv_posterior* net, F&& f) {
+    if (net->in_channels == 1 && net->in_width == 28) return f(GeoMnist{});
+    if (net->in_channels == 3 && net->in_width == 32) return f(GeoCifar{});
+    return RBNN_ERR_UNSUPPORTED;
+}
+template <class F> int for_activation(int act, F&& f) {
+    switch (act) {
+        case RBNN_ACT_RELU:  return f(std::integral_constant<int, RBNN_ACT_RELU>{});
+        case RBNN_ACT_LEAKY: return f(std::integral_constant<int, RBNN_ACT_LEAKY>{});
+        case RBNN_ACT_SIGM:  return f(std::integral_constant<int, RBNN_ACT_SIGM>{});
+        case RBNN_ACT_TANH:  return f(std::integral_constant<int, RBNN_ACT_TANH>{});
+    }
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+template <int ACT, class G>
+int launch_conv_forward(const ConvArgs& a, hipStream_t st) {
+    const long long t1 = (long long)a.S * a.N * G::P1SZ;
+    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a);
+    int rc = launch_status();
+    if (rc) return rc;
+    constexpr int LDSB = conv2_lds_floats<G>() * 4;
+    static unsigned long long attr = 0;                                   // per instantiation, one bit per device
+    if (!ensure_dynamic_lds((const void*)conv2_pool_kernel<ACT, G>, LDSB, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv2_pool_kernel<ACT, G>), dim3(grid_for_items((long long)a.N * a.S)), dim3(256), LDSB, st, a);
+    if ((rc = launch_status())) return rc;
+    const int items = ((a.N + 15) / 16) * a.S;
+    hipLaunchKernelGGL(conv_fc_kernel, dim3((items + 3) / 4), dim3(256), 0, st, a);
+    return launch_status();
 }
 
 }  // namespace
@@ -408,16 +493,19 @@ extern "C" {
 int rbnn_conv_workspace_query(const rbnn_conv_posterior* net, int32_t N, int32_t S, rbnn_conv_workspace_sizes* out) {
     if (!net || !out) return RBNN_ERR_NULL;
     if (net->hidden < 16 || (net->hidden & 15) || N < 1 || S < 1) return RBNN_ERR_SHAPE;
-    const size_t SN = (size_t)S * N, F = (size_t)net->hidden * NP2;
-    rbnn_conv_workspace_sizes z = {};
-    z.P = z.dZ = SN * RBNN_CPAD * sizeof(float);
-    z.P1 = SN * (size_t)P1SPLIT;                                  // fp32 image [32][12][12] (18 KiB) or the split image (24 KiB); the backward reuses it for dP1
-    z.st1 = SN * P1SZ;
-    z.Q2 = SN * F * sizeof(float);
-    z.st2 = SN * F;
-    z.G = SN * 784 * sizeof(float);
-    *out = z;
-    return RBNN_OK;
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        const size_t SN = (size_t)S * N, F = (size_t)net->hidden * G::NP2;
+        rbnn_conv_workspace_sizes z = {};
+        z.P = z.dZ = SN * RBNN_CPAD * sizeof(float);
+        z.P1 = SN * (size_t)G::P1STRIDE;                          // the fp32 image [32][P1W][P1W] in whole 1-KiB pieces, or the 24 KiB split image; the backward reuses it for dP1
+        z.st1 = SN * G::P1SZ;
+        z.Q2 = SN * F * sizeof(float);
+        z.st2 = SN * F;
+        z.G = SN * G::DIN * sizeof(float);
+        *out = z;
+        return (int)RBNN_OK;
+    });
 }
 
 int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ldx, int32_t N, const int32_t* sidx, int32_t S,
@@ -425,7 +513,7 @@ int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ld
     int rc = validate_conv(net);
     if (rc) return rc;
     if (!X || !ws || !ws->P || !ws->P1 || !ws->st1 || !ws->Q2 || !ws->st2) return RBNN_ERR_NULL;
-    if (N < 1 || S < 1 || ldx < 784) return RBNN_ERR_SHAPE;
+    if (N < 1 || S < 1 || ldx < net->in_channels * net->in_width * net->in_width) return RBNN_ERR_SHAPE;
     if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
     if (!aligned16(ws->P) || !aligned16(ws->P1) || !aligned16(ws->Q2)) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
@@ -434,25 +522,18 @@ int rbnn_conv_forward(const rbnn_conv_posterior* net, const float* X, int32_t ld
     a.K1w = net->K1w; a.K1b = net->K1b; a.K2w = net->K2w; a.K2b = net->K2b; a.Fw = net->Fw; a.Fb = net->Fb;
     a.Hc = net->hidden; a.C = net->n_classes; a.sidx = sidx; a.S = S;
     a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind;
-    const long long t1 = (long long)S * N * P1SZ;
-    const bool leaky = net->activation == RBNN_ACT_LEAKY;
-    if (leaky) hipLaunchKernelGGL(conv1_pool_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv1_pool_kernel<RBNN_ACT_RELU>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a);
-    if ((rc = launch_status())) return rc;
-    const int grid = grid_for_items((long long)N * S);
-    if (leaky) hipLaunchKernelGGL(conv2_pool_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv2_pool_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
-    if ((rc = launch_status())) return rc;
-    const int items = ((N + 15) / 16) * S;
-    hipLaunchKernelGGL(conv_fc_kernel, dim3((items + 3) / 4), dim3(256), 0, st, a);
-    return launch_status();
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        a.NP2 = G::NP2;
+        return for_activation(net->activation, [&](auto act) { return launch_conv_forward<decltype(act)::value, G>(a, st); });
+    });
 }
 
 int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows, int32_t k2_exp, int32_t p1_exp,
                             const rbnn_dev_scale* p1_dev_scale, const float* X,
                             int32_t ldx, int32_t N, const int32_t* sidx, int32_t S, int32_t out_kind,
                             const rbnn_conv_workspace* ws, void* stream) {
-    int rc = validate_conv(net);
+    int rc = validate_conv_split(net);
     if (rc) return rc;
     if (!K2_rows || !X || !ws || !ws->P || !ws->P1 || !ws->st1 || !ws->Q2 || !ws->st2) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || ldx < 784 || k2_exp < -100 || k2_exp > 100 || p1_exp < -100 || p1_exp > 100) return RBNN_ERR_SHAPE;
@@ -463,7 +544,7 @@ int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows,
     a.X = X; a.ldx = ldx; a.N = N;
     a.K1w = net->K1w; a.K1b = net->K1b; a.K2w = net->K2w; a.K2b = net->K2b; a.Fw = net->Fw; a.Fb = net->Fb;
     a.Hc = net->hidden; a.C = net->n_classes; a.sidx = sidx; a.S = S;
-    a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind;
+    a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind; a.NP2 = NP2;
     ConvSplitArgs sp = {};
     sp.K2r = (const char*)K2_rows; sp.k2_exp = k2_exp; sp.p1_exp = p1_exp; sp.p1_ds = p1_dev_scale; sp.P1s = (char*)ws->P1;   // ws->P1 holds 24 KiB per (s, n)
     const long long t1 = (long long)S * N * (P1W * P1W);
@@ -508,16 +589,19 @@ struct ConvBwdArgs {
     const float* dZ; const uint8_t* st1; const uint8_t* st2;
     const float* K1w; const float* K2cb; const float* Fw;
     int Hc; int C; int N; int S; const int* sidx;
-    float* dQ2;                                                          // [S][N][Hc*49] dL/d(pooled conv2 output) = dZ . Fw: aliases the forward's Q2
-    float* dP1;                                                          // [S][N][4608] dL/d(pooled conv1 output): aliases the forward's P1
-    float* G;                                                            // [S][N][784]
+    float* dQ2;                                                          // [S][N][Hc*NP2] dL/d(pooled conv2 output) = dZ . Fw: aliases the forward's Q2
+    float* dP1;                                                          // [S][N][P1SZ] dL/d(pooled conv1 output): aliases the forward's P1
+    float* G;                                                            // [S][N][DIN]
+    int NP2;                                                             // pooled conv2 positions per channel (conv_fc_bwd is geometry-agnostic)
 };
 
 // Linear^T on the matrix pipe: dQ2[n][f] = sum_c dZ[n][c] * Fw[c][f].  One wave = 16 points x 64 features (4 MFMA tiles,
-// K = 16 padded classes); Fw is read once per 16 points.
+// K = 16 padded classes); Fw is read once per 16 points.  SMOOTH (sigmoid / tanh): the result overwrites the forward's Q2 in
+// place, element by element, so act'(Q2) is taken from the value about to be overwritten and folded in here.
+template <bool SMOOTH, int ACT>
 __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
-    const int F = a.Hc * NP2, FT = (F + 63) / 64, NT = (a.N + 15) / 16;
+    const int F = a.Hc * a.NP2, FT = (F + 63) / 64, NT = (a.N + 15) / 16;
     const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= (long long)a.S * NT * FT) return;
     const int ft = (int)(item % FT), nt = (int)((item / FT) % NT), s = (int)(item / ((long long)FT * NT));
@@ -526,7 +610,7 @@ __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
     const f32x4 av = *(const f32x4*)(a.dZ + ((long long)s * a.N + n) * RBNN_CPAD + 4 * lg);     // A[i = n][k = lg] for K step r: class 4lg + r
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int f = ft * 64 + q * 16 + li;                                                  // F = 49*Hc is a multiple of 16
+        const int f = ft * 64 + q * 16 + li;                                                  // F = NP2*Hc is a multiple of 16
         if (ft * 64 + q * 16 >= F) break;
         f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -538,17 +622,24 @@ __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                                                         // d[r] = dQ2[n = 16nt + 4lg + r][f]
             const int nn = nt * 16 + 4 * lg + r;
-            if (nn < a.N) a.dQ2[((long long)s * a.N + nn) * F + f] = d[r];
+            if (nn < a.N) {
+                float* const dst = a.dQ2 + ((long long)s * a.N + nn) * F + f;
+                *dst = SMOOTH ? d[r] * act_grad_from_value<ACT>(*dst) : d[r];
+            }
         }
     }
 }
 
-template <int ACT>
+template <class G> constexpr int conv_bwd_lds_floats() { return 4 * 16 * G::PITCH * G::PITCH; }
+
+template <int ACT, class G>
 __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
-    constexpr int HCH = 16, IMG = HCH * 256, KCH = HCH * 25, NPT = 9;    // channels per chunk; image floats; K per chunk; 144/16 position tiles
-    __shared__ __attribute__((aligned(16))) float lds[4 * IMG];
+    constexpr int HCH = 16, PITCH = G::PITCH, CHS = PITCH * PITCH, IMG = HCH * CHS, KCH = HCH * 25, NPT = G::NPT1;
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS;
+    // channels per chunk; image pitch (gradient map + border 4); floats per channel / per wave image; K per chunk; position tiles of dP1
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 * IMG floats (1x28x28: 64 KiB, 3x32x32: 81 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    float* const img = lds + wave * IMG;                                 // this wave's zero-padded gradient image [16 hc][16][16]
+    float* const img = lds + wave * IMG;                                 // this wave's zero-padded gradient image [16 hc][PITCH][PITCH]
 
     const int NB = (a.N + 3) / 4;                                        // blocks per sample
     int id;
@@ -557,14 +648,17 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
     const int sw = a.sidx ? a.sidx[s] : s;
     if (n >= a.N) return;                                                // whole wave idle (ragged last block); no block barrier anywhere
     const long long sn = (long long)s * a.N + n;
-    const int F = a.Hc * NP2, KW = a.Hc * 25;
+    const int F = a.Hc * NP2_, KW = a.Hc * 25;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
 
     // K order inside a chunk is TAP-major: k = t*16 + hl, so one K tile = one tap (ky,kx) x 16 channels, and
-    // B[k = lg][j = li] of step r is img[(4lg + r)*256 + (Y - ky + 4)*16 + (X - kx + 4)].
+    // B[k = lg][j = li] of step r is img[(4lg + r)*CHS + (Y - ky + 4)*PITCH + (X - kx + 4)].
     int poff[NPT];
 #pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) { const int pos = pt * 16 + li; poff[pt] = (4 * lg) * 256 + (pos / P1W + 4) * 16 + pos % P1W + 4; }
+    for (int pt = 0; pt < NPT; ++pt) {                                   // positions past P1W^2 (ragged last tile): any valid offset, never stored
+        const int pos = min(pt * 16 + li, P1W_ * P1W_ - 1);
+        poff[pt] = (4 * lg) * CHS + (pos / P1W_ + 4) * PITCH + pos % P1W_ + 4;
+    }
     const float* const Wr0 = a.K2cb + ((long long)sw * C1 + li) * KW + 4 * lg;          // ci = li; [ci][chunk][tap][16 hl]
     const float* const Wr1 = Wr0 + (long long)16 * KW;                                   // ci = 16 + li
 
@@ -575,41 +669,52 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
         for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int i = lane; i < IMG / 4; i += 64) *(f32x4*)(img + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // the border stays zero
-    const int gy = lane >> 3, gx = lane & 7;                             // this lane's position (y, x) in the 8x8 gradient map
+    // this lane's positions (y, x) of the O2W x O2W gradient map: lane, lane + 64, ...
+    constexpr int NGP = (NPOS_ + 63) / 64;
     // the <= 4 stride-1 pooling windows (py,px) in {y-1,y} x {x-1,x} that contain (y,x); window q = 2dy+dx has (y,x) as its
     // element q, so it routes here iff its stashed argmax == q
-    int woff[4];
-    bool wok[4];
+    int woff[NGP][4], goff[NGP];
+    bool wok[NGP][4], gok[NGP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int py = gy - (q >> 1), px = gx - (q & 1);
-        wok[q] = py >= 0 && py < P2W && px >= 0 && px < P2W;
-        woff[q] = wok[q] ? py * P2W + px : 0;
+    for (int g = 0; g < NGP; ++g) {
+        const int gp = lane + 64 * g, gy = gp / O2W_, gx = gp % O2W_;
+        gok[g] = gp < NPOS_;
+        goff[g] = gok[g] ? (gy + 4) * PITCH + gx + 4 : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int py = gy - (q >> 1), px = gx - (q & 1);
+            wok[g][q] = gok[g] && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+            woff[g][q] = wok[g][q] ? py * P2W_ + px : 0;
+        }
     }
     for (int hc0 = 0; hc0 < a.Hc; hc0 += HCH) {
         // 1. interior of the padded image for channels hc0 .. hc0+15: pool-2 routing + activation derivative, gather form;
         //    loads are unconditional and batched 4 channels at a time (32 independent loads in flight)
+#pragma unroll
+        for (int g = 0; g < NGP; ++g) {
 #pragma unroll 1
-        for (int h4 = 0; h4 < HCH; h4 += 4) {
-            int st[4][4];
-            float dq[4][4];
+            for (int h4 = 0; h4 < HCH; h4 += 4) {
+                int st[4][4];
+                float dq[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long long fb = sn * F + (long long)min(hc0 + h4 + j, a.Hc - 1) * NP2;
+                for (int j = 0; j < 4; ++j) {
+                    const long long fb = sn * F + (long long)min(hc0 + h4 + j, a.Hc - 1) * NP2_;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { st[j][q] = a.st2[fb + woff[q]]; dq[j][q] = a.dQ2[fb + woff[q]]; }
-            }
+                    for (int q = 0; q < 4; ++q) { st[j][q] = a.st2[fb + woff[g][q]]; dq[j][q] = a.dQ2[fb + woff[g][q]]; }
+                }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (wok[q] && (st[j][q] & 3) == q) v += (st[j][q] & 4) ? dq[j][q] : dq[j][q] * slope;
-                img[(h4 + j) * 256 + (gy + 4) * 16 + gx + 4] = (hc0 + h4 + j < a.Hc) ? v : 0.f;
+                    for (int q = 0; q < 4; ++q)
+                        if (wok[g][q] && (st[j][q] & 3) == q)             // smooth activations: act' is already folded into dQ2
+                            v += (smooth_act<ACT>() || (st[j][q] & 4)) ? dq[j][q] : dq[j][q] * slope;
+                    if (gok[g]) img[(h4 + j) * CHS + goff[g]] = (hc0 + h4 + j < a.Hc) ? v : 0.f;
+                }
             }
         }
-        // 2. 25 K tiles = 25 taps x 16 channels.  A position tile spans rows Ya..Yb of the 12x12 output; tap row ky reaches it
-        //    only if some Y - ky lies in 0..7: the others multiply pure padding and are skipped (27 % of the MFMAs).
+        // 2. 25 K tiles = 25 taps x 16 channels.  A position tile spans rows Ya..Yb of the P1W x P1W output; tap row ky reaches it
+        //    only if some Y - ky lies in 0..O2W-1: the others multiply pure padding and are skipped (27 % of the MFMAs at 1x28x28).
         const float* const w0 = Wr0 + (long long)(hc0 / HCH) * KCH;
         const float* const w1 = Wr1 + (long long)(hc0 / HCH) * KCH;
         f32x4 a0 = *(const f32x4*)w0, a1 = *(const f32x4*)w1;
@@ -617,14 +722,14 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
         for (int t = 0; t < 25; ++t) {
             const f32x4 c0 = a0, c1 = a1;
             if (t + 1 < 25) { a0 = *(const f32x4*)(w0 + 16 * (t + 1)); a1 = *(const f32x4*)(w1 + 16 * (t + 1)); }
-            const int ky = t / 5, toff = ky * 16 + t % 5;                // image offset is poff - toff (scalar)
+            const int ky = t / 5, toff = ky * PITCH + t % 5;             // image offset is poff - toff (scalar)
             const float* const src = img - toff;
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
-                constexpr int dummy = 0; (void)dummy;
-                const int Ya = (16 * pt) / P1W, Yb = (16 * pt + 15) / P1W;
-                if (ky < Ya - 7 || ky > Yb) continue;                    // wave-uniform
-                const f32x4 b = (f32x4){src[poff[pt]], src[poff[pt] + 256], src[poff[pt] + 512], src[poff[pt] + 768]};
+                constexpr int last = P1W_ * P1W_ - 1;
+                const int Ya = (16 * pt) / P1W_, Yb = min(16 * pt + 15, last) / P1W_;
+                if (ky < Ya - (O2W_ - 1) || ky > Yb) continue;           // wave-uniform
+                const f32x4 b = (f32x4){src[poff[pt]], src[poff[pt] + CHS], src[poff[pt] + 2 * CHS], src[poff[pt] + 3 * CHS]};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[0][pt] = MFMA16(c0[r], b[r], acc[0][pt]);
@@ -633,15 +738,20 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
             }
         }
     }
-    // 3. acc[ct][pt][r] = dL/dP1[ci = 16ct + 4lg + r][pos = 16pt + li] -> memory (the forward's P1 buffer is dead by now);
-    //    conv1_bwd_kernel finishes the path.  (An in-kernel scatter of the 25 conv1 taps needs LDS float atomics, which
-    //    cost ~250 cycles per wave instruction: measured, they made the LDS the bottleneck of this kernel.)
+    // 3. acc[ct][pt][r] = dL/dP1[ci = 16ct + 4lg + r][pos = 16pt + li] -> memory, over the forward's P1 (dead after this read:
+    //    for sigmoid / tanh the activation value at the same index gives act', folded in here); conv1_bwd finishes the path.
+    //    (An in-kernel scatter of the 25 conv1 taps needs LDS float atomics, which cost ~250 cycles per wave instruction:
+    //    measured, they made the LDS the bottleneck of this kernel.)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.dP1[sn * P1SZ + (16 * ct + 4 * lg + r) * (P1W * P1W) + 16 * pt + li] = acc[ct][pt][r];
+            for (int r = 0; r < 4; ++r) {
+                if (16 * pt + li >= P1W_ * P1W_) continue;
+                float* const dst = a.dP1 + sn * G::P1SZ + (16 * ct + 4 * lg + r) * (P1W_ * P1W_) + 16 * pt + li;
+                *dst = smooth_act<ACT>() ? acc[ct][pt][r] * act_grad_from_value<ACT>(*dst) : acc[ct][pt][r];
+            }
 }
 
 // conv2^T in split-half precision: conv_bwd_kernel's structure (one wave = one (sample, point), no block barriers, the whole
@@ -800,36 +910,37 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
 // A pooled cell (c, py, px) routes its gradient to ONE conv1 output (Ya, Xa) = (2py + arg/2, 2px + arg%2); that output
 // touches pixel (Yo, Xo) through tap (Yo - Ya, Xo - Xa) if it lies in the 5x5 kernel.  Only cells with
 // py in [(Yo-4)/2, Yo/2], px likewise can qualify: at most 3 x 3 per channel.
-template <int ACT>
+template <int ACT, class G>
 __global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
-    // one block = one (sample, point): its 4608 pooled gradients (activation derivative and argmax position folded in)
-    // and the sample's 32x25 conv1 weights go to LDS once; each thread then gathers ~3 of the 784 pixels
-    __shared__ float gs[P1SZ];
-    __shared__ unsigned char as[P1SZ];
-    __shared__ float ws[C1 * 25];
+    // one block = one (sample, point): its P1SZ pooled gradients (activation derivative and argmax position folded in)
+    // and the sample's 32 x Cin x 25 conv1 weights go to LDS once; each thread then gathers some of the DIN input pixels
+    constexpr int P1W_ = G::P1W, IW = G::IW;
+    __shared__ float gs[G::P1SZ];
+    __shared__ unsigned char as[G::P1SZ];
+    __shared__ float ws[C1 * G::K1];
     const long long sn = blockIdx.x;
     const int s = (int)(sn / a.N), sw = a.sidx ? a.sidx[s] : s, tid = threadIdx.x;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
-    for (int e = tid; e < P1SZ; e += 256) {
-        const int st = a.st1[sn * P1SZ + e];
-        const float d = a.dP1[sn * P1SZ + e];
-        gs[e] = (st & 4) ? d : d * slope;
+    for (int e = tid; e < G::P1SZ; e += 256) {
+        const int st = a.st1[sn * G::P1SZ + e];
+        const float d = a.dP1[sn * G::P1SZ + e];
+        gs[e] = (smooth_act<ACT>() || (st & 4)) ? d : d * slope;          // smooth activations: act' was folded in by conv_bwd
         as[e] = (unsigned char)(st & 3);
     }
-    for (int e = tid; e < C1 * 25; e += 256) ws[e] = a.K1w[(long long)sw * C1 * 25 + e];
+    for (int e = tid; e < C1 * G::K1; e += 256) ws[e] = a.K1w[(long long)sw * C1 * G::K1 + e];
     __syncthreads();
-    for (int pix = tid; pix < 784; pix += 256) {
-        const int Yo = pix / 28, Xo = pix % 28;
-        const int py0 = max(0, (Yo - 4) >> 1), py1 = min(P1W - 1, Yo >> 1), px0 = max(0, (Xo - 4) >> 1), px1 = min(P1W - 1, Xo >> 1);
+    for (int pix = tid; pix < G::DIN; pix += 256) {
+        const int ci = pix / (IW * IW), Yo = (pix / IW) % IW, Xo = pix % IW;
+        const int py0 = max(0, (Yo - 4) >> 1), py1 = min(P1W_ - 1, Yo >> 1), px0 = max(0, (Xo - 4) >> 1), px1 = min(P1W_ - 1, Xo >> 1);
         float g = 0.f;
         for (int c = 0; c < C1; ++c)
             for (int py = py0; py <= py1; ++py)
                 for (int px = px0; px <= px1; ++px) {
-                    const int e = c * (P1W * P1W) + py * P1W + px, arg = as[e];
+                    const int e = c * (P1W_ * P1W_) + py * P1W_ + px, arg = as[e];
                     const int ky = Yo - (2 * py + (arg >> 1)), kx = Xo - (2 * px + (arg & 1));
-                    if (ky >= 0 && ky < 5 && kx >= 0 && kx < 5) g = fmaf(gs[e], ws[c * 25 + ky * 5 + kx], g);
+                    if (ky >= 0 && ky < 5 && kx >= 0 && kx < 5) g = fmaf(gs[e], ws[(c * G::CIN + ci) * 25 + ky * 5 + kx], g);
                 }
-        a.G[sn * 784 + pix] = g;
+        a.G[sn * G::DIN + pix] = g;
     }
 }
 
@@ -897,7 +1008,7 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
                     const long long e = sn * P1SZ + c * (P1W * P1W) + py * P1W + min(Xa >> 1, P1W - 1);
                     const int st = a.st1[e];
                     const float d = a.dP1[e];
-                    gv[pt][kb][r] = (Xa < 24) ? ((st & 4) ? d : d * slope) : 0.f;
+                    gv[pt][kb][r] = (Xa < 24) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
                     ar[pt][kb][r] = (st & 3) ^ (Xa & 1);                 // == 2*half for the row half that owns the argmax, with the right column parity
                 }
 #pragma unroll
@@ -936,6 +1047,38 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
     for (int Y = 24; Y < 28; ++Y) emit_row(Y);
 }
 
+// conv1^T: the matrix-pipe kernel is built for one input channel and 24-wide rows (1x28x28); other geometries take the VALU gather
+template <int ACT, class G>
+int launch_conv1_backward(const ConvBwdArgs& a, hipStream_t st) {
+#ifndef RBNN_CONV1_BWD_VALU
+    if constexpr (std::is_same<G, GeoMnist>::value) {
+        hipLaunchKernelGGL(conv1_bwd_mfma_kernel<ACT>, dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
+        return launch_status();
+    }
+#endif
+    hipLaunchKernelGGL((conv1_bwd_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(256), 0, st, a);
+    return launch_status();
+}
+
+}  // namespace
+
+namespace {
+template <int ACT, class G>
+int launch_conv_backward(const ConvBwdArgs& a, hipStream_t st) {
+    int rc;
+    {
+        const long long F = (long long)a.Hc * G::NP2, items = (long long)a.S * ((a.N + 15) / 16) * ((F + 63) / 64);
+        hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+        if ((rc = launch_status())) return rc;
+    }
+    const int grid = grid_for_items((long long)((a.N + 3) / 4) * a.S);
+    constexpr int LDSB = conv_bwd_lds_floats<G>() * 4;
+    static unsigned long long attr = 0;
+    if (!ensure_dynamic_lds((const void*)conv_bwd_kernel<ACT, G>, LDSB, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_bwd_kernel<ACT, G>), dim3(grid), dim3(256), LDSB, st, a);
+    if ((rc = launch_status())) return rc;
+    return launch_conv1_backward<ACT, G>(a, st);
+}
 }  // namespace
 
 extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_t* sidx, int32_t S, int32_t N,
@@ -948,54 +1091,35 @@ extern "C" int rbnn_conv_input_grad(const rbnn_conv_posterior* net, const int32_
     ConvBwdArgs a = {};
     a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = net->K2w_ci; a.Fw = net->Fw;
     a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
-    const int grid = grid_for_items((long long)((N + 3) / 4) * S);
-    const bool leaky = net->activation == RBNN_ACT_LEAKY;
     hipStream_t st = (hipStream_t)stream;
-    {
-        const long long F = (long long)net->hidden * NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
-        hipLaunchKernelGGL(conv_fc_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
-        if ((rc = launch_status())) return rc;
-    }
-    if (leaky) hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv_bwd_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
-    if ((rc = launch_status())) return rc;
-#ifdef RBNN_CONV1_BWD_VALU
-    if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
-#else
-    if (leaky) hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
-#endif
-    return launch_status();
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        a.NP2 = G::NP2;
+        return for_activation(net->activation, [&](auto act) { return launch_conv_backward<decltype(act)::value, G>(a, st); });
+    });
 }
 
 extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const void* K2_bwd, int32_t k2_exp, float fw_l1,
                                           const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
-    int rc = validate_conv(net);
+    int rc = validate_conv_split(net);
     if (rc) return rc;
     if (!K2_bwd || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
     if (!aligned16(K2_bwd) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
     ConvBwdArgs a = {};
     a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = nullptr; a.Fw = net->Fw;
-    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G; a.NP2 = NP2;
     const int grid = grid_for_items((long long)((N + 3) / 4) * S);
     const bool leaky = net->activation == RBNN_ACT_LEAKY;
     hipStream_t st = (hipStream_t)stream;
     {
         const long long F = (long long)net->hidden * NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
-        hipLaunchKernelGGL(conv_fc_bwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_fc_bwd_kernel<false, RBNN_ACT_LEAKY>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
         if ((rc = launch_status())) return rc;
     }
     if (leaky) hipLaunchKernelGGL(conv_bwd_split_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
     else       hipLaunchKernelGGL(conv_bwd_split_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
     if ((rc = launch_status())) return rc;
-#ifdef RBNN_CONV1_BWD_VALU
-    if (leaky) hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_LEAKY>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv1_bwd_kernel<RBNN_ACT_RELU>, dim3((unsigned)((long long)S * N)), dim3(256), 0, st, a);
-#else
-    if (leaky) hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_LEAKY>, dim3(grid), dim3(256), 0, st, a);
-    else       hipLaunchKernelGGL(conv1_bwd_mfma_kernel<RBNN_ACT_RELU>, dim3(grid), dim3(256), 0, st, a);
-#endif
-    return launch_status();
+    if (leaky) return launch_conv1_backward<RBNN_ACT_LEAKY, GeoMnist>(a, st);
+    return launch_conv1_backward<RBNN_ACT_RELU, GeoMnist>(a, st);
 }

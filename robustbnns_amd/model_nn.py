@@ -20,6 +20,12 @@ saved_NNs = {"model_0": {"dataset": "mnist", "hidden_size": 512, "activation": "
              "model_8": {"dataset": "mnist", "hidden_size": 1024, "activation": "leaky", "architecture": "fc2", "epochs": 10, "lr": 0.02},
              "model_9": {"dataset": "mnist", "hidden_size": 1024, "activation": "leaky", "architecture": "conv", "epochs": 10, "lr": 0.01}}
 
+
+def cifar_conv_enabled():
+    """Opt-in (RBNN_CIFAR_CONV=1): the build-defined CIFAR-shaped conv net; the reference raises NotImplementedError (model_nn.py:95-96)."""
+    return os.environ.get("RBNN_CIFAR_CONV", "0") == "1"
+
+
 _ACTIV = {"relu": nn.ReLU, "leaky": nn.LeakyReLU, "sigm": nn.Sigmoid, "tanh": nn.Tanh}
 
 
@@ -60,12 +66,18 @@ class NN(nn.Module):
                                        nn.Linear(hidden_size, hidden_size), activ(),
                                        nn.Linear(hidden_size, output_size))
         elif architecture == "conv":
+            if self.dataset_name not in ["mnist", "fashion_mnist"] and not cifar_conv_enabled():
+                raise NotImplementedError()                            # model_nn.py:95-96
+            # model_nn.py:106 sizes the head as int(hidden/16) * input_size, which equals the flattened conv output only for
+            # 28x28 inputs (49 * hidden).  With RBNN_CIFAR_CONV=1 (BASELINE.json configs[4]; no working reference counterpart,
+            # SURVEY 8a note) other datasets get the BUILD-DEFINED correctly sized head instead: ((W-4)/2 - 5)^2 * hidden.
+            head = int(hidden_size / (4 * 4)) * input_size
             if self.dataset_name not in ["mnist", "fashion_mnist"]:
-                raise NotImplementedError()
+                head = (((input_shape[1] - 4) // 2) - 5) ** 2 * hidden_size
             self.model = nn.Sequential(nn.Conv2d(in_channels, 32, kernel_size=5), activ(), nn.MaxPool2d(kernel_size=2),
                                        nn.Conv2d(32, hidden_size, kernel_size=5), activ(),
                                        nn.MaxPool2d(kernel_size=2, stride=1), nn.Flatten(),
-                                       nn.Linear(int(hidden_size / (4 * 4)) * input_size, output_size))
+                                       nn.Linear(head, output_size))
         else:
             raise NotImplementedError()
 

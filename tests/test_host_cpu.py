@@ -373,13 +373,26 @@ def test_conv_posterior_layout_and_roundtrip(golden):
     assert all(torch.equal(sd[k], post[k][0]) for k in sd)
     d = sp.descriptor()
     assert (d.activation, d.hidden, d.n_classes, d.n_stored) == (1, 16, 10, 2)
+    assert (d.in_channels, d.in_width) == (1, 28)
     with pytest.raises(NotImplementedError):
-        ConvStackedPosterior("leaky", (3, 32, 32), 10, 16, post, "cpu")          # model_nn.py:95-96
+        ConvStackedPosterior("leaky", (1, 32, 32), 10, 16, post, "cpu")          # only the two built geometries
     lib = _hip.load()
     out = _hip.ConvWorkspaceSizes()
     assert lib.rbnn_conv_workspace_query(C.byref(d), 100, 3, C.byref(out)) == 0
     assert out.P1 == 3 * 100 * 24576 and out.st1 == 3 * 100 * 4608 and out.Q2 == 3 * 100 * 16 * 49 * 4 and out.G == 3 * 100 * 784 * 4
     assert lib.rbnn_conv_forward(C.byref(d), None, 784, 4, None, 2, 0, None, None) == -1
+    # the CIFAR-shaped geometry (BASELINE.json configs[4]; build-defined head 81 * Hc): layout and workspace sizes
+    cif = O.synthetic_posterior("conv", 3 * 32 * 32, 16, 10, 2, 0.05, in_ch=3, head=81 * 16)
+    sc = ConvStackedPosterior("tanh", (3, 32, 32), 10, 16, cif, "cpu")
+    assert sc.K1w.shape == (2, 32, 75) and sc.Fw.shape == (2, 10, 81 * 16) and (sc.P1W, sc.P2W, sc.NP2, sc.D) == (14, 9, 81, 3072)
+    assert not sc.split_supported()
+    dc = sc.descriptor()
+    assert (dc.activation, dc.in_channels, dc.in_width) == (3, 3, 32)
+    assert lib.rbnn_conv_workspace_query(C.byref(dc), 10, 2, C.byref(out)) == 0
+    assert out.P1 == 20 * 25600 and out.st1 == 20 * 6272 and out.Q2 == 20 * 16 * 81 * 4 and out.st2 == 20 * 16 * 81 and out.G == 20 * 3072 * 4
+    assert lib.rbnn_conv_forward(C.byref(dc), C.c_void_p(16), 784, 4, None, 2, 0, C.byref(_hip.ConvWorkspace()), None) == -1
+    dc.in_width = 30
+    assert lib.rbnn_conv_workspace_query(C.byref(dc), 10, 2, C.byref(out)) == -3      # unsupported geometry
     bnn = model_bnn.BNN("mnist", 16, "leaky", "conv", "hmc", None, None, 2, 0, (1, 28, 28), 10)
     bnn.set_posterior_samples(post, "cpu")
     assert type(bnn._engine).__name__ == "ConvEngine" and bnn.posterior.S == 2
