@@ -50,43 +50,61 @@ struct ConvArgs {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// One block = one (sample, point): the sample's 32 x Cin x 25 weights and the point's image go to LDS once, then one thread per
+// pooled POSITION keeps its Cin x 6 x 6 input patch in registers and runs all 32 output channels over it (weights are LDS
+// broadcasts: ~16 FMAs per LDS read).  The first version (one thread per pooled output, patch and weights re-read from memory
+// by every thread: 1.6 FMAs per load) took 7.9 ms per pass at the CIFAR-shaped c5 bench.  Same accumulation order
+// (input channel, ky, kx), so the results are bit-identical to it.
 template <int ACT, class G>
 __global__ void __launch_bounds__(256) conv1_pool_kernel(const ConvArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one thread per pooled output (s, n, c, py, px)
-    if (i >= (long long)a.S * a.N * G::P1SZ) return;
-    const int e = (int)(i % G::P1SZ), c = e / (G::P1W * G::P1W), py = (e / G::P1W) % G::P1W, px = e % G::P1W;
-    const long long sn = i / G::P1SZ;
-    const int n = (int)(sn % a.N), s = (int)(sn / a.N);
+    constexpr int NPP = G::P1W * G::P1W, IW = G::IW;
+    static_assert(NPP <= 256, "one thread per pooled position");
+    __shared__ float wsh[C1 * G::K1];                                     // [c][ci*25 + ky*5 + kx]
+    __shared__ float xsh[G::DIN];
+    const long long sn = blockIdx.x;
+    const int n = (int)(sn % a.N), s = (int)(sn / a.N), tid = threadIdx.x;
     const int sw = a.sidx ? a.sidx[s] : s;
-    const float* const w = a.K1w + ((long long)sw * C1 + c) * G::K1;
-    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < C1 * G::K1; e += 256) wsh[e] = a.K1w[(long long)sw * C1 * G::K1 + e];
+    for (int e = tid; e < G::DIN; e += 256) xsh[e] = a.X[(long long)n * a.ldx + e];
+    __syncthreads();
+    if (tid >= NPP) return;
+    const int py = tid / G::P1W, px = tid % G::P1W;
+    float patch[G::CIN][6][6];
 #pragma unroll
-    for (int ci = 0; ci < G::CIN; ++ci) {                                 // channel-major accumulation, taps in (ky, kx) order
-        const float* const x = a.X + (long long)n * a.ldx + ci * (G::IW * G::IW) + (2 * py) * G::IW + 2 * px;
-        float patch[6][6];
+    for (int ci = 0; ci < G::CIN; ++ci)
 #pragma unroll
         for (int y = 0; y < 6; ++y)
 #pragma unroll
-            for (int xx = 0; xx < 6; ++xx) patch[y][xx] = x[y * G::IW + xx];
+            for (int xx = 0; xx < 6; ++xx) patch[ci][y][xx] = xsh[ci * (IW * IW) + (2 * py + y) * IW + 2 * px + xx];
+    float* const p1 = a.P1 + sn * G::P1SZ + tid;                         // dense [S][N][32][P1W][P1W]
+    uint8_t* const st = a.st1 + sn * G::P1SZ + tid;
+#pragma unroll 1
+    for (int c = 0; c < C1; ++c) {
+        const float* const w = wsh + c * G::K1;
+        float v4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+        for (int ci = 0; ci < G::CIN; ++ci)                               // channel-major accumulation, taps in (ky, kx) order
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
+            for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 5; ++ky)
+                for (int kx = 0; kx < 5; ++kx) {
+                    const float wk = w[ci * 25 + ky * 5 + kx];
 #pragma unroll
-                    for (int kx = 0; kx < 5; ++kx) v4[dy * 2 + dx] = fmaf(w[ci * 25 + ky * 5 + kx], patch[dy + ky][dx + kx], v4[dy * 2 + dx]);
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) v4[dy * 2 + dx] = fmaf(wk, patch[ci][dy + ky][dx + kx], v4[dy * 2 + dx]);
+                }
+        const float b = a.K1b[(long long)sw * C1 + c];
+        float best = 0.f, best_pre = 0.f;
+        int arg = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float pre = v4[q] + b, v = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+            if (q == 0 || v > best) { best = v; best_pre = pre; arg = q; }   // first maximum wins (torch max_pool2d)
+        }
+        p1[c * NPP] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
+        st[c * NPP] = (uint8_t)(arg | (best_pre > 0.f ? 4 : 0));
     }
-    const float b = a.K1b[(long long)sw * C1 + c];
-    float best = 0.f, best_pre = 0.f;
-    int arg = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float pre = v4[q] + b, v = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
-        if (q == 0 || v > best) { best = v; best_pre = pre; arg = q; }   // first maximum wins (torch max_pool2d)
-    }
-    a.P1[i] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);          // dense [S][N][P1SZ]
-    a.st1[i] = (uint8_t)(arg | (best_pre > 0.f ? 4 : 0));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -212,12 +230,27 @@ __global__ void __launch_bounds__(256) conv_fc_kernel(const ConvArgs a) {
     const float* const fw = a.Fw + ((long long)sw * a.C + c) * F + 4 * lg;
     const float* const q2 = a.Q2 + ((long long)s * a.N + n) * F + 4 * lg;
     const float cmask = li < a.C ? 1.f : 0.f;
-    f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int f = 0; f < F; f += 16) {                                      // F = NP2*Hc is a multiple of 16 (Hc is)
+    // F = NP2*Hc is a multiple of 16 (Hc is).  Four interleaved accumulation chains: back-to-back MFMAs on ONE accumulator would
+    // serialise on its latency, and a single fp32 chain over K = 25 088 .. 82 944 terms also carries 2x the rounding error.
+    f32x4 zq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int f = 0;
+    for (; f + 64 <= F; f += 64) {
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = *(const f32x4*)(fw + f + 16 * q) * cmask; bv[q] = *(const f32x4*)(q2 + f + 16 * q); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zq[q] = MFMA16(av[q][r], bv[q][r], zq[q]);
+    }
+    for (; f < F; f += 16) {
         const f32x4 av = *(const f32x4*)(fw + f) * cmask, bv = *(const f32x4*)(q2 + f);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) z = MFMA16(av[r], bv[r], z);
+        for (int r = 0; r < 4; ++r) zq[0] = MFMA16(av[r], bv[r], zq[0]);
     }
+    f32x4 z = (zq[0] + zq[1]) + (zq[2] + zq[3]);
     // lane (point li, lg) holds classes 4*lg + r
     float m = -INFINITY;
 #pragma unroll
@@ -472,8 +505,7 @@ template <class F> int for_activation(int act, F&& f) {
 
 template <int ACT, class G>
 int launch_conv_forward(const ConvArgs& a, hipStream_t st) {
-    const long long t1 = (long long)a.S * a.N * G::P1SZ;
-    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(256), 0, st, a);
     int rc = launch_status();
     if (rc) return rc;
     constexpr int LDSB = conv2_lds_floats<G>() * 4;
@@ -630,16 +662,22 @@ __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
     }
 }
 
-template <class G> constexpr int conv_bwd_lds_floats() { return 4 * 16 * G::PITCH * G::PITCH; }
+// zero-padded gradient image of one wave: 16 channels of (O2W data rows + 4 border rows) x PITCH, the 4 zero rows BELOW channel c
+// doubling as the 4 zero rows ABOVE channel c+1 (plus 4 rows above channel 0): the gather only ever reaches 4 rows past a
+// channel's data.  1x28x28: 12.3 KiB per wave (49 KiB per block, three blocks per CU), 3x32x32: 16 KiB (64 KiB, two).
+template <class G> constexpr int conv_bwd_img_floats() { return 16 * (G::O2W + 4) * G::PITCH + 4 * G::PITCH; }
+template <class G> constexpr int conv_bwd_lds_floats() { return 4 * conv_bwd_img_floats<G>(); }
 
 template <int ACT, class G>
 __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
-    constexpr int HCH = 16, PITCH = G::PITCH, CHS = PITCH * PITCH, IMG = HCH * CHS, KCH = HCH * 25, NPT = G::NPT1;
+    constexpr int HCH = 16, PITCH = G::PITCH, CHS = (G::O2W + 4) * PITCH, IMG = conv_bwd_img_floats<G>(), KCH = HCH * 25, NPT = G::NPT1;
     constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS;
-    // channels per chunk; image pitch (gradient map + border 4); floats per channel / per wave image; K per chunk; position tiles of dP1
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 * IMG floats (1x28x28: 64 KiB, 3x32x32: 81 KiB)
+    // channels per chunk; image pitch (gradient map + border 4); floats per channel (data rows + one shared border); floats per
+    // wave image; K per chunk; position tiles of dP1
+    static_assert(IMG % 4 == 0, "the image is cleared with 16-byte stores");
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 * IMG floats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    float* const img = lds + wave * IMG;                                 // this wave's zero-padded gradient image [16 hc][PITCH][PITCH]
+    float* const img = lds + wave * IMG + 4 * PITCH;                     // row 0 of channel 0 (4 zero rows above it); channel c at + c*CHS
 
     const int NB = (a.N + 3) / 4;                                        // blocks per sample
     int id;
@@ -652,23 +690,36 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
 
     // K order inside a chunk is TAP-major: k = t*16 + hl, so one K tile = one tap (ky,kx) x 16 channels, and
-    // B[k = lg][j = li] of step r is img[(4lg + r)*CHS + (Y - ky + 4)*PITCH + (X - kx + 4)].
+    // B[k = lg][j = li] of step r is img[(4lg + r)*CHS + (Y - ky)*PITCH + (X - kx + 4)]  (Y - ky in -4 .. O2W+3).
     int poff[NPT];
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) {                                   // positions past P1W^2 (ragged last tile): any valid offset, never stored
         const int pos = min(pt * 16 + li, P1W_ * P1W_ - 1);
-        poff[pt] = (4 * lg) * CHS + (pos / P1W_ + 4) * PITCH + pos % P1W_ + 4;
+        poff[pt] = (4 * lg) * CHS + (pos / P1W_) * PITCH + pos % P1W_ + 4;
     }
     const float* const Wr0 = a.K2cb + ((long long)sw * C1 + li) * KW + 4 * lg;          // ci = li; [ci][chunk][tap][16 hl]
     const float* const Wr1 = Wr0 + (long long)16 * KW;                                   // ci = 16 + li
 
-    f32x4 acc[2][NPT];
+    // Blocked accumulation: `acc` runs over FLUSH chunks (400 products each) and is then folded into `tot`.  One fp32 chain over
+    // all K = 25*Hc products (12 800 at Hc = 512) carries ~sqrt(K) roundings of the running sum; blocks of 800 carry
+    // ~sqrt(800) + sqrt(K/800) — measured against fp64 the per-point median error of the whole path drops accordingly.
+    // (The second register set fits two blocks per CU only while 2 * 2 * NPT tiles do: 1x28x28.  3x32x32 keeps one chain.)
+#ifndef RBNN_CONV_BWD_UNBLOCKED
+    constexpr bool BLOCKED = NPT <= 9;
+#else
+    constexpr bool BLOCKED = false;
+#endif
+    constexpr int FLUSH = 2, NTOT = BLOCKED ? NPT : 1;
+    f32x4 acc[2][NPT], tot[2][NTOT];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pt = 0; pt < NTOT; ++pt) tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
-    for (int i = lane; i < IMG / 4; i += 64) *(f32x4*)(img + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // the border stays zero
+    for (int i = lane; i < IMG / 4; i += 64) *(f32x4*)(lds + wave * IMG + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // the borders stay zero
     // this lane's positions (y, x) of the O2W x O2W gradient map: lane, lane + 64, ...
     constexpr int NGP = (NPOS_ + 63) / 64;
     // the <= 4 stride-1 pooling windows (py,px) in {y-1,y} x {x-1,x} that contain (y,x); window q = 2dy+dx has (y,x) as its
@@ -679,7 +730,7 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
     for (int g = 0; g < NGP; ++g) {
         const int gp = lane + 64 * g, gy = gp / O2W_, gx = gp % O2W_;
         gok[g] = gp < NPOS_;
-        goff[g] = gok[g] ? (gy + 4) * PITCH + gx + 4 : 0;
+        goff[g] = gok[g] ? gy * PITCH + gx + 4 : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int py = gy - (q >> 1), px = gx - (q & 1);
@@ -737,8 +788,14 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
                 }
             }
         }
+        if (BLOCKED && ((hc0 / HCH) % FLUSH == FLUSH - 1 || hc0 + HCH >= a.Hc)) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < (BLOCKED ? NPT : 0); ++pt) { tot[ct][pt] += acc[ct][pt]; acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
     }
-    // 3. acc[ct][pt][r] = dL/dP1[ci = 16ct + 4lg + r][pos = 16pt + li] -> memory, over the forward's P1 (dead after this read:
+    // 3. tot[ct][pt][r] = dL/dP1[ci = 16ct + 4lg + r][pos = 16pt + li] -> memory, over the forward's P1 (dead after this read:
     //    for sigmoid / tanh the activation value at the same index gives act', folded in here); conv1_bwd finishes the path.
     //    (An in-kernel scatter of the 25 conv1 taps needs LDS float atomics, which cost ~250 cycles per wave instruction:
     //    measured, they made the LDS the bottleneck of this kernel.)
@@ -750,7 +807,8 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
             for (int r = 0; r < 4; ++r) {
                 if (16 * pt + li >= P1W_ * P1W_) continue;
                 float* const dst = a.dP1 + sn * G::P1SZ + (16 * ct + 4 * lg + r) * (P1W_ * P1W_) + 16 * pt + li;
-                *dst = smooth_act<ACT>() ? acc[ct][pt][r] * act_grad_from_value<ACT>(*dst) : acc[ct][pt][r];
+                const float v = BLOCKED ? tot[ct][BLOCKED ? pt : 0][r] : acc[ct][pt][r];
+                *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
             }
 }
 
@@ -945,15 +1003,19 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
 }
 
 // pool-1 routing + conv1^T on the matrix pipe (the dispatched version; conv1_bwd_kernel above is its VALU gather form:
-// 3.32 ms at the conv-512 bench against 1.24 ms for this one).  One WAVE = one (sample, point), no barriers.
-//   dX[Y][X] = sum_{c, ky, kx} w[c][ky][kx] * R[c][Y - ky][X - kx],   R = the pooled gradient routed to its argmax position (24x24, one
-//   non-zero per 2x2 cell) times the activation derivative.
-// Per position row Ya the wave forms  T[tap][Xa] = sum_c w[c][tap] * R[c][Ya][Xa]  — a 32(taps, 25 used) x 32(c) x 32(Xa, 24 used)
+// 3.32 ms at the conv-512 bench against 1.24 ms for this one; 15.4 -> see profiles at the CIFAR-shaped c5 bench).
+// One WAVE = one (sample, point), no barriers.  Per input channel ci:
+//   dX[ci][Y][X] = sum_{c, ky, kx} w[c][ci][ky][kx] * R[c][Y - ky][X - kx],   R = the pooled gradient routed to its argmax position
+//   (O1 x O1, one non-zero per 2x2 cell) times the activation derivative.
+// Per position row Ya the wave forms  T[tap][Xa] = sum_c w[c][ci][tap] * R[c][Ya][Xa]  — a 32(taps, 25 used) x 32(c) x 32(Xa, O1 used)
 // fp32 MFMA product whose B operand is built in registers from the stash bytes and pooled gradients of pooled row Ya/2 — keeps the
 // last five rows of T in an LDS ring, and emits output row Y = Ya as a 25-term gather  dX[Y][X] = sum_tap T[tap][Y - ky][X - kx].
-template <int ACT>
+// With Cin > 1 the pass is repeated per input channel (the routed B operand is rebuilt from L2-resident data; the ring stays 62.5 KiB).
+template <int ACT, class G>
 __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
     constexpr int RING = 5, TROW = 25 * 32;                              // floats per ring row: [25 taps][32 Xa]
+    constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW;
+    static_assert(O1 <= 32 && IW <= 64, "a conv1 output row fits two 16-wide MFMA tiles; an input row fits one wave");
     __shared__ float lds[4 * RING * TROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int NB = (a.N + 3) / 4;
@@ -966,97 +1028,98 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
     float* const T = lds + wave * RING * TROW;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
 
-    // A operand: A[i = tap][k = c], K step r of channel block kb is c = 16kb + 4lg + r (one f32x4 per (tap tile, channel block))
-    f32x4 aw[2][2];
+    for (int ci = 0; ci < G::CIN; ++ci) {
+        // A operand: A[i = tap][k = c], K step r of channel block kb is c = 16kb + 4lg + r (one f32x4 per (tap tile, channel block))
+        f32x4 aw[2][2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tap = 16 * mt + li, c = 16 * kb + 4 * lg + r;
-                aw[mt][kb][r] = tap < 25 ? a.K1w[((long long)sw * C1 + c) * 25 + tap] : 0.f;
-            }
-    auto emit_row = [&](int Y) {                                         // output row Y from the ring (rows Y-4 .. Y of T)
-        if (lane < 28) {
-            float g = 0.f;
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky) {
-                const int Yp = Y - ky;
-                if (Yp < 0 || Yp > 23) continue;                         // wave-uniform
-                const float* const row = T + (Yp % RING) * TROW + ky * 5 * 32;
-#pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const int Xp = lane - kx;
-                    if (Xp >= 0 && Xp <= 23) g += row[kx * 32 + Xp];
-                }
-            }
-            a.G[sn * 784 + Y * 28 + lane] = g;
-        }
-    };
-    for (int py = 0; py < P1W; ++py) {
-        // this lane's 16 (channel, position) elements of pooled row py: pt = position tile (Xa = 16pt + li), kb, r as above
-        float gv[2][2][4];
-        int ar[2][2][4];
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int Xa = 16 * pt + li, c = 16 * kb + 4 * lg + r;
-                    const long long e = sn * P1SZ + c * (P1W * P1W) + py * P1W + min(Xa >> 1, P1W - 1);
-                    const int st = a.st1[e];
-                    const float d = a.dP1[e];
-                    gv[pt][kb][r] = (Xa < 24) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
-                    ar[pt][kb][r] = (st & 3) ^ (Xa & 1);                 // == 2*half for the row half that owns the argmax, with the right column parity
+                    const int tap = 16 * mt + li, c = 16 * kb + 4 * lg + r;
+                    aw[mt][kb][r] = tap < 25 ? a.K1w[((long long)sw * C1 + c) * G::K1 + ci * 25 + tap] : 0.f;
                 }
+        float* const Gout = a.G + sn * G::DIN + ci * (IW * IW);
+        auto emit_row = [&](int Y) {                                     // output row Y from the ring (rows Y-4 .. Y of T)
+            if (lane < IW) {
+                float g = 0.f;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int Ya = 2 * py + half;
-            f32x4 acc[2][2];
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int Yp = Y - ky;
+                    if (Yp < 0 || Yp > O1 - 1) continue;                 // wave-uniform
+                    const float* const row = T + (Yp % RING) * TROW + ky * 5 * 32;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float b[2];
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt) b[pt] = (ar[pt][kb][r] == 2 * half) ? gv[pt][kb][r] : 0.f;   // arg = 2*dy + dx
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = MFMA16(aw[mt][kb][r], b[pt], acc[mt][pt]);
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const int Xp = lane - kx;
+                        if (Xp >= 0 && Xp <= O1 - 1) g += row[kx * 32 + Xp];
+                    }
                 }
-            float* const row = T + (Ya % RING) * TROW;
+                Gout[Y * IW + lane] = g;
+            }
+        };
+        for (int py = 0; py < P1W_; ++py) {
+            // this lane's 16 (channel, position) elements of pooled row py: pt = position tile (Xa = 16pt + li), kb, r as above
+            float gv[2][2][4];
+            int ar[2][2][4];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int tap = 16 * mt + 4 * lg + r;            // acc[mt][pt][r] = T[tap][Xa = 16pt + li]
-                        if (tap < 25) row[tap * 32 + 16 * pt + li] = acc[mt][pt][r];
+                        const int Xa = 16 * pt + li, c = 16 * kb + 4 * lg + r;
+                        const long long e = sn * G::P1SZ + c * (P1W_ * P1W_) + py * P1W_ + min(Xa >> 1, P1W_ - 1);
+                        const int st = a.st1[e];
+                        const float d = a.dP1[e];
+                        gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
+                        ar[pt][kb][r] = (st & 3) ^ (Xa & 1);             // == 2*half for the row half that owns the argmax, with the right column parity
                     }
-            emit_row(Ya);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int Ya = 2 * py + half;
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float b[2];
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) b[pt] = (ar[pt][kb][r] == 2 * half) ? gv[pt][kb][r] : 0.f;   // arg = 2*dy + dx
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                            for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = MFMA16(aw[mt][kb][r], b[pt], acc[mt][pt]);
+                    }
+                float* const row = T + (Ya % RING) * TROW;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int tap = 16 * mt + 4 * lg + r;        // acc[mt][pt][r] = T[tap][Xa = 16pt + li]
+                            if (tap < 25) row[tap * 32 + 16 * pt + li] = acc[mt][pt][r];
+                        }
+                emit_row(Ya);
+            }
         }
+        for (int Y = O1; Y < IW; ++Y) emit_row(Y);
     }
-    for (int Y = 24; Y < 28; ++Y) emit_row(Y);
 }
 
-// conv1^T: the matrix-pipe kernel is built for one input channel and 24-wide rows (1x28x28); other geometries take the VALU gather
+// conv1^T: the matrix-pipe kernel; RBNN_CONV1_BWD_VALU keeps its VALU gather form selectable (same results up to summation order)
 template <int ACT, class G>
 int launch_conv1_backward(const ConvBwdArgs& a, hipStream_t st) {
 #ifndef RBNN_CONV1_BWD_VALU
-    if constexpr (std::is_same<G, GeoMnist>::value) {
-        hipLaunchKernelGGL(conv1_bwd_mfma_kernel<ACT>, dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
-        return launch_status();
-    }
-#endif
+    hipLaunchKernelGGL((conv1_bwd_mfma_kernel<ACT, G>), dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
+#else
     hipLaunchKernelGGL((conv1_bwd_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(256), 0, st, a);
+#endif
     return launch_status();
 }
 
