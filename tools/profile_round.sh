@@ -1,0 +1,56 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): the GPU test tier, smoke, every bench workload, rocprofv3 kernel-trace stats and PMC passes.
+# usage: tools/profile_round.sh <tag> [quick]       -> gpurun_out/<tag>/...   (copy what should be judged into profiles/<tag>/)
+set -u
+TAG=${1:-r02}
+QUICK=${2:-}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $R
+if [ -z "$QUICK" ]; then
+  (timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -vE "^(Saving|Loading|Producing|Evaluating|test accuracy|avg softmax|vanishing|increasing|null|image_idx| === |min = |$)" | tail -150) > $OUT/pytest_gpu.log
+  tail -2 $OUT/pytest_gpu.log
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+fi
+python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json
+if [ -z "$QUICK" ]; then
+  python bench.py --workload c3 --steps 2 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_c3.json
+  python bench.py --workload c4 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_c4.json
+  python bench.py --workload c5 --points 1024 --iters 10 --steps 1 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_c5_n1024_t10.json
+  python bench.py --workload conv --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_conv.json
+  python bench.py --workload fc2 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_fc2.json
+  python bench.py --workload c1 --steps 50 --warmup 5 --cpu-seconds 5 2>/dev/null | tail -1 > $OUT/bench_c1.json
+  RBNN_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 > $OUT/bench_c2_torchrun_1rank_forced_collectives.json
+fi
+cd /tmp
+prof() {   # prof <subdir> <workload> <extra bench args...>
+  local sub=$1 wl=$2; shift 2
+  mkdir -p $OUT/$sub
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$sub/trace -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/trace.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$sub/pmc_fetch -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/$sub/pmc_write -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_write.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/$sub/pmc_sq -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_sq.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/$sub/pmc_lds -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_lds.log 2>&1
+  python3 $R/tools/summarize_profile.py $OUT/$sub $wl > $OUT/$sub/summary.txt 2>&1
+  cp $OUT/$sub/trace/run_kernel_stats.csv $OUT/$sub/kernel_stats.csv 2>/dev/null
+  rm -rf $OUT/$sub/trace/run_kernel_trace.csv $OUT/$sub/pmc_*/run_kernel_trace.csv      # bulky; the summary keeps the per-kernel numbers
+  head -30 $OUT/$sub/summary.txt
+}
+prof c2 c2 --steps 5 --warmup 2
+if [ -z "$QUICK" ]; then
+  prof c5 c5 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
+  prof conv conv --steps 3 --warmup 1
+fi
+python3 - <<PY
+import json, glob, os
+out = {}
+for f in sorted(glob.glob("$OUT/*/pmc_traffic.json")):
+    d = json.load(open(f))
+    src = d.pop("source", None)
+    out.update(d)
+    out.setdefault("source", []).append(src)
+json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
+print(sorted(k for k in out if k != "source"))
+PY

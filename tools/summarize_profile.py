@@ -1,22 +1,56 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel stats + PMC passes) of tools/profile_bench.sh into a short text summary."""
-import csv, glob, os, sys, collections
+"""Condense the rocprofv3 CSV output of tools/profile_round.sh into a short text summary + the per-launch HBM traffic record.
+
+usage: summarize_profile.py <dir> [workload]
+<dir> holds trace/ (--kernel-trace --stats) and pmc_fetch/, pmc_write/, pmc_sq/, pmc_lds/ (one --pmc pass each; FETCH_SIZE and
+WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, "rocprofv3 PMC slots").  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE
+(KB -> bytes): on gfx950 FETCH_SIZE tallies the 128-B requests of wide streaming loads at 64 B (same guide, HBM section).
+Writes <dir>/pmc_traffic.json = {bench.py kernel key: {...}} for `workload`."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
 out = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
+
+# kernel-name fragment -> bench.py's roofline key (a key sums the kernels one C-ABI call launches)
+MAIN = [("fc_forward_split_kernel", "fc_forward_split"), ("fc_grad_split_kernel", "fc_input_grad_split"), ("split_dz_kernel", "fc_input_grad_split"),
+        ("fc_forward_kernel", "fc_forward"), ("fc_grad_kernel", "fc_input_grad"),
+        ("conv2_pool_split_kernel", "conv_forward_split"), ("conv1_pool_split_kernel", "conv_forward_split"),
+        ("conv_bwd_split_kernel", "conv_input_grad_split"),
+        ("conv2_pool_kernel", "conv_forward"), ("conv1_pool_kernel", "conv_forward"), ("conv_fc_kernel", "conv_forward"),
+        ("conv_bwd_kernel", "conv_input_grad"), ("conv_fc_bwd_kernel", "conv_input_grad"), ("conv1_bwd_mfma_kernel", "conv_input_grad")]
+SHORT = [k for k, _ in MAIN] + ["split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
+                                "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"]
+
 
 def rows(pattern):
     for f in glob.glob(os.path.join(out, pattern), recursive=True):
         with open(f) as fh:
             yield from csv.DictReader(fh)
 
+
 def short(name):
-    for k in ("fc_forward_split_kernel", "fc_grad_split_kernel", "split_dz_kernel", "split_rows_kernel", "fc_forward_kernel", "fc_grad_kernel", "reduce_samples", "loss_dlogits", "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"):
+    for k in SHORT:
         if k in name:
-            return k
+            geo = "<3,32>" if "Geo<3, 32>" in name else ""
+            return k + geo
     return name[:60]
 
+
+def key_of(name):
+    for k, v in MAIN:
+        if k in name:
+            return v
+    return None
+
+
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
-for r in sorted(rows("trace/**/*kernel_stats.csv"), key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))[:12]:
-    print(f"{short(r['Name']):26s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}")
+for r in sorted(rows("trace/**/*kernel_stats.csv"), key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))[:16]:
+    print(f"{short(r['Name']):32s} calls={r['Calls']:>5s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}")
 
 print("\n== kernel trace: per-kernel duration + resources ==")
 agg = collections.defaultdict(list)
@@ -25,12 +59,9 @@ for r in rows("trace/**/*kernel_trace.csv"):
     k = short(r["Kernel_Name"])
     agg[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     res[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
-for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:20]:
     v2 = sorted(v)
-    print(f"{k:26s} n={len(v):4d} avg_us={sum(v)/len(v):10.2f} med_us={v2[len(v)//2]:10.2f} min_us={v2[0]:10.2f}  vgpr/agpr/sgpr/lds/scratch/grid/wg={res[k]}")
-
-MAIN = {"fc_forward_kernel": "fc_forward", "fc_grad_kernel": "fc_input_grad",
-        "fc_forward_split_kernel": "fc_forward_split", "fc_grad_split_kernel": "fc_input_grad_split"}   # -> bench.py's traffic keys
+    print(f"{k:32s} n={len(v):4d} avg_us={sum(v)/len(v):10.2f} med_us={v2[len(v)//2]:10.2f} min_us={v2[0]:10.2f}  vgpr/agpr/sgpr/lds/scratch/grid/wg={res[k]}")
 
 
 def pmc(dirname, title):
@@ -40,24 +71,35 @@ def pmc(dirname, title):
     if acc:
         print(f"\n== PMC: {title} (mean per launch) ==")
     for k, d in acc.items():
-        if k not in MAIN:
+        if key_of(k) is None:
             continue
-        print(f"{k:26s} " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())))
+        print(f"{k:32s} " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())))
     return acc
+
 
 f = pmc("pmc_fetch", "FETCH_SIZE (KB; gfx950 reads x2 for wide streaming loads)")
 w = pmc("pmc_write", "WRITE_SIZE (KB)")
-pmc("pmc_sq", "SQ")
+sq = pmc("pmc_sq", "SQ")
 pmc("pmc_lds", "LDS / clock")
-import json
-tr = {}
-for k in MAIN:
-    if k in f and k in w:
-        fs = sum(f[k]["FETCH_SIZE"]) / len(f[k]["FETCH_SIZE"]); wsz = sum(w[k]["WRITE_SIZE"]) / len(w[k]["WRITE_SIZE"])
-        tr[MAIN[k]] = {"fetch_size_kb_raw": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": (2 * fs + wsz) * 1024,
-                 "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"}
+for k, d in sq.items():                                     # matrix-pipe utilisation: busy cycles vs the kernel's wall cycles
+    if key_of(k) and "SQ_VALU_MFMA_BUSY_CYCLES" in d and "SQ_BUSY_CYCLES" in d:
+        busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(d["SQ_VALU_MFMA_BUSY_CYCLES"])
+        print(f"   {k}: SQ_VALU_MFMA_BUSY_CYCLES per SIMD = {busy / 1024:.4g} (1024 SIMDs)")
+tr = collections.defaultdict(lambda: {"fetch_size_kb_raw": 0.0, "write_size_kb": 0.0, "kernels": []})
+for k in set(f) & set(w):
+    key = key_of(k)
+    if key is None:
+        continue
+    fs = sum(f[k]["FETCH_SIZE"]) / len(f[k]["FETCH_SIZE"])
+    wsz = sum(w[k]["WRITE_SIZE"]) / len(w[k]["WRITE_SIZE"])
+    tr[key]["fetch_size_kb_raw"] += fs
+    tr[key]["write_size_kb"] += wsz
+    tr[key]["kernels"].append(k)
+for key, d in tr.items():
+    d["hbm_bytes_per_launch"] = (2 * d["fetch_size_kb_raw"] + d["write_size_kb"]) * 1024
+    d["note"] = "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"
 if tr:
     print("\n== traffic json ==")
     print(json.dumps(tr))
-    tr["source"] = f"{out}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, c2 workload)"
-    json.dump(tr, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    json.dump({workload: tr, "source": f"{out}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {workload} workload)"},
+              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
