@@ -346,9 +346,14 @@ def main():
 
     def roofline(mode, evs_by_name, ms_per_step):
         kernels = {}
+        passes_timed = args.steps * passes * w["iters"]
         for name, evs in evs_by_name.items():
             ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
-            kernels[name] = {"launches": len(evs), "avg_ms": ms, "tflops": per_launch / (ms * 1e-3) / 1e12 if ms else None}
+            # launches per hot-path pass: 1, or the number of point blocks when the sample-sharded step is pipelined over blocks
+            # (each launch then covers 1/blocks of the points) or a conv job is cut into point blocks
+            lpp = max(1, round(len(evs) / max(1, passes_timed)))
+            kernels[name] = {"launches": len(evs), "launches_per_pass": lpp, "avg_ms": ms,
+                             "tflops": per_launch / lpp / (ms * 1e-3) / 1e12 if ms else None}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -361,7 +366,7 @@ def main():
         fp32_eq = kernels[dom]["tflops"]
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
              "traffic_source": traffic_src,      # PMC counters cannot be read inside this run: a committed rocprofv3 --pmc pass of the same command
-             "flop_per_launch": per_launch, "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
+             "flop_per_launch": per_launch / kernels[dom]["launches_per_pass"], "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
         if mode == "split" and dom in SPLIT_KERNELS:
             # matrix-pipe work of the split mode: 3 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
             r.update({"achieved": 3.0 * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": 3.0 * fp32_eq / F16_MFMA_PEAK_TFLOPS,

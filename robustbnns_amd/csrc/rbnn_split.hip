@@ -129,7 +129,7 @@ struct FwdSplitArgs {
 };
 
 template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
-__global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const FwdSplitArgs a) {
+__global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_split_kernel(const FwdSplitArgs a) {   // one block per CU (LDS): WH*WN/4 waves per SIMD
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int ROWB = 128;                                  // bytes per tile row: 32 columns x (hi + lo)
     constexpr int TILEB = (BH + BN) * ROWB;                    // bytes per LDS stage buffer
@@ -179,20 +179,22 @@ __global__ void __launch_bounds__(64 * WH * WN, 2) fc_forward_split_kernel(const
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // per-lane byte offsets from the block-uniform bases Ws / Xs fit 32 bits (the host checks H*ldw*4 and N*ldx*4 < 2^32):
+        // a uniform 64-bit base + one 32-bit VGPR offset per piece instead of 64-bit per-lane addresses (which spilled)
         auto stage = [&](int kt, int buf) {
             char* const Wt = ldsb + buf * TILEB;
             char* const Xt = Wt + BH * ROWB;
-            const long long koff = (long long)kt * ROWB + src_off;
+            const unsigned koff = (unsigned)kt * ROWB + (unsigned)src_off;
 #pragma unroll
             for (int i = 0; i < WP; ++i) {
                 const int q = wave + NW * i;
-                glds16((const float*)(Ws + (long long)(hc0 + 8 * q + prow) * a.ldw * 4 + koff), (float*)(Wt + q * 1024));
+                glds16((const float*)(Ws + ((unsigned)(hc0 + 8 * q + prow) * (unsigned)a.ldw * 4u + koff)), (float*)(Wt + q * 1024));
             }
 #pragma unroll
             for (int i = 0; i < XP; ++i) {
                 const int q = wave + NW * i;
                 const int n = min(n0 + 8 * q + prow, a.N - 1);  // rows past N repeat the last point; never stored
-                glds16((const float*)(Xs + (long long)n * a.ldx * 4 + koff), (float*)(Xt + q * 1024));
+                glds16((const float*)(Xs + ((unsigned)n * (unsigned)a.ldx * 4u + koff)), (float*)(Xt + q * 1024));
             }
         };
         stage(0, 0);
@@ -809,6 +811,8 @@ int rbnn_fc_forward_split(const rbnn_posterior* net, const rbnn_split_images* sp
     const int H = net->hidden, ld = sp->ld_rows;
     if (H < 128 || (H % 128) || ld < net->in_features || (ld & 31) || ldx != ld) return RBNN_ERR_SHAPE;
     if (net->n_classes < 1 || net->n_classes > RBNN_CPAD || N < 1 || S < 1) return RBNN_ERR_SHAPE;
+    // the kernels address a sample's weight image and the input image with 32-bit byte offsets from a 64-bit base
+    if ((long long)H * ld * 4 >= (1LL << 32) || (long long)N * ld * 4 >= (1LL << 32) || (long long)N * H * 4 >= (1LL << 32)) return RBNN_ERR_SHAPE;
     if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
     if (!aligned16(X_split) || !aligned16(sp->W1_rows) || !aligned16(ws->P) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
     if (fc2 && (!sp->Wm_rows || !net->bm || !ws->hid1 || (bm ? !ws->mask2 : !ws->dact2))) return RBNN_ERR_NULL;
