@@ -59,8 +59,10 @@ typedef enum rbnn_out_kind { RBNN_OUT_PROBS = 0, RBNN_OUT_LOGITS = 1 } rbnn_out_
  *   RBNN_LOSS_MEAN_PROB   CE(mean_s p_s, y)        fgsm/pgd on a BNN   adversarialAttacks.py:74-78, :97-101
  *   RBNN_LOSS_PER_SAMPLE  mean_s CE(p_s, y)        loss_gradient       lossGradients.py:29-40
  *   RBNN_LOSS_MEAN_LOGIT  CE(mean_s z_s, y)        fgsm/pgd on NN / Ensemble_NN (P holds logits)
- *   RBNN_LOSS_UPSTREAM    caller supplies dL/d(mean_s p_s) [N,C] (autograd hook) */
-typedef enum rbnn_loss_mode { RBNN_LOSS_MEAN_PROB = 0, RBNN_LOSS_PER_SAMPLE = 1, RBNN_LOSS_MEAN_LOGIT = 2, RBNN_LOSS_UPSTREAM = 3 } rbnn_loss_mode;
+ *   RBNN_LOSS_UPSTREAM    caller supplies dL/d(mean_s p_s) [N,C] (autograd hook on BNN.forward: the softmax backward is applied)
+ *   RBNN_LOSS_UPSTREAM_LOGIT  caller supplies dL/d(mean_s z_s) [N,C] (autograd hook on NN / Ensemble_NN.forward: P holds logits) */
+typedef enum rbnn_loss_mode { RBNN_LOSS_MEAN_PROB = 0, RBNN_LOSS_PER_SAMPLE = 1, RBNN_LOSS_MEAN_LOGIT = 2, RBNN_LOSS_UPSTREAM = 3,
+                              RBNN_LOSS_UPSTREAM_LOGIT = 4 } rbnn_loss_mode;
 
 /* Stacked posterior of a fully-connected net (model_nn.py:77-91; state_dict keys in comments). */
 typedef struct rbnn_posterior {
@@ -125,7 +127,7 @@ int rbnn_reduce_samples(const float *P, int32_t n_samples, int32_t n_points, int
 /* dZ[s,n,:] = dL/dlogits_s for the chosen loss; `Psum` [N,ldp] is sum_s P[s] over ALL samples of
  * the job (after the all-reduce when samples are sharded), `inv_S` = 1/(total samples),
  * `labels` int32[N] (argmax of the one-hot, lossGradients.py:23, adversarialAttacks.py:120),
- * `G_up` [N,ldp] only for RBNN_LOSS_UPSTREAM.
+ * `G_up` [N,ldp] only for RBNN_LOSS_UPSTREAM / RBNN_LOSS_UPSTREAM_LOGIT.
  * Replaces CrossEntropyLoss()(output,label) + the softmax part of loss.backward():
  * adversarialAttacks.py:76-78, :99-101; lossGradients.py:34-36 (closed form). */
 int rbnn_loss_dlogits(int32_t mode, const float *P, const float *Psum, int32_t ldp, const float *G_up,

@@ -17,7 +17,7 @@ CPAD = 16
 ACTIVATIONS = {"relu": 0, "leaky": 1, "sigm": 2, "tanh": 3}          # model_nn.py:66-75
 ARCHS = {"fc": 0, "fc2": 1}                                           # model_nn.py:77-91
 OUT_PROBS, OUT_LOGITS = 0, 1
-LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_MEAN_LOGIT, LOSS_UPSTREAM = 0, 1, 2, 3
+LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_MEAN_LOGIT, LOSS_UPSTREAM, LOSS_UPSTREAM_LOGIT = 0, 1, 2, 3, 4
 
 _fp = C.c_void_p
 

@@ -672,7 +672,9 @@ __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
 // zero-padded gradient image of one wave (layout: struct Geo): 4 zero rows, then 16 channels of CHS floats, then 8 floats of
 // slack (the last row's right border).  1x28x28: 9.5 KiB per wave (38 KiB per block), 3x32x32: 12.5 KiB (50 KiB per block).
 template <class G> constexpr int conv_bwd_img_floats() { return 4 * G::PITCH + 16 * G::CHS + 8; }
-template <class G> constexpr int conv_bwd_lds_floats() { return 4 * conv_bwd_img_floats<G>(); }
+// + the staging area of one chunk's pooled gradients (16 x NP2 floats) and stash bytes (16 x NP2), brought in by LDS-DMA
+template <class G> constexpr int conv_bwd_stage_floats() { return (16 * G::NP2 * 5 + 15) / 16 * 4; }
+template <class G> constexpr int conv_bwd_lds_floats() { return 4 * (conv_bwd_img_floats<G>() + conv_bwd_stage_floats<G>()); }
 
 template <int ACT, class G>
 __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
@@ -682,9 +684,12 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
     // channels per chunk; image pitch (gradient map + border 4); floats per channel (data rows + one shared border); floats per
     // wave image; K per chunk; position tiles of dP1
     static_assert(IMG % 4 == 0, "the image is cleared with 16-byte stores");
-    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 * IMG floats
+    constexpr int NFL = HCH * NP2_, STG = conv_bwd_stage_floats<G>(), WLDS = IMG + STG;
+    extern __shared__ __attribute__((aligned(16))) float lds[];          // 4 * (IMG + STG) floats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-    float* const img = lds + wave * IMG + 4 * PITCH;                     // row 0 of channel 0 (4 zero rows above it); channel c at + c*CHS
+    float* const img = lds + wave * WLDS + 4 * PITCH;                    // row 0 of channel 0 (4 zero rows above it); channel c at + c*CHS
+    float* const sdq = lds + wave * WLDS + IMG;                          // [16 hc][NP2] pooled gradients of the chunk
+    unsigned char* const sst = (unsigned char*)(sdq + NFL);              // [16 hc][NP2] stash bytes
 
     const int NB = (a.N + 3) / 4;                                        // blocks per sample
     int id;
@@ -725,7 +730,7 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
         for (int pt = 0; pt < NTOT; ++pt) tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int i = lane; i < IMG / 4; i += 64) *(f32x4*)(lds + wave * IMG + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // the borders stay zero
+    for (int i = lane; i < IMG / 4; i += 64) *(f32x4*)(lds + wave * WLDS + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};   // the borders stay zero
     // this lane's positions (y, x) of the O2W x O2W gradient map: lane, lane + 64, ...
     constexpr int NGP = (NPOS_ + 63) / 64;
     // the <= 4 stride-1 pooling windows (py,px) in {y-1,y} x {x-1,x} that contain (y,x); window q = 2dy+dx has (y,x) as its
@@ -744,20 +749,38 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
             woff[g][q] = wok[g][q] ? py * P2W_ + px : 0;
         }
     }
+    // The chunk's 16 x NP2 pooled gradients and stash bytes are contiguous in memory: they come in by 4-byte-per-lane LDS-DMA
+    // (coalesced, no registers), issued right after the previous chunk's routing has read the staging area, so they land under
+    // that chunk's MFMAs; the routing then gathers from LDS instead of from memory (the scattered global loads of the routing —
+    // 32 per lane per 4 channels — were ~30 % of this kernel: the matrix pipe sat at 69 % busy).
+    auto dma4 = [&](const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
+    };
+    auto stage_chunk = [&](int hc0) {                                    // lane p of instruction q lands at byte 256q + 4p of its region
+        const long long fb = sn * F + (long long)hc0 * NP2_;             // a multiple of 4: the stash dwords are aligned
+#pragma unroll
+        for (int q = 0; q < (NFL + 63) / 64; ++q)
+            if (q * 64 + lane < NFL) dma4(a.dQ2 + fb + q * 64 + lane, sdq + q * 64);
+#pragma unroll
+        for (int q = 0; q < (NFL + 255) / 256; ++q)
+            if (q * 256 + 4 * lane < NFL) dma4(a.st2 + fb + q * 256 + 4 * lane, sst + q * 256);
+    };
+    stage_chunk(0);
     for (int hc0 = 0; hc0 < a.Hc; hc0 += HCH) {
-        // 1. interior of the padded image for channels hc0 .. hc0+15: pool-2 routing + activation derivative, gather form;
-        //    loads are unconditional and batched 4 channels at a time (32 independent loads in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0): this chunk's staging has landed (wave-local, no barrier)
+        asm volatile("" ::: "memory");
+        // 1. interior of the padded image for channels hc0 .. hc0+15: pool-2 routing + activation derivative, gather form
 #pragma unroll
         for (int g = 0; g < NGP; ++g) {
-#pragma unroll 1
+#pragma unroll
             for (int h4 = 0; h4 < HCH; h4 += 4) {
                 int st[4][4];
                 float dq[4][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const long long fb = sn * F + (long long)min(hc0 + h4 + j, a.Hc - 1) * NP2_;
+                    const int fb = (h4 + j) * NP2_;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { st[j][q] = a.st2[fb + woff[g][q]]; dq[j][q] = a.dQ2[fb + woff[g][q]]; }
+                    for (int q = 0; q < 4; ++q) { st[j][q] = sst[fb + woff[g][q]]; dq[j][q] = sdq[fb + woff[g][q]]; }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -766,10 +789,12 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_kernel(const ConvBwdArgs a) {
                     for (int q = 0; q < 4; ++q)
                         if (wok[g][q] && (st[j][q] & 3) == q)             // smooth activations: act' is already folded into dQ2
                             v += (smooth_act<ACT>() || (st[j][q] & 4)) ? dq[j][q] : dq[j][q] * slope;
-                    if (gok[g]) img[(h4 + j) * CHS + goff[g]] = (hc0 + h4 + j < a.Hc) ? v : 0.f;
+                    if (gok[g]) img[(h4 + j) * CHS + goff[g]] = v;        // Hc is a multiple of 16: every channel of the chunk exists
                 }
             }
         }
+        asm volatile("" ::: "memory");
+        if (hc0 + HCH < a.Hc) stage_chunk(hc0 + HCH);                    // the staging area is free again: the next chunk's rows fly under the MFMAs
         // 2. 25 K tiles = 25 taps x 16 channels.  A position tile spans rows Ya..Yb of the P1W x P1W output; tap row ky reaches it
         //    only if some Y - ky lies in 0..O2W-1: the others multiply pure padding and are skipped (27 % of the MFMAs at 1x28x28).
         const float* const w0 = Wr0 + (long long)(hc0 / HCH) * KCH;

@@ -499,8 +499,9 @@ __global__ void loss_dlogits_kernel(int mode, const float* __restrict__ P, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[4 * q + r] = v[r];
     }
-    const int y = (mode == RBNN_LOSS_UPSTREAM) ? -1 : labels[n];
-    if (mode == RBNN_LOSS_UPSTREAM) {
+    const bool upstream = mode == RBNN_LOSS_UPSTREAM || mode == RBNN_LOSS_UPSTREAM_LOGIT;
+    const int y = upstream ? -1 : labels[n];
+    if (upstream) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) g[c] = (c < C) ? Gup[(long long)n * ldp + c] * inv_S : 0.f;
     } else {
@@ -517,7 +518,7 @@ __global__ void loss_dlogits_kernel(int mode, const float* __restrict__ P, const
         for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (t[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
     }
     float out[16];
-    if (mode == RBNN_LOSS_MEAN_LOGIT) {
+    if (mode == RBNN_LOSS_MEAN_LOGIT || mode == RBNN_LOSS_UPSTREAM_LOGIT) {        // P holds logits: dZ_s = dL/d(mean logits) / S, no softmax backward
 #pragma unroll
         for (int c = 0; c < 16; ++c) out[c] = g[c];
     } else {
@@ -898,8 +899,8 @@ int rbnn_reduce_samples(const float* P, int32_t S, int32_t N, int32_t C, float s
 int rbnn_loss_dlogits(int32_t mode, const float* P, const float* Psum, int32_t ldp, const float* G_up, const int32_t* labels,
                       int32_t S, float inv_S, int32_t N, int32_t C, float* dZ, void* stream) {
     if (!P || !dZ) return RBNN_ERR_NULL;
-    if (mode < RBNN_LOSS_MEAN_PROB || mode > RBNN_LOSS_UPSTREAM) return RBNN_ERR_UNSUPPORTED;
-    if (mode == RBNN_LOSS_UPSTREAM ? !G_up : !labels) return RBNN_ERR_NULL;
+    if (mode < RBNN_LOSS_MEAN_PROB || mode > RBNN_LOSS_UPSTREAM_LOGIT) return RBNN_ERR_UNSUPPORTED;
+    if ((mode == RBNN_LOSS_UPSTREAM || mode == RBNN_LOSS_UPSTREAM_LOGIT) ? !G_up : !labels) return RBNN_ERR_NULL;
     if ((mode == RBNN_LOSS_MEAN_PROB || mode == RBNN_LOSS_MEAN_LOGIT) && !Psum) return RBNN_ERR_NULL;
     if (S < 1 || N < 1 || C < 1 || C > RBNN_CPAD || ldp < C) return RBNN_ERR_SHAPE;
     const long long total = (long long)S * N;

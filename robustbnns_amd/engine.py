@@ -25,7 +25,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import (LOSS_MEAN_LOGIT, LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_UPSTREAM, OUT_LOGITS, OUT_PROBS)
+from ._hip import (LOSS_MEAN_LOGIT, LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_UPSTREAM, LOSS_UPSTREAM_LOGIT, OUT_LOGITS, OUT_PROBS)
 
 _WS_DTYPE = {"mask1": torch.int32, "mask2": torch.int32}
 
@@ -200,10 +200,9 @@ class AttackEngine:
             out = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
         if self.world == 1:
             self.k.reduce_samples(ws["P"], S, N, self.post.C, 1.0 / S, out)         # model_bnn.py:257
-        else:
-            self.k.reduce_samples(ws["P"], S, N, self.post.C, 1.0, out)
+        else:       # sample-sharded: every rank scales its partial sum by 1 / (samples over all ranks); the all-reduce finishes the mean
+            self.k.reduce_samples(ws["P"], S, N, self.post.C, 1.0 / self.total_samples(S), out)
             self._allreduce(out)
-            out.mul_(1.0 / self.total_samples(S))
         return out
 
     def forward(self, x, n_samples, seeds=None, logits=False):
@@ -224,11 +223,8 @@ class AttackEngine:
         self._forward_kernels(Xp, sidx, S, OUT_LOGITS if logits else OUT_PROBS, ws)
         gup = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
         gup[:, :C] = grad_out.to(self.device, torch.float32)
-        if logits:      # d mean_s z_s: dZ_s = grad/S for every sample -> write it through the upstream mode on "P = 1"
-            dZ = ws["dZ"].view(S, N, _hip.CPAD)
-            dZ.copy_((gup / S_tot).unsqueeze(0).expand(S, N, _hip.CPAD))
-        else:
-            self.k.loss_dlogits(LOSS_UPSTREAM, ws["P"], None, gup, None, S, 1.0 / S_tot, N, C, ws["dZ"])
+        # probabilities: dZ_s = softmax backward of grad/S through p_s; logits (d mean_s z_s): dZ_s = grad/S for every sample
+        self.k.loss_dlogits(LOSS_UPSTREAM_LOGIT if logits else LOSS_UPSTREAM, ws["P"], None, gup, None, S, 1.0 / S_tot, N, C, ws["dZ"])
         n_slabs = self._grad_kernels(sidx, S, N, ws)
         G = ws["Gsum"] if "Gsum" in ws else ws["G"]
         self.k.sum_slabs(ws["slabs"], n_slabs, N, self.post.Dp, 1.0, G)

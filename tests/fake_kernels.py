@@ -43,13 +43,13 @@ class FakeKernels:
     def loss_dlogits(self, mode, P, Psum, G_up, labels, S, inv_S, N, C, dZ):
         p = P.view(S, N, _hip.CPAD)[:, :, :C]
         lab = None if labels is None else labels.long()
-        if mode == _hip.LOSS_UPSTREAM:
+        if mode in (_hip.LOSS_UPSTREAM, _hip.LOSS_UPSTREAM_LOGIT):
             G = (G_up[:, :C] * inv_S).unsqueeze(0)
         elif mode == _hip.LOSS_PER_SAMPLE:
             G = (torch.softmax(p, -1) - torch.nn.functional.one_hot(lab, C).float().unsqueeze(0)) * inv_S
         else:
             G = ((torch.softmax(Psum[:, :C] * inv_S, -1) - torch.nn.functional.one_hot(lab, C).float()) * inv_S).unsqueeze(0)
-        out = G.expand(S, N, C) if mode == _hip.LOSS_MEAN_LOGIT else p * (G - (G * p).sum(-1, keepdim=True))
+        out = G.expand(S, N, C) if mode in (_hip.LOSS_MEAN_LOGIT, _hip.LOSS_UPSTREAM_LOGIT) else p * (G - (G * p).sum(-1, keepdim=True))
         d = dZ.view(S, N, _hip.CPAD)
         d.zero_()
         d[:, :, :C] = out
