@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 if [ -z "$QUICK" ]; then
-  (timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -vE "^(Saving|Loading|Producing|Evaluating|test accuracy|avg softmax|vanishing|increasing|null|image_idx| === |min = |$)" | tail -150) > $OUT/pytest_gpu.log
+  (timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -vE "^(Saving|Loading|Producing|Evaluating|test accuracy|avg softmax|vanishing|increasing|null|image_idx| === |min = |$)" | tail -400) > $OUT/pytest_gpu.log
   tail -2 $OUT/pytest_gpu.log
   python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 fi
