@@ -543,7 +543,7 @@ struct GradSplitArgs {
 enum { GRAD_FC = 0, GRAD_FC2_STEP1 = 1, GRAD_FC2_STEP2 = 2 };
 
 template <int ACT, int TD, int NTW, int NW, int MODE>
-__global__ void __launch_bounds__(64 * NW, 2) fc_grad_split_kernel(const GradSplitArgs a) {
+__global__ void __launch_bounds__(64 * NW, (TD * NTW > 32 ? 1 : 2)) fc_grad_split_kernel(const GradSplitArgs a) {   // wide column groups: one wave per SIMD, up to 512 registers
     constexpr bool GEN = MODE != GRAD_FC2_STEP2;               // dA generated from dZ, or read from memory
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);   // act' from the 1-bit stash, or an fp32 stream
     constexpr bool STREAM = !GEN || !BITMASK;                  // a per-lane fp32 operand (A itself, or act') is prefetched from memory
@@ -750,6 +750,9 @@ template <int ACT, int MODE>
 int launch_grad_split(const GradSplitArgs& a, hipStream_t st) {
 #ifdef RBNN_GRAD_SPLIT_TD14
     if (MODE == GRAD_FC && a.Dt > 7) return launch_grad_split_cfg<ACT, 14, 2, 8, MODE>(a, st);
+#endif
+#ifdef RBNN_GRAD_SPLIT_TDW                                      // experiment: 4 waves x 4 point tiles x TDW column tiles, one block per CU
+    if (MODE == GRAD_FC && a.Dt > 7) return launch_grad_split_cfg<ACT, RBNN_GRAD_SPLIT_TDW, 4, 4, MODE>(a, st);
 #endif
     // 7 or 4 column tiles per block.  A partial last group skips its missing tiles' MFMAs, so padding costs little; every
     // group pays the dA generator (or the A-operand reads) again, so FEWER groups win: 7 wherever that saves a group

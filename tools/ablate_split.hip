@@ -25,10 +25,10 @@ int main(int argc, char** argv) {
     void *w1r, *w1c, *w2g, *xs;
     hipMalloc(&w1r, (size_t)S * H * LD * 4); hipMalloc(&w1c, (size_t)S * H * D * 4); hipMalloc(&w2g, (size_t)S * (H / 16) * 1024); hipMalloc(&xs, (size_t)N * LD * 4);
     sp.w1_exp = 16; sp.w2_exp = 16; sp.ld_rows = LD; sp.ld_cols = D;
-    rbnn_split_rows(net.W1, (int64_t)S * H, D, D, sp.w1_exp, w1r, LD, nullptr);
+    rbnn_split_rows(net.W1, (int64_t)S * H, D, D, sp.w1_exp, nullptr, w1r, LD, nullptr);
     rbnn_split_cols(net.W1, S, H, D, D, sp.w1_exp, w1c, D, nullptr);
     rbnn_split_w2gen(net.W2, S, C, H, sp.w2_exp, w2g, nullptr);
-    rbnn_split_rows(X, N, D, D, 14, xs, LD, nullptr);
+    rbnn_split_rows(X, N, D, D, 14, nullptr, xs, LD, nullptr);
     sp.W1_rows = w1r; sp.W1_cols = w1c; sp.W2_gen = w2g;
     rbnn_workspace_sizes sz; rbnn_workspace_query(&net, N, S, 0, &sz);
     rbnn_workspace ws = {};
@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
         for (int r = 0; r < reps + 1; ++r) {
             int ns = 0;
             hipEventRecord(e0, nullptr);
-            const int rc = which == 0 ? rbnn_fc_forward_split(&net, &sp, xs, LD, 14, N, nullptr, S, RBNN_OUT_PROBS, &ws, nullptr)
+            const int rc = which == 0 ? rbnn_fc_forward_split(&net, &sp, xs, LD, 14, nullptr, N, nullptr, S, RBNN_OUT_PROBS, &ws, nullptr)
                                       : rbnn_fc_input_grad_split(&net, &sp, nullptr, S, N, 0, &ws, &sws, &ns, nullptr);
             hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
             if (rc) { printf("rc=%d (%s)\n", rc, rbnn_strerror(rc)); return 1; }
