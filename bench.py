@@ -188,9 +188,9 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override N (debug)")
     ap.add_argument("--samples", type=int, default=0, help="override S per GPU (debug)")
     ap.add_argument("--iters", type=int, default=0, help="override the PGD iteration count (debug)")
-    ap.add_argument("--precision", default="exact", choices=["exact", "split", "fast"],
-                    help="arithmetic of the line's top level (exact = IEEE fp32 on the fp32 MFMA; the split mode is reported as a sub-record)")
-    ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision mode at N=1")
+    ap.add_argument("--precision", default="exact", choices=["exact", "triple", "split", "fast"],
+                    help="arithmetic of the line's top level (exact = IEEE fp32 on the fp32 MFMA; the triple and split modes are reported as sub-records)")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision modes at N=1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -253,6 +253,12 @@ def main():
 
         def fc_input_grad_split(self, *a, **kw):                          # includes the small dZ re-scaling kernel
             return self._timed("fc_input_grad", super().fc_input_grad_split, *a, **kw)
+
+        def fc_forward_triple(self, *a, **kw):
+            return self._timed("fc_forward", super().fc_forward_triple, *a, **kw)
+
+        def fc_input_grad_triple(self, *a, **kw):                         # includes the small dZ re-scaling kernel
+            return self._timed("fc_input_grad", super().fc_input_grad_triple, *a, **kw)
 
         def conv_forward(self, *a, **kw):
             return self._timed("conv_forward", super().conv_forward, *a, **kw)
@@ -338,7 +344,9 @@ def main():
                         "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel (+ conv_fc_bwd, conv1_bwd)"},
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
+    KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel"}
     SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}
+    PRODUCTS = {"split": 3.0, "triple": 6.0}                                # f16 MFMA products per algorithmic fp32 MAC
     if w["arch"] == "fc2":
         KNAMES["split"].update({"fc_forward": "fc_forward_split_kernel (x2: layer 1 -> split image, layer 2)",
                                 "fc_input_grad": "fc_grad_split_kernel (x2: per-sample step through Wm, then W1; + split_dz)"})
@@ -359,7 +367,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and not args.points and not args.samples:
             rec = json.load(open(pmc))
-            key = dom + ("_split" if mode == "split" and dom in SPLIT_KERNELS else "")
+            key = dom + ("_" + mode if mode in PRODUCTS and dom in SPLIT_KERNELS else "")
             ent = rec.get(args.workload, rec if args.workload == "c2" else {}).get(key, {})
             traffic = ent.get("hbm_bytes_per_launch")
             traffic_src = rec.get("source") if traffic is not None else None
@@ -367,10 +375,11 @@ def main():
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
              "traffic_source": traffic_src,      # PMC counters cannot be read inside this run: a committed rocprofv3 --pmc pass of the same command
              "flop_per_launch": per_launch / kernels[dom]["launches_per_pass"], "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
-        if mode == "split" and dom in SPLIT_KERNELS:
-            # matrix-pipe work of the split mode: 3 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
-            r.update({"achieved": 3.0 * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": 3.0 * fp32_eq / F16_MFMA_PEAK_TFLOPS,
-                      "pipe": "v_mfma_f32_16x16x32_f16, 3 products per fp32 MAC", "fp32_equivalent_tflops": fp32_eq,
+        if mode in PRODUCTS and dom in SPLIT_KERNELS:
+            # matrix-pipe work of the split / triple mode: 3 / 6 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
+            np_ = PRODUCTS[mode]
+            r.update({"achieved": np_ * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": np_ * fp32_eq / F16_MFMA_PEAK_TFLOPS,
+                      "pipe": "v_mfma_f32_16x16x32_f16, %d products per fp32 MAC" % np_, "fp32_equivalent_tflops": fp32_eq,
                       "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS})
         else:
             r.update({"achieved": fp32_eq, "peak": FP32_MFMA_PEAK_TFLOPS, "frac": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
@@ -384,17 +393,21 @@ def main():
         return r
 
     DTYPES = {"exact": "f32",
+              "triple": "f32 (full-width operands as three f16 pieces: 6 exact f16 MFMA product terms per fp32 product, f32 accumulate)",
               "split": "f32 carried as f16 hi+lo pairs: 3 f16 MFMA products per fp32 product, f32 accumulate (2^-22 per product)"}
+    SUBKEY = {"exact": "exact_fp32_mode", "triple": "triple_f16x6_mode", "split": "split_f16x3_mode"}
     mode, dt, evs = run(args.precision)
-    other = None
+    others = []
     if world == 1 and not args.no_other_mode:
-        want = "split" if mode == "exact" else "exact"
-        try:
-            other = run(want)                                             # the other precision mode on the same workload
-        except _hip.HipError:
-            other = None                                                  # the split kernels do not cover this posterior
-        if other is not None and other[0] != want:
-            other = None
+        for want in ("exact", "triple", "split"):                         # the other precision modes on the same workload
+            if want == mode:
+                continue
+            try:
+                o = run(want)
+            except _hip.HipError:
+                continue                                                  # those kernels do not cover this posterior
+            if o[0] == want:
+                others.append(o)
 
     import ctypes
     ctypes.CDLL(None).fflush(None)          # every rank: anything RCCL left in C stdio goes out before rank 0's JSON line
@@ -412,11 +425,10 @@ def main():
                        "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters)) if v}},
             "roofline": roofline(mode, evs, ms_per_step),
         }
-        if other is not None:
+        for other in others:
             o_ms = 1e3 * other[1] / args.steps
-            key = "split_f16x3_mode" if other[0] == "split" else "exact_fp32_mode"
-            out[key] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],
-                        "roofline": roofline(other[0], other[2], o_ms)}
+            out[SUBKEY[other[0]]] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],
+                                     "roofline": roofline(other[0], other[2], o_ms)}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -62,6 +62,11 @@ class SplitImages(C.Structure):
                 ("h1_exp", C.c_int32)]
 
 
+class TripleImages(C.Structure):
+    _fields_ = [("W1_rows", _fp), ("W1_cols", _fp), ("W2_gen", _fp), ("ld_rows", C.c_int32), ("ld_cols", C.c_int32),
+                ("w1_exp", C.c_int32), ("w2_exp", C.c_int32)]
+
+
 SPLIT_WS_KEYS = ("X_split", "dZ_gen", "g_scale")
 
 
@@ -108,6 +113,13 @@ SIGNATURES = {
     "rbnn_split_workspace_query": (_i32, [_PP, C.POINTER(SplitImages), _i32, _i32, C.POINTER(SplitWorkspaceSizes)]),
     "rbnn_fc_input_grad_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(SplitWorkspace),
                                         C.POINTER(_i32), _fp]),
+    "rbnn_triple_workspace_query": (_i32, [_PP, C.POINTER(TripleImages), _i32, _i32, C.POINTER(SplitWorkspaceSizes)]),
+    "rbnn_triple_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
+    "rbnn_triple_cols": (_i32, [_fp, _i64, _i32, _i32, _i32, _i32, _fp, _i32, _fp]),
+    "rbnn_triple_w2gen": (_i32, [_fp, _i32, _i32, _i32, _i32, _fp, _fp]),
+    "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
+    "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(SplitWorkspace),
+                                         C.POINTER(_i32), _fp]),
 }
 
 _lib = None
@@ -128,7 +140,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 4:
+        if lib.rbnn_abi_version() != 5:
             raise HipError("librbnn_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -281,6 +293,44 @@ class HipKernels:
         n = C.c_int32(0)
         check(self.lib.rbnn_fc_input_grad_split(C.byref(net.descriptor()), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
                                                 C.byref(sw), C.byref(n), stream_of(ws["dZ"])), "rbnn_fc_input_grad_split")
+        return n.value
+
+    # -- triple-split ("f16x6") mode: full-width fp32 operands on the f16 matrix pipe ---------------------
+    def triple_rows(self, src, cols, scale_exp, out, ld_dst, dev_scale=None):
+        """src: [..., ld_src] fp32 rows -> out: triple-rows image (int16 storage, 3 halves per element)."""
+        require_gpu(src, "src")
+        ld_src = src.shape[-1]
+        check(self.lib.rbnn_triple_rows(ptr(src), src.numel() // ld_src, cols, ld_src, scale_exp, ptr(dev_scale), ptr(out), ld_dst,
+                                        stream_of(src)), "rbnn_triple_rows")
+
+    def triple_cols(self, W, rows, cols, scale_exp, out, ld_dst):
+        require_gpu(W, "W")
+        check(self.lib.rbnn_triple_cols(ptr(W), W.numel() // (rows * W.shape[-1]), rows, cols, W.shape[-1], scale_exp, ptr(out),
+                                        ld_dst, stream_of(W)), "rbnn_triple_cols")
+
+    def triple_w2gen(self, W2, Cn, H, scale_exp, out):
+        require_gpu(W2, "W2")
+        check(self.lib.rbnn_triple_w2gen(ptr(W2), W2.numel() // (Cn * H), Cn, H, scale_exp, ptr(out), stream_of(W2)), "rbnn_triple_w2gen")
+
+    def triple_workspace_sizes(self, net, images, N, S):
+        out = SplitWorkspaceSizes()
+        check(self.lib.rbnn_triple_workspace_query(C.byref(net.descriptor()), C.byref(images), N, S, C.byref(out)),
+              "rbnn_triple_workspace_query")
+        return {k: getattr(out, k) for k in SPLIT_WS_KEYS}
+
+    def fc_forward_triple(self, net, images, Xt, ld, x_exp, N, sidx, S, out_kind, ws, dev_scale=None):
+        w = self._ws(ws)
+        check(self.lib.rbnn_fc_forward_triple(C.byref(net.descriptor()), C.byref(images), ptr(Xt), ld, x_exp, ptr(dev_scale), N,
+                                              ptr(sidx), S, out_kind, C.byref(w), stream_of(Xt)), "rbnn_fc_forward_triple")
+
+    def fc_input_grad_triple(self, net, images, sidx, S, N, chunk, ws, sws):
+        w = self._ws(ws)
+        sw = SplitWorkspace()
+        for k in SPLIT_WS_KEYS:
+            setattr(sw, k, ptr(sws.get(k)))
+        n = C.c_int32(0)
+        check(self.lib.rbnn_fc_input_grad_triple(C.byref(net.descriptor()), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
+                                                 C.byref(sw), C.byref(n), stream_of(ws["dZ"])), "rbnn_fc_input_grad_triple")
         return n.value
 
     # -- conv architecture ---------------------------------------------------------------------------

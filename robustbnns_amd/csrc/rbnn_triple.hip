@@ -1,0 +1,747 @@
+// rbnn_triple.hip — the "f16x6" mode of the two big contractions (gfx950 / MI355X): FULL-WIDTH fp32 operands on the f16 matrix pipe.
+//
+// rbnn_kernels.hip multiplies on v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak); rbnn_split.hip carries an operand as TWO halves
+// (22-23 significant bits: narrower than fp32, hence opt-in).  Here every fp32 operand v is carried as THREE halves
+//
+//      v * 2^e  =  p0 + p1 + p2,     p0 = fp16(v*2^e),  p1 = fp16(v*2^e - p0),  p2 = fp16(v*2^e - p0 - p1)
+//
+// 3 x 11 significand bits + 2 sign bits cover fp32's 24 exactly: the sum is EXACT (bit for bit the fp32 value) for every
+// |v| >= 2^-15 * max|tensor| — e is chosen so that max|v * 2^e| <= 2^14, and fp16's last subnormal bit is 2^-24 — and within
+// 2^-39 * max|tensor| absolutely below that.  A product is formed as
+//
+//      a*b  ~=  a0*b2 + a2*b0 + a1*b1 + a1*b0 + a0*b1 + a0*b0          (six f16 MFMAs, smallest terms first)
+//
+// each term exact in the fp32 accumulator's multiplier; the three dropped terms (a1*b2, a2*b1, a2*b2) are <= 2^-32 |a*b|.
+// So the ONLY rounding is the fp32 accumulation — the same as in the fp32 MFMA kernels (and in any fp32 GEMM), whose
+// summation order differs between implementations anyway.  Arithmetic ceiling: 2516.6 / 6 = 419 TFLOP/s fp32-equivalent,
+// 2.7x the fp32 MFMA peak.
+//
+// Images:
+//   "triple rows"  [R][ld/32][3][32] halves: per row and per K stage of 32 columns, 64 B of p0, 64 B of p1, 64 B of p2
+//                  (6 bytes per element).  A stage tile in LDS is three PLANE tiles of 64-B rows; a lane's MFMA operand
+//                  (8 K values) is one ds_read_b128 per plane; chunk swizzle `swz` (rbnn_common.hpp) as for fp32 64-B rows.
+//   "triple cols"  [S][H/32][4 lg][3][ld][8] halves: the backward's B operand, K-slot order = the dA generator's output order.
+// Lane maps as in rbnn_split.hip (v_mfma_f32_16x16x32_f16): a[j] = A[li][8*lg + j], b[j] = B[8*lg + j][li], acc[r] = D[4*lg + r][li].
+#include "rbnn_common.hpp"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ void split3(float v, _Float16& p0, _Float16& p1, _Float16& p2) {
+    p0 = (_Float16)v;
+    float r = v - (float)p0;                                    // exact (Sterbenz / the remainder of a rounding is representable)
+    p1 = (_Float16)r;
+    r -= (float)p1;
+    p2 = (_Float16)r;
+}
+
+// ===================================================================================================
+// fp32 rows -> triple-rows image.  One thread per (row, group of 8 columns): three 16-B stores.
+// ===================================================================================================
+__global__ void triple_rows_kernel(const float* __restrict__ src, long long rows, int cols, int ld_src, float scale,
+                                   const rbnn_dev_scale* __restrict__ ds, uint4* __restrict__ dst, int groups) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * groups) return;
+    if (ds) scale = ds->scale;
+    const long long r = i / groups;
+    const int g = (int)(i % groups);
+    const float* const p = src + r * ld_src + 8 * g;
+    union { f16x8 v; uint4 u; } o[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (8 * g + j < cols) ? p[j] * scale : 0.f;
+        _Float16 a, b, c;
+        split3(v, a, b, c);
+        o[0].v[j] = a; o[1].v[j] = b; o[2].v[j] = c;
+    }
+    // 16-B units: row r has (groups / 4) stages of 12 units: [plane][4 chunks]
+    uint4* const out = dst + (r * (groups >> 2) + (g >> 2)) * 12 + (g & 3);
+    out[0] = o[0].u; out[4] = o[1].u; out[8] = o[2].u;
+}
+
+// ===================================================================================================
+// T1: stacked forward.  One block = one (BN-point tile, sample) item, WH x WN waves, each HTW x NTW accumulator tiles:
+//   acc[h][n] = sum_d W[s][h][d] * X[n][d]        (A operand = W rows, B operand = X rows; D = [h][n])
+// K runs in stages of 32 columns = one MFMA K step.  A stage tile is 3 planes x (BH + BN) rows of 64 B, brought in by LDS-DMA
+// in 1-KiB pieces of 16 rows; physical 16-B chunk of logical chunk c in row r is c ^ swz(r), applied on the SOURCE address.
+// Epilogue = the exact kernel's (bias, activation, 1-bit stash, skinny H->C layer on the fp32 MFMA, softmax).
+// ===================================================================================================
+struct FwdX3Args {
+    const char* X;  int ldx;  int N;                           // triple-rows image of the inputs [N][ldx] (ldx elements, % 32 == 0)
+    const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // triple-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
+    const float* b;  const float* W2;  const float* b2;  int C;  int H;
+    const int* sidx;  int S;  int NT;  float out_scale;        // out_scale = 2^-(e_x + e_w)
+    float* P;  uint32_t* mask;  float* dact;  int out_kind;
+    const rbnn_dev_scale* x_ds;                                // != NULL: out_scale *= x_ds->inv_scale
+};
+
+template <int ACT, int WH, int HTW, int WN, int NTW>
+__global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kernel(const FwdX3Args a) {
+    constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
+    constexpr int PLANEB = (BH + BN) * 64;                     // one plane of a stage tile
+    constexpr int TILEB = 3 * PLANEB;
+    constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);
+    constexpr int NW = WH * WN;
+    constexpr int WPP = BH / 16 / NW, XPP = BN / 16 / NW;     // DMA pieces (16 rows of one plane) per wave per plane
+    static_assert((BH / 16) % NW == 0 && (BN / 16) % NW == 0, "whole pieces per wave");
+    static_assert(HTW % 2 == 0 && HTW <= 8, "a wave's h range is whole 32-bit mask words, at most 4");
+    static_assert(WH * BN * 64 <= 2 * TILEB, "the Z^T reduction scratch aliases the tile buffers");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * TILEB bytes
+    char* const ldsb = (char*)lds;
+    float* const zred = lds;
+
+    int id;
+    if (!item_of_block(blockIdx.x, a.NT * a.S, id)) return;
+    int ntile, s;                                              // 2-D blocked item order, see fc_forward_kernel
+    {
+        const int full = a.S / 8, per = 8 * a.NT;
+        if (id < full * per) { ntile = (id % per) / 8; s = (id / per) * 8 + id % 8; }
+        else { const int rem = id - full * per, cnt = a.S - full * 8; ntile = rem / cnt; s = full * 8 + rem % cnt; }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int wave_h = wave % WH, wave_n = wave / WH;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const float out_scale = a.x_ds ? a.out_scale * a.x_ds->inv_scale : a.out_scale;
+    const char* const Ws = a.W + (long long)sw * a.w_sample_bytes;
+    const int n0 = ntile * BN;
+    const int HW = a.H >> 5;
+    // DMA piece = 16 rows x 64 B of one plane: lane p lands at row (p >> 2), physical chunk p & 3, so it fetches logical chunk
+    // (p & 3) ^ swz(row); pieces start at multiples of 16 rows, so swz(row) = swz(p >> 2)
+    const int prow = lane >> 2;
+    const unsigned src_off = (unsigned)(((lane & 3) ^ swz(prow)) * 16);
+    // fragment read of row li (any 16-row tile), K chunk lg
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);
+
+    f32x4 zacc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) zacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane row offsets (bytes) of this wave's pieces; 32-bit (the host checks H*ldw*6 and N*ldx*6 < 2^32)
+    unsigned xrow[XPP];
+#pragma unroll
+    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min(n0 + 16 * (wave + NW * i) + prow, a.N - 1) * (unsigned)a.ldx * 6u + src_off;
+
+    for (int hc0 = 0; hc0 < a.H; hc0 += BH) {
+        f32x4 acc[HTW][NTW];
+#pragma unroll
+        for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        unsigned wrow[WPP];
+#pragma unroll
+        for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(hc0 + 16 * (wave + NW * i) + prow) * (unsigned)a.ldw * 6u + src_off;
+
+        auto stage = [&](int kt, int buf) {
+            char* const T = ldsb + buf * TILEB;
+            const unsigned koff = (unsigned)kt * 192u;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < WPP; ++i)
+                    glds16((const float*)(Ws + (wrow[i] + koff + 64u * p)), (float*)(T + p * PLANEB + (wave + NW * i) * 1024));
+#pragma unroll
+                for (int i = 0; i < XPP; ++i)
+                    glds16((const float*)(a.X + (xrow[i] + koff + 64u * p)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * i) * 1024));
+            }
+        };
+        stage(0, 0);
+        ring_wait_barrier<0>();
+        for (int kt = 0; kt < a.KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < a.KT) stage(kt + 1, buf ^ 1);          // lands while this stage is multiplied
+            const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 16 * 64 + foff;
+            const char* const Xt = ldsb + buf * TILEB + BH * 64 + (wave_n * NTW) * 16 * 64 + foff;
+            f16x8 b0[NTW], b1[NTW], b2[NTW], a0, a1, a2, a0n, a1n, a2n;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                b0[nt] = *(const f16x8*)(Xt + nt * 1024);
+                b1[nt] = *(const f16x8*)(Xt + PLANEB + nt * 1024);
+                b2[nt] = *(const f16x8*)(Xt + 2 * PLANEB + nt * 1024);
+            }
+            a0 = *(const f16x8*)(Wt);
+            a1 = *(const f16x8*)(Wt + PLANEB);
+            a2 = *(const f16x8*)(Wt + 2 * PLANEB);
+            a0n = a0; a1n = a1; a2n = a2;
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht) {
+                if (ht + 1 < HTW) {
+                    a0n = *(const f16x8*)(Wt + (ht + 1) * 1024);
+                    a1n = *(const f16x8*)(Wt + PLANEB + (ht + 1) * 1024);
+                    a2n = *(const f16x8*)(Wt + 2 * PLANEB + (ht + 1) * 1024);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a0, b2[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a2, b0[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a1, b1[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a1, b0[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a0, b1[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a0, b0[nt], acc[ht][nt]);
+                a0 = a0n; a1 = a1n; a2 = a2n;
+            }
+            // pin the order: B fragments + A(0) first, then per h tile half its MFMAs, the next tile's three reads, the rest
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * NTW + 3, 0);
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW, 0);
+                if (ht + 1 < HTW) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW, 0);
+            }
+            ring_wait_barrier<0>();                            // stage kt+1 landed; everyone is done with stage kt
+        }
+
+        // ---- epilogue of this h chunk: scale, bias, activation, derivative stash, skinny output layer ----
+        const int hw0 = hc0 + (wave_h * HTW) * 16;
+        unsigned mine[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) mine[nt] = 0u;
+#pragma unroll
+        for (int ht = 0; ht < HTW; ++ht) {
+            const int hrow = hw0 + ht * 16 + 4 * lg;           // acc[ht][nt][r] is hidden unit hrow + r
+            const f32x4 bias = *(const f32x4*)(a.b + (long long)sw * a.H + hrow);
+            f32x4 w2f = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (li < a.C) w2f = *(const f32x4*)(a.W2 + ((long long)sw * a.C + li) * a.H + hrow);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = n0 + (wave_n * NTW + nt) * 16 + li;
+                f32x4 v = acc[ht][nt] * out_scale + bias, hv;
+                unsigned bits = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bits |= (v[r] > 0.f ? 1u : 0u) << r;
+                    hv[r] = act_fwd<ACT>(v[r]);
+                }
+                if (BITMASK) {
+                    unsigned part = bits << (16 * (ht & 1) + 4 * lg);
+                    part |= __shfl_xor(part, 16);
+                    part |= __shfl_xor(part, 32);
+                    if (lg == (ht >> 1)) mine[nt] |= part;
+                }
+                if (!BITMASK && a.dact && n < a.N) {
+                    f32x4 dv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dv[r] = act_grad_from_value<ACT>(hv[r]);
+                    *(f32x4*)(a.dact + ((long long)s * a.N + n) * a.H + hrow) = dv;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
+            }
+        }
+        if (BITMASK && a.mask) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int n = n0 + (wave_n * NTW + nt) * 16 + li;
+                if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * HW + (hw0 >> 5) + lg) * mask_ld(a.N) + n] = mine[nt];
+            }
+        }
+    }
+
+    // Z^T partials of the WH waves that split h -> LDS -> one thread per point finishes the softmax.
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+        *(f32x4*)(zred + (wave_h * BN + (wave_n * NTW + nt) * 16 + li) * 16 + 4 * lg) = zacc[nt];
+    __syncthreads();
+    if (tid < BN) {
+        const int n = n0 + tid;
+        float z[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 sum = *(const f32x4*)(zred + tid * 16 + 4 * q);
+#pragma unroll
+            for (int w = 1; w < WH; ++w) sum += *(const f32x4*)(zred + (w * BN + tid) * 16 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[4 * q + r] = sum[r];
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < a.C) { z[c] += a.b2[(long long)sw * a.C + c]; m = fmaxf(m, z[c]); }
+            else z[c] = 0.f;
+        }
+        if (a.out_kind == RBNN_OUT_PROBS) {
+            float den = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c < a.C) { z[c] = expf(z[c] - m); den += z[c]; }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c < a.C) z[c] = z[c] / den;
+        }
+        if (n < a.N) {
+            float* const dst = a.P + ((long long)s * a.N + n) * RBNN_CPAD;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dst + 4 * q) = (f32x4){z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]};
+        }
+    }
+}
+
+template <int ACT, int WH, int HTW, int WN, int NTW>
+int launch_forward_x3_cfg(FwdX3Args a, hipStream_t st) {
+    constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
+    constexpr int LDSB = 2 * 3 * (BH + BN) * 64;
+    static_assert(LDSB <= 160 * 1024, "LDS");
+    a.NT = (a.N + BN - 1) / BN;
+    auto kern = fc_forward_x3_kernel<ACT, WH, HTW, WN, NTW>;
+    static unsigned long long attr_done = 0;                    // per instantiation, one bit per device
+    if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
+    const int grid = grid_for_items((long long)a.NT * a.S);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WH * WN), LDSB, st, a);
+    return launch_status();
+}
+
+#ifndef RBNN_X3_FWD_CFG
+#define RBNN_X3_FWD_CFG 4, 4, 2, 4                              // 256 h x 128 n, 8 waves of 64 h x 64 n, 144 KB of LDS
+#endif
+
+template <int ACT>
+int launch_forward_x3_act(const FwdX3Args& a, hipStream_t st) {
+    if (a.H % 256 == 0) return launch_forward_x3_cfg<ACT, RBNN_X3_FWD_CFG>(a, st);
+    if (a.H % 128 == 0) return launch_forward_x3_cfg<ACT, 2, 4, 2, 4>(a, st);   // 128 h x 128 n, 4 waves
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+int launch_forward_x3(int act, const FwdX3Args& a, hipStream_t st) {
+    switch (act) {
+#ifndef RBNN_FAST_BUILD
+        case RBNN_ACT_RELU:  return launch_forward_x3_act<RBNN_ACT_RELU>(a, st);
+#endif
+        case RBNN_ACT_LEAKY: return launch_forward_x3_act<RBNN_ACT_LEAKY>(a, st);
+#ifndef RBNN_FAST_BUILD
+        case RBNN_ACT_SIGM:  return launch_forward_x3_act<RBNN_ACT_SIGM>(a, st);
+        case RBNN_ACT_TANH:  return launch_forward_x3_act<RBNN_ACT_TANH>(a, st);
+#endif
+    }
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+// ===================================================================================================
+// Image builders of the backward.
+// ===================================================================================================
+// W1 "triple cols" image: out[m][hb][lg][p][d][j] (p = piece 0..2; 8 halves j) = piece p of W[m][32*hb + 16*(j>>2) + 4*lg + (j&3)][d] * scale.
+__global__ void triple_cols_kernel(const float* __restrict__ W, long long n_mats, int rows, int cols, int ld_src, float scale,
+                                   uint4* __restrict__ dst, int ld_dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int HB = rows / 32;
+    if (i >= n_mats * HB * 4 * ld_dst) return;
+    const int d = (int)(i % ld_dst);
+    const int lg = (int)((i / ld_dst) % 4);
+    const long long mh = i / (4LL * ld_dst);                   // m * HB + hb
+    const long long m = mh / HB;
+    const int hb = (int)(mh % HB);
+    union { f16x8 v; uint4 u; } o[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int h = 32 * hb + 16 * (j >> 2) + 4 * lg + (j & 3);
+        const float v = (d < cols) ? W[(m * rows + h) * ld_src + d] * scale : 0.f;
+        _Float16 a, b, c;
+        split3(v, a, b, c);
+        o[0].v[j] = a; o[1].v[j] = b; o[2].v[j] = c;
+    }
+    const long long base = ((mh * 4 + lg) * 3) * ld_dst;       // 16-byte units
+    dst[base + d] = o[0].u;
+    dst[base + ld_dst + d] = o[1].u;
+    dst[base + 2 * ld_dst + d] = o[2].u;
+}
+
+// K-slot plan of the dA generator: TWO f16 MFMAs (64 K slots) chained on one accumulator form all six products of the C <= 10
+// classes.  Classes 0..7 fill whole 8-slot chunks, classes 8, 9 share a "tail" chunk.  With w_p / d_p = piece p of W2[c][h] / dZ[n][c]:
+//   dZ row of a point (64 B):  chunk 0 = d0[c0..7]   chunk 1 = d1[c0..7]   chunk 2 = d2[c0..7]   chunk 3 = T = [d0c8 d0c9 d1c8 d1c9 d2c8 d2c9 d0c8 d0c9]
+//   MFMA 1, lane group lg:     dZ chunks {0, 1, 0, 3}      W2 side { w0[c0..7], w0[c0..7], w1[c0..7], [w0c8 w0c9 w0c8 w0c9 w0c8 w0c9 w1c8 w1c9] }
+//   MFMA 2, lane group lg:     dZ chunks {1, 2, 0, 3}      W2 side { w1[c0..7], w0[c0..7], w2[c0..7], [w2c8 w2c9 w1c8 w1c9 0 0 0 0] }
+// => (w0 d0) (w0 d1) (w1 d0) | (w1 d1) (w0 d2) (w2 d0) for c < 8, and the same six for c = 8, 9 out of the tail chunks.
+// W2 generator image: out[m][t][k][lane][8] = W2 side of MFMA k+1 for hidden unit 16*t + li: 2 KiB per 16-unit tile.
+__global__ void triple_w2gen_kernel(const float* __restrict__ W2, int n_mats, int C, int H, float scale, uint4* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n_mats * (H / 16) * 128) return;
+    const int lane = (int)(i & 63), li = lane & 15, lg = lane >> 4, k = (int)((i >> 6) & 1);
+    const int t = (int)((i >> 7) % (H / 16));
+    const long long m = (i >> 7) / (H / 16);
+    _Float16 w[3][10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+        const float v = (c < C) ? W2[(m * C + c) * H + 16 * t + li] * scale : 0.f;
+        split3(v, w[0][c], w[1][c], w[2][c]);
+    }
+    union { f16x8 v; uint4 u; } o;
+    const _Float16 z = (_Float16)0.f;
+    if (lg < 3) {
+        const int piece = (k == 0) ? (lg == 2 ? 1 : 0) : (lg == 0 ? 1 : (lg == 1 ? 0 : 2));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = piece == 0 ? w[0][j] : (piece == 1 ? w[1][j] : w[2][j]);
+    } else if (k == 0) {
+        o.v[0] = w[0][8]; o.v[1] = w[0][9]; o.v[2] = w[0][8]; o.v[3] = w[0][9];
+        o.v[4] = w[0][8]; o.v[5] = w[0][9]; o.v[6] = w[1][8]; o.v[7] = w[1][9];
+    } else {
+        o.v[0] = w[2][8]; o.v[1] = w[2][9]; o.v[2] = w[1][8]; o.v[3] = w[1][9];
+        o.v[4] = z; o.v[5] = z; o.v[6] = z; o.v[7] = z;
+    }
+    dst[i] = o.u;
+}
+
+// dZ generator image + per-point scale: e(n) = 13 - ilogb(max_{s,c} |dZ[s][n][c]|); out[s][n][chunk ^ dz_swz3(n)] per the plan above;
+// gscale[n] = 2^-e(n).  Points n >= N get zeros.  (Block = 16 points x 16 sample lanes, as split_dz_kernel.)
+__host__ __device__ __forceinline__ int dz_swz3(long long n) { return (int)((0 - (n >> 2)) & 3); }
+
+__global__ void __launch_bounds__(256) triple_dz_kernel(const float* __restrict__ dZ, int S, int N, long long N_pad, int C,
+                                                        uint4* __restrict__ dst, float* __restrict__ gscale) {
+    __shared__ float red[16][17];
+    const int p = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long long n = (long long)blockIdx.x * 16 + p;
+    float m = 0.f;
+    if (n < N)
+        for (int s = q; s < S; s += 16) {
+            const float* const src = dZ + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 v = *(const f32x4*)(src + 4 * k);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * k + r < C) m = fmaxf(m, fabsf(v[r]));
+            }
+        }
+    red[q][p] = m;
+    __syncthreads();
+    m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i][p]);
+    int e = 0;
+    if (m > 0.f && m < INFINITY) e = min(13 - ilogbf(m), 120);
+    if (q == 0) gscale[n] = ldexpf(1.f, -e);
+    const int sw = dz_swz3(n);
+    for (int s = q; s < S; s += 16) {
+        _Float16 d[3][10];
+        float v[12];
+        if (n < N) {
+            const float* const src = dZ + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 t = *(const f32x4*)(src + 4 * k);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * k + r] = t[r];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const float x = (n < N && c < C) ? ldexpf(v[c], e) : 0.f;
+            split3(x, d[0][c], d[1][c], d[2][c]);
+        }
+        uint4* const o = dst + ((long long)s * N_pad + n) * 4;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            union { f16x8 v; uint4 u; } w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w.v[j] = d[ch][j];
+            o[ch ^ sw] = w.u;
+        }
+        union { f16x8 v; uint4 u; } t;
+        t.v[0] = d[0][8]; t.v[1] = d[0][9]; t.v[2] = d[1][8]; t.v[3] = d[1][9];
+        t.v[4] = d[2][8]; t.v[5] = d[2][9]; t.v[6] = d[0][8]; t.v[7] = d[0][9];
+        o[3 ^ sw] = t.u;
+    }
+}
+
+// ===================================================================================================
+// T2: input gradient.  One block = one (256-point tile, TD*16-column group, chunk of samples) item, 4 waves of 64 points:
+//   acc[n][d] += sum_h dA[n][h] * W1[s][h][d],   dA[n][h] = act'(A_s[n][h]) * sum_c dZ[s][n][c] * W2[s][c][h]
+// A stage is 32 hidden units of one sample = ONE K step of the f16 MFMA:
+//   generator  (dA^T)[h][n] for the stage's two 16-unit tiles: two chained f16 MFMAs per (tile, point tile), fp32 result;
+//   split      x act' (1-bit stash) x 2^GEN_Q on the VALU, then the three halves: the accumulator layout IS the A-operand layout
+//              of the main MFMA with K slot 8*lg + 4*t + r (the order of the triple-cols image);
+//   main       6 f16 MFMAs per (point tile, column tile), B operand (W1 pieces) from the stage's LDS tile.
+// The stage's W1 tile, W2 generator tiles and stash words arrive by LDS-DMA one stage ahead.  The dZ generator image of a
+// wave's own 64 points (4 KiB per sample) lives in a SINGLE buffer: the wave itself re-fills it for the next sample during
+// the last stage of the current one, after its generator reads (two blocks per CU need <= 80 KB each).
+// ===================================================================================================
+#define GEN_Q3 (-17)                                           // |generator| <= 16 * 2^14 * 2^14 = 2^32  ->  |dA| <= 2^15 < fp16 max
+
+struct GradX3Args {
+    const char* dzg;  long long n_pad;  const float* gscale;  const uint32_t* mask;
+    const char* W1c;  int ldc;                                  // triple-cols image, ldc columns
+    const char* W2g;                                            // generator image [S_total][H/16][2 KiB]
+    int H;  int HW;  const int* sidx;  int S;  int chunk;  int nchunks;
+    int N;  int NT;  int ND;  int Dt;
+    float* out;  int ldo;  float out_scale;                     // slabs [nchunks][N][ldo]; out_scale = 2^-(e_w2 + GEN_Q3 + e_w1)
+};
+
+template <int ACT, int TD>
+__global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) {
+    constexpr int NTW = 4, NW = 4, BM = 256, LD = TD * 16;
+    constexpr int W1B = 12 * LD * 16;                          // bytes: [4 lg][3 pieces][LD columns][16 B]
+    constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + NW - 1) / NW;
+    constexpr int BUFB = W1B + 4096 + 1024;                    // + 2 generator tiles of 2 KiB + 256 stash words
+    constexpr int DZB = BM * 64;
+    static_assert(W1B % 1024 == 0, "whole DMA pieces");
+    static_assert(ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY, "1-bit stash activations");
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * BUFB + DZB bytes
+    char* const ldsb = (char*)lds;
+    char* const dzl = ldsb + 2 * BUFB;
+
+    int id;
+    if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
+    const int ntile = id % a.NT, dg = (id / a.NT) % a.ND, ch = id / (a.NT * a.ND);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int nb = ntile * BM + wave * (NTW * 16);
+    const int dc0 = dg * LD;
+    const int Dp = a.Dt * 16;
+    const int ntd = min(TD, a.Dt - dg * TD);                   // valid column tiles of this group (the last group may be partial)
+    const int s_begin = ch * a.chunk, s_end = min(a.S, s_begin + a.chunk);
+    const int HS = a.H / 32, nst = (s_end - s_begin) * HS;
+
+    int goff[PPW];                                             // per-lane source offsets (bytes, from the stage's image base) of this wave's W1 pieces
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int f = (wave + NW * i) * 1024 + lane * 16, seg = f / (LD * 16), d = (f % (LD * 16)) >> 4;
+        goff[i] = (seg * a.ldc + min(dc0 + d, a.ldc - 1)) * 16;   // columns past the image: any valid address, never stored
+    }
+
+    f32x4 acc[NTW][TD];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto dz_issue = [&](int s) {                                // this wave's 64 points x 64 B of sample s -> its own region of dzl
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            glds16((const float*)(a.dzg + (((long long)s * a.n_pad + nb + j * 16) * 64) + lane * 16), (float*)(dzl + wave * 4096 + j * 1024));
+    };
+    auto stage_issue = [&](int st, int buf) {
+        const int si = st / HS, hb = st % HS, s = s_begin + si;
+        const int sw = a.sidx ? a.sidx[s] : s;
+        const char* const Wb = a.W1c + ((long long)sw * HS + hb) * 12 * a.ldc * 16;
+        char* const B = ldsb + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            if (wave + NW * i < NPIECE) glds16((const float*)(Wb + goff[i]), (float*)(B + (wave + NW * i) * 1024));
+        // generator tiles 2*hb, 2*hb + 1 of this sample = 4 KiB contiguous: one piece per wave
+        glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb) * 2048) + wave * 1024 + lane * 16), (float*)(B + W1B + wave * 1024));
+        if (wave == NW - 1)                                     // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
+            glds16((const float*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM + 4 * lane), (float*)(B + W1B + 4096));
+    };
+
+    dz_issue(s_begin);
+    stage_issue(0, 0);
+    ring_wait_barrier<0>();
+    const float c_pos = ldexpf(1.f, GEN_Q3), c_neg = (ACT == RBNN_ACT_RELU) ? 0.f : LEAKY_SLOPE * ldexpf(1.f, GEN_Q3);
+    const int dzc1 = (lg == 2 ? 0 : lg), dzc2 = (lg == 0 ? 1 : (lg == 1 ? 2 : (lg == 2 ? 0 : 3)));   // dZ chunk of MFMA 1 / 2 for this lane group
+    const int sz = dz_swz3(li);
+    const char* const dzw = dzl + wave * 4096 + li * 64;
+    f16x8 da0[NTW], da1[NTW], da2[NTW];                        // A operand of the main MFMA: this wave's 4 point tiles, one stage
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1, hb = st % HS;
+        if (st + 1 < nst) stage_issue(st + 1, buf ^ 1);
+        const char* const B = ldsb + buf * BUFB;
+
+        // ---- generator + split ----
+        {
+            const f16x8 w00 = *(const f16x8*)(B + W1B + lane * 16);            // tile 0: MFMA 1, MFMA 2
+            const f16x8 w01 = *(const f16x8*)(B + W1B + 1024 + lane * 16);
+            const f16x8 w10 = *(const f16x8*)(B + W1B + 2048 + lane * 16);     // tile 1
+            const f16x8 w11 = *(const f16x8*)(B + W1B + 3072 + lane * 16);
+            const unsigned* const Mk = (const unsigned*)(B + W1B + 4096) + wave * (NTW * 16) + li;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const f16x8 dz1 = *(const f16x8*)(dzw + nt * 1024 + ((dzc1 ^ sz) * 16));
+                const f16x8 dz2 = *(const f16x8*)(dzw + nt * 1024 + ((dzc2 ^ sz) * 16));
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 g0 = MFMA_H(w01, dz2, MFMA_H(w00, dz1, z)), g1 = MFMA_H(w11, dz2, MFMA_H(w10, dz1, z));
+                const unsigned mw = Mk[nt * 16] >> (4 * lg);   // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = g0[r] * (((mw >> r) & 1u) ? c_pos : c_neg);
+                    const float v1 = g1[r] * (((mw >> (16 + r)) & 1u) ? c_pos : c_neg);
+                    _Float16 x0, x1, x2;
+                    split3(v0, x0, x1, x2);
+                    da0[nt][r] = x0; da1[nt][r] = x1; da2[nt][r] = x2;
+                    split3(v1, x0, x1, x2);
+                    da0[nt][4 + r] = x0; da1[nt][4 + r] = x1; da2[nt][4 + r] = x2;
+                }
+            }
+        }
+        if (hb == HS - 1 && st + 1 < nst) {                     // last stage of a sample: the dZ reads above are this wave's last of it
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): those reads have returned
+            asm volatile("" ::: "memory");
+            dz_issue(s_begin + st / HS + 1);                   // lands under the main MFMAs; the stage barrier's vmcnt(0) covers it
+        }
+        // ---- main: column-tile major ----
+        const char* const Bw = B + (lg * 3 * LD + li) * 16;
+        f16x8 b0 = *(const f16x8*)(Bw), b1 = *(const f16x8*)(Bw + LD * 16), b2 = *(const f16x8*)(Bw + 2 * LD * 16), b0n = b0, b1n = b1, b2n = b2;
+#pragma unroll
+        for (int dt = 0; dt < TD; ++dt) {
+            if (dt < ntd) {                                     // block-uniform; the loop stays fully unrolled (acc in registers)
+                if (dt + 1 < TD) {
+                    b0n = *(const f16x8*)(Bw + (dt + 1) * 256);
+                    b1n = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
+                    b2n = *(const f16x8*)(Bw + 2 * LD * 16 + (dt + 1) * 256);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], b2, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da2[nt], b0, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da1[nt], b1, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da1[nt], b0, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], b1, acc[nt][dt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], b0, acc[nt][dt]);
+                b0 = b0n; b1 = b1n; b2 = b2n;
+            }
+        }
+        ring_wait_barrier<0>();                                // next stage landed; everyone is done with this one
+    }
+
+    // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li], un-scaled per point ----
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nb + nt * 16 + 4 * lg + r;
+            if (n >= a.N) continue;
+            const float gs = a.gscale[n] * a.out_scale;
+            float* const dst = a.out + ((long long)ch * a.N + n) * a.ldo;
+#pragma unroll
+            for (int dt = 0; dt < TD; ++dt) {
+                const int d = dc0 + dt * 16 + li;
+                if (d >= Dp) continue;
+                dst[d] = acc[nt][dt][r] * gs;
+            }
+        }
+}
+
+template <int ACT, int TD>
+int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
+    constexpr int LDSB = 2 * (12 * TD * 16 * 16 + 5120) + 256 * 64;
+    static_assert(2 * LDSB <= 160 * 1024, "two blocks per CU");
+    a.NT = (a.N + 255) / 256;
+    a.ND = (a.Dt + TD - 1) / TD;
+    auto kern = fc_grad_x3_kernel<ACT, TD>;
+    static unsigned long long attr_done = 0;
+    if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
+    const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, st, a);
+    return launch_status();
+}
+
+template <int ACT>
+int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
+    if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7>(a, st);
+    return launch_grad_x3_cfg<ACT, 4>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbnn_triple_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                     const rbnn_dev_scale* dev_scale, void* dst, int32_t ld_dst, void* stream) {
+    if (!src || !dst) return RBNN_ERR_NULL;
+    if (rows < 1 || cols < 1 || ld_src < cols || ld_dst < cols || (ld_dst & 31)) return RBNN_ERR_SHAPE;
+    if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(dst)) return RBNN_ERR_ALIGN;
+    const int groups = ld_dst / 8;
+    const long long total = (long long)rows * groups;
+    hipLaunchKernelGGL(triple_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, (long long)rows, cols, ld_src, ldexpf(1.f, scale_exp), dev_scale, (uint4*)dst, groups);
+    return launch_status();
+}
+
+int rbnn_triple_cols(const float* W, int64_t n_mats, int32_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                     void* dst, int32_t ld_dst, void* stream) {
+    if (!W || !dst) return RBNN_ERR_NULL;
+    if (n_mats < 1 || rows < 32 || (rows & 31) || cols < 1 || ld_src < cols || ld_dst < cols || (ld_dst & 15)) return RBNN_ERR_SHAPE;
+    if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(dst)) return RBNN_ERR_ALIGN;
+    const long long total = (long long)n_mats * (rows / 32) * 4 * ld_dst;
+    hipLaunchKernelGGL(triple_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W, (long long)n_mats, rows, cols, ld_src, ldexpf(1.f, scale_exp), (uint4*)dst, ld_dst);
+    return launch_status();
+}
+
+int rbnn_triple_w2gen(const float* W2, int32_t n_mats, int32_t C, int32_t H, int32_t scale_exp, void* dst, void* stream) {
+    if (!W2 || !dst) return RBNN_ERR_NULL;
+    if (n_mats < 1 || C < 1 || C > 10 || H < 16 || (H & 15)) return RBNN_ERR_SHAPE;
+    if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(dst)) return RBNN_ERR_ALIGN;
+    const long long total = (long long)n_mats * (H / 16) * 128;
+    hipLaunchKernelGGL(triple_w2gen_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       W2, n_mats, C, H, ldexpf(1.f, scale_exp), (uint4*)dst);
+    return launch_status();
+}
+
+int rbnn_triple_workspace_query(const rbnn_posterior* net, const rbnn_triple_images* tp, int32_t N, int32_t S,
+                                rbnn_split_workspace_sizes* out) {
+    if (!net || !tp || !out) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || tp->ld_rows < net->in_features || (tp->ld_rows & 31)) return RBNN_ERR_SHAPE;
+    rbnn_split_workspace_sizes z = {};
+    z.X_split = (size_t)N * tp->ld_rows * 6;
+    z.dZ_gen = (size_t)S * mask_ld(N) * 64;
+    z.g_scale = (size_t)mask_ld(N) * sizeof(float);
+    *out = z;
+    return RBNN_OK;
+}
+
+int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const void* X_triple, int32_t ldx,
+                           int32_t x_exp, const rbnn_dev_scale* dev_scale, int32_t N, const int32_t* sidx, int32_t S,
+                           int32_t out_kind, const rbnn_workspace* ws, void* stream) {
+    if (!net || !tp || !X_triple || !ws || !ws->P || !tp->W1_rows) return RBNN_ERR_NULL;
+    if (!net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
+    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    const int H = net->hidden, ld = tp->ld_rows;
+    if (H < 128 || (H % 128) || ld < net->in_features || (ld & 31) || ldx != ld) return RBNN_ERR_SHAPE;
+    if (net->n_classes < 1 || net->n_classes > RBNN_CPAD || N < 1 || S < 1) return RBNN_ERR_SHAPE;
+    // the kernel addresses a sample's weight image and the input image with 32-bit byte offsets from a 64-bit base
+    if ((long long)H * ld * 6 >= (1LL << 32) || (long long)N * ld * 6 >= (1LL << 32)) return RBNN_ERR_SHAPE;
+    if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
+    if (!aligned16(X_triple) || !aligned16(tp->W1_rows) || !aligned16(ws->P) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
+    FwdX3Args a = {};
+    a.X = (const char*)X_triple; a.ldx = ldx; a.N = N;
+    a.W = (const char*)tp->W1_rows; a.w_sample_bytes = (long long)H * ld * 6; a.ldw = ld; a.KT = ld / 32;
+    a.b = net->b1; a.W2 = net->W2; a.b2 = net->b2; a.C = net->n_classes; a.H = H;
+    a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -((dev_scale ? 0 : x_exp) + tp->w1_exp)); a.x_ds = dev_scale;
+    a.P = ws->P; a.mask = ws->mask1; a.dact = ws->dact1; a.out_kind = out_kind;
+    return launch_forward_x3(net->activation, a, (hipStream_t)stream);
+}
+
+int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const int32_t* sidx, int32_t S,
+                              int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_split_workspace* sws,
+                              int32_t* n_slabs_out, void* stream) {
+    if (!net || !tp || !ws || !sws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
+    if (!tp->W1_cols || !tp->W2_gen || !sws->dZ_gen || !sws->g_scale) return RBNN_ERR_NULL;
+    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
+    if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
+    if (tp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
+    if (!aligned16(tp->W1_cols) || !aligned16(tp->W2_gen) || !aligned16(sws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (chunk <= 0) {                                           // the exact mode's slab plan (same workspace)
+        rbnn_workspace_sizes q;
+        const int rc = rbnn_workspace_query(net, N, S, 0, &q);
+        if (rc) return rc;
+        chunk = q.chunk;
+    }
+    if (chunk > S) chunk = S;
+    const int nchunks = (S + chunk - 1) / chunk;
+    if (n_slabs_out) *n_slabs_out = nchunks;
+    const long long n_pad = mask_ld(N);
+    hipLaunchKernelGGL(triple_dz_kernel, dim3((unsigned)(n_pad / 16)), dim3(256), 0, st,
+                       ws->dZ, S, N, n_pad, C, (uint4*)sws->dZ_gen, sws->g_scale);
+    if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
+    GradX3Args g = {};
+    g.dzg = (const char*)sws->dZ_gen; g.n_pad = n_pad; g.gscale = sws->g_scale; g.mask = ws->mask1;
+    g.W1c = (const char*)tp->W1_cols; g.ldc = tp->ld_cols; g.W2g = (const char*)tp->W2_gen;
+    g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N; g.Dt = Dp / 16;
+    g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
+    g.out_scale = ldexpf(1.f, -(tp->w2_exp + GEN_Q3 + tp->w1_exp));
+#ifndef RBNN_FAST_BUILD
+    if (net->activation == RBNN_ACT_RELU) return launch_grad_x3<RBNN_ACT_RELU>(g, st);
+#endif
+    return launch_grad_x3<RBNN_ACT_LEAKY>(g, st);
+}
+
+}  // extern "C"

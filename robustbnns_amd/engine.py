@@ -80,8 +80,14 @@ class AttackEngine:
         same 1e-5 parity bar, and the same adversarial accuracy in the split-vs-exact tests) — OPT-IN, raises where the split
         kernels do not cover the posterior.  fast: split where it applies, else exact.  RBNN_PRECISION sets the default."""
         want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
-        if want not in ("auto", "exact", "split", "fast"):
-            raise ValueError(f"precision={want!r}: expected 'auto', 'exact', 'split' or 'fast'")
+        if want not in ("auto", "exact", "triple", "split", "fast"):
+            raise ValueError(f"precision={want!r}: expected 'auto', 'exact', 'triple', 'split' or 'fast'")
+        if want == "triple":
+            # full-width fp32 operands as three fp16 pieces, six exact product terms on the f16 matrix pipe, fp32 accumulation
+            # (rbnn_triple.hip): fp32-MFMA-grade results (the only rounding left is the accumulation) at ~1.5x the speed
+            if not (bool(getattr(self.post, "triple_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)):
+                raise _hip.HipError("precision='triple' covers fc posteriors with relu / leaky, hidden % 128 == 0 and classes <= 10, on the GPU")
+            return "triple"
         ok = bool(getattr(self.post, "split_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
         if want == "split" and not ok:
             raise _hip.HipError("precision='split' covers fc / fc2 posteriors with hidden % 128 == 0 and classes <= 10, and the conv "
@@ -155,8 +161,9 @@ class AttackEngine:
                     ws[name] = torch.empty(sizes[name] // 4, dtype=_WS_DTYPE.get(name, torch.float32), device=self.device)
             ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
             ws["G"] = torch.empty(N, self.post.Dp, dtype=torch.float32, device=self.device)
-            if self.precision == "split":
-                ssz = self.k.split_workspace_sizes(self.post, self.post.split_images(), N, S)
+            if self.precision in ("split", "triple"):
+                ssz = (self.k.split_workspace_sizes(self.post, self.post.split_images(), N, S) if self.precision == "split"
+                       else self.k.triple_workspace_sizes(self.post, self.post.triple_images(), N, S))
                 ws["split"] = {"X_split": torch.empty(ssz["X_split"] // 2, dtype=torch.int16, device=self.device),
                                "dZ_gen": torch.empty(ssz["dZ_gen"] // 2, dtype=torch.int16, device=self.device),
                                "g_scale": torch.empty(ssz["g_scale"] // 4, dtype=torch.float32, device=self.device)}
@@ -167,6 +174,11 @@ class AttackEngine:
 
     # ------------------------------------------------------------------ kernel hooks (overridden for the conv architecture)
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
+        if self.precision == "triple":
+            img = self.post.triple_images()
+            ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
+            self.k.triple_rows(Xp, self.post.D, 0, ws["split"]["X_split"], img.ld_rows, dev_scale=ds)
+            return self.k.fc_forward_triple(self.post, img, ws["split"]["X_split"], img.ld_rows, 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scale=ds)
         if self.precision != "split":
             return self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
         img = self.post.split_images()
@@ -175,6 +187,8 @@ class AttackEngine:
         self.k.fc_forward_split(self.post, img, ws["split"]["X_split"], img.ld_rows, 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
 
     def _grad_kernels(self, sidx, S, N, ws):
+        if self.precision == "triple":
+            return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
         if self.precision != "split" or (self.post.arch == "fc2" and os.environ.get("RBNN_FC2_BWD_EXACT") == "1"):
             return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
         return self.k.fc_input_grad_split(self.post, self.post.split_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
@@ -184,7 +198,7 @@ class AttackEngine:
         layer / conv1 output), computed ON THE DEVICE by rbnn_input_scales — two 16-byte records the kernels read, no
         device->host sync.  `iterates`: later PGD iterates are clamp(., 0, 1) of something (adversarialAttacks.py:105), so
         |x| <= max(|x0|, 1) bounds them all and one record serves the whole attack; FGSM differentiates at x0 itself."""
-        if self.precision != "split":
+        if self.precision not in ("split", "triple"):
             return None
         mul, add, cap = self.post.scale_bounds()
         out = torch.empty(8, dtype=torch.int32, device=self.device)

@@ -74,6 +74,7 @@ class StackedPosterior:
         self._pack()
         self._desc = None
         self._split = None
+        self._triple = None
 
     # ------------------------------------------------------------------ split-half ("f16x3") precision mode
     def split_supported(self):
@@ -111,6 +112,33 @@ class StackedPosterior:
                 self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
             self._split = (img, keep)                            # the tensors keep the device memory alive
         return self._split[0]
+
+    # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands
+    def triple_supported(self):
+        """The triple kernels cover fc with relu / leaky, hidden % 128 == 0 and <= 10 classes."""
+        return (self.arch == "fc" and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
+                and self.device.type == "cuda")
+
+    def triple_images(self):
+        """rbnn_triple_images of this posterior (built once, resident): W1 as triple rows (forward A operand, 6 B per weight),
+        W1 as triple cols (backward B operand), W2 as the dA-generator image."""
+        if self._triple is None:
+            k = _hip.HipKernels()
+            S, H, Dp, D, Cn = self.S, self.Hp, self.Dp, self.D, self.C
+            ld = round_up(D, 32)
+            w1_exp = scale_exp(float(self.W1.abs().max()))
+            w2_exp = scale_exp(float(self.W2.abs().max()))
+            rows = torch.empty(S * H, ld * 3, dtype=torch.int16, device=self.device)
+            cols = torch.empty(S * (H // 32) * 12 * Dp * 8, dtype=torch.int16, device=self.device)
+            gen = torch.empty(S * (H // 16) * 1024, dtype=torch.int16, device=self.device)
+            k.triple_rows(self.W1, D, w1_exp, rows, ld)
+            k.triple_cols(self.W1, H, D, w1_exp, cols, Dp)
+            k.triple_w2gen(self.W2, Cn, H, w2_exp, gen)
+            img = _hip.TripleImages()
+            img.W1_rows, img.W1_cols, img.W2_gen = rows.data_ptr(), cols.data_ptr(), gen.data_ptr()
+            img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = ld, Dp, w1_exp, w2_exp
+            self._triple = (img, [rows, cols, gen])               # the tensors keep the device memory alive
+        return self._triple[0]
 
     def scale_bounds(self):
         """(mul, add, cap) of rbnn_input_scales' record 1 — the bound of the fc2 hidden-activation image given max|x|:
@@ -183,6 +211,6 @@ class StackedPosterior:
         for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
             t = getattr(self, name)
             setattr(out, name, None if t is None else t[lo:hi].contiguous())
-        out.S, out._desc, out._split = hi - lo, None, None
+        out.S, out._desc, out._split, out._triple = hi - lo, None, None, None
         out._pack()
         return out

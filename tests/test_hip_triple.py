@@ -1,0 +1,248 @@
+"""GPU parity tests of the triple-split ("f16x6") mode (-m gpu): full-width fp32 operands on the f16 matrix pipe.
+
+  images       the three fp16 pieces of every operand sum to the fp32 value BIT FOR BIT (|v| >= 2^-15 max|tensor|)
+  oracle       forward / loss gradients / mean-probability gradients vs the fp64 oracle on ragged sizes, every tile configuration
+  golden       the reference's fixtures through the reference's call surface (RBNN_PRECISION=triple), attack -> evaluation triples
+  full size    C2 (S=100) FGSM and C3-shaped PGD: 288 rows on 256-point tile edges vs the fp64 oracle with the kernels' own
+               activation decisions; triple vs exact mode: the triple mode's error vs fp64 is NOT larger than the fp32 MFMA's
+Everything goes through the C-ABI (robustbnns_amd._hip); the oracle is the checker only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import bnn_oracle as O
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
+TOL, TAU, KINK, DEV = 1e-5, 1e-3, 2e-6, "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from robustbnns_amd import _hip
+    _hip.load()
+
+
+def _halves(t):
+    """int16 storage -> float64 values of the fp16 bit patterns."""
+    return torch.from_numpy(t.cpu().numpy().view(np.float16).astype(np.float64))
+
+
+# ------------------------------------------------------------------ images
+def test_triple_rows_image_is_bit_exact():
+    """rbnn_triple_rows: p0 + p1 + p2 == v * 2^e exactly for every |v| >= 2^-15 * max|v| (fp32's 24 bits fit in 3 x 11 + 2 signs; the
+    last fp16 subnormal bit is 2^-24 and max|v * 2^e| >= 2^13); below that the error is at most 2^-25 in scaled units."""
+    from robustbnns_amd import _hip
+    from robustbnns_amd.posterior import scale_exp
+    k = _hip.HipKernels()
+    g = torch.Generator().manual_seed(5)
+    rows, cols, ld = 37, 100, 128
+    v = torch.randn(rows, cols, generator=g) * torch.exp(torch.randn(rows, cols, generator=g) * 3.0)     # ~5 decades of magnitudes
+    v[0, :8] = torch.tensor([1.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0e-5, -7.1e-9, 0.0, 255.0 / 255, 1.0 / 255])
+    e = scale_exp(float(v.abs().max()))
+    out = torch.zeros(rows, ld * 3, dtype=torch.int16, device=DEV)
+    k.triple_rows(v.to(DEV).contiguous(), cols, e, out, ld)
+    torch.cuda.synchronize()
+    img = _halves(out).reshape(rows, ld // 32, 3, 32)
+    assert torch.isfinite(img).all()
+    rec = img.sum(2).reshape(rows, ld)                          # fp64 sum of three fp16 values: exact
+    want = torch.zeros(rows, ld, dtype=torch.float64)
+    want[:, :cols] = v.double() * 2.0 ** e
+    big = want.abs() >= 0.5
+    assert int(big.sum()) > 0.1 * rows * cols and int((~big).sum()) > 0.1 * rows * cols      # both regimes are exercised
+    assert torch.equal(rec[big], want[big])                     # bit for bit
+    assert float((rec - want).abs().max()) <= 2.0 ** -25
+    assert float(img[:, :, 0].abs().max()) <= 2.0 ** 14
+
+
+def test_triple_cols_and_generator_images():
+    """rbnn_triple_cols / rbnn_triple_w2gen: layouts documented in include/robustbnns_hip.h and rbnn_triple.hip, values exact."""
+    from robustbnns_amd import _hip
+    from robustbnns_amd.posterior import scale_exp
+    k = _hip.HipKernels()
+    g = torch.Generator().manual_seed(6)
+    S, Hn, Dn, ldc, Cn = 2, 64, 40, 48, 10
+    W = torch.randn(S, Hn, Dn, generator=g) * 0.05
+    e = scale_exp(float(W.abs().max()))
+    out = torch.zeros(S * (Hn // 32) * 12 * ldc * 8, dtype=torch.int16, device=DEV)
+    k.triple_cols(W.to(DEV).contiguous(), Hn, Dn, e, out, ldc)
+    img = _halves(out).reshape(S, Hn // 32, 4, 3, ldc, 8).sum(3)               # [S, hb, lg, d, j]
+    j = torch.arange(8)
+    for lg in range(4):
+        h = 16 * (j >> 2) + 4 * lg + (j & 3)                                    # unit within the 32-block of K slot 8*lg + j
+        for hb in range(Hn // 32):
+            want = (W[:, 32 * hb + h, :].double() * 2.0 ** e).permute(0, 2, 1)  # [S, d, j]
+            assert torch.equal(img[:, hb, lg, :Dn, :], want)
+            assert float(img[:, hb, lg, Dn:, :].abs().max()) == 0.0
+    W2 = torch.randn(S, Cn, Hn, generator=g) * 0.05
+    e2 = scale_exp(float(W2.abs().max()))
+    gen = torch.zeros(S * (Hn // 16) * 1024, dtype=torch.int16, device=DEV)
+    k.triple_w2gen(W2.to(DEV).contiguous(), Cn, Hn, e2, gen)
+    gi = _halves(gen).reshape(S, Hn // 16, 2, 4, 16, 8)                         # [S, t, mfma, lg, li, slot]
+    p = O_split3(W2.double() * 2.0 ** e2)                                       # [3, S, C, H]
+    for t in range(Hn // 16):
+        hs = slice(16 * t, 16 * t + 16)
+        w = lambda piece, c: p[piece][:, c, hs]                                 # [S, 16]
+        for (mf, lg, piece) in [(0, 0, 0), (0, 1, 0), (0, 2, 1), (1, 0, 1), (1, 1, 0), (1, 2, 2)]:
+            for c in range(8):
+                assert torch.equal(gi[:, t, mf, lg, :, c], w(piece, c))
+        tail1 = [(0, 8), (0, 9), (0, 8), (0, 9), (0, 8), (0, 9), (1, 8), (1, 9)]
+        tail2 = [(2, 8), (2, 9), (1, 8), (1, 9)]
+        for sl, (piece, c) in enumerate(tail1):
+            assert torch.equal(gi[:, t, 0, 3, :, sl], w(piece, c))
+        for sl, (piece, c) in enumerate(tail2):
+            assert torch.equal(gi[:, t, 1, 3, :, sl], w(piece, c))
+        assert float(gi[:, t, 1, 3, :, 4:].abs().max()) == 0.0
+
+
+def O_split3(v):
+    """fp64 restatement of the device split: three round-to-nearest fp16 pieces."""
+    f16 = lambda t: torch.from_numpy(t.numpy().astype(np.float32).astype(np.float16).astype(np.float64))
+    p0 = f16(v)
+    p1 = f16(v - p0)
+    p2 = f16(v - p0 - p1)
+    return p0, p1, p2
+
+
+# ------------------------------------------------------------------ oracle, ragged sizes
+CASES = [  # act, H, C, S, N
+    ("leaky", 512, 10, 5, 300), ("relu", 512, 10, 3, 77), ("leaky", 256, 10, 7, 257), ("leaky", 128, 3, 4, 129),
+    ("relu", 384, 7, 2, 40), ("leaky", 1024, 10, 2, 130),
+]
+
+
+@pytest.mark.parametrize("act,Hn,Cn,S,N", CASES)
+def test_triple_vs_fp64_oracle(act, Hn, Cn, S, N):
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    Dn = 784
+    post = O.synthetic_posterior("fc", Dn, Hn, Cn, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=7)
+    sp = StackedPosterior("fc", act, (1, 28, 28), Cn, Hn, post, DEV)
+    assert sp.triple_supported()
+    eng = AttackEngine(sp, precision="triple")
+    assert eng.precision == "triple"
+    p64 = O.bnn_forward(x.double(), O.cast(post, torch.float64), "fc", act, S)
+    assert rel_err(eng.forward(x, S).cpu(), p64) < TOL
+    margin = O.kink_margin(x.double(), O.cast(post, torch.float64), "fc", act, S)
+    ok = margin > KINK
+    assert int(ok.sum()) >= 0.5 * N
+    lab = y.argmax(-1)
+    g64 = O.loss_gradients(x.double(), y, O.cast(post, torch.float64), "fc", act, S)
+    assert rel_err(eng.loss_gradients(x, y, S).cpu()[ok], g64[ok]) < TOL
+    gm64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), "fc", act, S)
+    G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :Dn].cpu().reshape(x.shape)
+    assert rel_err(G[ok], gm64[ok]) < TOL
+    adv = eng.fgsm(x, y, S, 0.3).cpu()
+    ref_adv = torch.clamp(x + 0.3 * gm64.sign().float(), 0, 1)
+    safe = (gm64.abs() > TAU * gm64.abs().reshape(N, -1).max(1)[0].reshape(N, 1, 1, 1)) & ok.reshape(N, 1, 1, 1)
+    assert int((((adv - ref_adv).abs() > 1e-6) & safe).sum()) == 0
+    # sample subsets through the index buffer, logits output
+    idx = [S - 1, 0]
+    p_idx = O.bnn_forward(x.double(), O.cast(post, torch.float64), "fc", act, 2, seeds=idx)
+    assert rel_err(eng.forward(x, 2, seeds=idx).cpu(), p_idx) < TOL
+
+
+def test_triple_is_refused_where_it_does_not_apply():
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    post = O.synthetic_posterior("fc", 784, 512, 10, 2, 0.05)
+    with pytest.raises(_hip.HipError):
+        AttackEngine(StackedPosterior("fc", "tanh", (1, 28, 28), 10, 512, post, DEV), precision="triple")
+    post = O.synthetic_posterior("fc", 784, 64, 10, 2, 0.05)
+    with pytest.raises(_hip.HipError):
+        AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), 10, 64, post, DEV), precision="triple")
+
+
+# ------------------------------------------------------------------ golden fixtures through the reference's call surface
+@pytest.mark.parametrize("name", ["mnist_fc_h512_s8_n8_leaky", "mnist_fc_h512_s8_n8_relu"])
+def test_golden_cases_in_triple_mode(golden, name, monkeypatch):
+    from robustbnns_amd import adversarialAttacks as A
+    from robustbnns_amd import _hip
+    from test_hip_parity import adv_equal, make_bnn
+    monkeypatch.setenv("RBNN_PRECISION", "triple")
+    g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
+    eng = bnn._engine
+    assert eng.precision == "triple"
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
+    seeds = [int(s) for s in g.arr["forward_seeds"]]
+    assert rel_err(bnn.forward(x.to(DEV), n_samples=len(seeds), seeds=seeds).cpu(), g.t("forward_probs_seeds")) < TOL
+    assert rel_err(eng.loss_gradients(x, y, m["S"]).cpu(), g.t("loss_gradients")) < TOL
+    assert rel_err(eng.loss_gradients(x, y, m["S_half"]).cpu(), g.t("loss_gradients_half")) < TOL
+    G = eng.gradient(eng.pad_inputs(x), y.argmax(-1).int().to(DEV), None, m["S"], _hip.LOSS_MEAN_PROB)
+    assert rel_err(G[:, :eng.post.D].cpu().reshape(x.shape), g.t("meanprob_grad")) < TOL
+    hyper = {"epsilon": m["eps"]}
+    adv = A.attack(net=bnn, x_test=x, y_test=y, dataset_name=m["dataset"], device=DEV, method="fgsm", filename=bnn.name,
+                   hyperparams=hyper, n_samples=m["S"])
+    adv_equal(adv, g.t("fgsm"), g.t("meanprob_grad"))
+    oa, aa, rob = A.attack_evaluation(net=bnn, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=m["S"])
+    assert (oa, aa) == (float(g.arr["eval_orig_acc"]), float(g.arr["eval_adv_acc"]))
+    assert float((rob.cpu() - g.t("eval_softmax_rob")).abs().max()) < 1e-5
+    idx = torch.from_numpy(g.arr["pgd_idx"])
+    adv = A.attack(net=bnn, x_test=x[idx], y_test=y[idx], dataset_name=m["dataset"], device=DEV, method="pgd", filename=bnn.name,
+                   hyperparams=hyper, n_samples=m["S"])
+    oa, aa, rob = A.attack_evaluation(net=bnn, x_test=x[idx], x_attack=adv, y_test=y[idx], device=DEV, n_samples=m["S"])
+    assert (oa, aa) == (float(g.arr["eval_pgd_orig_acc"]), float(g.arr["eval_pgd_adv_acc"]))
+    err = (rob.cpu() - g.t("eval_pgd_softmax_rob")).abs()
+    same = ((adv.cpu() - g.t("pgd")).abs().reshape(len(idx), -1) > 1e-6).sum(1) == 0
+    assert float(err[same].max() if same.any() else 0.0) < 1e-5 and float(err.max()) < 1e-3
+
+
+# ------------------------------------------------------------------ full size: C2 FGSM and C3-shaped PGD
+@pytest.mark.parametrize("S,method", [(100, "fgsm"), (500, "pgd")])
+def test_triple_full_size_against_oracle_and_exact_mode(S, method):
+    """C2 (S=100, FGSM) and C3 (S=500, PGD T=40) at N=10 000.  (1) 288 rows on both sides of 256-point tile edges vs the fp64 oracle
+    with the kernels' own activation decisions: < 1e-5 on every row, and the triple mode's error is not larger than the fp32-MFMA
+    mode's (x1.25 slack: both are fp32-accumulation noise).  (2) Triple vs exact: same gradients on the points with identical
+    decisions, adversarial images equal except noise-level gradient components, identical accuracies, robustness within 1e-5 on
+    identical images.  (3) eps-ball / range / bit-determinism of the whole attack."""
+    import test_hip_round2 as R2
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    N, Dn, Hn, eps = 10000, R2.D, R2.H, 0.3
+    post = R2.big_posterior(S, seed=61 + S)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), R2.C, seed=62)
+    sp = StackedPosterior("fc", "leaky", (1, 28, 28), R2.C, Hn, post, DEV)
+    lab = y.argmax(-1)
+    rows = R2.EDGE_ROWS
+    res = {}
+    for precision in ("exact", "triple"):
+        eng = AttackEngine(sp, precision=precision)
+        G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :Dn].cpu()
+        mask = R2.hip_activation_mask(eng, N, S, rows)
+        words = eng.workspace(N, S)["mask1"].view(S, Hn // 32, -1)[:, :, :N].clone()
+        pinned, margin, worst_flip = R2.oracle_gradients_fp64(x[rows], lab[rows], post, S, "mean_prob", hip_mask=mask)
+        den = pinned.abs().max(1)[0]
+        err = ((G[rows].double() - pinned).abs().max(1)[0] / den)
+        assert float(err.max()) < TOL and worst_flip < KINK
+        adv = eng.fgsm(x, y, S, eps) if method == "fgsm" else eng.pgd(x, y, S, eps, alpha=None, iters=40)
+        a = adv.cpu()
+        assert float((a - x).abs().max()) <= eps + 1e-6 and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+        res[precision] = dict(eng=eng, G=G, words=words, err=err, adv=adv)
+    e_x, e_t = res["exact"]["err"], res["triple"]["err"]
+    print(f"[triple vs exact] {method} S={S}: error vs fp64 (pinned decisions, 288 rows)  exact: median {float(e_x.median()):.2e} max "
+          f"{float(e_x.max()):.2e}   triple: median {float(e_t.median()):.2e} max {float(e_t.max()):.2e}")
+    assert float(e_t.median()) <= 1.25 * float(e_x.median()) and float(e_t.max()) <= 1.25 * float(e_x.max()) + 1e-7
+    same_dec = (res["exact"]["words"] == res["triple"]["words"]).all(0).all(0).cpu()
+    assert int((~same_dec).sum()) < 0.1 * N
+    assert rel_err(res["triple"]["G"][same_dec], res["exact"]["G"][same_dec]) < TOL
+    a_e, a_t = res["exact"]["adv"].cpu().reshape(N, -1), res["triple"]["adv"].cpu().reshape(N, -1)
+    diff = (a_e - a_t).abs() > 1e-6
+    print(f"    points with a differing activation decision {int((~same_dec).sum())}/{N}; pixels differing {int(diff.sum())} of "
+          f"{diff.numel()}; images differing {int(diff.any(1).sum())}")
+    if method == "fgsm":
+        Gx = res["exact"]["G"]
+        safe = Gx.abs() > TAU * Gx.abs().max(1, keepdim=True)[0]
+        assert int((diff & safe)[same_dec].sum()) == 0
+    oa_e, aa_e, rob_e, _, _ = res["exact"]["eng"].evaluate(x, res["exact"]["adv"], y, S)
+    oa_x, aa_x, rob_x, _, _ = res["triple"]["eng"].evaluate(x, res["exact"]["adv"], y, S)          # both modes score the SAME images
+    assert oa_e == oa_x and aa_e == aa_x and float((rob_e - rob_x).abs().max()) < 1e-5
+    oa_t, aa_t, rob_t, _, _ = res["triple"]["eng"].evaluate(x, res["triple"]["adv"], y, S)
+    same_img = ~diff.any(1)
+    d_rob = (rob_e - rob_t).abs().cpu()
+    print(f"    accuracy: original {oa_e} / {oa_t}, adversarial {aa_e} / {aa_t}; softmax_rob |diff| on identical images "
+          f"{float(d_rob[same_img].max()) if same_img.any() else 0.0:.2e}, overall max {float(d_rob.max()):.2e}")
+    assert oa_e == oa_t and abs(aa_e - aa_t) <= 0.1
+    assert float(d_rob[same_img].max() if same_img.any() else 0.0) < 1e-5
+    eng = res["triple"]["eng"]
+    again = eng.fgsm(x, y, S, eps) if method == "fgsm" else eng.pgd(x, y, S, eps, alpha=None, iters=40)
+    assert torch.equal(again, res["triple"]["adv"])                                               # bit-deterministic
