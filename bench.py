@@ -18,11 +18,13 @@ N GPUs: one process per GPU; the posterior is SAMPLE-sharded (each rank holds it
 samples: weak scaling) and each step all-reduces sum_s p_s [N,16] and the summed gradients [N,784] over RCCL/xGMI
 (north star).  `--shard points` replicates the samples and splits points instead (no collective).
 
-Precision (`--precision`, default exact).  The line's TOP LEVEL is IEEE-fp32 arithmetic: both GEMMs on
-v_mfma_f32_16x16x4_f32 ("exact", dtype f32) — the reference's arithmetic.  The faster split-half mode (every fp32 operand
-an fp16 hi+lo pair, 3 f16 MFMA products per fp32 product, fp32 accumulation; operands ~22-23 bits wide, i.e. narrower than
-fp32, parity-tested to the same 1e-5 bar) is timed afterwards at N=1 and reported as the sub-record `split_f16x3_mode`;
-`--precision split` puts it on top instead, labelled as such.
+Precision (`--precision`, default auto = the package's default).  Every mode computes on fp32 VALUES with fp32 accumulation; they
+differ in the matrix pipe used.  "exact": both GEMMs on v_mfma_f32_16x16x4_f32.  "triple" (what auto resolves to on the fc
+workloads c2 / c3 / c4): every fp32 operand carried at FULL width as three fp16 pieces (exact, bit for bit), six exact product
+terms per fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulation — nothing is narrower than fp32, the only rounding is the
+accumulation as on the fp32 MFMA (tests/test_hip_triple.py: error vs fp64 below the fp32-MFMA kernels').  "split" (opt-in): two
+fp16 pieces, 3 products — operands 22-23 bits, narrower than fp32.  The modes that are not on top are timed afterwards at N=1
+and reported as sub-records (`exact_fp32_mode`, `triple_f16x6_mode`, `split_f16x3_mode`).
 
 The JSON line carries `roofline` for the dominant kernel (the other GEMM kernel is listed beside it under roofline.kernels),
 timed with HIP events on the launch stream inside the timed region, and `cpu_baseline`: the loop-structured oracle port
@@ -188,8 +190,10 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override N (debug)")
     ap.add_argument("--samples", type=int, default=0, help="override S per GPU (debug)")
     ap.add_argument("--iters", type=int, default=0, help="override the PGD iteration count (debug)")
-    ap.add_argument("--precision", default="exact", choices=["exact", "triple", "split", "fast"],
-                    help="arithmetic of the line's top level (exact = IEEE fp32 on the fp32 MFMA; the triple and split modes are reported as sub-records)")
+    ap.add_argument("--precision", default="auto", choices=["auto", "exact", "triple", "split", "fast"],
+                    help="arithmetic of the line's top level.  auto (the package default) = triple (full-width fp32 operands as three f16 pieces, "
+                         "six exact product terms, f32 accumulate) where those kernels cover the workload, else exact (fp32 MFMA); the other "
+                         "modes are reported as sub-records")
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision modes at N=1")
     args = ap.parse_args()
 

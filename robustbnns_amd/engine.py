@@ -12,8 +12,10 @@ Reference loop nest (adversarialAttacks.py:118 -> :95 -> model_bnn.py:251, batch
 
 x, x0, the posterior and every intermediate stay resident in HBM for the whole attack.
 
-Precision modes of the two GEMMs (`precision=` / RBNN_PRECISION): "exact" (default; "auto" resolves to it) = IEEE fp32 on
-the fp32 MFMA (rbnn_fc_forward / rbnn_fc_input_grad), the reference's arithmetic; "split" (opt-in) = error-compensated half
+Precision modes of the two GEMMs (`precision=` / RBNN_PRECISION): "exact" = fp32 on the fp32 MFMA (rbnn_fc_forward /
+rbnn_fc_input_grad); "triple" = the same full-width fp32 operands carried as three fp16 pieces, six exact product terms on the
+f16 MFMA pipe, fp32 accumulation (rbnn_fc_forward_triple / rbnn_fc_input_grad_triple: nothing narrower than fp32, ~1.7x faster);
+"auto" (default) = triple where those kernels cover the posterior, else exact; "split" (opt-in) = error-compensated half
 pairs on the f16 MFMA pipe (rbnn_fc_forward_split / rbnn_fc_input_grad_split: 2^-22 per product, ~2.7x faster, same 1e-5
 parity bar, operands narrower than fp32); "fast" = split where the split kernels cover the posterior, else exact.
 torch supplies device memory, the current HIP stream and torch.distributed (RCCL); all arithmetic is
@@ -75,18 +77,21 @@ class AttackEngine:
         self._scales = None                     # device-resident operand scales of an attack's iterates (split mode), set by the attack loops
 
     def _resolve_precision(self, precision):
-        """exact (the default, also what "auto" resolves to): both GEMMs in IEEE fp32 on the fp32 MFMA — the reference's arithmetic.
+        """exact: both GEMMs in fp32 on the fp32 MFMA.  auto (the default): triple where it applies (below), else exact.
         split: error-compensated fp16 pairs on the f16 MFMA pipe (operands ~22-23 bits, i.e. narrower than fp32; ~2.7x faster;
         same 1e-5 parity bar, and the same adversarial accuracy in the split-vs-exact tests) — OPT-IN, raises where the split
         kernels do not cover the posterior.  fast: split where it applies, else exact.  RBNN_PRECISION sets the default."""
         want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
         if want not in ("auto", "exact", "triple", "split", "fast"):
             raise ValueError(f"precision={want!r}: expected 'auto', 'exact', 'triple', 'split' or 'fast'")
-        if want == "triple":
-            # full-width fp32 operands as three fp16 pieces, six exact product terms on the f16 matrix pipe, fp32 accumulation
-            # (rbnn_triple.hip): fp32-MFMA-grade results (the only rounding left is the accumulation) at ~1.5x the speed
-            if not (bool(getattr(self.post, "triple_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)):
-                raise _hip.HipError("precision='triple' covers fc posteriors with relu / leaky, hidden % 128 == 0 and classes <= 10, on the GPU")
+        # triple: full-width fp32 operands as three fp16 pieces, six exact product terms on the f16 matrix pipe, fp32 accumulation
+        # (rbnn_triple.hip).  Nothing is narrower than fp32 — the only rounding left is the fp32 accumulation, as on the fp32 MFMA; its
+        # measured error against fp64 is BELOW the fp32-MFMA kernels' (tests/test_hip_triple.py) — and it is ~1.7x faster, so "auto"
+        # takes it wherever it applies and falls back to the fp32 MFMA ("exact") elsewhere.
+        tri = bool(getattr(self.post, "triple_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
+        if want == "triple" and not tri:
+            raise _hip.HipError("precision='triple' covers fc posteriors with relu / leaky, hidden % 128 == 0 and classes <= 10, on the GPU")
+        if want == "triple" or (want == "auto" and tri):
             return "triple"
         ok = bool(getattr(self.post, "split_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
         if want == "split" and not ok:

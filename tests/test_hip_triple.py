@@ -97,6 +97,33 @@ def test_triple_cols_and_generator_images():
         assert float(gi[:, t, 1, 3, :, 4:].abs().max()) == 0.0
 
 
+def test_triple_forward_reproduces_single_products_bit_for_bit():
+    """One input pixel = 1, W2 = identity on the first units, relu, logits out: logit c = W1[c, 0] * 1 — a single fp32 product.
+    The triple forward must return the fp32 weight BIT FOR BIT for every weight down to 2^-15 of the largest one: all three
+    pieces — including the fp16-subnormal low pieces of the small weights — go through the f16 MFMA unflushed and their sum is
+    exact in the fp32 accumulator.  (The two-piece split mode cannot do this: it drops the last 1-2 bits.)"""
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    Dn, Hn, Cn, S, N = 784, 128, 10, 2, 16
+    g = torch.Generator().manual_seed(11)
+    W1 = torch.zeros(S, Hn, Dn)
+    W1[:, :, 1:] = torch.rand(S, Hn, Dn - 1, generator=g) - 0.5            # multiplied by x = 0
+    W1[:, 0, 1] = 1.0                                                      # the largest weight of each sample: fixes the image scale at 2^14
+    expo = torch.stack([torch.arange(0, 10), torch.arange(5, 15)]).float()                 # weights from 2^0 down to 2^-14 of the largest
+    mant = 1.0 + torch.randint(0, 2 ** 23, (S, Cn), generator=g).float() * 2.0 ** -23      # full 24-bit significands in [1, 2)
+    w = mant * 2.0 ** (-expo - 1.0)                                                        # < 1 = the largest weight
+    W1[:, :Cn, 0] = w
+    W2 = torch.zeros(S, Cn, Hn)
+    W2[:, torch.arange(Cn), torch.arange(Cn)] = 1.0
+    post = {"model.1.weight": W1, "model.1.bias": torch.zeros(S, Hn), "model.3.weight": W2, "model.3.bias": torch.zeros(S, Cn)}
+    x = torch.zeros(N, 1, 28, 28)
+    x[:, 0, 0, 0] = 1.0
+    eng = AttackEngine(StackedPosterior("fc", "relu", (1, 28, 28), Cn, Hn, post, DEV), precision="triple")
+    for si in range(S):
+        z = eng.forward(x, 1, seeds=[si], logits=True).cpu()
+        bad = (z != w[si].expand(N, Cn)).any(0)
+        assert not bad.any(), f"sample {si}: weights at 2^-(1+{expo[si][bad].tolist()}) of the largest are not reproduced exactly: {z[0][bad]} vs {w[si][bad]}"
+
+
 def O_split3(v):
     """fp64 restatement of the device split: three round-to-nearest fp16 pieces."""
     f16 = lambda t: torch.from_numpy(t.numpy().astype(np.float32).astype(np.float16).astype(np.float64))

@@ -22,15 +22,8 @@
 //                  (8 K values) is one ds_read_b128 per plane; chunk swizzle `swz` (rbnn_common.hpp) as for fp32 64-B rows.
 //   "triple cols"  [S][H/32][4 lg][3][ld][8] halves: the backward's B operand, K-slot order = the dA generator's output order.
 // Lane maps as in rbnn_split.hip (v_mfma_f32_16x16x32_f16): a[j] = A[li][8*lg + j], b[j] = B[8*lg + j][li], acc[r] = D[4*lg + r][li].
-#include "rbnn_common.hpp"
+#include "../robustbnns_amd/csrc/rbnn_common.hpp"
 #include <algorithm>
-
-#ifndef RBNN_X3_BARRIER_END
-#define RBNN_X3_BARRIER_END 0
-#endif
-#ifndef RBNN_X3_SPREAD
-#define RBNN_X3_SPREAD 0                                      // 1: LDS-DMA pieces issued one at a time inside the MFMA / vector-only phases instead of at the
-#endif                                                        //    stage top — measured equal (forward) to 1 % slower (backward): profiles/r02t/experiments.txt
 
 namespace {
 
@@ -40,36 +33,6 @@ __device__ __forceinline__ void split3(float v, _Float16& p0, _Float16& p1, _Flo
     p1 = (_Float16)r;
     r -= (float)p1;
     p2 = (_Float16)r;
-}
-
-// The backward's dA pieces for two adjacent hidden units (bits BIT, BIT + 1 of the stash word): act' multiplier m = bit ? cp : cn
-// (sign-extended bit-field + bit-select), then the three fp16 pieces of g * m, each by one fused v_fma_mix* that rounds to f16
-// and writes its half of the packed result — 11 vector instructions per pair.  (Plain C++ compiles to ~18: hipcc re-derives
-// the pieces through f32 round trips and SLP-packs them into v_pk_* ops, and the kernel is bound by vector-instruction ISSUE.)
-// FIRST: these are the first reads of a generator MFMA's result — the 7 wait states an XDL write needs before a VALU read
-// (the compiler cannot see into the asm to insert them).
-#define RBNN_X3_PAIR_BODY \
-    "v_bfe_i32 %[me], %[mw], %[b0], 1\n\t" \
-    "v_bfe_i32 %[mo], %[mw], %[b1], 1\n\t" \
-    "v_bfi_b32 %[me], %[me], %[cp], %[cn]\n\t" \
-    "v_bfi_b32 %[mo], %[mo], %[cp], %[cn]\n\t" \
-    "v_fma_mixlo_f16 %[d0], %[ge], %[me], 0\n\t" \
-    "v_fma_mixhi_f16 %[d0], %[go], %[mo], 0\n\t" \
-    "v_fma_mix_f32 %[re], %[ge], %[me], -%[d0] op_sel_hi:[0,0,1]\n\t" \
-    "v_fma_mix_f32 %[ro], %[go], %[mo], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
-    "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t" \
-    "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t" \
-    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-#define RBNN_X3_PAIR_OPS \
-    : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [me] "=&v"(me), [mo] "=&v"(mo), [re] "=&v"(re), [ro] "=&v"(ro) \
-    : [ge] "v"(ge), [go] "v"(go), [mw] "v"(mw), [cp] "v"(cp), [cn] "v"(cn), [one] "v"(one), [b0] "n"(BIT), [b1] "n"(BIT + 1)
-template <int BIT, bool FIRST>
-__device__ __forceinline__ void split3_pair(float ge, float go, unsigned mw, unsigned cp, unsigned cn, float one,
-                                            unsigned& d0, unsigned& d1, unsigned& d2) {
-    unsigned me, mo;
-    float re, ro;
-    if constexpr (FIRST) asm volatile("s_nop 7\n\t" RBNN_X3_PAIR_BODY RBNN_X3_PAIR_OPS);
-    else asm volatile(RBNN_X3_PAIR_BODY RBNN_X3_PAIR_OPS);   // volatile: the pairs of one MFMA result stay behind the FIRST one
 }
 
 // ===================================================================================================
@@ -135,8 +98,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         if (id < full * per) { ntile = (id % per) / 8; s = (id / per) * 8 + id % 8; }
         else { const int rem = id - full * per, cnt = a.S - full * 8; ntile = rem / cnt; s = full * 8 + rem % cnt; }
     }
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations (M0) become SALU work
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int wave_h = wave % WH, wave_n = wave / WH;
     const int sw = a.sidx ? a.sidx[s] : s;
     const float out_scale = a.x_ds ? a.out_scale * a.x_ds->inv_scale : a.out_scale;
@@ -154,97 +116,73 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) zacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane row offsets (bytes) of this wave's pieces; 32-bit (the host checks H*ldw*6 and N*ldx*6 < 2^32).  W rows are relative to
-    // the h chunk: the chunk's base goes into the uniform part of the address.
-    unsigned xrow[XPP], wrow[WPP];
+    // per-lane row offsets (bytes) of this wave's pieces; 32-bit (the host checks H*ldw*6 and N*ldx*6 < 2^32)
+    unsigned xrow[XPP];
 #pragma unroll
     for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min(n0 + 16 * (wave + NW * i) + prow, a.N - 1) * (unsigned)a.ldx * 6u + src_off;
-#pragma unroll
-    for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(16 * (wave + NW * i) + prow) * (unsigned)a.ldw * 6u + src_off;
 
-    // The K stages of all h chunks form ONE software pipeline: stage g = (chunk g / KT, columns 32 * (g % KT)), buffer g & 1; the
-    // first stage of the next chunk is in flight while a chunk's epilogue runs.  The pieces of stage g + 1 (PPS per wave) are
-    // issued BETWEEN stage g's MFMA groups, not at its top next to the LDS reads (an LDS-DMA instruction costs ~60 cycles among
-    // MFMAs against 100-185 there), all within the first two h tiles so that they land before the stage ends.
-    constexpr int PPS = 3 * (WPP + XPP);
-    const int G = (a.H / BH) * a.KT;
-    auto piece = [&](int c, int kt, int buf, int i) {           // chunk c, columns 32 * kt -> buffer buf; i: compile-time constant, plane i / (WPP + XPP)
-        char* const T = ldsb + buf * TILEB;
-        const int p = i / (WPP + XPP), j = i % (WPP + XPP);
-        const unsigned koff = (unsigned)kt * 192u + 64u * p;
-        if (j < WPP) glds16((const float*)(Ws + (long long)c * BH * a.ldw * 6 + (wrow[j < WPP ? j : 0] + koff)), (float*)(T + p * PLANEB + (wave + NW * j) * 1024));
-        else glds16((const float*)(a.X + (xrow[j >= WPP ? j - WPP : 0] + koff)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * (j - WPP)) * 1024));
-    };
+    for (int hc0 = 0; hc0 < a.H; hc0 += BH) {
+        f32x4 acc[HTW][NTW];
 #pragma unroll
-    for (int i = 0; i < PPS; ++i) piece(0, 0, 0, i);
-    ring_wait_barrier<0>();
+        for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        unsigned wrow[WPP];
+#pragma unroll
+        for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(hc0 + 16 * (wave + NW * i) + prow) * (unsigned)a.ldw * 6u + src_off;
 
-    f32x4 acc[HTW][NTW];
+        auto stage = [&](int kt, int buf) {
+            char* const T = ldsb + buf * TILEB;
+            const unsigned koff = (unsigned)kt * 192u;
 #pragma unroll
-    for (int ht = 0; ht < HTW; ++ht)
+            for (int p = 0; p < 3; ++p) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    int kt = 0, ch = 0;                                        // stage g = (chunk ch, K stage kt)
-    for (int g = 0; g < G; ++g) {
-        const int buf = g & 1;
-        // next stage; the very last one re-fetches itself into the idle buffer (1 stage in G: keeps the body branch-free)
-        const bool wrap = kt + 1 == a.KT, last = g + 1 == G;
-        const int ktn = last ? kt : (wrap ? 0 : kt + 1), chn = (wrap && !last) ? ch + 1 : ch;
-        const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 16 * 64 + foff;
-        const char* const Xt = ldsb + buf * TILEB + BH * 64 + (wave_n * NTW) * 16 * 64 + foff;
-        f16x8 b0[NTW], b1[NTW], b2[NTW], a0, a1, a2, a0n, a1n, a2n;
-        if (!RBNN_X3_SPREAD && !(RBNN_ABL & 1)) {
+                for (int i = 0; i < WPP; ++i)
+                    glds16((const float*)(Ws + (wrow[i] + koff + 64u * p)), (float*)(T + p * PLANEB + (wave + NW * i) * 1024));
 #pragma unroll
-            for (int i = 0; i < PPS; ++i) piece(chn, ktn, buf ^ 1, i);
-        }
+                for (int i = 0; i < XPP; ++i)
+                    glds16((const float*)(a.X + (xrow[i] + koff + 64u * p)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * i) * 1024));
+            }
+        };
+        stage(0, 0);
+        ring_wait_barrier<0>();
+        for (int kt = 0; kt < a.KT; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < a.KT) stage(kt + 1, buf ^ 1);          // lands while this stage is multiplied
+            const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 16 * 64 + foff;
+            const char* const Xt = ldsb + buf * TILEB + BH * 64 + (wave_n * NTW) * 16 * 64 + foff;
+            f16x8 b0[NTW], b1[NTW], b2[NTW], a0, a1, a2, a0n, a1n, a2n;
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            b0[nt] = *(const f16x8*)(Xt + nt * 1024);
-            b1[nt] = *(const f16x8*)(Xt + PLANEB + nt * 1024);
-            b2[nt] = *(const f16x8*)(Xt + 2 * PLANEB + nt * 1024);
-        }
-        a0 = *(const f16x8*)(Wt);
-        a1 = *(const f16x8*)(Wt + PLANEB);
-        a2 = *(const f16x8*)(Wt + 2 * PLANEB);
-        a0n = a0; a1n = a1; a2n = a2;
-        constexpr int PER_HT = (PPS + 1) / 2;                   // pieces issued inside h tile 0 and inside h tile 1
-        static_assert(PER_HT <= 6, "one piece after each of an h tile's six product groups at most");
+            for (int nt = 0; nt < NTW; ++nt) {
+                b0[nt] = *(const f16x8*)(Xt + nt * 1024);
+                b1[nt] = *(const f16x8*)(Xt + PLANEB + nt * 1024);
+                b2[nt] = *(const f16x8*)(Xt + 2 * PLANEB + nt * 1024);
+            }
+            a0 = *(const f16x8*)(Wt);
+            a1 = *(const f16x8*)(Wt + PLANEB);
+            a2 = *(const f16x8*)(Wt + 2 * PLANEB);
+            a0n = a0; a1n = a1; a2n = a2;
 #pragma unroll
-        for (int ht = 0; ht < HTW; ++ht) {
-            // six product groups of NTW MFMAs, smallest terms first; between them (fenced: the scheduler would otherwise cluster all
-            // memory instructions at the top) one DMA piece at a time, and the next h tile's three fragment reads after the third
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const f16x8 av = (k == 1) ? a2 : ((k == 2 || k == 3) ? a1 : a0);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const f16x8 bv = (k == 0) ? b2[nt] : ((k == 2 || k == 4) ? b1[nt] : b0[nt]);
-                    acc[ht][nt] = MFMA_H(av, bv, acc[ht][nt]);
-                }
-                if (RBNN_X3_SPREAD) {
-                    const int i = ht * PER_HT + k;
-                    if (ht < 2 && k < PER_HT && i < PPS && !(RBNN_ABL & 1)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        piece(chn, ktn, buf ^ 1, i);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (k == 2 && ht + 1 < HTW) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        a0n = *(const f16x8*)(Wt + (ht + 1) * 1024);
-                        a1n = *(const f16x8*)(Wt + PLANEB + (ht + 1) * 1024);
-                        a2n = *(const f16x8*)(Wt + 2 * PLANEB + (ht + 1) * 1024);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (k == 0 && ht + 1 < HTW) {
+            for (int ht = 0; ht < HTW; ++ht) {
+                if (ht + 1 < HTW) {
                     a0n = *(const f16x8*)(Wt + (ht + 1) * 1024);
                     a1n = *(const f16x8*)(Wt + PLANEB + (ht + 1) * 1024);
                     a2n = *(const f16x8*)(Wt + 2 * PLANEB + (ht + 1) * 1024);
                 }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a0, b2[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a2, b0[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a1, b1[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a1, b0[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a0, b1[nt], acc[ht][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[ht][nt] = MFMA_H(a0, b0[nt], acc[ht][nt]);
+                a0 = a0n; a1 = a1n; a2 = a2n;
             }
-            a0 = a0n; a1 = a1n; a2 = a2n;
-        }
-        if (!RBNN_X3_SPREAD) {
             // pin the order: B fragments + A(0) first, then per h tile half its MFMAs, the next tile's three reads, the rest
             __builtin_amdgcn_sched_group_barrier(0x100, 3 * NTW + 3, 0);
 #pragma unroll
@@ -253,24 +191,10 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                 if (ht + 1 < HTW) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW, 0);
             }
+            ring_wait_barrier<0>();                            // stage kt+1 landed; everyone is done with stage kt
         }
-        if (RBNN_X3_BARRIER_END) __builtin_amdgcn_sched_barrier(0);   // keep the hand-off behind the stage's last MFMA
-        if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();           // stage g+1 landed; everyone is done with stage g
-        const int hc0 = ch * BH;
-        kt = wrap ? 0 : kt + 1;
-        ch = wrap ? ch + 1 : ch;
-        if (!wrap) continue;
 
         // ---- epilogue of this h chunk: scale, bias, activation, derivative stash, skinny output layer ----
-        if (RBNN_ABL & 8) {                                    // diagnostic: keep the accumulators live, skip the epilogue
-            float t = 0.f;
-#pragma unroll
-            for (int ht = 0; ht < HTW; ++ht)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) { t += acc[ht][nt][0] + acc[ht][nt][1] + acc[ht][nt][2] + acc[ht][nt][3]; acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-            if (t == 12345.678f) a.P[tid] = t;
-            continue;
-        }
         const int hw0 = hc0 + (wave_h * HTW) * 16;
         unsigned mine[NTW];
 #pragma unroll
@@ -285,7 +209,6 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
             for (int nt = 0; nt < NTW; ++nt) {
                 const int n = n0 + (wave_n * NTW + nt) * 16 + li;
                 f32x4 v = acc[ht][nt] * out_scale + bias, hv;
-                acc[ht][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 unsigned bits = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -316,7 +239,6 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
             }
         }
     }
-    if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
     // Z^T partials of the WH waves that split h -> LDS -> one thread per point finishes the softmax.
 #pragma unroll
@@ -558,8 +480,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
     const int ntile = id % a.NT, dg = (id / a.NT) % a.ND, ch = id / (a.NT * a.ND);
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations (M0) and piece selection become SALU work
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int nb = ntile * BM + wave * (NTW * 16);
     const int dc0 = dg * LD;
     const int Dp = a.Dt * 16;
@@ -567,14 +488,12 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     const int s_begin = ch * a.chunk, s_end = min(a.S, s_begin + a.chunk);
     const int HS = a.H / 32, nst = (s_end - s_begin) * HS;
 
-    // LDS-DMA sources are a block-uniform 64-bit base (SGPR pair) + one 32-bit per-lane offset: no vector address arithmetic per piece
-    unsigned goff[PPW];                                        // this wave's W1 pieces: byte offsets from the stage's image base
+    int goff[PPW];                                             // per-lane source offsets (bytes, from the stage's image base) of this wave's W1 pieces
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int f = (wave + NW * i) * 1024 + lane * 16, seg = f / (LD * 16), d = (f % (LD * 16)) >> 4;
-        goff[i] = (unsigned)(seg * a.ldc + min(dc0 + d, a.ldc - 1)) * 16u;   // columns past the image: any valid address, never stored
+        goff[i] = (seg * a.ldc + min(dc0 + d, a.ldc - 1)) * 16;   // columns past the image: any valid address, never stored
     }
-    const unsigned loff = (unsigned)lane * 16u;
 
     f32x4 acc[NTW][TD];
 #pragma unroll
@@ -583,62 +502,39 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
         for (int dt = 0; dt < TD; ++dt) acc[nt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto dz_issue = [&](int s) {                                // this wave's 64 points x 64 B of sample s -> its own region of dzl
-        const char* const src = a.dzg + ((long long)s * a.n_pad + nb) * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16((const float*)(src + j * 1024 + loff), (float*)(dzl + wave * 4096 + j * 1024));
+        for (int j = 0; j < 4; ++j)
+            glds16((const float*)(a.dzg + (((long long)s * a.n_pad + nb + j * 16) * 64) + lane * 16), (float*)(dzl + wave * 4096 + j * 1024));
     };
-    // The DMA pieces of a stage, per wave: 0 .. PPW-1 its W1 pieces, PPW its generator-tile piece (tiles 2*hb, 2*hb + 1 of the sample
-    // are 4 KiB contiguous: one piece per wave), PPW + 1 the stash words (the block's 256 points = 1 KiB; last wave only).
-    constexpr int NDMA = PPW + 2, DPN = (NDMA + NTW - 1) / NTW;   // issued DPN at a time between the generator's point tiles
-    struct StageSrc { const char* W; const char* G; const char* M; char* B; };
-    auto stage_src = [&](int st, int buf) {
+    auto stage_issue = [&](int st, int buf) {
         const int si = st / HS, hb = st % HS, s = s_begin + si;
         const int sw = a.sidx ? a.sidx[s] : s;
-        StageSrc r;
-        r.W = a.W1c + ((long long)sw * HS + hb) * 12 * a.ldc * 16;
-        r.G = a.W2g + ((long long)sw * (a.H / 16) + 2 * hb) * 2048 + wave * 1024;
-        r.M = (const char*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM);
-        r.B = ldsb + buf * BUFB;
-        return r;
-    };
-    auto issue_piece = [&](const StageSrc& q, int i) {          // i is a compile-time constant at every call site
-        if (i < PPW) {
-            if (wave + NW * i < NPIECE) glds16((const float*)(q.W + goff[i < PPW ? i : 0]), (float*)(q.B + (wave + NW * i) * 1024));
-        } else if (i == PPW) {
-            glds16((const float*)(q.G + loff), (float*)(q.B + W1B + wave * 1024));
-        } else if (i == PPW + 1) {
-            if (wave == NW - 1) glds16((const float*)(q.M + loff), (float*)(q.B + W1B + 4096));
-        }
+        const char* const Wb = a.W1c + ((long long)sw * HS + hb) * 12 * a.ldc * 16;
+        char* const B = ldsb + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            if (wave + NW * i < NPIECE) glds16((const float*)(Wb + goff[i]), (float*)(B + (wave + NW * i) * 1024));
+        // generator tiles 2*hb, 2*hb + 1 of this sample = 4 KiB contiguous: one piece per wave
+        glds16((const float*)(a.W2g + (((long long)sw * (a.H / 16) + 2 * hb) * 2048) + wave * 1024 + lane * 16), (float*)(B + W1B + wave * 1024));
+        if (wave == NW - 1)                                     // stash words [S][H/32][N_pad]: the block's 256 points = 1 KiB
+            glds16((const float*)(a.mask + ((long long)s * a.HW + hb) * a.n_pad + ntile * BM + 4 * lane), (float*)(B + W1B + 4096));
     };
 
     dz_issue(s_begin);
-    {
-        const StageSrc q = stage_src(0, 0);
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) issue_piece(q, i);
-    }
+    stage_issue(0, 0);
     ring_wait_barrier<0>();
-    const unsigned cp_bits = __float_as_uint(ldexpf(1.f, GEN_Q3));
-    const unsigned cn_bits = (ACT == RBNN_ACT_RELU) ? 0u : __float_as_uint(LEAKY_SLOPE * ldexpf(1.f, GEN_Q3));
+    const float c_pos = ldexpf(1.f, GEN_Q3), c_neg = (ACT == RBNN_ACT_RELU) ? 0.f : LEAKY_SLOPE * ldexpf(1.f, GEN_Q3);
     const int dzc1 = (lg == 2 ? 0 : lg), dzc2 = (lg == 0 ? 1 : (lg == 1 ? 2 : (lg == 2 ? 0 : 3)));   // dZ chunk of MFMA 1 / 2 for this lane group
     const int sz = dz_swz3(li);
     const char* const dzw = dzl + wave * 4096 + li * 64;
     f16x8 da0[NTW], da1[NTW], da2[NTW];                        // A operand of the main MFMA: this wave's 4 point tiles, one stage
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, hb = st % HS;
-        // next stage's pieces: issued between the generator's point tiles, where the wave is in a vector-only phase (an LDS-DMA
-        // instruction costs 25-60 cycles there against 100-185 at the top of the stage next to the LDS reads) and early enough to land
-        const bool more = !(RBNN_ABL & 1) && st + 1 < nst;
-        const StageSrc q = stage_src(more ? st + 1 : st, buf ^ 1);
+        if (st + 1 < nst) stage_issue(st + 1, buf ^ 1);
         const char* const B = ldsb + buf * BUFB;
-        const bool gen_on = !(RBNN_ABL & 16) || st == 0;
-        if (more && (!gen_on || !RBNN_X3_SPREAD)) {
-#pragma unroll
-            for (int i = 0; i < NDMA; ++i) issue_piece(q, i);
-        }
 
         // ---- generator + split ----
-        if (gen_on) {
+        {
             const f16x8 w00 = *(const f16x8*)(B + W1B + lane * 16);            // tile 0: MFMA 1, MFMA 2
             const f16x8 w01 = *(const f16x8*)(B + W1B + 1024 + lane * 16);
             const f16x8 w10 = *(const f16x8*)(B + W1B + 2048 + lane * 16);     // tile 1
@@ -651,20 +547,19 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const f32x4 g0 = MFMA_H(w01, dz2, MFMA_H(w00, dz1, z)), g1 = MFMA_H(w11, dz2, MFMA_H(w10, dz1, z));
                 const unsigned mw = Mk[nt * 16] >> (4 * lg);   // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
-                // the kernel is bound by vector-instruction ISSUE (profiles/r02t), so the split is hand-scheduled: split3_pair
-                union { f16x8 v; unsigned u[4]; } o0, o1, o2;
-                split3_pair<0, true>(g0[0], g0[1], mw, cp_bits, cn_bits, 1.f, o0.u[0], o1.u[0], o2.u[0]);
-                split3_pair<2, false>(g0[2], g0[3], mw, cp_bits, cn_bits, 1.f, o0.u[1], o1.u[1], o2.u[1]);
-                split3_pair<16, true>(g1[0], g1[1], mw, cp_bits, cn_bits, 1.f, o0.u[2], o1.u[2], o2.u[2]);
-                split3_pair<18, false>(g1[2], g1[3], mw, cp_bits, cn_bits, 1.f, o0.u[3], o1.u[3], o2.u[3]);
-                da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
-                if (RBNN_X3_SPREAD && more) {
 #pragma unroll
-                    for (int i = nt * DPN; i < (nt + 1) * DPN && i < NDMA; ++i) issue_piece(q, i);
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = g0[r] * (((mw >> r) & 1u) ? c_pos : c_neg);
+                    const float v1 = g1[r] * (((mw >> (16 + r)) & 1u) ? c_pos : c_neg);
+                    _Float16 x0, x1, x2;
+                    split3(v0, x0, x1, x2);
+                    da0[nt][r] = x0; da1[nt][r] = x1; da2[nt][r] = x2;
+                    split3(v1, x0, x1, x2);
+                    da0[nt][4 + r] = x0; da1[nt][4 + r] = x1; da2[nt][4 + r] = x2;
                 }
             }
         }
-        if (!(RBNN_ABL & 1) && hb == HS - 1 && st + 1 < nst) {  // last stage of a sample: the dZ reads above are this wave's last of it
+        if (hb == HS - 1 && st + 1 < nst) {                     // last stage of a sample: the dZ reads above are this wave's last of it
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): those reads have returned
             asm volatile("" ::: "memory");
@@ -696,9 +591,8 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
                 b0 = b0n; b1 = b1n; b2 = b2n;
             }
         }
-        if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();           // next stage landed; everyone is done with this one
+        ring_wait_barrier<0>();                                // next stage landed; everyone is done with this one
     }
-    if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
     // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li], un-scaled per point ----
 #pragma unroll
