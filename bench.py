@@ -355,6 +355,8 @@ def main():
         KNAMES["split"].update({"fc_forward": "fc_forward_split_kernel (x2: layer 1 -> split image, layer 2)",
                                 "fc_input_grad": "fc_grad_split_kernel (x2: per-sample step through Wm, then W1; + split_dz)"})
         KNAMES["exact"].update({"fc_forward": "fc_forward_kernel (x2)", "fc_input_grad": "fc_grad_kernel (x2)"})
+        KNAMES["triple"].update({"fc_forward": "fc_forward_x3_kernel (x2: layer 1 -> triple image, layer 2)",
+                                 "fc_input_grad": "fc_grad_x3_kernel (x2: per-sample step through Wm, then W1; + triple_dz)"})
 
     def roofline(mode, evs_by_name, ms_per_step):
         kernels = {}

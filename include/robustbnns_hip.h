@@ -343,21 +343,35 @@ int rbnn_fc_input_grad_split(const rbnn_posterior *net, const rbnn_split_images 
  * bit for bit, for |v| >= 2^-15 * max|tensor| (3 x 11 significand bits cover fp32's 24; within 2^-39 * max|tensor| below
  * that) — and a*b = a0*b2 + a2*b0 + a1*b1 + a1*b0 + a0*b1 + a0*b0 (six f16 MFMAs, exact terms; the dropped terms are
  * <= 2^-32 |a*b|), accumulated in fp32: the only rounding left is the fp32 accumulation, as in rbnn_fc_forward / rbnn_fc_input_grad.
- * Architecture fc, hidden % 128 == 0; forward: all four activations; input gradient: relu / leaky, <= 10 classes.
+ * Architectures fc and fc2, hidden % 128 == 0; forward: all four activations; input gradient: relu / leaky, <= 10 classes.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct rbnn_triple_images {
     const void *W1_rows;           /* rbnn_triple_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/32,3,32] halves */
     const void *W1_cols;           /* rbnn_triple_cols image of W1 (backward B operand): [S_total,H/32,4,3,ld_cols,8] halves         */
-    const void *W2_gen;            /* rbnn_triple_w2gen image of W2 (backward dA generator): [S_total,H/16,2,64,8] halves            */
+    const void *W2_gen;            /* rbnn_triple_w2gen image of the OUTPUT layer (backward dA generator): [S_total,H/16,2,64,8] halves */
     int32_t ld_rows;               /* columns per row of W1_rows, multiple of 32, >= D                                              */
     int32_t ld_cols;               /* columns of W1_cols = in_stride (D_pad)                                                        */
     int32_t w1_exp;                /* W1_rows and W1_cols hold W1 * 2^w1_exp                                                        */
-    int32_t w2_exp;                /* W2_gen holds W2 * 2^w2_exp                                                                    */
+    int32_t w2_exp;                /* W2_gen holds the output layer * 2^w2_exp                                                      */
+    /* fc2: */
+    const void *Wm_rows;           /* rbnn_triple_rows image of Wm viewed as [S_total*H, H] rows, holding Wm * 2^wm_exp (forward)    */
+    const void *Wm_cols;           /* rbnn_triple_cols image of Wm [S_total,H/32,4,3,H,8] (backward step 1)                         */
+    int32_t wm_exp;
+    int32_t h1_exp;                /* layer-1 activations are carried as h * 2^h1_exp = p0 + p1 + p2 in tws->hid_triple; set from the */
+                                   /* bound max_h sum_d |W1[h,d]| * max|x| + max|b1| (or record [1] of rbnn_input_scales)           */
 } rbnn_triple_images;
 
-/* sizes of the rbnn_split_workspace buffers for the triple mode (X_split then holds the 6-byte-per-element triple-rows image) */
+/* per-problem scratch of the triple mode */
+typedef struct rbnn_triple_workspace {
+    void  *X_triple;               /* [N, ld_rows] triple-rows image of the current inputs (caller fills it with rbnn_triple_rows)  */
+    void  *dZ_gen;                 /* [S, N_pad, 64 B] dA-generator image of dZ, written by rbnn_fc_input_grad_triple               */
+    float *g_scale;                /* [N_pad] per-point 2^-e(n) of that image                                                       */
+    void  *hid_triple;             /* fc2: [S, N, H] triple-rows image of the hidden activations (6 bytes per element)              */
+} rbnn_triple_workspace;
+typedef struct rbnn_triple_workspace_sizes { size_t X_triple, dZ_gen, g_scale, hid_triple; } rbnn_triple_workspace_sizes;
+
 int rbnn_triple_workspace_query(const rbnn_posterior *net, const rbnn_triple_images *tp, int32_t n_points,
-                                int32_t n_samples, rbnn_split_workspace_sizes *out);
+                                int32_t n_samples, rbnn_triple_workspace_sizes *out);
 
 /* dst[r, k, p, :] = piece p (p0 = fp16(v), p1 = fp16(v - p0), p2 = fp16(v - p0 - p1)) of v = src[r, 32k..32k+31] * 2^scale_exp
  * (0 past `cols`): the triple-rows image [rows, ld_dst/32, 3, 32] halves.  ld_dst % 32 == 0.  scale_exp / dev_scale as rbnn_split_rows. */
@@ -374,17 +388,18 @@ int rbnn_triple_cols(const float *W, int64_t n_mats, int32_t rows, int32_t cols,
 int rbnn_triple_w2gen(const float *W2, int32_t n_mats, int32_t n_classes, int32_t hidden, int32_t scale_exp, void *dst,
                       void *stream);
 
-/* rbnn_fc_forward on triple images: same outputs (ws->P, ws->mask1 / ws->dact1).  X_triple = rbnn_triple_rows(X, N, D, ., x_exp, ., ldx)
- * with ldx == tp->ld_rows; dev_scale != NULL: record [0] of rbnn_input_scales replaces x_exp, read on the device. */
-int rbnn_fc_forward_triple(const rbnn_posterior *net, const rbnn_triple_images *tp, const void *X_triple, int32_t ldx,
-                           int32_t x_exp, const rbnn_dev_scale *dev_scale, int32_t n_points, const int32_t *sample_idx,
+/* rbnn_fc_forward on triple images: same outputs (ws->P, ws->mask1 / ws->dact1; fc2: ws->mask2 / ws->dact2).  tws->X_triple =
+ * rbnn_triple_rows(X, N, D, ., x_exp, ., tp->ld_rows); dev_scales != NULL: the two records of rbnn_input_scales — [0] replaces
+ * x_exp, [1] replaces tp->h1_exp (fc2) — read on the device. */
+int rbnn_fc_forward_triple(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_triple_workspace *tws,
+                           int32_t x_exp, const rbnn_dev_scale *dev_scales, int32_t n_points, const int32_t *sample_idx,
                            int32_t n_samples, int32_t out_kind, const rbnn_workspace *ws, void *stream);
 
-/* rbnn_fc_input_grad on triple images: same slabs (ws->slabs, already un-scaled), from ws->dZ and ws->mask1.  Re-scales dZ per
- * point (2^e(n)) like rbnn_fc_input_grad_split; sws->dZ_gen / g_scale sized by rbnn_triple_workspace_query. */
+/* rbnn_fc_input_grad on triple images: same slabs (ws->slabs, already un-scaled), from ws->dZ and ws->mask1 (fc2: two steps
+ * through ws->dhid1, with ws->mask2).  Re-scales dZ per point (2^e(n)) like rbnn_fc_input_grad_split. */
 int rbnn_fc_input_grad_triple(const rbnn_posterior *net, const rbnn_triple_images *tp, const int32_t *sample_idx,
                               int32_t n_samples, int32_t n_points, int32_t chunk, const rbnn_workspace *ws,
-                              const rbnn_split_workspace *sws, int32_t *n_slabs_out, void *stream);
+                              const rbnn_triple_workspace *tws, int32_t *n_slabs_out, void *stream);
 
 #ifdef __cplusplus
 }

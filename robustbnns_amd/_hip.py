@@ -64,7 +64,19 @@ class SplitImages(C.Structure):
 
 class TripleImages(C.Structure):
     _fields_ = [("W1_rows", _fp), ("W1_cols", _fp), ("W2_gen", _fp), ("ld_rows", C.c_int32), ("ld_cols", C.c_int32),
-                ("w1_exp", C.c_int32), ("w2_exp", C.c_int32)]
+                ("w1_exp", C.c_int32), ("w2_exp", C.c_int32), ("Wm_rows", _fp), ("Wm_cols", _fp), ("wm_exp", C.c_int32),
+                ("h1_exp", C.c_int32)]
+
+
+TRIPLE_WS_KEYS = ("X_triple", "dZ_gen", "g_scale", "hid_triple")
+
+
+class TripleWorkspace(C.Structure):
+    _fields_ = [(k, _fp) for k in TRIPLE_WS_KEYS]
+
+
+class TripleWorkspaceSizes(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in TRIPLE_WS_KEYS]
 
 
 SPLIT_WS_KEYS = ("X_split", "dZ_gen", "g_scale")
@@ -113,12 +125,12 @@ SIGNATURES = {
     "rbnn_split_workspace_query": (_i32, [_PP, C.POINTER(SplitImages), _i32, _i32, C.POINTER(SplitWorkspaceSizes)]),
     "rbnn_fc_input_grad_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(SplitWorkspace),
                                         C.POINTER(_i32), _fp]),
-    "rbnn_triple_workspace_query": (_i32, [_PP, C.POINTER(TripleImages), _i32, _i32, C.POINTER(SplitWorkspaceSizes)]),
+    "rbnn_triple_workspace_query": (_i32, [_PP, C.POINTER(TripleImages), _i32, _i32, C.POINTER(TripleWorkspaceSizes)]),
     "rbnn_triple_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
     "rbnn_triple_cols": (_i32, [_fp, _i64, _i32, _i32, _i32, _i32, _fp, _i32, _fp]),
     "rbnn_triple_w2gen": (_i32, [_fp, _i32, _i32, _i32, _i32, _fp, _fp]),
-    "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
-    "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(SplitWorkspace),
+    "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(TripleWorkspace), _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
+    "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(TripleWorkspace),
                                          C.POINTER(_i32), _fp]),
 }
 
@@ -313,24 +325,28 @@ class HipKernels:
         check(self.lib.rbnn_triple_w2gen(ptr(W2), W2.numel() // (Cn * H), Cn, H, scale_exp, ptr(out), stream_of(W2)), "rbnn_triple_w2gen")
 
     def triple_workspace_sizes(self, net, images, N, S):
-        out = SplitWorkspaceSizes()
+        out = TripleWorkspaceSizes()
         check(self.lib.rbnn_triple_workspace_query(C.byref(net.descriptor()), C.byref(images), N, S, C.byref(out)),
               "rbnn_triple_workspace_query")
-        return {k: getattr(out, k) for k in SPLIT_WS_KEYS}
+        return {k: getattr(out, k) for k in TRIPLE_WS_KEYS}
 
-    def fc_forward_triple(self, net, images, Xt, ld, x_exp, N, sidx, S, out_kind, ws, dev_scale=None):
-        w = self._ws(ws)
-        check(self.lib.rbnn_fc_forward_triple(C.byref(net.descriptor()), C.byref(images), ptr(Xt), ld, x_exp, ptr(dev_scale), N,
-                                              ptr(sidx), S, out_kind, C.byref(w), stream_of(Xt)), "rbnn_fc_forward_triple")
+    @staticmethod
+    def _tws(tws):
+        t = TripleWorkspace()
+        for k in TRIPLE_WS_KEYS:
+            setattr(t, k, ptr(tws.get(k)))
+        return t
 
-    def fc_input_grad_triple(self, net, images, sidx, S, N, chunk, ws, sws):
-        w = self._ws(ws)
-        sw = SplitWorkspace()
-        for k in SPLIT_WS_KEYS:
-            setattr(sw, k, ptr(sws.get(k)))
+    def fc_forward_triple(self, net, images, tws, x_exp, N, sidx, S, out_kind, ws, dev_scales=None):
+        w, t = self._ws(ws), self._tws(tws)
+        check(self.lib.rbnn_fc_forward_triple(C.byref(net.descriptor()), C.byref(images), C.byref(t), x_exp, ptr(dev_scales), N,
+                                              ptr(sidx), S, out_kind, C.byref(w), stream_of(tws["X_triple"])), "rbnn_fc_forward_triple")
+
+    def fc_input_grad_triple(self, net, images, sidx, S, N, chunk, ws, tws):
+        w, t = self._ws(ws), self._tws(tws)
         n = C.c_int32(0)
         check(self.lib.rbnn_fc_input_grad_triple(C.byref(net.descriptor()), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
-                                                 C.byref(sw), C.byref(n), stream_of(ws["dZ"])), "rbnn_fc_input_grad_triple")
+                                                 C.byref(t), C.byref(n), stream_of(ws["dZ"])), "rbnn_fc_input_grad_triple")
         return n.value
 
     # -- conv architecture ---------------------------------------------------------------------------

@@ -25,6 +25,9 @@
 #include "rbnn_common.hpp"
 #include <algorithm>
 
+#ifndef RBNN_X3_FWD_SB
+#define RBNN_X3_FWD_SB 4                                      // forward: samples per XCD-resident group of blocks
+#endif
 #ifndef RBNN_X3_BARRIER_END
 #define RBNN_X3_BARRIER_END 0
 #endif
@@ -72,6 +75,19 @@ __device__ __forceinline__ void split3_pair(float ge, float go, unsigned mw, uns
     else asm volatile(RBNN_X3_PAIR_BODY RBNN_X3_PAIR_OPS);   // volatile: the pairs of one MFMA result stay behind the FIRST one
 }
 
+// The same for two plain fp32 values (fc2 step 2: the A operand comes from memory): 6 vector instructions per pair.
+__device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
+    float re, ro;
+    asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"
+        "v_fma_mix_f32 %[re], %[ve], %[one], -%[d0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[ro], %[vo], %[one], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t"
+        "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro)
+        : [ve] "v"(ve), [vo] "v"(vo), [one] "v"(one));
+}
+
 // ===================================================================================================
 // fp32 rows -> triple-rows image.  One thread per (row, group of 8 columns): three 16-B stores.
 // ===================================================================================================
@@ -110,9 +126,12 @@ struct FwdX3Args {
     const int* sidx;  int S;  int NT;  float out_scale;        // out_scale = 2^-(e_x + e_w)
     float* P;  uint32_t* mask;  float* dact;  int out_kind;
     const rbnn_dev_scale* x_ds;                                // != NULL: out_scale *= x_ds->inv_scale
+    // fc2: layer 1 (!LAYER2) writes the hidden activations as a per-sample triple-rows image [S][N][H] (value * hid_scale = p0 + p1 + p2);
+    // layer 2 reads it as its X operand (x_sample_bytes = N * H * 6)
+    long long x_sample_bytes;  char* hid;  float hid_scale;  const rbnn_dev_scale* hid_ds;
 };
 
-template <int ACT, int WH, int HTW, int WN, int NTW>
+template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
 __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kernel(const FwdX3Args a) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int PLANEB = (BH + BN) * 64;                     // one plane of a stage tile
@@ -129,18 +148,25 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.S, id)) return;
-    int ntile, s;                                              // 2-D blocked item order, see fc_forward_kernel
+    // 2-D blocked item order: the ~32 blocks resident on an XCD together are SB samples x (32 / SB) point tiles.  A block streams its
+    // sample's W1 image (H * ldw * 6 B) and its X tile (BN * ldx * 6 B), both shared through that XCD's L2 with the co-resident blocks
+    // of the same sample / tile: bytes from beyond the L2 per 32 blocks ~ SB * |W1| + (32 / SB) * |X tile|, minimal at SB = 2..4 here
+    // (2.46 MB vs 0.61 MB); the exact kernel's SB = 8 cost 33 % more (profiles/r02t: FETCH_SIZE)
+    constexpr int SB = RBNN_X3_FWD_SB;
+    int ntile, s;
     {
-        const int full = a.S / 8, per = 8 * a.NT;
-        if (id < full * per) { ntile = (id % per) / 8; s = (id / per) * 8 + id % 8; }
-        else { const int rem = id - full * per, cnt = a.S - full * 8; ntile = rem / cnt; s = full * 8 + rem % cnt; }
+        const int full = a.S / SB, per = SB * a.NT;
+        if (id < full * per) { ntile = (id % per) / SB; s = (id / per) * SB + id % SB; }
+        else { const int rem = id - full * per, cnt = a.S - full * SB; ntile = rem / cnt; s = full * SB + rem % cnt; }
     }
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations (M0) become SALU work
     const int wave_h = wave % WH, wave_n = wave / WH;
     const int sw = a.sidx ? a.sidx[s] : s;
     const float out_scale = a.x_ds ? a.out_scale * a.x_ds->inv_scale : a.out_scale;
+    const float hid_scale = (!LAYER2 && a.hid_ds) ? a.hid_ds->scale : a.hid_scale;
     const char* const Ws = a.W + (long long)sw * a.w_sample_bytes;
+    const char* const Xs = a.X + (long long)s * a.x_sample_bytes;
     const int n0 = ntile * BN;
     const int HW = a.H >> 5;
     // DMA piece = 16 rows x 64 B of one plane: lane p lands at row (p >> 2), physical chunk p & 3, so it fetches logical chunk
@@ -173,7 +199,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         const int p = i / (WPP + XPP), j = i % (WPP + XPP);
         const unsigned koff = (unsigned)kt * 192u + 64u * p;
         if (j < WPP) glds16((const float*)(Ws + (long long)c * BH * a.ldw * 6 + (wrow[j < WPP ? j : 0] + koff)), (float*)(T + p * PLANEB + (wave + NW * j) * 1024));
-        else glds16((const float*)(a.X + (xrow[j >= WPP ? j - WPP : 0] + koff)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * (j - WPP)) * 1024));
+        else glds16((const float*)(Xs + (xrow[j >= WPP ? j - WPP : 0] + koff)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * (j - WPP)) * 1024));
     };
 #pragma unroll
     for (int i = 0; i < PPS; ++i) piece(0, 0, 0, i);
@@ -280,7 +306,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
             const int hrow = hw0 + ht * 16 + 4 * lg;           // acc[ht][nt][r] is hidden unit hrow + r
             const f32x4 bias = *(const f32x4*)(a.b + (long long)sw * a.H + hrow);
             f32x4 w2f = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (li < a.C) w2f = *(const f32x4*)(a.W2 + ((long long)sw * a.C + li) * a.H + hrow);
+            if (LAYER2 && li < a.C) w2f = *(const f32x4*)(a.W2 + ((long long)sw * a.C + li) * a.H + hrow);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const int n = n0 + (wave_n * NTW + nt) * 16 + li;
@@ -304,8 +330,30 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                     for (int r = 0; r < 4; ++r) dv[r] = act_grad_from_value<ACT>(hv[r]);
                     *(f32x4*)(a.dact + ((long long)s * a.N + n) * a.H + hrow) = dv;
                 }
+                if (LAYER2) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
+                    for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
+                } else {
+                    // the three pieces of the lane's four units = 8 bytes per plane; lanes lg (even) and lg + 1 hold the two halves of a
+                    // 16-byte chunk: swap so that the even lane stores the whole p0 and p2 chunks and the odd lane the whole p1 chunk
+                    union { _Float16 h[4]; unsigned w[2]; } q0, q1, q2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) split3(hv[r] * hid_scale, q0.h[r], q1.h[r], q2.h[r]);
+                    const bool odd = lg & 1;
+                    const unsigned s0 = odd ? q0.w[0] : q1.w[0], s1 = odd ? q0.w[1] : q1.w[1];
+                    const unsigned r0 = __shfl_xor(s0, 16), r1 = __shfl_xor(s1, 16);      // even gets the partner's p0, odd the partner's p1
+                    const unsigned t0 = __shfl_xor(q2.w[0], 16), t1 = __shfl_xor(q2.w[1], 16);
+                    if (n < a.N) {
+                        // row n of sample s: stage hrow / 32 = 192 B = [plane][4 chunks of 16 B]; this pair's chunk = (hrow % 32) / 8
+                        char* const row = a.hid + ((long long)s * a.N + n) * a.H * 6 + (hrow >> 5) * 192 + ((hrow & 31) >> 3) * 16;
+                        if (!odd) {
+                            *(uint4*)(row) = make_uint4(q0.w[0], q0.w[1], r0, r1);
+                            *(uint4*)(row + 128) = make_uint4(q2.w[0], q2.w[1], t0, t1);
+                        } else {
+                            *(uint4*)(row + 64) = make_uint4(r0, r1, q1.w[0], q1.w[1]);
+                        }
+                    }
+                }
             }
         }
         if (BITMASK && a.mask) {
@@ -318,6 +366,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     }
     if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
+    if (!LAYER2) return;
     // Z^T partials of the WH waves that split h -> LDS -> one thread per point finishes the softmax.
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -355,13 +404,13 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     }
 }
 
-template <int ACT, int WH, int HTW, int WN, int NTW>
+template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
 int launch_forward_x3_cfg(FwdX3Args a, hipStream_t st) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int LDSB = 2 * 3 * (BH + BN) * 64;
     static_assert(LDSB <= 160 * 1024, "LDS");
     a.NT = (a.N + BN - 1) / BN;
-    auto kern = fc_forward_x3_kernel<ACT, WH, HTW, WN, NTW>;
+    auto kern = fc_forward_x3_kernel<ACT, WH, HTW, WN, NTW, LAYER2>;
     static unsigned long long attr_done = 0;                    // per instantiation, one bit per device
     if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.S);
@@ -373,22 +422,23 @@ int launch_forward_x3_cfg(FwdX3Args a, hipStream_t st) {
 #define RBNN_X3_FWD_CFG 4, 4, 2, 4                              // 256 h x 128 n, 8 waves of 64 h x 64 n, 144 KB of LDS
 #endif
 
-template <int ACT>
+template <int ACT, bool LAYER2>
 int launch_forward_x3_act(const FwdX3Args& a, hipStream_t st) {
-    if (a.H % 256 == 0) return launch_forward_x3_cfg<ACT, RBNN_X3_FWD_CFG>(a, st);
-    if (a.H % 128 == 0) return launch_forward_x3_cfg<ACT, 2, 4, 2, 4>(a, st);   // 128 h x 128 n, 4 waves
+    if (a.H % 256 == 0) return launch_forward_x3_cfg<ACT, RBNN_X3_FWD_CFG, LAYER2>(a, st);
+    if (a.H % 128 == 0) return launch_forward_x3_cfg<ACT, 2, 4, 2, 4, LAYER2>(a, st);   // 128 h x 128 n, 4 waves
     return RBNN_ERR_UNSUPPORTED;
 }
 
+template <bool LAYER2>
 int launch_forward_x3(int act, const FwdX3Args& a, hipStream_t st) {
     switch (act) {
 #ifndef RBNN_FAST_BUILD
-        case RBNN_ACT_RELU:  return launch_forward_x3_act<RBNN_ACT_RELU>(a, st);
+        case RBNN_ACT_RELU:  return launch_forward_x3_act<RBNN_ACT_RELU, LAYER2>(a, st);
 #endif
-        case RBNN_ACT_LEAKY: return launch_forward_x3_act<RBNN_ACT_LEAKY>(a, st);
+        case RBNN_ACT_LEAKY: return launch_forward_x3_act<RBNN_ACT_LEAKY, LAYER2>(a, st);
 #ifndef RBNN_FAST_BUILD
-        case RBNN_ACT_SIGM:  return launch_forward_x3_act<RBNN_ACT_SIGM>(a, st);
-        case RBNN_ACT_TANH:  return launch_forward_x3_act<RBNN_ACT_TANH>(a, st);
+        case RBNN_ACT_SIGM:  return launch_forward_x3_act<RBNN_ACT_SIGM, LAYER2>(a, st);
+        case RBNN_ACT_TANH:  return launch_forward_x3_act<RBNN_ACT_TANH, LAYER2>(a, st);
 #endif
     }
     return RBNN_ERR_UNSUPPORTED;
@@ -540,10 +590,16 @@ struct GradX3Args {
     int H;  int HW;  const int* sidx;  int S;  int chunk;  int nchunks;
     int N;  int NT;  int ND;  int Dt;
     float* out;  int ldo;  float out_scale;                     // slabs [nchunks][N][ldo]; out_scale = 2^-(e_w2 + GEN_Q3 + e_w1)
+    // fc2.  X3_FC2_STEP1 (one sample per block): out = dhid1 [S][N][H] = act'(A1) * (dA2 . Wm), KEPT SCALED (x out_scale, no per-point
+    // un-scaling): it is the fp32 source of step 2's A operand.  X3_FC2_STEP2: A operand read from `amem` and split in registers.
+    const uint32_t* omask;  int OHW;                            // step 1: stash of the layer below [S][H/32][N_pad]
+    const float* amem;                                          // step 2: [S][N][H]
 };
+enum { X3_FC = 0, X3_FC2_STEP1 = 1, X3_FC2_STEP2 = 2 };
 
-template <int ACT, int TD>
+template <int ACT, int TD, int MODE>
 __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) {
+    constexpr bool GEN = MODE != X3_FC2_STEP2;                 // dA generated from dZ, or read from memory
     constexpr int NTW = 4, NW = 4, BM = 256, LD = TD * 16;
     constexpr int W1B = 12 * LD * 16;                          // bytes: [4 lg][3 pieces][LD columns][16 B]
     constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + NW - 1) / NW;
@@ -589,7 +645,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     };
     // The DMA pieces of a stage, per wave: 0 .. PPW-1 its W1 pieces, PPW its generator-tile piece (tiles 2*hb, 2*hb + 1 of the sample
     // are 4 KiB contiguous: one piece per wave), PPW + 1 the stash words (the block's 256 points = 1 KiB; last wave only).
-    constexpr int NDMA = PPW + 2, DPN = (NDMA + NTW - 1) / NTW;   // issued DPN at a time between the generator's point tiles
+    constexpr int NDMA = GEN ? PPW + 2 : PPW, DPN = (NDMA + NTW - 1) / NTW;   // issued DPN at a time between the generator's point tiles
     struct StageSrc { const char* W; const char* G; const char* M; char* B; };
     auto stage_src = [&](int st, int buf) {
         const int si = st / HS, hb = st % HS, s = s_begin + si;
@@ -611,12 +667,26 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
         }
     };
 
-    dz_issue(s_begin);
+    if (GEN) dz_issue(s_begin);
     {
         const StageSrc q = stage_src(0, 0);
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) issue_piece(q, i);
     }
+    // step 2: the A operand of stage st (this lane: point li of each tile, units 16t + 4lg + r of the stage's 32) is loaded from memory
+    // one stage ahead, AFTER the next stage's LDS-DMA has been issued, so that the barrier's vmcnt(0) covers both
+    f32x4 am[GEN ? 1 : NTW][2];
+    auto load_a = [&](int st) {
+        const int s = s_begin + st / HS, h0 = (st % HS) * 32;
+#pragma unroll
+        for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt) {
+            const int n = min(nb + nt * 16 + li, a.N - 1);     // rows past N: any valid row, never stored
+            const float* const src = a.amem + ((long long)s * a.N + n) * a.H + h0 + 4 * lg;
+            am[nt][0] = *(const f32x4*)src;
+            am[nt][1] = *(const f32x4*)(src + 16);
+        }
+    };
+    if (!GEN) load_a(0);
     ring_wait_barrier<0>();
     const unsigned cp_bits = __float_as_uint(ldexpf(1.f, GEN_Q3));
     const unsigned cn_bits = (ACT == RBNN_ACT_RELU) ? 0u : __float_as_uint(LEAKY_SLOPE * ldexpf(1.f, GEN_Q3));
@@ -631,11 +701,24 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
         const bool more = !(RBNN_ABL & 1) && st + 1 < nst;
         const StageSrc q = stage_src(more ? st + 1 : st, buf ^ 1);
         const char* const B = ldsb + buf * BUFB;
-        const bool gen_on = !(RBNN_ABL & 16) || st == 0;
+        const bool gen_on = GEN && (!(RBNN_ABL & 16) || st == 0);
+        if (!GEN) {                                            // split this stage's A (already in registers), then fetch the next one
+#pragma unroll
+            for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt) {
+                union { f16x8 v; unsigned u[4]; } o0, o1, o2;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    split3_plain_pair(am[nt][t][0], am[nt][t][1], 1.f, o0.u[2 * t], o1.u[2 * t], o2.u[2 * t]);
+                    split3_plain_pair(am[nt][t][2], am[nt][t][3], 1.f, o0.u[2 * t + 1], o1.u[2 * t + 1], o2.u[2 * t + 1]);
+                }
+                da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
+            }
+        }
         if (more && (!gen_on || !RBNN_X3_SPREAD)) {
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) issue_piece(q, i);
         }
+        if (!GEN && st + 1 < nst) load_a(st + 1);
 
         // ---- generator + split ----
         if (gen_on) {
@@ -664,7 +747,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
                 }
             }
         }
-        if (!(RBNN_ABL & 1) && hb == HS - 1 && st + 1 < nst) {  // last stage of a sample: the dZ reads above are this wave's last of it
+        if (GEN && !(RBNN_ABL & 1) && hb == HS - 1 && st + 1 < nst) {  // last stage of a sample: the dZ reads above are this wave's last of it
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0): those reads have returned
             asm volatile("" ::: "memory");
@@ -707,24 +790,29 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
         for (int r = 0; r < 4; ++r) {
             const int n = nb + nt * 16 + 4 * lg + r;
             if (n >= a.N) continue;
-            const float gs = a.gscale[n] * a.out_scale;
+            const float gs = (MODE == X3_FC2_STEP1) ? a.out_scale : a.gscale[n] * a.out_scale;
             float* const dst = a.out + ((long long)ch * a.N + n) * a.ldo;
 #pragma unroll
             for (int dt = 0; dt < TD; ++dt) {
                 const int d = dc0 + dt * 16 + li;
                 if (d >= Dp) continue;
-                dst[d] = acc[nt][dt][r] * gs;
+                float v = acc[nt][dt][r] * gs;
+                if (MODE == X3_FC2_STEP1) {                     // derivative of the layer below: unit d of point n, sample ch
+                    const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n];
+                    v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
+                }
+                dst[d] = v;
             }
         }
 }
 
-template <int ACT, int TD>
+template <int ACT, int TD, int MODE>
 int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
     constexpr int LDSB = 2 * (12 * TD * 16 * 16 + 5120) + 256 * 64;
     static_assert(2 * LDSB <= 160 * 1024, "two blocks per CU");
     a.NT = (a.N + 255) / 256;
     a.ND = (a.Dt + TD - 1) / TD;
-    auto kern = fc_grad_x3_kernel<ACT, TD>;
+    auto kern = fc_grad_x3_kernel<ACT, TD, MODE>;
     static unsigned long long attr_done = 0;
     if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
@@ -732,10 +820,20 @@ int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
     return launch_status();
 }
 
-template <int ACT>
+// 7 or 4 column tiles per block: every group pays the dA generator (or the A-operand reads) again, so fewer groups win — 7 wherever
+// that saves a group (a partial last group skips its missing tiles' MFMAs)
+template <int ACT, int MODE>
 int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
-    if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7>(a, st);
-    return launch_grad_x3_cfg<ACT, 4>(a, st);
+    if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7, MODE>(a, st);
+    return launch_grad_x3_cfg<ACT, 4, MODE>(a, st);
+}
+
+template <int MODE>
+int launch_grad_x3_act(int act, const GradX3Args& a, hipStream_t st) {
+#ifndef RBNN_FAST_BUILD
+    if (act == RBNN_ACT_RELU) return launch_grad_x3<RBNN_ACT_RELU, MODE>(a, st);
+#endif
+    return launch_grad_x3<RBNN_ACT_LEAKY, MODE>(a, st);
 }
 
 }  // namespace
@@ -779,51 +877,71 @@ int rbnn_triple_w2gen(const float* W2, int32_t n_mats, int32_t C, int32_t H, int
 }
 
 int rbnn_triple_workspace_query(const rbnn_posterior* net, const rbnn_triple_images* tp, int32_t N, int32_t S,
-                                rbnn_split_workspace_sizes* out) {
+                                rbnn_triple_workspace_sizes* out) {
     if (!net || !tp || !out) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || tp->ld_rows < net->in_features || (tp->ld_rows & 31)) return RBNN_ERR_SHAPE;
-    rbnn_split_workspace_sizes z = {};
-    z.X_split = (size_t)N * tp->ld_rows * 6;
+    rbnn_triple_workspace_sizes z = {};
+    z.X_triple = (size_t)N * tp->ld_rows * 6;
     z.dZ_gen = (size_t)S * mask_ld(N) * 64;
     z.g_scale = (size_t)mask_ld(N) * sizeof(float);
+    z.hid_triple = net->arch == RBNN_ARCH_FC2 ? (size_t)S * N * net->hidden * 6 : 0;
     *out = z;
     return RBNN_OK;
 }
 
-int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const void* X_triple, int32_t ldx,
-                           int32_t x_exp, const rbnn_dev_scale* dev_scale, int32_t N, const int32_t* sidx, int32_t S,
+int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_triple_workspace* tws,
+                           int32_t x_exp, const rbnn_dev_scale* dev_scales, int32_t N, const int32_t* sidx, int32_t S,
                            int32_t out_kind, const rbnn_workspace* ws, void* stream) {
-    if (!net || !tp || !X_triple || !ws || !ws->P || !tp->W1_rows) return RBNN_ERR_NULL;
+    if (!net || !tp || !tws || !tws->X_triple || !ws || !ws->P || !tp->W1_rows) return RBNN_ERR_NULL;
     if (!net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
-    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
     if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2, bm = net->activation == RBNN_ACT_RELU || net->activation == RBNN_ACT_LEAKY;
     const int H = net->hidden, ld = tp->ld_rows;
-    if (H < 128 || (H % 128) || ld < net->in_features || (ld & 31) || ldx != ld) return RBNN_ERR_SHAPE;
+    if (H < 128 || (H % 128) || ld < net->in_features || (ld & 31)) return RBNN_ERR_SHAPE;
     if (net->n_classes < 1 || net->n_classes > RBNN_CPAD || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     // the kernel addresses a sample's weight image and the input image with 32-bit byte offsets from a 64-bit base
-    if ((long long)H * ld * 6 >= (1LL << 32) || (long long)N * ld * 6 >= (1LL << 32)) return RBNN_ERR_SHAPE;
+    if ((long long)H * ld * 6 >= (1LL << 32) || (long long)N * ld * 6 >= (1LL << 32) || (long long)N * H * 6 >= (1LL << 32)) return RBNN_ERR_SHAPE;
     if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
-    if (!aligned16(X_triple) || !aligned16(tp->W1_rows) || !aligned16(ws->P) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
+    if (!aligned16(tws->X_triple) || !aligned16(tp->W1_rows) || !aligned16(ws->P) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
+    if (fc2 && (!tp->Wm_rows || !net->bm || !tws->hid_triple || (bm ? !ws->mask2 : !ws->dact2))) return RBNN_ERR_NULL;
+    if (fc2 && (!aligned16(tp->Wm_rows) || !aligned16(tws->hid_triple) || !aligned16(net->bm))) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
     FwdX3Args a = {};
-    a.X = (const char*)X_triple; a.ldx = ldx; a.N = N;
+    a.X = (const char*)tws->X_triple; a.ldx = ld; a.N = N; a.x_sample_bytes = 0;
     a.W = (const char*)tp->W1_rows; a.w_sample_bytes = (long long)H * ld * 6; a.ldw = ld; a.KT = ld / 32;
     a.b = net->b1; a.W2 = net->W2; a.b2 = net->b2; a.C = net->n_classes; a.H = H;
-    a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -((dev_scale ? 0 : x_exp) + tp->w1_exp)); a.x_ds = dev_scale;
+    a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -((dev_scales ? 0 : x_exp) + tp->w1_exp)); a.x_ds = dev_scales;
     a.P = ws->P; a.mask = ws->mask1; a.dact = ws->dact1; a.out_kind = out_kind;
-    return launch_forward_x3(net->activation, a, (hipStream_t)stream);
+    if (!fc2) return launch_forward_x3<true>(net->activation, a, st);
+    // fc2: layer 1 -> hidden activations as a triple-rows image in tws->hid_triple, scaled by 2^h1_exp (the caller bounds |h|:
+    // max_h sum_d |W1[h,d]| * max|x| + max|b1|; record [1] of rbnn_input_scales on the device); layer 2 reads it per sample
+    a.hid = (char*)tws->hid_triple; a.hid_scale = ldexpf(1.f, tp->h1_exp); a.hid_ds = dev_scales ? dev_scales + 1 : nullptr;
+    int rc = launch_forward_x3<false>(net->activation, a, st);
+    if (rc) return rc;
+    FwdX3Args b = a;
+    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)N * H * 6;
+    b.W = (const char*)tp->Wm_rows; b.w_sample_bytes = (long long)H * H * 6; b.ldw = H; b.KT = H / 32;
+    b.b = net->bm; b.out_scale = ldexpf(1.f, -((dev_scales ? 0 : tp->h1_exp) + tp->wm_exp));
+    b.x_ds = dev_scales ? dev_scales + 1 : nullptr; b.hid_ds = nullptr;
+    b.mask = ws->mask2; b.dact = ws->dact2; b.hid = nullptr;
+    return launch_forward_x3<true>(net->activation, b, st);
 }
 
 int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const int32_t* sidx, int32_t S,
-                              int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_split_workspace* sws,
+                              int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_triple_workspace* tws,
                               int32_t* n_slabs_out, void* stream) {
-    if (!net || !tp || !ws || !sws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
-    if (!tp->W1_cols || !tp->W2_gen || !sws->dZ_gen || !sws->g_scale) return RBNN_ERR_NULL;
-    if (net->arch != RBNN_ARCH_FC) return RBNN_ERR_UNSUPPORTED;
+    if (!net || !tp || !ws || !tws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
+    if (!tp->W1_cols || !tp->W2_gen || !tws->dZ_gen || !tws->g_scale) return RBNN_ERR_NULL;
+    if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
     if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2;
     const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
     if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     if (tp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
-    if (!aligned16(tp->W1_cols) || !aligned16(tp->W2_gen) || !aligned16(sws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
+    if (!aligned16(tp->W1_cols) || !aligned16(tp->W2_gen) || !aligned16(tws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
+    if (fc2 && (!tp->Wm_cols || !ws->dhid1 || !ws->mask2)) return RBNN_ERR_NULL;
+    if (fc2 && (!aligned16(tp->Wm_cols) || !aligned16(ws->dhid1))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (chunk <= 0) {                                           // the exact mode's slab plan (same workspace)
         rbnn_workspace_sizes q;
@@ -836,18 +954,34 @@ int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_image
     if (n_slabs_out) *n_slabs_out = nchunks;
     const long long n_pad = mask_ld(N);
     hipLaunchKernelGGL(triple_dz_kernel, dim3((unsigned)(n_pad / 16)), dim3(256), 0, st,
-                       ws->dZ, S, N, n_pad, C, (uint4*)sws->dZ_gen, sws->g_scale);
+                       ws->dZ, S, N, n_pad, C, (uint4*)tws->dZ_gen, tws->g_scale);
     if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
     GradX3Args g = {};
-    g.dzg = (const char*)sws->dZ_gen; g.n_pad = n_pad; g.gscale = sws->g_scale; g.mask = ws->mask1;
-    g.W1c = (const char*)tp->W1_cols; g.ldc = tp->ld_cols; g.W2g = (const char*)tp->W2_gen;
-    g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N; g.Dt = Dp / 16;
-    g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
-    g.out_scale = ldexpf(1.f, -(tp->w2_exp + GEN_Q3 + tp->w1_exp));
-#ifndef RBNN_FAST_BUILD
-    if (net->activation == RBNN_ACT_RELU) return launch_grad_x3<RBNN_ACT_RELU>(g, st);
-#endif
-    return launch_grad_x3<RBNN_ACT_LEAKY>(g, st);
+    g.dzg = (const char*)tws->dZ_gen; g.n_pad = n_pad; g.gscale = tws->g_scale;
+    g.W2g = (const char*)tp->W2_gen;
+    g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N;
+    if (!fc2) {
+        g.mask = ws->mask1; g.W1c = (const char*)tp->W1_cols; g.ldc = tp->ld_cols; g.Dt = Dp / 16;
+        g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
+        g.out_scale = ldexpf(1.f, -(tp->w2_exp + GEN_Q3 + tp->w1_exp));
+        return launch_grad_x3_act<X3_FC>(net->activation, g, st);
+    }
+    // fc2 step 1, one sample per block: dhid1[s] = act'(A1_s) * ((act'(A2_s) * (dZ_s . W3_s)) . Wm_s), kept scaled:
+    //   stored = dhid1 * 2^(e(n) + e_w3 + GEN_Q3 + e_wm - Q2),  Q2 = 14 + ceil(log2 H): |dA2 scaled| <= 2^15, |Wm scaled| <= 2^14, K = H
+    //   => |stored| <= 2^15: in fp16 range, ready to be split as step 2's A operand
+    int q2 = 14;
+    while ((1 << (q2 - 14)) < H) ++q2;
+    g.mask = ws->mask2; g.W1c = (const char*)tp->Wm_cols; g.ldc = H; g.Dt = H / 16;
+    g.chunk = 1; g.nchunks = S; g.out = ws->dhid1; g.ldo = H; g.out_scale = ldexpf(1.f, -q2);
+    g.omask = ws->mask1; g.OHW = H / 32;
+    int rc = launch_grad_x3_act<X3_FC2_STEP1>(net->activation, g, st);
+    if (rc) return rc;
+    // fc2 step 2: slabs[k] = sum_{s in chunk k} dhid1[s] . W1_s; acc = g * 2^(e(n) + e_w3 + GEN_Q3 + e_wm - Q2 + e_w1)
+    GradX3Args h = g;
+    h.amem = ws->dhid1; h.W1c = (const char*)tp->W1_cols; h.ldc = tp->ld_cols; h.Dt = Dp / 16;
+    h.chunk = chunk; h.nchunks = nchunks; h.out = ws->slabs; h.ldo = Dp;
+    h.out_scale = ldexpf(1.f, -(tp->w2_exp + GEN_Q3 + tp->wm_exp - q2 + tp->w1_exp));
+    return launch_grad_x3_act<X3_FC2_STEP2>(net->activation, h, st);
 }
 
 }  // extern "C"

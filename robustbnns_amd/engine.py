@@ -90,7 +90,7 @@ class AttackEngine:
         # takes it wherever it applies and falls back to the fp32 MFMA ("exact") elsewhere.
         tri = bool(getattr(self.post, "triple_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
         if want == "triple" and not tri:
-            raise _hip.HipError("precision='triple' covers fc posteriors with relu / leaky, hidden % 128 == 0 and classes <= 10, on the GPU")
+            raise _hip.HipError("precision='triple' covers fc / fc2 posteriors with relu / leaky, hidden % 128 == 0 and classes <= 10, on the GPU")
         if want == "triple" or (want == "auto" and tri):
             return "triple"
         ok = bool(getattr(self.post, "split_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
@@ -166,12 +166,16 @@ class AttackEngine:
                     ws[name] = torch.empty(sizes[name] // 4, dtype=_WS_DTYPE.get(name, torch.float32), device=self.device)
             ws["Psum"] = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
             ws["G"] = torch.empty(N, self.post.Dp, dtype=torch.float32, device=self.device)
-            if self.precision in ("split", "triple"):
-                ssz = (self.k.split_workspace_sizes(self.post, self.post.split_images(), N, S) if self.precision == "split"
-                       else self.k.triple_workspace_sizes(self.post, self.post.triple_images(), N, S))
+            if self.precision == "split":
+                ssz = self.k.split_workspace_sizes(self.post, self.post.split_images(), N, S)
                 ws["split"] = {"X_split": torch.empty(ssz["X_split"] // 2, dtype=torch.int16, device=self.device),
                                "dZ_gen": torch.empty(ssz["dZ_gen"] // 2, dtype=torch.int16, device=self.device),
                                "g_scale": torch.empty(ssz["g_scale"] // 4, dtype=torch.float32, device=self.device)}
+            if self.precision == "triple":
+                tsz = self.k.triple_workspace_sizes(self.post, self.post.triple_images(), N, S)
+                ws["triple"] = {k: torch.empty(max(1, v // 2), dtype=torch.int16, device=self.device) for k, v in tsz.items() if v}
+                ws["triple"]["g_scale"] = ws["triple"]["g_scale"].view(torch.float32)
+                ws.pop("hid1", None)                                # the hidden activations live in the triple image instead
             if len(self._ws_cache) > 6:
                 self._ws_cache.clear()
             self._ws_cache[key] = ws
@@ -182,8 +186,8 @@ class AttackEngine:
         if self.precision == "triple":
             img = self.post.triple_images()
             ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
-            self.k.triple_rows(Xp, self.post.D, 0, ws["split"]["X_split"], img.ld_rows, dev_scale=ds)
-            return self.k.fc_forward_triple(self.post, img, ws["split"]["X_split"], img.ld_rows, 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scale=ds)
+            self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds)
+            return self.k.fc_forward_triple(self.post, img, ws["triple"], 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
         if self.precision != "split":
             return self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
         img = self.post.split_images()
@@ -193,7 +197,7 @@ class AttackEngine:
 
     def _grad_kernels(self, sidx, S, N, ws):
         if self.precision == "triple":
-            return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
+            return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["triple"])
         if self.precision != "split" or (self.post.arch == "fc2" and os.environ.get("RBNN_FC2_BWD_EXACT") == "1"):
             return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
         return self.k.fc_input_grad_split(self.post, self.post.split_images(), sidx, S, N, ws["chunk"], ws, ws["split"])

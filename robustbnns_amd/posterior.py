@@ -115,8 +115,8 @@ class StackedPosterior:
 
     # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands
     def triple_supported(self):
-        """The triple kernels cover fc with relu / leaky, hidden % 128 == 0 and <= 10 classes."""
-        return (self.arch == "fc" and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
+        """The triple kernels cover fc and fc2 with relu / leaky, hidden % 128 == 0 and <= 10 classes."""
+        return (self.arch in ("fc", "fc2") and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
                 and self.device.type == "cuda")
 
     def triple_images(self):
@@ -137,7 +137,18 @@ class StackedPosterior:
             img = _hip.TripleImages()
             img.W1_rows, img.W1_cols, img.W2_gen = rows.data_ptr(), cols.data_ptr(), gen.data_ptr()
             img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = ld, Dp, w1_exp, w2_exp
-            self._triple = (img, [rows, cols, gen])               # the tensors keep the device memory alive
+            keep = [rows, cols, gen]
+            if self.arch == "fc2":                               # the middle layer: Wm as triple rows [S*H, H] (forward) and triple cols (backward step 1)
+                wm_exp = scale_exp(float(self.Wm.abs().max()))
+                wm_rows = torch.empty(S * H, H * 3, dtype=torch.int16, device=self.device)
+                k.triple_rows(self.Wm, H, wm_exp, wm_rows, H)
+                wm_cols = torch.empty(S * (H // 32) * 12 * H * 8, dtype=torch.int16, device=self.device)
+                k.triple_cols(self.Wm, H, H, wm_exp, wm_cols, H)
+                img.Wm_rows, img.Wm_cols, img.wm_exp = wm_rows.data_ptr(), wm_cols.data_ptr(), wm_exp
+                keep += [wm_rows, wm_cols]
+                # |h1| <= max_h sum_d |W1[h,d]| * max|x| + max|b1|: the per-call exponent of the hidden image (scale_bounds)
+                self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
+            self._triple = (img, keep)                           # the tensors keep the device memory alive
         return self._triple[0]
 
     def scale_bounds(self):
@@ -146,7 +157,8 @@ class StackedPosterior:
         |tanh(a)| <= min(|a|, 1); sigmoid <= 1).  fc has no such operand: the record is unused."""
         if self.arch != "fc2":
             return 0.0, 0.0, math.inf
-        self.split_images()
+        if not hasattr(self, "_h1_bound"):
+            self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
         w_l1, b_max = self._h1_bound
         if self.activation == "sigm":
             return 0.0, 1.0, 1.0

@@ -134,31 +134,34 @@ def O_split3(v):
 
 
 # ------------------------------------------------------------------ oracle, ragged sizes
-CASES = [  # act, H, C, S, N
-    ("leaky", 512, 10, 5, 300), ("relu", 512, 10, 3, 77), ("leaky", 256, 10, 7, 257), ("leaky", 128, 3, 4, 129),
-    ("relu", 384, 7, 2, 40), ("leaky", 1024, 10, 2, 130),
+CASES = [  # arch, act, H, C, S, N
+    ("fc", "leaky", 512, 10, 5, 300), ("fc", "relu", 512, 10, 3, 77), ("fc", "leaky", 256, 10, 7, 257), ("fc", "leaky", 128, 3, 4, 129),
+    ("fc", "relu", 384, 7, 2, 40), ("fc", "leaky", 1024, 10, 2, 130),
+    # fc2 = the reference's saved model_1 / 3 / 5 / 7 family: layer 1 writes the hidden activations as a triple image, the backward
+    # runs in two steps through the fp32 dhid1 buffer
+    ("fc2", "leaky", 512, 10, 3, 300), ("fc2", "relu", 256, 10, 4, 77), ("fc2", "leaky", 128, 4, 2, 257), ("fc2", "leaky", 1024, 10, 2, 40),
 ]
 
 
-@pytest.mark.parametrize("act,Hn,Cn,S,N", CASES)
-def test_triple_vs_fp64_oracle(act, Hn, Cn, S, N):
+@pytest.mark.parametrize("arch,act,Hn,Cn,S,N", CASES)
+def test_triple_vs_fp64_oracle(arch, act, Hn, Cn, S, N):
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
     Dn = 784
-    post = O.synthetic_posterior("fc", Dn, Hn, Cn, S, 0.05)
+    post = O.synthetic_posterior(arch, Dn, Hn, Cn, S, 0.05)
     x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=7)
-    sp = StackedPosterior("fc", act, (1, 28, 28), Cn, Hn, post, DEV)
+    sp = StackedPosterior(arch, act, (1, 28, 28), Cn, Hn, post, DEV)
     assert sp.triple_supported()
     eng = AttackEngine(sp, precision="triple")
     assert eng.precision == "triple"
-    p64 = O.bnn_forward(x.double(), O.cast(post, torch.float64), "fc", act, S)
+    p64 = O.bnn_forward(x.double(), O.cast(post, torch.float64), arch, act, S)
     assert rel_err(eng.forward(x, S).cpu(), p64) < TOL
-    margin = O.kink_margin(x.double(), O.cast(post, torch.float64), "fc", act, S)
+    margin = O.kink_margin(x.double(), O.cast(post, torch.float64), arch, act, S)
     ok = margin > KINK
-    assert int(ok.sum()) >= 0.5 * N
+    assert int(ok.sum()) >= 0.4 * N
     lab = y.argmax(-1)
-    g64 = O.loss_gradients(x.double(), y, O.cast(post, torch.float64), "fc", act, S)
+    g64 = O.loss_gradients(x.double(), y, O.cast(post, torch.float64), arch, act, S)
     assert rel_err(eng.loss_gradients(x, y, S).cpu()[ok], g64[ok]) < TOL
-    gm64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), "fc", act, S)
+    gm64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), arch, act, S)
     G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :Dn].cpu().reshape(x.shape)
     assert rel_err(G[ok], gm64[ok]) < TOL
     adv = eng.fgsm(x, y, S, 0.3).cpu()
@@ -167,7 +170,7 @@ def test_triple_vs_fp64_oracle(act, Hn, Cn, S, N):
     assert int((((adv - ref_adv).abs() > 1e-6) & safe).sum()) == 0
     # sample subsets through the index buffer, logits output
     idx = [S - 1, 0]
-    p_idx = O.bnn_forward(x.double(), O.cast(post, torch.float64), "fc", act, 2, seeds=idx)
+    p_idx = O.bnn_forward(x.double(), O.cast(post, torch.float64), arch, act, 2, seeds=idx)
     assert rel_err(eng.forward(x, 2, seeds=idx).cpu(), p_idx) < TOL
 
 

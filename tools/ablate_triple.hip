@@ -1,8 +1,8 @@
 // Diagnostic: time the triple-split GEMM kernels of the C2 workload (variants via -D flags; see tools/run_variants_triple.sh).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_FAST_BUILD <-D...> -o /tmp/ablt tools/ablate_triple.hip
 #include "../robustbnns_amd/csrc/rbnn_kernels.hip"
-#ifdef RBNN_TRIPLE_V1
-#include "rbnn_triple_v1.hip"
+#ifdef RBNN_TRIPLE_ALT                                     // A/B against another version of the kernels: put it at tools/rbnn_triple_alt.hip
+#include "rbnn_triple_alt.hip"
 #else
 #include "../robustbnns_amd/csrc/rbnn_triple.hip"
 #endif
@@ -38,8 +38,8 @@ int main(int argc, char** argv) {
     rbnn_workspace ws = {};
     hipMalloc(&ws.P, sz.P); hipMalloc(&ws.dZ, sz.dZ); hipMalloc(&ws.mask1, sz.mask1); hipMalloc(&ws.slabs, sz.slabs);
     { float* t = dev_rand((size_t)S * N * 16, 0.01f, 6); hipMemcpy(ws.dZ, t, sz.dZ, hipMemcpyDeviceToDevice); hipFree(t); }
-    rbnn_split_workspace_sizes ssz; rbnn_triple_workspace_query(&net, &tp, N, S, &ssz);
-    rbnn_split_workspace sws = {}; sws.X_split = xs; hipMalloc(&sws.dZ_gen, ssz.dZ_gen); hipMalloc((void**)&sws.g_scale, ssz.g_scale);
+    rbnn_triple_workspace_sizes ssz; rbnn_triple_workspace_query(&net, &tp, N, S, &ssz);
+    rbnn_triple_workspace sws = {}; sws.X_triple = xs; hipMalloc(&sws.dZ_gen, ssz.dZ_gen); hipMalloc((void**)&sws.g_scale, ssz.g_scale);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const double flop = 2.0 * N * S * ((double)D * H + (double)H * C);
     for (int which = 0; which < 2; ++which) {
@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
         for (int r = 0; r < reps + 1; ++r) {
             int ns = 0;
             hipEventRecord(e0, nullptr);
-            const int rc = which == 0 ? rbnn_fc_forward_triple(&net, &tp, xs, LD, 14, nullptr, N, nullptr, S, RBNN_OUT_PROBS, &ws, nullptr)
+            const int rc = which == 0 ? rbnn_fc_forward_triple(&net, &tp, &sws, 14, nullptr, N, nullptr, S, RBNN_OUT_PROBS, &ws, nullptr)
                                       : rbnn_fc_input_grad_triple(&net, &tp, nullptr, S, N, 0, &ws, &sws, &ns, nullptr);
             hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
             if (rc) { printf("rc=%d (%s)\n", rc, rbnn_strerror(rc)); return 1; }

@@ -17,13 +17,14 @@ out = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
 
 # kernel-name fragment -> bench.py's roofline key (a key sums the kernels one C-ABI call launches)
-MAIN = [("fc_forward_split_kernel", "fc_forward_split"), ("fc_grad_split_kernel", "fc_input_grad_split"), ("split_dz_kernel", "fc_input_grad_split"),
+MAIN = [("fc_forward_x3_kernel", "fc_forward_triple"), ("fc_grad_x3_kernel", "fc_input_grad_triple"), ("triple_dz_kernel", "fc_input_grad_triple"),
+        ("fc_forward_split_kernel", "fc_forward_split"), ("fc_grad_split_kernel", "fc_input_grad_split"), ("split_dz_kernel", "fc_input_grad_split"),
         ("fc_forward_kernel", "fc_forward"), ("fc_grad_kernel", "fc_input_grad"),
         ("conv2_pool_split_kernel", "conv_forward_split"), ("conv1_pool_split_kernel", "conv_forward_split"),
         ("conv_bwd_split_kernel", "conv_input_grad_split"),
         ("conv2_pool_kernel", "conv_forward"), ("conv1_pool_kernel", "conv_forward"), ("conv_fc_kernel", "conv_forward"),
         ("conv_bwd_kernel", "conv_input_grad"), ("conv_fc_bwd_kernel", "conv_input_grad"), ("conv1_bwd_mfma_kernel", "conv_input_grad")]
-SHORT = [k for k, _ in MAIN] + ["split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
+SHORT = [k for k, _ in MAIN] + ["triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
                                 "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"]
 
 
