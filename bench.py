@@ -267,6 +267,9 @@ def main():
         def conv_forward(self, *a, **kw):
             return self._timed("conv_forward", super().conv_forward, *a, **kw)
 
+        def conv_forward_triple(self, *a, **kw):
+            return self._timed("conv_forward", super().conv_forward_triple, *a, **kw)
+
         def conv_forward_split(self, *a, **kw):
             return self._timed("conv_forward", super().conv_forward_split, *a, **kw)
 
@@ -348,8 +351,12 @@ def main():
                         "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel (+ conv_fc_bwd, conv1_bwd)"},
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
-    KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel"}
-    SPLIT_KERNELS = {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}
+    KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel",
+                        "conv_forward": "conv2_pool_x3_kernel (+ conv1_pool, conv_fc)",
+                        "conv_input_grad": "conv_bwd_kernel (+ conv_fc_bwd, conv1_bwd; fp32 MFMA)"}
+    # which C-ABI calls run on the f16 pipe in each mode (the rest of that mode's calls are the fp32-MFMA kernels)
+    F16_KERNELS = {"split": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"},
+                   "triple": {"fc_forward", "fc_input_grad", "conv_forward"}}
     PRODUCTS = {"split": 3.0, "triple": 6.0}                                # f16 MFMA products per algorithmic fp32 MAC
     if w["arch"] == "fc2":
         KNAMES["split"].update({"fc_forward": "fc_forward_split_kernel (x2: layer 1 -> split image, layer 2)",
@@ -373,7 +380,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and not args.points and not args.samples:
             rec = json.load(open(pmc))
-            key = dom + ("_" + mode if mode in PRODUCTS and dom in SPLIT_KERNELS else "")
+            key = dom + ("_" + mode if dom in F16_KERNELS.get(mode, ()) else "")
             ent = rec.get(args.workload, rec if args.workload == "c2" else {}).get(key, {})
             traffic = ent.get("hbm_bytes_per_launch")
             traffic_src = rec.get("source") if traffic is not None else None
@@ -381,7 +388,7 @@ def main():
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
              "traffic_source": traffic_src,      # PMC counters cannot be read inside this run: a committed rocprofv3 --pmc pass of the same command
              "flop_per_launch": per_launch / kernels[dom]["launches_per_pass"], "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
-        if mode in PRODUCTS and dom in SPLIT_KERNELS:
+        if dom in F16_KERNELS.get(mode, ()):
             # matrix-pipe work of the split / triple mode: 3 / 6 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
             np_ = PRODUCTS[mode]
             r.update({"achieved": np_ * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": np_ * fp32_eq / F16_MFMA_PEAK_TFLOPS,

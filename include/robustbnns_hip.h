@@ -256,6 +256,16 @@ int rbnn_conv_forward_split(const rbnn_conv_posterior *net, const void *K2_rows,
                             int32_t n_points, const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                             const rbnn_conv_workspace *ws, void *stream);
 
+/* rbnn_conv_forward with conv2 in the triple-split ("f16x6") mode (both geometries, relu / leaky): full-width fp32 operands as three
+ * fp16 pieces, six exact product terms per product on the f16 matrix pipe, fp32 accumulation (see the triple-split section below).
+ * K2_triple = rbnn_triple_rows image of model.3.weight regrouped [S_total*Hc, 25 taps * 32 ci] (K tap-major) holding W * 2^k2_exp;
+ * the pooled conv1 activations (computed in fp32 by the exact conv1 kernel into ws->P1) are split on the fly, scaled by 2^p1_exp or
+ * by record [1] of rbnn_input_scales (p1_dev_scale != NULL).  Same outputs as rbnn_conv_forward; rbnn_conv_input_grad follows it unchanged. */
+int rbnn_conv_forward_triple(const rbnn_conv_posterior *net, const void *K2_triple, int32_t k2_exp, int32_t p1_exp,
+                             const rbnn_dev_scale *p1_dev_scale, const float *X, int32_t ldx, int32_t n_points,
+                             const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
+                             const rbnn_conv_workspace *ws, void *stream);
+
 /* rbnn_conv_input_grad with conv2^T in split-half precision.  K2_bwd = rbnn_split_rows image of model.3.weight regrouped
  * [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8]: element (ci; chunk, t, lg, j) = W[hc = 16*chunk + 8*(lg&1) + j, ci,
  * tap = 2t + (lg>>1)] * 2^k2_exp (0 for the padded 26th tap); fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed

@@ -117,6 +117,8 @@ SIGNATURES = {
     "rbnn_conv_input_grad_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                        C.POINTER(ConvWorkspace), _fp]),
+    "rbnn_conv_forward_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
+                                        C.POINTER(ConvWorkspace), _fp]),
     "rbnn_input_scales": (_i32, [_fp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _fp, _fp]),
     "rbnn_split_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
     "rbnn_fc_forward_split": (_i32, [_PP, C.POINTER(SplitImages), _fp, _i32, _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
@@ -374,6 +376,13 @@ class HipKernels:
         check(self.lib.rbnn_conv_forward_split(C.byref(net.descriptor()), ptr(K2_rows), k2_exp, p1_exp, ptr(p1_dev_scale), ptr(X),
                                                X.stride(0), X.shape[0],
                                                ptr(sidx), S, out_kind, C.byref(w), stream_of(X)), "rbnn_conv_forward_split")
+
+    def conv_forward_triple(self, net, K2_triple, k2_exp, p1_exp, X, sidx, S, out_kind, ws, p1_dev_scale=None):
+        require_gpu(X, "X")
+        w = self._conv_ws(ws)
+        check(self.lib.rbnn_conv_forward_triple(C.byref(net.descriptor()), ptr(K2_triple), k2_exp, p1_exp, ptr(p1_dev_scale), ptr(X),
+                                                X.stride(0), X.shape[0], ptr(sidx), S, out_kind, C.byref(w), stream_of(X)),
+              "rbnn_conv_forward_triple")
 
     def conv_input_grad_split(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):
         w = self._conv_ws(ws)

@@ -55,6 +55,23 @@ class ConvStackedPosterior:
         self.K2ci = self.K2w.view(S, self.H // 16, 16, 32, 25).permute(0, 3, 1, 4, 2).reshape(S, 32, self.H * 25).contiguous()
         self._desc = None
         self._split = None
+        self._triple = None
+
+    # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands on the f16 pipe
+    def triple_supported(self):
+        """The triple conv2 kernels cover both geometries with relu / leaky (every saved conv model of the reference is leaky)."""
+        return self.device.type == "cuda" and self.activation in ("relu", "leaky")
+
+    def triple_images(self):
+        """(K2 triple-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32], its exponent) — built once, resident."""
+        if self._triple is None:
+            S, H = self.S, self.H
+            k2 = self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2).reshape(S * H, 800).contiguous()      # k = tap*32 + ci
+            k2_exp = scale_exp(float(k2.abs().max()))
+            rows = torch.empty(S * H, 800 * 3, dtype=torch.int16, device=self.device)
+            _hip.HipKernels().triple_rows(k2, 800, k2_exp, rows, 800)
+            self._triple = (rows, k2_exp)
+        return self._triple
 
     # ------------------------------------------------------------------ split-half precision mode (forward conv2)
     def split_supported(self):
@@ -91,8 +108,9 @@ class ConvStackedPosterior:
     def scale_bounds(self):
         """(mul, add, cap) of rbnn_input_scales' record 1: |P1| <= max_c(sum_taps |K1w_c|) * max|x| + max|K1b| bounds the pooled
         conv1 activations (relu / leaky: |act(a)| <= |a|)."""
-        _, _, w_l1, b_max = self.split_images()[:4]
-        return w_l1, b_max, float("inf")
+        if not hasattr(self, "_p1_bound"):
+            self._p1_bound = (float(self.K1w.abs().sum(-1).max()), float(self.K1b.abs().max()))
+        return self._p1_bound[0], self._p1_bound[1], float("inf")
 
     def descriptor(self):
         if self._desc is None:
@@ -195,6 +213,10 @@ class ConvEngine(AttackEngine):
         return oa, aa, torch.cat([p[2] for p in parts]), torch.cat([p[3] for p in parts]), torch.cat([p[4] for p in parts])
 
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
+        if self.precision == "triple":
+            rows, k2_exp = self.post.triple_images()
+            ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
+            return self.k.conv_forward_triple(self.post, rows, k2_exp, 0, Xp, sidx, S, out_kind, ws, p1_dev_scale=ds[4:])
         if self.precision != "split":
             return self.k.conv_forward(self.post, Xp, sidx, S, out_kind, ws)
         rows, k2_exp = self.post.split_images()[:2]

@@ -477,6 +477,201 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_split_kernel(const ConvArgs
     }
 }
 
+// =====================================================================================================
+// Triple-split ("f16x6") conv2 forward: the technique of rbnn_triple.hip — every fp32 operand carried at FULL width as three
+// fp16 pieces, six exact product terms per fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulation — on the layer that holds
+// 98 % of the MACs, for BOTH geometries.  Structure = conv2_pool_split_kernel's (K tap-major: one K step = one tap over the 32
+// input channels; the B operand of a lane is one ds_read_b128 per piece from the point's channel-last image resident in LDS):
+//   * conv1 is the exact conv1_pool_kernel (fp32 P1 image, ~2 % of the MACs); each block splits its two points' images into
+//     the three piece planes while loading them: img[point][piece][pos = y*P1W + x][32 ci] halves, 16-byte channel octet o at
+//     o ^ (((pos >> 2) & 1) << 1), scaled by the device record of rbnn_input_scales (|P1| <= sum|K1w| * max|x| + max|K1b|);
+//   * A = model.3.weight regrouped [hc][tap][ci] as a triple-rows image (rbnn_triple_rows, 25 K stages of 192 B per channel),
+//     staged per tap through three plane tiles of 64-B rows (fc_forward_x3_kernel's ring and `swz` chunk swizzle);
+//   * block = 8 waves = 4 channel groups (HTW tiles of 16 channels each) x 2 points; WROWS = 64 * HTW channels per chunk.
+//     1x28x28: WROWS 256 (96 KB of weight tiles + 2 x 27 KB images); 3x32x32: WROWS 128 (48 KB + 2 x 37 KB).
+// =====================================================================================================
+struct ConvX3Args {
+    const char* K2t; int k2_exp; int p1_exp;                             // triple-rows image of [S_total*Hc][25*32]
+    const rbnn_dev_scale* p1_ds;                                         // != NULL: the P1 scale lives on the device (rbnn_input_scales record [1])
+};
+
+__device__ __forceinline__ void conv_split3(float v, _Float16& p0, _Float16& p1, _Float16& p2) {
+    p0 = (_Float16)v;
+    float r = v - (float)p0;
+    p1 = (_Float16)r;
+    r -= (float)p1;
+    p2 = (_Float16)r;
+}
+
+template <class G, int WROWS> struct ConvX3Lds {
+    static constexpr int PLANEW = WROWS * 64, TILEW = 3 * PLANEW;        // one tap's weight tile: 3 planes of WROWS 64-B rows
+    static constexpr int IPOS = G::P1W * G::P1W, IMGP = IPOS * 64, IMGB = 3 * IMGP;   // one point's image: 3 planes of IPOS 64-B position records
+    static constexpr int SCR = 8 * 16 * G::NPOS * 4;                     // the eight waves' pooling tiles (epilogue; alias the weight buffers)
+    static constexpr int WBUF = (2 * TILEW > SCR ? 2 * TILEW : SCR);
+    static constexpr int BYTES = WBUF + 2 * IMGB;
+};
+
+template <int ACT, class G, int WROWS>
+__global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a, const ConvX3Args x) {
+    using L = ConvX3Lds<G, WROWS>;
+    constexpr int HTW = WROWS / 64, NPT = G::NPT2, NW = 8;
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NPOS_ = G::NPOS, NP2_ = G::NP2;
+    constexpr int WPP = WROWS / 16 / NW;                                  // DMA pieces (16 rows of one plane) per wave per plane
+    static_assert(WROWS % 128 == 0 && L::BYTES <= 160 * 1024, "whole pieces per wave; LDS");
+    static_assert((16 * NP2_) % 4 == 0, "four pooled cells per lane");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const ldsb = (char*)lds;
+    char* const imgs = ldsb + L::WBUF;
+
+    const int NB = (a.N + 1) / 2;                                         // blocks per sample
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, nb0 = (id % NB) * 2;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, wp = wave >> 2;                              // channel group, point of the pair
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const int n = min(nb0 + wp, a.N - 1);                                 // a ragged last block computes its first point twice, stores once
+    const bool live = nb0 + wp < a.N;
+    const long long sn = (long long)s * a.N + n;
+    const char* const Ws = x.K2t + (long long)sw * a.Hc * (K2 * 6);
+    const int F = a.Hc * NP2_;
+    const float p1_scale = x.p1_ds ? x.p1_ds->scale : ldexpf(1.f, x.p1_exp);
+    const float out_scale = x.p1_ds ? ldexpf(1.f, -x.k2_exp) * x.p1_ds->inv_scale : ldexpf(1.f, -(x.k2_exp + x.p1_exp));
+
+    // both points' fp32 images [32 ci][IPOS] -> three piece planes, channel-last, in LDS: one (position, channel octet) per thread-item
+    for (int i = tid; i < 2 * L::IPOS * 4; i += 512) {
+        const int pt2 = i / (L::IPOS * 4), rem = i % (L::IPOS * 4), pos = rem >> 2, o = rem & 3;
+        const float* const src = a.P1 + ((long long)s * a.N + min(nb0 + pt2, a.N - 1)) * G::P1SZ + (8 * o) * L::IPOS + pos;
+        union { f16x8 v; uint4 u; } q0, q1, q2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 e0, e1, e2;
+            conv_split3(src[j * L::IPOS] * p1_scale, e0, e1, e2);
+            q0.v[j] = e0; q1.v[j] = e1; q2.v[j] = e2;
+        }
+        char* const dst = imgs + pt2 * L::IMGB + pos * 64 + ((o ^ (((pos >> 2) & 1) << 1)) * 16);
+        *(uint4*)dst = q0.u;
+        *(uint4*)(dst + L::IMGP) = q1.u;
+        *(uint4*)(dst + 2 * L::IMGP) = q2.u;
+    }
+    const int prow = lane >> 2;
+    const unsigned src_off = (unsigned)(((lane & 3) ^ swz(prow)) * 16);
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);
+    // image position of output position 16pt + li (tap 0,0); positions past NPOS read (0,0), never stored
+    int pbase[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) { const int pos = pt * 16 + li; pbase[pt] = pos < NPOS_ ? (pos / O2W_) * P1W_ + pos % O2W_ : 0; }
+    const char* const img = imgs + wp * L::IMGB;
+    unsigned wrow[WPP];
+#pragma unroll
+    for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(16 * (wave + NW * i) + prow);
+
+    for (int hc0 = 0; hc0 < a.Hc; hc0 += WROWS) {
+        f32x4 acc[HTW][NPT];
+#pragma unroll
+        for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto stage = [&](int tap, int buf) {
+            char* const T = ldsb + buf * L::TILEW;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < WPP; ++i) {
+                    const unsigned row = min((unsigned)hc0 + wrow[i], (unsigned)a.Hc - 1u);   // rows past Hc repeat the last channel; never stored
+                    glds16((const float*)(Ws + ((long long)row * (K2 * 6) + tap * 192 + 64 * p + src_off)), (float*)(T + p * L::PLANEW + (wave + NW * i) * 1024));
+                }
+        };
+        stage(0, 0);
+        __syncthreads();                                                 // also orders the image fill (first chunk) / the previous chunk's pooling tiles
+        for (int tap = 0; tap < 25; ++tap) {
+            const int buf = tap & 1;
+            if (tap + 1 < 25) stage(tap + 1, buf ^ 1);
+            const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 16 * 64 + foff;
+            const int toff = (tap / 5) * P1W_ + (tap % 5);
+            f16x8 b0[NPT], b1[NPT], b2[NPT];
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int p = pbase[pt] + toff;
+                const char* const src = img + p * 64 + ((lg ^ (((p >> 2) & 1) << 1)) * 16);
+                b0[pt] = *(const f16x8*)src;
+                b1[pt] = *(const f16x8*)(src + L::IMGP);
+                b2[pt] = *(const f16x8*)(src + 2 * L::IMGP);
+            }
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht) {
+                const f16x8 a0 = *(const f16x8*)(Wt + ht * 1024), a1 = *(const f16x8*)(Wt + L::PLANEW + ht * 1024),
+                            a2 = *(const f16x8*)(Wt + 2 * L::PLANEW + ht * 1024);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b2[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a2, b0[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a1, b1[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a1, b0[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b1[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b0[pt], acc[ht][pt]);
+            }
+            ring_wait_barrier<0>();                                      // tap+1's weights landed; everyone is done with this tile
+        }
+        // epilogue (as conv2_pool_kernel): scale, bias, 2x2 / stride-1 max-pool of the pre-activations through a per-wave LDS tile
+        // (aliases the weight buffers: every wave passed the barrier above), activation, stash
+        float* const my = (float*)ldsb + wave * 16 * NPOS_;
+#pragma unroll
+        for (int ht = 0; ht < HTW; ++ht) {
+            const int hcb = hc0 + (wq * HTW + ht) * 16;                    // wave-uniform
+            if (hcb >= a.Hc) break;
+            const f32x4 bias = *(const f32x4*)(a.K2b + (long long)sw * a.Hc + hcb + 4 * lg);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pt * 16 + li < NPOS_) my[(4 * lg + r) * NPOS_ + pt * 16 + li] = acc[ht][pt][r] * out_scale + bias[r];
+            // four consecutive pooled cells per lane: one 16-byte store of Q2 and one 4-byte store of the stash (the tile's 16 x NP2
+            // cells are contiguous in both)
+            for (int i4 = lane; i4 < 16 * NP2_ / 4 && live; i4 += 64) {
+                f32x4 q;
+                unsigned stw = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = 4 * i4 + j, hl = idx / NP2_, p = idx % NP2_, base = hl * NPOS_ + (p / P2W_) * O2W_ + (p % P2W_);
+                    float best = my[base];
+                    int arg = 0;
+                    if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
+                    if (my[base + O2W_] > best) { best = my[base + O2W_]; arg = 2; }
+                    if (my[base + O2W_ + 1] > best) { best = my[base + O2W_ + 1]; arg = 3; }
+                    q[j] = act_fwd<ACT>(best);
+                    stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
+                }
+                const long long o = sn * F + (long long)hcb * NP2_ + 4 * i4;           // a multiple of 4
+                *(f32x4*)(a.Q2 + o) = q;
+                *(unsigned*)(a.st2 + o) = stw;
+            }
+        }
+        __syncthreads();                                                 // the pooling tiles alias the weight buffers of the next chunk
+    }
+}
+
+template <int ACT, class G>
+int launch_conv_forward_x3(const ConvArgs& a, const ConvX3Args& x, hipStream_t st) {
+    constexpr int WROWS = (G::CIN == 1 ? 256 : 128);
+    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(256), 0, st, a);
+    int rc = launch_status();
+    if (rc) return rc;
+    constexpr int LDSB = ConvX3Lds<G, WROWS>::BYTES;
+    static unsigned long long attr = 0;                                   // per instantiation, one bit per device
+    if (!ensure_dynamic_lds((const void*)conv2_pool_x3_kernel<ACT, G, WROWS>, LDSB, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv2_pool_x3_kernel<ACT, G, WROWS>), dim3(grid_for_items((long long)((a.N + 1) / 2) * a.S)), dim3(512), LDSB, st, a, x);
+    if ((rc = launch_status())) return rc;
+    const int items = ((a.N + 15) / 16) * a.S;
+    hipLaunchKernelGGL(conv_fc_kernel, dim3((items + 3) / 4), dim3(256), 0, st, a);
+    return launch_status();
+}
+
 int validate_conv(const rbnn_conv_posterior* net) {
     if (!net || !net->K1w || !net->K1b || !net->K2w || !net->K2b || !net->Fw || !net->Fb) return RBNN_ERR_NULL;
     if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
@@ -602,6 +797,33 @@ int rbnn_conv_forward_split(const rbnn_conv_posterior* net, const void* K2_rows,
     const int items = ((N + 15) / 16) * S;
     hipLaunchKernelGGL(conv_fc_kernel, dim3((items + 3) / 4), dim3(256), 0, st, a);
     return launch_status();
+}
+
+int rbnn_conv_forward_triple(const rbnn_conv_posterior* net, const void* K2_triple, int32_t k2_exp, int32_t p1_exp,
+                             const rbnn_dev_scale* p1_dev_scale, const float* X, int32_t ldx, int32_t N, const int32_t* sidx,
+                             int32_t S, int32_t out_kind, const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    if (!K2_triple || !X || !ws || !ws->P || !ws->P1 || !ws->st1 || !ws->Q2 || !ws->st2) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || ldx < net->in_channels * net->in_width * net->in_width) return RBNN_ERR_SHAPE;
+    if (k2_exp < -100 || k2_exp > 100 || p1_exp < -100 || p1_exp > 100) return RBNN_ERR_SHAPE;
+    if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
+    if (!aligned16(K2_triple) || !aligned16(ws->P) || !aligned16(ws->P1) || !aligned16(ws->Q2)) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a = {};
+    a.X = X; a.ldx = ldx; a.N = N;
+    a.K1w = net->K1w; a.K1b = net->K1b; a.K2w = net->K2w; a.K2b = net->K2b; a.Fw = net->Fw; a.Fb = net->Fb;
+    a.Hc = net->hidden; a.C = net->n_classes; a.sidx = sidx; a.S = S;
+    a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind;
+    ConvX3Args x = {};
+    x.K2t = (const char*)K2_triple; x.k2_exp = k2_exp; x.p1_exp = p1_exp; x.p1_ds = p1_dev_scale;
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        a.NP2 = G::NP2;
+        if (net->activation == RBNN_ACT_RELU) return launch_conv_forward_x3<RBNN_ACT_RELU, G>(a, x, st);
+        return launch_conv_forward_x3<RBNN_ACT_LEAKY, G>(a, x, st);
+    });
 }
 
 }  // extern "C"

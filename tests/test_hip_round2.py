@@ -529,6 +529,11 @@ CONV_CASES = [  # act, shape, C, Hc, S, N, std, precision
     ("leaky", (3, 32, 32), 10, 16, 2, 9, 0.05, "exact"), ("leaky", (3, 32, 32), 10, 64, 3, 37, 0.04, "exact"),
     ("relu", (3, 32, 32), 10, 512, 2, 64, 0.02, "exact"), ("leaky", (3, 32, 32), 10, 272, 1, 5, 0.03, "exact"),
     ("tanh", (3, 32, 32), 7, 32, 2, 18, 0.05, "exact"), ("sigm", (3, 32, 32), 10, 16, 1, 4, 0.05, "exact"),
+    # triple-split conv2 (full-width operands on the f16 pipe): both geometries, ragged point counts and channel counts
+    ("leaky", (1, 28, 28), 10, 512, 2, 64, 0.03, "triple"), ("leaky", (1, 28, 28), 10, 1024, 2, 63, 0.02, "triple"),
+    ("relu", (1, 28, 28), 10, 64, 3, 71, 0.05, "triple"), ("leaky", (1, 28, 28), 4, 272, 1, 9, 0.03, "triple"),
+    ("leaky", (3, 32, 32), 10, 16, 2, 9, 0.05, "triple"), ("relu", (3, 32, 32), 10, 512, 2, 64, 0.02, "triple"),
+    ("leaky", (3, 32, 32), 10, 272, 1, 5, 0.03, "triple"),
 ]
 
 
