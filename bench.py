@@ -276,6 +276,9 @@ def main():
         def conv_input_grad(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad, *a, **kw)
 
+        def conv_input_grad_triple(self, *a, **kw):
+            return self._timed("conv_input_grad", super().conv_input_grad_triple, *a, **kw)
+
         def conv_input_grad_split(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad_split, *a, **kw)
 
@@ -353,10 +356,10 @@ def main():
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
     KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel",
                         "conv_forward": "conv2_pool_x3_kernel (+ conv1_pool, conv_fc)",
-                        "conv_input_grad": "conv_bwd_kernel (+ conv_fc_bwd, conv1_bwd; fp32 MFMA)"}
+                        "conv_input_grad": "conv_bwd_x3_kernel (+ conv_fc_bwd, conv1_bwd)"}
     # which C-ABI calls run on the f16 pipe in each mode (the rest of that mode's calls are the fp32-MFMA kernels)
     F16_KERNELS = {"split": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"},
-                   "triple": {"fc_forward", "fc_input_grad", "conv_forward"}}
+                   "triple": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}}
     PRODUCTS = {"split": 3.0, "triple": 6.0}                                # f16 MFMA products per algorithmic fp32 MAC
     if w["arch"] == "fc2":
         KNAMES["split"].update({"fc_forward": "fc_forward_split_kernel (x2: layer 1 -> split image, layer 2)",

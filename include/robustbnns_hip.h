@@ -266,6 +266,13 @@ int rbnn_conv_forward_triple(const rbnn_conv_posterior *net, const void *K2_trip
                              const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                              const rbnn_conv_workspace *ws, void *stream);
 
+/* rbnn_conv_input_grad with conv2^T in the triple-split mode (both geometries, relu / leaky).  K2_bwd = rbnn_triple_rows image of
+ * model.3.weight regrouped [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8] exactly as for rbnn_conv_input_grad_split (one
+ * 192-byte stage per (chunk, tap pair)); fw_l1 = max_f sum_c |model.7.weight[c, f]|.  Same G as rbnn_conv_input_grad. */
+int rbnn_conv_input_grad_triple(const rbnn_conv_posterior *net, const void *K2_bwd, int32_t k2_exp, float fw_l1,
+                                const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
+                                const rbnn_conv_workspace *ws, void *stream);
+
 /* rbnn_conv_input_grad with conv2^T in split-half precision.  K2_bwd = rbnn_split_rows image of model.3.weight regrouped
  * [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8]: element (ci; chunk, t, lg, j) = W[hc = 16*chunk + 8*(lg&1) + j, ci,
  * tap = 2t + (lg>>1)] * 2^k2_exp (0 for the padded 26th tap); fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed

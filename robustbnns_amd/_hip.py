@@ -117,6 +117,7 @@ SIGNATURES = {
     "rbnn_conv_input_grad_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                        C.POINTER(ConvWorkspace), _fp]),
+    "rbnn_conv_input_grad_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                         C.POINTER(ConvWorkspace), _fp]),
     "rbnn_input_scales": (_i32, [_fp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _fp, _fp]),
@@ -383,6 +384,12 @@ class HipKernels:
         check(self.lib.rbnn_conv_forward_triple(C.byref(net.descriptor()), ptr(K2_triple), k2_exp, p1_exp, ptr(p1_dev_scale), ptr(X),
                                                 X.stride(0), X.shape[0], ptr(sidx), S, out_kind, C.byref(w), stream_of(X)),
               "rbnn_conv_forward_triple")
+
+    def conv_input_grad_triple(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):
+        w = self._conv_ws(ws)
+        check(self.lib.rbnn_conv_input_grad_triple(C.byref(net.descriptor()), ptr(K2_bwd), k2_exp, fw_l1, ptr(sidx), S, N, C.byref(w),
+                                                   stream_of(ws["dZ"])), "rbnn_conv_input_grad_triple")
+        return S
 
     def conv_input_grad_split(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):
         w = self._conv_ws(ws)

@@ -63,14 +63,23 @@ class ConvStackedPosterior:
         return self.device.type == "cuda" and self.activation in ("relu", "leaky")
 
     def triple_images(self):
-        """(K2 triple-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32], its exponent) — built once, resident."""
+        """(K2 triple-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32] for the forward, its exponent, the backward's
+        image [S*32 ci, chunk(Hc/16) x 13 tap pairs x lg(4 = tap parity*2 + channel octet) x 8 channels], max_f sum_c |Fw[c,f]|) —
+        built once, resident."""
         if self._triple is None:
             S, H = self.S, self.H
+            k = _hip.HipKernels()
             k2 = self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2).reshape(S * H, 800).contiguous()      # k = tap*32 + ci
             k2_exp = scale_exp(float(k2.abs().max()))
             rows = torch.empty(S * H, 800 * 3, dtype=torch.int16, device=self.device)
-            _hip.HipKernels().triple_rows(k2, 800, k2_exp, rows, 800)
-            self._triple = (rows, k2_exp)
+            k.triple_rows(k2, 800, k2_exp, rows, 800)
+            w26 = torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device)
+            w26[..., :25] = self.K2w.view(S, H, 32, 25)
+            kb = w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3).reshape(S * 32, (H // 16) * 13 * 32).contiguous()
+            bwd = torch.empty(kb.shape[0], kb.shape[1] * 3, dtype=torch.int16, device=self.device)
+            k.triple_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
+            fw_l1 = float(self.Fw.abs().sum(1).max())
+            self._triple = (rows, k2_exp, bwd, fw_l1)
         return self._triple
 
     # ------------------------------------------------------------------ split-half precision mode (forward conv2)
@@ -214,7 +223,7 @@ class ConvEngine(AttackEngine):
 
     def _forward_kernels(self, Xp, sidx, S, out_kind, ws):
         if self.precision == "triple":
-            rows, k2_exp = self.post.triple_images()
+            rows, k2_exp = self.post.triple_images()[:2]
             ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
             return self.k.conv_forward_triple(self.post, rows, k2_exp, 0, Xp, sidx, S, out_kind, ws, p1_dev_scale=ds[4:])
         if self.precision != "split":
@@ -224,6 +233,9 @@ class ConvEngine(AttackEngine):
         self.k.conv_forward_split(self.post, rows, k2_exp, 0, Xp, sidx, S, out_kind, ws, p1_dev_scale=ds[4:])
 
     def _grad_kernels(self, sidx, S, N, ws):
+        if self.precision == "triple" and os.environ.get("RBNN_CONV_BWD_EXACT") != "1":
+            _, k2_exp, bwd, fw_l1 = self.post.triple_images()
+            return self.k.conv_input_grad_triple(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)
         if self.precision != "split" or os.environ.get("RBNN_CONV_BWD_EXACT") == "1":
             return self.k.conv_input_grad(self.post, sidx, S, N, ws)
         _, k2_exp, _, _, bwd, fw_l1 = self.post.split_images()

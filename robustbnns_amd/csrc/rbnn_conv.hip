@@ -1217,6 +1217,205 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
             for (int r = 0; r < 4; ++r) a.dP1[sn * P1SZ + (16 * ct + 4 * lg + r) * (P1W * P1W) + 16 * pt + li] = acc[ct][pt][r] * out_scale;
 }
 
+// conv2^T in the triple-split mode, BOTH geometries: conv_bwd_split_kernel's structure (one wave = one (sample, point), no block
+// barriers, the whole dP1^T[32 ci][P1W^2 pos] in 2 x NPT1 accumulator tiles) with three piece planes and six product terms.  The
+// chunk's zero-padded gradient image is stored channel-last in conv_bwd_kernel's shared-border geometry (pitch = P1W: a row's
+// right border is the next row's left border): img[piece][(O2W + 8) * PITCH + 8 positions][16 hc] halves.  A K step is TWO taps x
+// 16 channels (lanes lg = 0,1: tap 2t, channel octets 0,1; lg = 2,3: tap 2t + 1), 13 steps per chunk (the 26th tap has zero
+// weights).  A = model.3.weight regrouped [ci][chunk][step][lg][8] as a triple-rows image (one 192-B stage per step), read straight
+// from memory and shared by the block's waves through L1.  The gradients are scaled per (sample, point) by a power of two from
+// max|dZ| * max_f sum_c |Fw[c][f]| (x4 for the overlapping pool windows), divided out in the epilogue.  NWB waves per block, one block
+// per CU (23 / 31 KB of LDS per wave).
+template <class G> struct ConvBwdX3Lds {
+    static constexpr int HCH = 16;
+    static constexpr int IPB = (G::O2W + 8) * G::PITCH + 8;              // positions of a wave's padded image
+    static constexpr int PLANE = IPB * HCH * 2;                           // bytes of one piece plane
+    static constexpr int NFL = HCH * G::NP2;                              // pooled cells per chunk
+    static constexpr int STG = (NFL * 5 + 15) / 16 * 16;                  // staging: NFL dQ2 floats + NFL stash bytes
+    static constexpr int WAVE = 3 * PLANE + STG;
+    // waves per block (one block per CU).  The kernel keeps TWO accumulator sets (blocked accumulation, below): 2 x 2 x NPT1 tiles =
+    // 144 registers at 1x28x28 — six waves, two of the SIMDs hold two (256 registers each) — and 208 at 3x32x32: four waves, one per
+    // SIMD (512 registers); LDS would allow 6 / 5
+    static constexpr int NWB = G::NPT1 <= 9 ? 6 : 4;
+    static_assert(NWB * WAVE <= 160 * 1024, "LDS");
+};
+
+template <int ACT, class G>
+__global__ void __launch_bounds__(64 * ConvBwdX3Lds<G>::NWB, (ConvBwdX3Lds<G>::NWB + 3) / 4) conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp, float fw_l1) {
+    using L = ConvBwdX3Lds<G>;
+    constexpr int HCH = L::HCH, NPT = G::NPT1, PLANE = L::PLANE, NSTEP = 13, NFL = L::NFL, NWB = L::NWB;
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, PITCH = G::PITCH;
+    static_assert(PITCH == P1W_ && PLANE % 16 == 0 && L::WAVE % 16 == 0, "shared-border image; 16-byte clears");
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* const lds = (char*)lds_f;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const img = lds + wave * L::WAVE;
+    float* const sdq = (float*)(img + 3 * PLANE);                          // [16 hc][NP2] pooled gradients of the chunk
+    unsigned char* const sst = (unsigned char*)(img + 3 * PLANE + NFL * 4);   // [16 hc][NP2] stash bytes
+
+    const int NB = (a.N + NWB - 1) / NWB;
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, n = (id % NB) * NWB + wave;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    if (n >= a.N) return;                                                // whole wave idle (ragged last block); no block barrier anywhere
+    const long long sn = (long long)s * a.N + n;
+    const int F = a.Hc * NP2_, NCH = a.Hc / HCH;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+
+    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1
+    float dzmax = fabsf(a.dZ[sn * RBNN_CPAD + li]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
+    const float bound = 4.f * dzmax * fw_l1;
+    int e = 0;
+    if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
+    const float in_scale = ldexpf(1.f, e), out_scale = ldexpf(1.f, -(e + k2_exp));
+
+    // image position of output position 16pt + li for tap (0,0): row 4 is the first gradient row, column 4 the first gradient column
+    int poff[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) poff[pt] = 4 * PITCH + min(pt * 16 + li, P1W_ * P1W_ - 1) + 4;
+    // weight rows: row = sw*32 + ci; one 192-byte stage per (chunk, step): piece p at 64p, lane group lg at 16lg
+    const long long rowb = (long long)NCH * NSTEP * 192;
+    const char* const Wr0 = K2b + ((long long)sw * C1 + li) * rowb + lg * 16;
+    const char* const Wr1 = Wr0 + 16 * rowb;
+
+    // Blocked accumulation, as conv_bwd_kernel: `acc` runs over FLUSH chunks (2 x 13 steps x 6 terms = 156 accumulations) and is then
+    // folded into `tot` — one fp32 chain over all 78 * Hc / 16 accumulations carried 4-7x the rounding error of the fp32-MFMA kernel
+    // (measured against fp64 at Hc = 1024: median 3.0e-6 unblocked)
+    constexpr int FLUSH = 2;
+    f32x4 acc[2][NPT], tot[2][NPT];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) { acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f}; tot[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    for (int i = lane; i < 3 * PLANE / 16; i += 64) *(uint4*)(img + 16 * i) = make_uint4(0, 0, 0, 0);   // the borders stay zero
+    // this lane's positions (gy, gx) of the O2W x O2W gradient map: lane, lane + 64, ...; window q = 2dy + dx of the <= 4 stride-1
+    // pooling windows containing it routes here iff its stashed argmax == q
+    constexpr int NGP = (NPOS_ + 63) / 64;
+    int woff[NGP][4], goff[NGP];
+    bool wok[NGP][4], gok[NGP];
+#pragma unroll
+    for (int g = 0; g < NGP; ++g) {
+        const int gp = lane + 64 * g, gy = gp / O2W_, gx = gp % O2W_;
+        gok[g] = gp < NPOS_;
+        goff[g] = gok[g] ? ((gy + 4) * PITCH + gx + 4) * (HCH * 2) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int py = gy - (q >> 1), px = gx - (q & 1);
+            wok[g][q] = gok[g] && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+            woff[g][q] = wok[g][q] ? py * P2W_ + px : 0;
+        }
+    }
+    auto dma4 = [&](const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
+    };
+    auto stage_chunk = [&](int ch) {                                       // lane p of instruction q lands at byte 256q + 4p of its region
+        const long long fb = sn * F + (long long)ch * NFL;                 // a multiple of 4: the stash dwords are aligned
+#pragma unroll
+        for (int q = 0; q < (NFL + 63) / 64; ++q)
+            if (q * 64 + lane < NFL) dma4(a.dQ2 + fb + q * 64 + lane, sdq + q * 64);
+#pragma unroll
+        for (int q = 0; q < (NFL + 255) / 256; ++q)
+            if (q * 256 + 4 * lane < NFL) dma4(a.st2 + fb + q * 256 + 4 * lane, sst + q * 256);
+    };
+    stage_chunk(0);
+    for (int ch = 0; ch < NCH; ++ch) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): this chunk's staging has landed (wave-local, no barrier)
+        asm volatile("" ::: "memory");
+        // 1. interior of the image for channels 16ch .. 16ch+15: pool-2 routing + activation derivative (gather form), scaled, split
+#pragma unroll
+        for (int g = 0; g < NGP; ++g) {
+            union { f16x8 v; uint4 u; } q0[2], q1[2], q2[2];
+#pragma unroll
+            for (int h4 = 0; h4 < HCH; h4 += 4) {
+                int st[4][4];
+                float dq[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int fb = (h4 + j) * NP2_;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { st[j][q] = sst[fb + woff[g][q]]; dq[j][q] = sdq[fb + woff[g][q]]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (wok[g][q] && (st[j][q] & 3) == q) v += (st[j][q] & 4) ? dq[j][q] : dq[j][q] * slope;
+                    _Float16 e0, e1, e2;
+                    conv_split3(v * in_scale, e0, e1, e2);
+                    q0[h4 >> 3].v[(h4 & 4) + j] = e0; q1[h4 >> 3].v[(h4 & 4) + j] = e1; q2[h4 >> 3].v[(h4 & 4) + j] = e2;
+                }
+            }
+            if (gok[g]) {
+                char* const mine = img + goff[g];
+                *(uint4*)(mine) = q0[0].u;             *(uint4*)(mine + 16) = q0[1].u;
+                *(uint4*)(mine + PLANE) = q1[0].u;     *(uint4*)(mine + PLANE + 16) = q1[1].u;
+                *(uint4*)(mine + 2 * PLANE) = q2[0].u; *(uint4*)(mine + 2 * PLANE + 16) = q2[1].u;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (ch + 1 < NCH) stage_chunk(ch + 1);                             // the staging area is free again: next chunk's rows fly under the MFMAs
+        // 2. 13 K steps = tap pairs x 16 channels; a position tile whose rows no tap row of the pair can reach multiplies pure
+        //    padding and is skipped
+        const char* const w0 = Wr0 + (long long)ch * NSTEP * 192;
+        const char* const w1 = Wr1 + (long long)ch * NSTEP * 192;
+        f16x8 a00 = *(const f16x8*)w0, a01 = *(const f16x8*)(w0 + 64), a02 = *(const f16x8*)(w0 + 128);
+        f16x8 a10 = *(const f16x8*)w1, a11 = *(const f16x8*)(w1 + 64), a12 = *(const f16x8*)(w1 + 128);
+#pragma unroll 1
+        for (int t = 0; t < NSTEP; ++t) {
+            const f16x8 c00 = a00, c01 = a01, c02 = a02, c10 = a10, c11 = a11, c12 = a12;
+            if (t + 1 < NSTEP) {
+                a00 = *(const f16x8*)(w0 + 192 * (t + 1)); a01 = *(const f16x8*)(w0 + 192 * (t + 1) + 64); a02 = *(const f16x8*)(w0 + 192 * (t + 1) + 128);
+                a10 = *(const f16x8*)(w1 + 192 * (t + 1)); a11 = *(const f16x8*)(w1 + 192 * (t + 1) + 64); a12 = *(const f16x8*)(w1 + 192 * (t + 1) + 128);
+            }
+            const int tA = 2 * t, tB = min(2 * t + 1, 24);               // the padded 26th tap has zero weights: any image offset will do
+            const int kyA = tA / 5, kyB = tB / 5;
+            const int tap = (lg >> 1) ? tB : tA;                          // this lane's tap
+            const char* const src = img + (lg & 1) * 16 - ((tap / 5) * PITCH + tap % 5) * (HCH * 2);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                constexpr int last = P1W_ * P1W_ - 1;
+                const int Ya = (16 * pt) / P1W_, Yb = min(16 * pt + 15, last) / P1W_;
+                if ((kyA < Ya - (O2W_ - 1) || kyA > Yb) && (kyB < Ya - (O2W_ - 1) || kyB > Yb)) continue;   // wave-uniform
+                const char* const bp = src + poff[pt] * (HCH * 2);
+                const f16x8 b0 = *(const f16x8*)bp, b1 = *(const f16x8*)(bp + PLANE), b2 = *(const f16x8*)(bp + 2 * PLANE);
+                acc[0][pt] = MFMA_H(c00, b2, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c10, b2, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c02, b0, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c12, b0, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c01, b1, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c11, b1, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c01, b0, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c11, b0, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c00, b1, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c10, b1, acc[1][pt]);
+                acc[0][pt] = MFMA_H(c00, b0, acc[0][pt]);
+                acc[1][pt] = MFMA_H(c10, b0, acc[1][pt]);
+            }
+        }
+        if (ch % FLUSH == FLUSH - 1 || ch + 1 == NCH) {
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) { tot[ct][pt] += acc[ct][pt]; acc[ct][pt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * pt + li >= P1W_ * P1W_) continue;
+                a.dP1[sn * G::P1SZ + (16 * ct + 4 * lg + r) * (P1W_ * P1W_) + 16 * pt + li] = tot[ct][pt][r] * out_scale;
+            }
+}
+
 // pool-1 routing + activation derivative + conv1^T (in_channels = 1), gather form: one thread per input pixel (Yo, Xo).
 // A pooled cell (c, py, px) routes its gradient to ONE conv1 output (Ya, Xa) = (2py + arg/2, 2px + arg%2); that output
 // touches pixel (Yo, Xo) through tap (Yo - Ya, Xo - Xa) if it lies in the 5x5 kernel.  Only cells with
@@ -1438,4 +1637,39 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
     if ((rc = launch_status())) return rc;
     if (leaky) return launch_conv1_backward<RBNN_ACT_LEAKY, GeoMnist>(a, st);
     return launch_conv1_backward<RBNN_ACT_RELU, GeoMnist>(a, st);
+}
+
+extern "C" int rbnn_conv_input_grad_triple(const rbnn_conv_posterior* net, const void* K2_bwd, int32_t k2_exp, float fw_l1,
+                                           const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
+    if (!K2_bwd || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
+    if (!aligned16(K2_bwd) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
+    ConvBwdArgs a = {};
+    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = nullptr; a.Fw = net->Fw;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
+    hipStream_t st = (hipStream_t)stream;
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        using L = ConvBwdX3Lds<G>;
+        a.NP2 = G::NP2;
+        return for_activation(net->activation, [&](auto actc) {
+            constexpr int ACT = (decltype(actc)::value == RBNN_ACT_RELU) ? RBNN_ACT_RELU : RBNN_ACT_LEAKY;   // sigmoid / tanh were refused above
+            int rc2;
+            {
+                const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+                hipLaunchKernelGGL((conv_fc_bwd_kernel<false, RBNN_ACT_LEAKY>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+                if ((rc2 = launch_status())) return rc2;
+            }
+            constexpr int LDSB = L::NWB * L::WAVE;
+            static unsigned long long attr = 0;
+            if (!ensure_dynamic_lds((const void*)conv_bwd_x3_kernel<ACT, G>, LDSB, attr)) return (int)RBNN_ERR_LAUNCH;
+            const int grid = grid_for_items((long long)((N + L::NWB - 1) / L::NWB) * S);
+            hipLaunchKernelGGL((conv_bwd_x3_kernel<ACT, G>), dim3(grid), dim3(64 * L::NWB), LDSB, st, a, (const char*)K2_bwd, k2_exp, fw_l1);
+            if ((rc2 = launch_status())) return rc2;
+            return launch_conv1_backward<ACT, G>(a, st);
+        });
+    });
 }

@@ -230,7 +230,7 @@ def _bnn(g):
     return bnn
 
 
-@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("precision", ["exact", "fast", "auto"])       # auto = the package default: triple on fc-512 and on conv relu / leaky
 @pytest.mark.parametrize("name", E2E_CASES)
 def test_end_to_end_attack_then_evaluation(golden, name, precision, monkeypatch):
     """adversarialAttacks.py:111-143 then :151-198 entirely on the HIP path: attack() produces the images, attack_evaluation()
