@@ -75,6 +75,25 @@ __device__ __forceinline__ void split3_pair(float ge, float go, unsigned mw, uns
     else asm volatile(RBNN_X3_PAIR_BODY RBNN_X3_PAIR_OPS);   // volatile: the pairs of one MFMA result stay behind the FIRST one
 }
 
+// The same with the two multipliers given (sigmoid / tanh: act' comes from an fp32 stream, already times 2^GEN_Q3): 7 per pair.
+template <bool FIRST>
+__device__ __forceinline__ void split3_pair_m(float ge, float go, float me, float mo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
+    float re, ro;
+#define RBNN_X3_PAIRM_BODY \
+    "v_fma_mixlo_f16 %[d0], %[ge], %[me], 0\n\t" \
+    "v_fma_mixhi_f16 %[d0], %[go], %[mo], 0\n\t" \
+    "v_fma_mix_f32 %[re], %[ge], %[me], -%[d0] op_sel_hi:[0,0,1]\n\t" \
+    "v_fma_mix_f32 %[ro], %[go], %[mo], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
+    "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t" \
+    "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t" \
+    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#define RBNN_X3_PAIRM_OPS \
+    : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro) \
+    : [ge] "v"(ge), [go] "v"(go), [me] "v"(me), [mo] "v"(mo), [one] "v"(one)
+    if constexpr (FIRST) asm volatile("s_nop 7\n\t" RBNN_X3_PAIRM_BODY RBNN_X3_PAIRM_OPS);
+    else asm volatile(RBNN_X3_PAIRM_BODY RBNN_X3_PAIRM_OPS);
+}
+
 // The same for two plain fp32 values (fc2 step 2: the A operand comes from memory): 6 vector instructions per pair.
 __device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
     float re, ro;
@@ -594,19 +613,21 @@ struct GradX3Args {
     // un-scaling): it is the fp32 source of step 2's A operand.  X3_FC2_STEP2: A operand read from `amem` and split in registers.
     const uint32_t* omask;  int OHW;                            // step 1: stash of the layer below [S][H/32][N_pad]
     const float* amem;                                          // step 2: [S][N][H]
+    const float* dact;  const float* odact;                     // sigmoid / tanh: act' as fp32 [S][N][H] (this layer / the layer below)
 };
 enum { X3_FC = 0, X3_FC2_STEP1 = 1, X3_FC2_STEP2 = 2 };
 
 template <int ACT, int TD, int MODE>
 __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) {
     constexpr bool GEN = MODE != X3_FC2_STEP2;                 // dA generated from dZ, or read from memory
+    constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);   // act' from the 1-bit stash, or an fp32 stream (sigmoid / tanh)
+    constexpr bool STREAM = !GEN || !BITMASK;                  // a per-lane fp32 operand (A itself, or act') is prefetched from memory
     constexpr int NTW = 4, NW = 4, BM = 256, LD = TD * 16;
     constexpr int W1B = 12 * LD * 16;                          // bytes: [4 lg][3 pieces][LD columns][16 B]
     constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + NW - 1) / NW;
     constexpr int BUFB = W1B + 4096 + 1024;                    // + 2 generator tiles of 2 KiB + 256 stash words
     constexpr int DZB = BM * 64;
     static_assert(W1B % 1024 == 0, "whole DMA pieces");
-    static_assert(ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY, "1-bit stash activations");
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * BUFB + DZB bytes
     char* const ldsb = (char*)lds;
     char* const dzl = ldsb + 2 * BUFB;
@@ -645,7 +666,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     };
     // The DMA pieces of a stage, per wave: 0 .. PPW-1 its W1 pieces, PPW its generator-tile piece (tiles 2*hb, 2*hb + 1 of the sample
     // are 4 KiB contiguous: one piece per wave), PPW + 1 the stash words (the block's 256 points = 1 KiB; last wave only).
-    constexpr int NDMA = GEN ? PPW + 2 : PPW, DPN = (NDMA + NTW - 1) / NTW;   // issued DPN at a time between the generator's point tiles
+    constexpr int NDMA = GEN ? (BITMASK ? PPW + 2 : PPW + 1) : PPW, DPN = (NDMA + NTW - 1) / NTW;   // issued DPN at a time between the generator's point tiles
     struct StageSrc { const char* W; const char* G; const char* M; char* B; };
     auto stage_src = [&](int st, int buf) {
         const int si = st / HS, hb = st % HS, s = s_begin + si;
@@ -662,7 +683,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
             if (wave + NW * i < NPIECE) glds16((const float*)(q.W + goff[i < PPW ? i : 0]), (float*)(q.B + (wave + NW * i) * 1024));
         } else if (i == PPW) {
             glds16((const float*)(q.G + loff), (float*)(q.B + W1B + wave * 1024));
-        } else if (i == PPW + 1) {
+        } else if (BITMASK && i == PPW + 1) {
             if (wave == NW - 1) glds16((const float*)(q.M + loff), (float*)(q.B + W1B + 4096));
         }
     };
@@ -675,20 +696,23 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     }
     // step 2: the A operand of stage st (this lane: point li of each tile, units 16t + 4lg + r of the stage's 32) is loaded from memory
     // one stage ahead, AFTER the next stage's LDS-DMA has been issued, so that the barrier's vmcnt(0) covers both
-    f32x4 am[GEN ? 1 : NTW][2];
+    // (sigmoid / tanh in the generator modes: the same prefetch carries act' of the stage's units instead)
+    f32x4 am[STREAM ? NTW : 1][2];
     auto load_a = [&](int st) {
         const int s = s_begin + st / HS, h0 = (st % HS) * 32;
+        const float* const base = GEN ? a.dact : a.amem;
 #pragma unroll
-        for (int nt = 0; nt < (GEN ? 0 : NTW); ++nt) {
+        for (int nt = 0; nt < (STREAM ? NTW : 0); ++nt) {
             const int n = min(nb + nt * 16 + li, a.N - 1);     // rows past N: any valid row, never stored
-            const float* const src = a.amem + ((long long)s * a.N + n) * a.H + h0 + 4 * lg;
+            const float* const src = base + ((long long)s * a.N + n) * a.H + h0 + 4 * lg;
             am[nt][0] = *(const f32x4*)src;
             am[nt][1] = *(const f32x4*)(src + 16);
         }
     };
-    if (!GEN) load_a(0);
+    if (STREAM) load_a(0);
     ring_wait_barrier<0>();
-    const unsigned cp_bits = __float_as_uint(ldexpf(1.f, GEN_Q3));
+    const float c_pos = ldexpf(1.f, GEN_Q3);
+    const unsigned cp_bits = __float_as_uint(c_pos);
     const unsigned cn_bits = (ACT == RBNN_ACT_RELU) ? 0u : __float_as_uint(LEAKY_SLOPE * ldexpf(1.f, GEN_Q3));
     const int dzc1 = (lg == 2 ? 0 : lg), dzc2 = (lg == 0 ? 1 : (lg == 1 ? 2 : (lg == 2 ? 0 : 3)));   // dZ chunk of MFMA 1 / 2 for this lane group
     const int sz = dz_swz3(li);
@@ -718,7 +742,12 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) issue_piece(q, i);
         }
-        if (!GEN && st + 1 < nst) load_a(st + 1);
+        f32x4 dm[(GEN && STREAM) ? NTW : 1][2];                // sigmoid / tanh: this stage's act' x 2^GEN_Q3 (copied before the next prefetch)
+        if (GEN && STREAM) {
+#pragma unroll
+            for (int nt = 0; nt < ((GEN && STREAM) ? NTW : 0); ++nt) { dm[nt][0] = am[nt][0] * c_pos; dm[nt][1] = am[nt][1] * c_pos; }
+        }
+        if (STREAM && st + 1 < nst) load_a(st + 1);
 
         // ---- generator + split ----
         if (gen_on) {
@@ -733,13 +762,21 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
                 const f16x8 dz2 = *(const f16x8*)(dzw + nt * 1024 + ((dzc2 ^ sz) * 16));
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
                 const f32x4 g0 = MFMA_H(w01, dz2, MFMA_H(w00, dz1, z)), g1 = MFMA_H(w11, dz2, MFMA_H(w10, dz1, z));
-                const unsigned mw = Mk[nt * 16] >> (4 * lg);   // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
                 // the kernel is bound by vector-instruction ISSUE (profiles/r02t), so the split is hand-scheduled: split3_pair
                 union { f16x8 v; unsigned u[4]; } o0, o1, o2;
-                split3_pair<0, true>(g0[0], g0[1], mw, cp_bits, cn_bits, 1.f, o0.u[0], o1.u[0], o2.u[0]);
-                split3_pair<2, false>(g0[2], g0[3], mw, cp_bits, cn_bits, 1.f, o0.u[1], o1.u[1], o2.u[1]);
-                split3_pair<16, true>(g1[0], g1[1], mw, cp_bits, cn_bits, 1.f, o0.u[2], o1.u[2], o2.u[2]);
-                split3_pair<18, false>(g1[2], g1[3], mw, cp_bits, cn_bits, 1.f, o0.u[3], o1.u[3], o2.u[3]);
+                if constexpr (BITMASK) {
+                    const unsigned mw = Mk[nt * 16] >> (4 * lg);   // bit r: unit 4*lg + r; bit 16 + r: unit 16 + 4*lg + r
+                    split3_pair<0, true>(g0[0], g0[1], mw, cp_bits, cn_bits, 1.f, o0.u[0], o1.u[0], o2.u[0]);
+                    split3_pair<2, false>(g0[2], g0[3], mw, cp_bits, cn_bits, 1.f, o0.u[1], o1.u[1], o2.u[1]);
+                    split3_pair<16, true>(g1[0], g1[1], mw, cp_bits, cn_bits, 1.f, o0.u[2], o1.u[2], o2.u[2]);
+                    split3_pair<18, false>(g1[2], g1[3], mw, cp_bits, cn_bits, 1.f, o0.u[3], o1.u[3], o2.u[3]);
+                } else {
+                    constexpr int q = (GEN && STREAM) ? 1 : 0;     // (dm has one dummy entry in the other instantiations)
+                    split3_pair_m<true>(g0[0], g0[1], dm[q * nt][0][0], dm[q * nt][0][1], 1.f, o0.u[0], o1.u[0], o2.u[0]);
+                    split3_pair_m<false>(g0[2], g0[3], dm[q * nt][0][2], dm[q * nt][0][3], 1.f, o0.u[1], o1.u[1], o2.u[1]);
+                    split3_pair_m<true>(g1[0], g1[1], dm[q * nt][1][0], dm[q * nt][1][1], 1.f, o0.u[2], o1.u[2], o2.u[2]);
+                    split3_pair_m<false>(g1[2], g1[3], dm[q * nt][1][2], dm[q * nt][1][3], 1.f, o0.u[3], o1.u[3], o2.u[3]);
+                }
                 da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
                 if (RBNN_X3_SPREAD && more) {
 #pragma unroll
@@ -798,8 +835,12 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
                 if (d >= Dp) continue;
                 float v = acc[nt][dt][r] * gs;
                 if (MODE == X3_FC2_STEP1) {                     // derivative of the layer below: unit d of point n, sample ch
-                    const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n];
-                    v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
+                    if (BITMASK) {
+                        const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n];
+                        v = ((w >> (d & 31)) & 1u) ? v : (ACT == RBNN_ACT_RELU ? 0.f : v * LEAKY_SLOPE);
+                    } else {
+                        v *= a.odact[((long long)ch * a.N + n) * a.ldo + d];
+                    }
                 }
                 dst[d] = v;
             }
@@ -832,6 +873,7 @@ template <int MODE>
 int launch_grad_x3_act(int act, const GradX3Args& a, hipStream_t st) {
 #ifndef RBNN_FAST_BUILD
     if (act == RBNN_ACT_RELU) return launch_grad_x3<RBNN_ACT_RELU, MODE>(a, st);
+    if (act == RBNN_ACT_SIGM || act == RBNN_ACT_TANH) return launch_grad_x3<RBNN_ACT_SIGM, MODE>(a, st);   // both read act' from the stream
 #endif
     return launch_grad_x3<RBNN_ACT_LEAKY, MODE>(a, st);
 }
@@ -931,16 +973,18 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
 int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const int32_t* sidx, int32_t S,
                               int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_triple_workspace* tws,
                               int32_t* n_slabs_out, void* stream) {
-    if (!net || !tp || !ws || !tws || !ws->dZ || !ws->slabs || !ws->mask1) return RBNN_ERR_NULL;
+    if (!net || !tp || !ws || !tws || !ws->dZ || !ws->slabs) return RBNN_ERR_NULL;
     if (!tp->W1_cols || !tp->W2_gen || !tws->dZ_gen || !tws->g_scale) return RBNN_ERR_NULL;
     if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
-    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
-    const bool fc2 = net->arch == RBNN_ARCH_FC2;
+    if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2, bm = net->activation == RBNN_ACT_RELU || net->activation == RBNN_ACT_LEAKY;
+    if (bm ? !ws->mask1 : !ws->dact1) return RBNN_ERR_NULL;
+    if (fc2 && (bm ? !ws->mask2 : !ws->dact2)) return RBNN_ERR_NULL;
     const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
     if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     if (tp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
     if (!aligned16(tp->W1_cols) || !aligned16(tp->W2_gen) || !aligned16(tws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
-    if (fc2 && (!tp->Wm_cols || !ws->dhid1 || !ws->mask2)) return RBNN_ERR_NULL;
+    if (fc2 && (!tp->Wm_cols || !ws->dhid1)) return RBNN_ERR_NULL;
     if (fc2 && (!aligned16(tp->Wm_cols) || !aligned16(ws->dhid1))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     if (chunk <= 0) {                                           // the exact mode's slab plan (same workspace)
@@ -961,7 +1005,7 @@ int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_image
     g.W2g = (const char*)tp->W2_gen;
     g.H = H; g.HW = H / 32; g.sidx = sidx; g.S = S; g.N = N;
     if (!fc2) {
-        g.mask = ws->mask1; g.W1c = (const char*)tp->W1_cols; g.ldc = tp->ld_cols; g.Dt = Dp / 16;
+        g.mask = ws->mask1; g.dact = ws->dact1; g.W1c = (const char*)tp->W1_cols; g.ldc = tp->ld_cols; g.Dt = Dp / 16;
         g.chunk = chunk; g.nchunks = nchunks; g.out = ws->slabs; g.ldo = Dp;
         g.out_scale = ldexpf(1.f, -(tp->w2_exp + GEN_Q3 + tp->w1_exp));
         return launch_grad_x3_act<X3_FC>(net->activation, g, st);
@@ -971,7 +1015,7 @@ int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_image
     //   => |stored| <= 2^15: in fp16 range, ready to be split as step 2's A operand
     int q2 = 14;
     while ((1 << (q2 - 14)) < H) ++q2;
-    g.mask = ws->mask2; g.W1c = (const char*)tp->Wm_cols; g.ldc = H; g.Dt = H / 16;
+    g.mask = ws->mask2; g.dact = ws->dact2; g.odact = ws->dact1; g.W1c = (const char*)tp->Wm_cols; g.ldc = H; g.Dt = H / 16;
     g.chunk = 1; g.nchunks = S; g.out = ws->dhid1; g.ldo = H; g.out_scale = ldexpf(1.f, -q2);
     g.omask = ws->mask1; g.OHW = H / 32;
     int rc = launch_grad_x3_act<X3_FC2_STEP1>(net->activation, g, st);

@@ -115,9 +115,8 @@ class StackedPosterior:
 
     # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands
     def triple_supported(self):
-        """The triple kernels cover fc and fc2 with relu / leaky, hidden % 128 == 0 and <= 10 classes."""
-        return (self.arch in ("fc", "fc2") and self.activation in ("relu", "leaky") and self.Hp % 128 == 0 and self.C <= 10
-                and self.device.type == "cuda")
+        """The triple kernels cover fc and fc2 (all four activations) with hidden % 128 == 0 and <= 10 classes."""
+        return self.arch in ("fc", "fc2") and self.Hp % 128 == 0 and self.C <= 10 and self.device.type == "cuda"
 
     def triple_images(self):
         """rbnn_triple_images of this posterior (built once, resident): W1 as triple rows (forward A operand, 6 B per weight),

@@ -140,6 +140,8 @@ CASES = [  # arch, act, H, C, S, N
     # fc2 = the reference's saved model_1 / 3 / 5 / 7 family: layer 1 writes the hidden activations as a triple image, the backward
     # runs in two steps through the fp32 dhid1 buffer
     ("fc2", "leaky", 512, 10, 3, 300), ("fc2", "relu", 256, 10, 4, 77), ("fc2", "leaky", 128, 4, 2, 257), ("fc2", "leaky", 1024, 10, 2, 40),
+    # sigmoid / tanh: act' travels as an fp32 stream instead of the 1-bit stash
+    ("fc", "sigm", 512, 10, 3, 130), ("fc", "tanh", 256, 10, 2, 77), ("fc2", "tanh", 512, 10, 2, 90), ("fc2", "sigm", 128, 5, 3, 40),
 ]
 
 
@@ -177,11 +179,13 @@ def test_triple_vs_fp64_oracle(arch, act, Hn, Cn, S, N):
 def test_triple_is_refused_where_it_does_not_apply():
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
     post = O.synthetic_posterior("fc", 784, 512, 10, 2, 0.05)
-    with pytest.raises(_hip.HipError):
-        AttackEngine(StackedPosterior("fc", "tanh", (1, 28, 28), 10, 512, post, DEV), precision="triple")
     post = O.synthetic_posterior("fc", 784, 64, 10, 2, 0.05)
     with pytest.raises(_hip.HipError):
         AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), 10, 64, post, DEV), precision="triple")
+    from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
+    cpost = O.synthetic_posterior("conv", 784, 16, 10, 1, 0.05, in_ch=1, head=49 * 16)
+    with pytest.raises(_hip.HipError):
+        ConvEngine(ConvStackedPosterior("tanh", (1, 28, 28), 10, 16, cpost, DEV), precision="triple")
 
 
 # ------------------------------------------------------------------ golden fixtures through the reference's call surface
