@@ -1226,6 +1226,9 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
 // from memory and shared by the block's waves through L1.  The gradients are scaled per (sample, point) by a power of two from
 // max|dZ| * max_f sum_c |Fw[c][f]| (x4 for the overlapping pool windows), divided out in the epilogue.  NWB waves per block, one block
 // per CU (23 / 31 KB of LDS per wave).
+#ifndef RBNN_CONVBWD_X3_UNROLL
+#define RBNN_CONVBWD_X3_UNROLL 0      // 1: the 13-step loop fully unrolled (one basic block per chunk) — measured SLOWER: 18.1 -> 19.6 ms (1x28x28), 31.8 -> 38.2 (3x32x32)
+#endif
 template <class G> struct ConvBwdX3Lds {
     static constexpr int HCH = 16;
     static constexpr int IPB = (G::O2W + 8) * G::PITCH + 8;              // positions of a wave's padded image
@@ -1366,7 +1369,11 @@ __global__ void __launch_bounds__(64 * ConvBwdX3Lds<G>::NWB, (ConvBwdX3Lds<G>::N
         const char* const w1 = Wr1 + (long long)ch * NSTEP * 192;
         f16x8 a00 = *(const f16x8*)w0, a01 = *(const f16x8*)(w0 + 64), a02 = *(const f16x8*)(w0 + 128);
         f16x8 a10 = *(const f16x8*)w1, a11 = *(const f16x8*)(w1 + 64), a12 = *(const f16x8*)(w1 + 128);
+#if RBNN_CONVBWD_X3_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
         for (int t = 0; t < NSTEP; ++t) {
             const f16x8 c00 = a00, c01 = a01, c02 = a02, c10 = a10, c11 = a11, c12 = a12;
             if (t + 1 < NSTEP) {
@@ -1377,13 +1384,23 @@ __global__ void __launch_bounds__(64 * ConvBwdX3Lds<G>::NWB, (ConvBwdX3Lds<G>::N
             const int kyA = tA / 5, kyB = tB / 5;
             const int tap = (lg >> 1) ? tB : tA;                          // this lane's tap
             const char* const src = img + (lg & 1) * 16 - ((tap / 5) * PITCH + tap % 5) * (HCH * 2);
+            // Every tile is its own basic block (the skip test is a wave-uniform branch), so the scheduler cannot move a tile's three B
+            // fragment reads above the previous tile's MFMAs: with ONE wave per SIMD (3x32x32) the LDS latency would be exposed once per
+            // 12 MFMAs.  PREF: read the NEXT tile's fragments unconditionally before this tile's branch (3 wasted reads per skipped tile).
+            constexpr bool PREF = L::NWB <= 4;
+            f16x8 n0, n1, n2;
+            if (PREF) { const char* const bp = src + poff[0] * (HCH * 2); n0 = *(const f16x8*)bp; n1 = *(const f16x8*)(bp + PLANE); n2 = *(const f16x8*)(bp + 2 * PLANE); }
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
                 constexpr int last = P1W_ * P1W_ - 1;
                 const int Ya = (16 * pt) / P1W_, Yb = min(16 * pt + 15, last) / P1W_;
+                f16x8 b0, b1, b2;
+                if (PREF) {
+                    b0 = n0; b1 = n1; b2 = n2;
+                    if (pt + 1 < NPT) { const char* const bp = src + poff[pt + 1 < NPT ? pt + 1 : pt] * (HCH * 2); n0 = *(const f16x8*)bp; n1 = *(const f16x8*)(bp + PLANE); n2 = *(const f16x8*)(bp + 2 * PLANE); }
+                }
                 if ((kyA < Ya - (O2W_ - 1) || kyA > Yb) && (kyB < Ya - (O2W_ - 1) || kyB > Yb)) continue;   // wave-uniform
-                const char* const bp = src + poff[pt] * (HCH * 2);
-                const f16x8 b0 = *(const f16x8*)bp, b1 = *(const f16x8*)(bp + PLANE), b2 = *(const f16x8*)(bp + 2 * PLANE);
+                if (!PREF) { const char* const bp = src + poff[pt] * (HCH * 2); b0 = *(const f16x8*)bp; b1 = *(const f16x8*)(bp + PLANE); b2 = *(const f16x8*)(bp + 2 * PLANE); }
                 acc[0][pt] = MFMA_H(c00, b2, acc[0][pt]);
                 acc[1][pt] = MFMA_H(c10, b2, acc[1][pt]);
                 acc[0][pt] = MFMA_H(c02, b0, acc[0][pt]);
