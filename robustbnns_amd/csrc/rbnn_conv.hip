@@ -1239,7 +1239,10 @@ template <class G> struct ConvBwdX3Lds {
     // waves per block (one block per CU).  The kernel keeps TWO accumulator sets (blocked accumulation, below): 2 x 2 x NPT1 tiles =
     // 144 registers at 1x28x28 — six waves, two of the SIMDs hold two (256 registers each) — and 208 at 3x32x32: four waves, one per
     // SIMD (512 registers); LDS would allow 6 / 5
-    static constexpr int NWB = G::NPT1 <= 9 ? 6 : 4;
+#ifndef RBNN_CONVBWD_X3_NWB_SMALL
+#define RBNN_CONVBWD_X3_NWB_SMALL 6
+#endif
+    static constexpr int NWB = G::NPT1 <= 9 ? RBNN_CONVBWD_X3_NWB_SMALL : 4;
     static_assert(NWB * WAVE <= 160 * 1024, "LDS");
 };
 
