@@ -198,6 +198,12 @@ def test_golden_cases_in_triple_mode(golden, name, monkeypatch):
     g = golden(name); m = g.meta; bnn = make_bnn(g); x, y = g.t("x"), g.t("y")
     eng = bnn._engine
     assert eng.precision == "triple"
+    # how far each arithmetic mode lands from the reference's own fp32 values (printed with -s: the modes are interchangeable here)
+    from robustbnns_amd import AttackEngine
+    for mode in ("triple", "exact"):
+        e2 = AttackEngine(eng.post, precision=mode)
+        print(f"[golden {name}] {mode}: forward {rel_err(e2.forward(x, m['S']).cpu(), g.t('forward_probs')):.2e}  "
+              f"loss_gradients {rel_err(e2.loss_gradients(x, y, m['S']).cpu(), g.t('loss_gradients')):.2e} (rel. to the reference's values)")
     assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
     seeds = [int(s) for s in g.arr["forward_seeds"]]
     assert rel_err(bnn.forward(x.to(DEV), n_samples=len(seeds), seeds=seeds).cpu(), g.t("forward_probs_seeds")) < TOL

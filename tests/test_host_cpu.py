@@ -119,6 +119,38 @@ def test_precision_resolution_and_scale_exponent(monkeypatch):
         AttackEngine(sp, kernels=FakeKernels(), precision="split")
     with pytest.raises(ValueError):
         AttackEngine(sp, kernels=FakeKernels(), precision="fp8")
+    # the triple mode (what auto picks on the GPU) needs device-resident images and the real kernels: refused, never silently replaced
+    assert not sp.triple_supported()
+    monkeypatch.delenv("RBNN_PRECISION")
+    assert AttackEngine(sp, kernels=FakeKernels(), precision="auto").precision == "exact"
+    with pytest.raises(_hip.HipError):
+        AttackEngine(sp, kernels=FakeKernels(), precision="triple")
+    # a sharded posterior drops its images (they are rebuilt for the shard's own samples)
+    sh = sp.shard(0, 2)
+    assert sh.S == 1 and sh._triple is None and sh._split is None
+
+
+def test_triple_abi_rejects_bad_arguments():
+    """The triple entry points of the C-ABI validate like the others (host-side checks only: no kernel is launched)."""
+    import ctypes as C
+    lib = _hip.load()
+    img, tws, ws = _hip.TripleImages(), _hip.TripleWorkspace(), _hip.Workspace()
+    net = _hip.Posterior()
+    assert lib.rbnn_fc_forward_triple(None, C.byref(img), C.byref(tws), 0, None, 8, None, 2, 0, C.byref(ws), None) == -1
+    assert lib.rbnn_fc_forward_triple(C.byref(net), C.byref(img), C.byref(tws), 0, None, 8, None, 2, 0, C.byref(ws), None) == -1   # no images
+    assert lib.rbnn_fc_input_grad_triple(C.byref(net), C.byref(img), None, 2, 8, 0, C.byref(ws), C.byref(tws), None, None) == -1
+    assert lib.rbnn_triple_rows(None, 4, 32, 32, 0, None, None, 32, None) == -1
+    assert lib.rbnn_triple_rows(C.c_void_p(16), 4, 40, 40, 0, None, C.c_void_p(16), 40, None) == -2          # ld_dst % 32
+    assert lib.rbnn_triple_cols(C.c_void_p(16), 1, 48, 16, 16, 0, C.c_void_p(16), 16, None) == -2             # rows % 32
+    assert lib.rbnn_triple_w2gen(C.c_void_p(16), 1, 11, 128, 0, C.c_void_p(16), None) == -2                   # > 10 classes
+    sizes = _hip.TripleWorkspaceSizes()
+    net.arch, net.in_features, net.hidden = 1, 784, 512
+    img.ld_rows = 800
+    assert lib.rbnn_triple_workspace_query(C.byref(net), C.byref(img), 100, 7, C.byref(sizes)) == 0
+    assert (sizes.X_triple, sizes.hid_triple, sizes.g_scale) == (100 * 800 * 6, 7 * 100 * 512 * 6, 256 * 4)
+    cnet = _hip.ConvPosterior()
+    assert lib.rbnn_conv_forward_triple(C.byref(cnet), None, 0, 0, None, None, 784, 4, None, 1, 0, None, None) != 0
+    assert lib.rbnn_conv_input_grad_triple(C.byref(cnet), None, 0, 1.0, None, 1, 4, None, None) != 0
 
 
 def test_compute_refuses_cpu_tensors():
