@@ -1,0 +1,89 @@
+"""Sample-sharded step with the REAL kernels in TWO processes (-m gpu): world_size 2 over gloo on device tensors, both ranks on cuda:0.
+
+The 8-GPU job runs this engine code over RCCL with one rank per GPU; a 1-GPU box cannot host two RCCL ranks, but gloo accepts device
+tensors, so the whole sharded step — every rank's forward / backward kernels through the C-ABI, the asynchronous all-reduces of
+sum_s p_s and of the summed gradients, pipelined over point blocks — runs here across two processes and must reproduce the
+single-process result on the full posterior: gradients to 1e-5 (the partial sums are added in a different order), FGSM images equal
+except noise-level gradient components, identical replicas on both ranks.  Runs in the package's default precision (auto = triple at
+H = 512) and on the fp32 MFMA."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, precision, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["RBNN_COMM_BLOCKS"], os.environ["RBNN_COMM_MIN_POINTS"] = "2", "256"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import bnn_oracle as O
+        from robustbnns_amd import _hip
+        from robustbnns_amd.engine import AttackEngine
+        from robustbnns_amd.posterior import StackedPosterior
+        dev = "cuda:0"
+        D, H, C, S, N = 784, 512, 10, 6, 1100
+        post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
+        x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=5)
+        full = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, dev)
+        eng = AttackEngine(full.shard(rank, world), group=dist.group.WORLD, total_samples=S, precision=precision)
+        assert eng.world == 2 and eng._comm_blocks(N) == 2 and eng.post.S == S // world
+        lab = y.argmax(-1).int().to(dev)
+        out = {"probs": eng.forward(x, eng.post.S).cpu(), "lg": eng.loss_gradients(x, y, eng.post.S).cpu(),
+               "gm": eng.gradient(eng.pad_inputs(x), lab, None, eng.post.S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().clone(),
+               "fgsm": eng.fgsm(x, y, eng.post.S, 0.3).cpu(), "pgd": eng.pgd(x[:600], y[:600], eng.post.S, 0.3, iters=4).cpu()}
+        torch.cuda.synchronize()
+        t = out["fgsm"].clone()                                  # every rank holds the same (replicated) adversarial images
+        dist.broadcast(t, src=0)
+        assert torch.equal(t, out["fgsm"])
+        if rank == 0:
+            single = AttackEngine(full, precision=precision)
+            ref = {"probs": single.forward(x, S).cpu(), "lg": single.loss_gradients(x, y, S).cpu(),
+                   "gm": single.gradient(single.pad_inputs(x), lab, None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().clone(),
+                   "fgsm": single.fgsm(x, y, S, 0.3).cpu(), "pgd": single.pgd(x[:600], y[:600], S, 0.3, iters=4).cpu()}
+            errs = {"mode": eng.precision}
+            for k in ("probs", "lg", "gm"):
+                a, b = out[k].reshape(N, -1).double(), ref[k].reshape(N, -1).double()
+                errs[k] = float(((a - b).abs().max(1)[0] / b.abs().max(1)[0]).max())
+            safe = ref["gm"].abs() > 1e-3 * ref["gm"].abs().max(1, keepdim=True)[0]
+            errs["fgsm_bad"] = int((((out["fgsm"] - ref["fgsm"]).abs().reshape(N, -1) > 1e-6) & safe).sum())
+            errs["pgd_frac"] = float(((out["pgd"] - ref["pgd"]).abs() > 1e-6).double().mean())
+            q.put(errs)
+    except Exception as exc:                                     # report instead of hanging the parent on q.get
+        if rank == 0:
+            q.put({"error": repr(exc)})
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["auto", "exact"])
+def test_two_ranks_real_kernels_match_single_process(precision):
+    assert torch.cuda.is_available(), "this test needs the MI355X"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    errs = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert "error" not in errs, errs
+    assert all(p.exitcode == 0 for p in procs)
+    print(f"[2 ranks, real kernels, {errs['mode']}] {errs}")
+    assert errs["mode"] == ("triple" if precision == "auto" else "exact")
+    assert errs["probs"] < 1e-6 and errs["lg"] < 1e-5 and errs["gm"] < 1e-5, errs
+    assert errs["fgsm_bad"] == 0 and errs["pgd_frac"] < 0.02, errs
