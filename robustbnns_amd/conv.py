@@ -59,8 +59,14 @@ class ConvStackedPosterior:
 
     # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands on the f16 pipe
     def triple_supported(self):
-        """The triple conv2 kernels cover both geometries with relu / leaky (every saved conv model of the reference is leaky)."""
-        return self.device.type == "cuda" and self.activation in ("relu", "leaky")
+        """The triple conv2 kernels cover both geometries with relu / leaky (every saved conv model of the reference is leaky), for
+        posteriors whose conv2 weights have an ordinary dynamic range (posterior.narrow_range)."""
+        if not (self.device.type == "cuda" and self.activation in ("relu", "leaky")):
+            return False
+        if getattr(self, "_range_ok", None) is None:
+            from .posterior import narrow_range
+            self._range_ok = narrow_range(self.K2w)
+        return self._range_ok
 
     def triple_images(self):
         """(K2 triple-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32] for the forward, its exponent, the backward's

@@ -30,6 +30,22 @@ def padded_hidden(H):
     return max(32, H)
 
 
+def narrow_range(*tensors, ratio=4096.0):
+    """True when every tensor's largest magnitude is within `ratio` (2^12) of its mean magnitude (the mean, unlike the rms, is not
+    carried by a single outlier).  The triple images carry a value exactly while |v| >= 2^-15 * max|tensor| and to 2^-39 * max|tensor|
+    absolutely below that: with max <= 2^12 * mean|v| the absolute error of ANY element is <= 2^-27 of a typical element, i.e. below
+    fp32's own resolution of it.  A posterior with a wilder dynamic range (one huge outlier weight) is left to the fp32 MFMA kernels,
+    whose per-element precision does not depend on the rest of the tensor."""
+    for t in tensors:
+        if t is None:
+            continue
+        m = float(t.abs().max())
+        r = float(t.abs().double().mean())
+        if not (m <= ratio * r) or m == 0.0 or m != m or m == float("inf"):
+            return False
+    return True
+
+
 def scale_exp(max_abs, target=14):
     """e with max_abs * 2^e <= 2^target: the power-of-two scale of a split-half image (rbnn_split_rows & co)."""
     if not (max_abs > 0.0) or math.isinf(max_abs):
@@ -75,6 +91,7 @@ class StackedPosterior:
         self._desc = None
         self._split = None
         self._triple = None
+        self._range_ok = None
 
     # ------------------------------------------------------------------ split-half ("f16x3") precision mode
     def split_supported(self):
@@ -115,8 +132,13 @@ class StackedPosterior:
 
     # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands
     def triple_supported(self):
-        """The triple kernels cover fc and fc2 (all four activations) with hidden % 128 == 0 and <= 10 classes."""
-        return self.arch in ("fc", "fc2") and self.Hp % 128 == 0 and self.C <= 10 and self.device.type == "cuda"
+        """The triple kernels cover fc and fc2 (all four activations) with hidden % 128 == 0 and <= 10 classes — and posteriors whose
+        weight tensors have an ordinary dynamic range (narrow_range): anything else stays on the fp32 MFMA."""
+        if not (self.arch in ("fc", "fc2") and self.Hp % 128 == 0 and self.C <= 10 and self.device.type == "cuda"):
+            return False
+        if self._range_ok is None:
+            self._range_ok = narrow_range(self.W1, self.W2, self.Wm)
+        return self._range_ok
 
     def triple_images(self):
         """rbnn_triple_images of this posterior (built once, resident): W1 as triple rows (forward A operand, 6 B per weight),
@@ -222,6 +244,6 @@ class StackedPosterior:
         for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
             t = getattr(self, name)
             setattr(out, name, None if t is None else t[lo:hi].contiguous())
-        out.S, out._desc, out._split, out._triple = hi - lo, None, None, None
+        out.S, out._desc, out._split, out._triple, out._range_ok = hi - lo, None, None, None, None
         out._pack()
         return out

@@ -178,6 +178,13 @@ def test_triple_vs_fp64_oracle(arch, act, Hn, Cn, S, N):
 
 def test_triple_is_refused_where_it_does_not_apply():
     from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    # a posterior with one huge outlier weight: its small weights would be carried to 2^-39 of the OUTLIER — auto keeps the fp32 MFMA
+    wild = O.synthetic_posterior("fc", 784, 512, 10, 2, 0.05)
+    wild["model.1.weight"][0, 3, 5] = 1.0e5
+    sp = StackedPosterior("fc", "leaky", (1, 28, 28), 10, 512, wild, DEV)
+    assert not sp.triple_supported() and AttackEngine(sp).precision == "exact"
+    with pytest.raises(_hip.HipError):
+        AttackEngine(sp, precision="triple")
     post = O.synthetic_posterior("fc", 784, 512, 10, 2, 0.05)
     post = O.synthetic_posterior("fc", 784, 64, 10, 2, 0.05)
     with pytest.raises(_hip.HipError):
