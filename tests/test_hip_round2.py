@@ -104,7 +104,7 @@ def c3():
     return StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, DEV), post, x, y
 
 
-@pytest.mark.parametrize("precision", ["exact", "split"])
+@pytest.mark.parametrize("precision", ["exact", "split", "triple"])
 def test_c3_full_size_pgd(c3, precision):
     from robustbnns_amd import AttackEngine, _hip
     sp, post, x, y = c3
@@ -135,7 +135,7 @@ def test_c3_full_size_pgd(c3, precision):
 
 
 # ------------------------------------------------------------------ C4's per-GPU share
-@pytest.mark.parametrize("precision", ["exact", "split"])
+@pytest.mark.parametrize("precision", ["exact", "split", "triple"])
 def test_c4_share_loss_gradients_and_fgsm(precision):
     """BASELINE.json configs[3]: S=2000 sharded 8-way = 250 samples on this GPU, N=10 000: expected loss gradients (per-sample
     loss) and FGSM (mean-probability loss) against the fp64 oracle on 288 rows; fused norms against host norms."""

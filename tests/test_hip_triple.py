@@ -293,3 +293,67 @@ def test_triple_full_size_against_oracle_and_exact_mode(S, method):
     eng = res["triple"]["eng"]
     again = eng.fgsm(x, y, S, eps) if method == "fgsm" else eng.pgd(x, y, S, eps, alpha=None, iters=40)
     assert torch.equal(again, res["triple"]["adv"])                                               # bit-deterministic
+
+
+# ------------------------------------------------------------------ fc2 and conv at bench-like sizes: triple against the fp32-MFMA mode
+def test_fc2_bench_shape_triple_vs_exact():
+    """fc2-512 (the reference's saved model_1 shape) at S=24, N=3000: the two-step triple backward (through the fp32 dhid1 buffer and the
+    in-register A split) against the fp32-MFMA kernels on the same posterior — gradients on the points whose activation decisions
+    agree in both layers, FGSM images, evaluation triple."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    S, N, Hn, Cn, Dn = 24, 3000, 512, 10, 784
+    post = O.synthetic_posterior("fc2", Dn, Hn, Cn, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=71)
+    sp = StackedPosterior("fc2", "leaky", (1, 28, 28), Cn, Hn, post, DEV)
+    lab = y.argmax(-1).int().to(DEV)
+    out = {}
+    for mode in ("exact", "triple"):
+        eng = AttackEngine(sp, precision=mode)
+        G = eng.gradient(eng.pad_inputs(x), lab, None, S, _hip.LOSS_MEAN_PROB)[:, :Dn].cpu().clone()
+        ws = eng.workspace(N, S)
+        masks = torch.cat([ws["mask1"].view(S, Hn // 32, -1)[:, :, :N], ws["mask2"].view(S, Hn // 32, -1)[:, :, :N]], 1).clone()
+        out[mode] = dict(G=G, masks=masks, probs=eng.forward(x, S).cpu(), adv=eng.fgsm(x, y, S, 0.3).cpu(), eng=eng)
+    same = (out["exact"]["masks"] == out["triple"]["masks"]).all(0).all(0).cpu()
+    assert int((~same).sum()) < 0.1 * N
+    assert rel_err(out["triple"]["probs"], out["exact"]["probs"]) < 1e-6
+    assert rel_err(out["triple"]["G"][same], out["exact"]["G"][same]) < TOL
+    Gx = out["exact"]["G"]
+    safe = (Gx.abs() > TAU * Gx.abs().max(1, keepdim=True)[0]) & same[:, None]
+    diff = (out["exact"]["adv"] - out["triple"]["adv"]).abs().reshape(N, -1) > 1e-6
+    assert int((diff & safe).sum()) == 0
+    ev_e = out["exact"]["eng"].evaluate(x, out["exact"]["adv"], y, S)
+    ev_t = out["triple"]["eng"].evaluate(x, out["exact"]["adv"], y, S)
+    assert ev_e[0] == ev_t[0] and ev_e[1] == ev_t[1] and float((ev_e[2] - ev_t[2]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("shape,N,S", [((1, 28, 28), 300, 3), ((3, 32, 32), 150, 2)])
+def test_conv_bench_shape_triple_vs_exact(shape, N, S):
+    """conv-512 on both geometries at a few hundred points: the triple conv2 forward / conv2^T backward against the fp32-MFMA kernels on
+    the same posterior — probabilities and gradients to 1e-5, the gradients on the points whose pooling / sign decisions (both byte stashes) are
+    identical in the two modes; FGSM images equal there except noise-level gradient components."""
+    from robustbnns_amd import _hip
+    from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
+    Hc, Cn = 512, 10
+    Din = shape[0] * shape[1] * shape[2]
+    q2 = ((shape[1] - 4) // 2) - 5
+    post = O.synthetic_posterior("conv", Din, Hc, Cn, S, 0.03, in_ch=shape[0], head=q2 * q2 * Hc)
+    x, y = O.synthetic_inputs(N, shape, Cn, seed=81)
+    sp = ConvStackedPosterior("leaky", shape, Cn, Hc, post, DEV)
+    lab = y.argmax(-1).int().to(DEV)
+    out = {}
+    for mode in ("exact", "triple"):
+        eng = ConvEngine(sp, precision=mode)
+        assert eng.precision == mode
+        probs = eng.forward(x, S).cpu()
+        G = eng.gradient(eng.pad_inputs(x), lab, None, S, _hip.LOSS_MEAN_PROB).cpu().reshape(N, -1).clone()
+        ws = eng.workspace(N, S)
+        st1, st2 = ws["st1"].view(S, N, -1).clone(), ws["st2"].view(S, N, -1).clone()
+        out[mode] = dict(G=G, probs=probs, st1=st1, st2=st2, adv=eng.fgsm(x, y, S, 0.1).cpu().reshape(N, -1))
+    same = ((out["exact"]["st1"] == out["triple"]["st1"]).all(2).all(0) & (out["exact"]["st2"] == out["triple"]["st2"]).all(2).all(0)).cpu()
+    print(f"[conv {shape} triple vs exact] points with identical decisions: {int(same.sum())}/{N}")
+    assert int(same.sum()) > 0.8 * N
+    assert rel_err(out["triple"]["probs"], out["exact"]["probs"]) < TOL          # (each mode sits ~1e-6 from fp64 at 3x32x32: a 41 472-term head)
+    assert rel_err(out["triple"]["G"][same], out["exact"]["G"][same]) < TOL
+    Gx = out["exact"]["G"]
+    safe = (Gx.abs() > TAU * Gx.abs().max(1, keepdim=True)[0]) & same[:, None]
+    assert int((((out["exact"]["adv"] - out["triple"]["adv"]).abs() > 1e-6) & safe).sum()) == 0
