@@ -328,6 +328,7 @@ def test_split_mode_operand_scales(k):
 
 
 @pytest.mark.parametrize("arch,shape,C,H,S,N,precision", [("fc", (1, 28, 28), 10, 512, 6, 300, "split"), ("fc", (1, 28, 28), 10, 512, 6, 300, "exact"),
+                                                          ("fc", (1, 28, 28), 10, 512, 6, 300, "triple"), ("fc2", (1, 28, 28), 10, 256, 3, 300, "triple"),
                                                           ("fc", (1, 2, 1), 2, 64, 10, 100, "exact"), ("fc2", (1, 28, 28), 10, 64, 3, 70, "exact")])
 def test_pgd_hip_graph_replay_is_bit_identical(arch, shape, C, H, S, N, precision, monkeypatch):
     """PGD runs iteration 1 eagerly and replays a captured HIP graph for the rest: same launches, same bits as the eager loop."""

@@ -357,3 +357,34 @@ def test_conv_bench_shape_triple_vs_exact(shape, N, S):
     Gx = out["exact"]["G"]
     safe = (Gx.abs() > TAU * Gx.abs().max(1, keepdim=True)[0]) & same[:, None]
     assert int((((out["exact"]["adv"] - out["triple"]["adv"]).abs() > 1e-6) & safe).sum()) == 0
+
+
+def test_triple_mode_heavy_tails_and_sparse_inputs():
+    """ONE power-of-two scale per tensor, taken from its largest magnitude: outlier weights (0.1 % at 100x the bulk — inside the
+    dynamic-range guard), MNIST-like inputs (80 % exact zeros, saturated ones) and a few all-zero images.  The triple mode must stay
+    at the fp32-MFMA kernels' own error against fp64 (outlier weights make the logits large: fp32 itself is the yardstick)."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    Dn, Hn, Cn, S, N = 784, 256, 10, 5, 200
+    post = O.synthetic_posterior("fc", Dn, Hn, Cn, S, 0.03)
+    g = torch.Generator().manual_seed(17)
+    for k in ("model.1.weight", "model.3.weight"):
+        m = torch.rand(post[k].shape, generator=g) < 1e-3
+        post[k] = torch.where(m, post[k] * 100.0, post[k])
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=8)
+    x = torch.where(torch.rand(x.shape, generator=g) < 0.8, torch.zeros_like(x), x)
+    x = torch.where(torch.rand(x.shape, generator=g) < 0.05, torch.ones_like(x), x)
+    x[:3] = 0.0
+    p64 = O.cast(post, torch.float64)
+    sp = StackedPosterior("fc", "leaky", (1, 28, 28), Cn, Hn, post, DEV)
+    assert sp.triple_supported()
+    lab = y.argmax(-1)
+    ref = O.meanprob_gradients(x.double(), lab, p64, "fc", "leaky", S)
+    ok = O.kink_margin(x.double(), p64, "fc", "leaky", S) > KINK
+    err = {}
+    for mode in ("exact", "triple"):
+        eng = AttackEngine(sp, precision=mode)
+        assert rel_err(eng.forward(x, S).cpu(), O.bnn_forward(x.double(), p64, "fc", "leaky", S)) < TOL
+        G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :Dn].cpu().reshape(x.shape)
+        err[mode] = rel_err(G[ok], ref[ok])
+    print(f"heavy tails: triple {err['triple']:.2e}  fp32 MFMA {err['exact']:.2e}")
+    assert err["triple"] < max(TOL, 1.25 * err["exact"])
