@@ -256,7 +256,7 @@ int rbnn_conv_forward_split(const rbnn_conv_posterior *net, const void *K2_rows,
                             int32_t n_points, const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                             const rbnn_conv_workspace *ws, void *stream);
 
-/* rbnn_conv_forward with conv2 in the triple-split ("f16x6") mode (both geometries, relu / leaky): full-width fp32 operands as three
+/* rbnn_conv_forward with conv2 in the triple-split ("f16x6") mode (both geometries, all four activations): full-width fp32 operands as three
  * fp16 pieces, six exact product terms per product on the f16 matrix pipe, fp32 accumulation (see the triple-split section below).
  * K2_triple = rbnn_triple_rows image of model.3.weight regrouped [S_total*Hc, 25 taps * 32 ci] (K tap-major) holding W * 2^k2_exp;
  * the pooled conv1 activations (computed in fp32 by the exact conv1 kernel into ws->P1) are split on the fly, scaled by 2^p1_exp or
@@ -266,7 +266,7 @@ int rbnn_conv_forward_triple(const rbnn_conv_posterior *net, const void *K2_trip
                              const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                              const rbnn_conv_workspace *ws, void *stream);
 
-/* rbnn_conv_input_grad with conv2^T in the triple-split mode (both geometries, relu / leaky).  K2_bwd = rbnn_triple_rows image of
+/* rbnn_conv_input_grad with conv2^T in the triple-split mode (both geometries, all four activations).  K2_bwd = rbnn_triple_rows image of
  * model.3.weight regrouped [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8] exactly as for rbnn_conv_input_grad_split (one
  * 192-byte stage per (chunk, tap pair)); fw_l1 = max_f sum_c |model.7.weight[c, f]|.  Same G as rbnn_conv_input_grad. */
 int rbnn_conv_input_grad_triple(const rbnn_conv_posterior *net, const void *K2_bwd, int32_t k2_exp, float fw_l1,
@@ -360,7 +360,7 @@ int rbnn_fc_input_grad_split(const rbnn_posterior *net, const rbnn_split_images 
  * bit for bit, for |v| >= 2^-15 * max|tensor| (3 x 11 significand bits cover fp32's 24; within 2^-39 * max|tensor| below
  * that) — and a*b = a0*b2 + a2*b0 + a1*b1 + a1*b0 + a0*b1 + a0*b0 (six f16 MFMAs, exact terms; the dropped terms are
  * <= 2^-32 |a*b|), accumulated in fp32: the only rounding left is the fp32 accumulation, as in rbnn_fc_forward / rbnn_fc_input_grad.
- * Architectures fc and fc2, hidden % 128 == 0; forward: all four activations; input gradient: relu / leaky, <= 10 classes.
+ * Architectures fc and fc2, hidden % 128 == 0, all four activations, <= 10 classes in the input gradient.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct rbnn_triple_images {
     const void *W1_rows;           /* rbnn_triple_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/32,3,32] halves */

@@ -59,9 +59,9 @@ class ConvStackedPosterior:
 
     # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands on the f16 pipe
     def triple_supported(self):
-        """The triple conv2 kernels cover both geometries with relu / leaky (every saved conv model of the reference is leaky), for
-        posteriors whose conv2 weights have an ordinary dynamic range (posterior.narrow_range)."""
-        if not (self.device.type == "cuda" and self.activation in ("relu", "leaky")):
+        """The triple conv2 kernels cover both geometries and all four activations, for posteriors whose conv2 weights have an ordinary
+        dynamic range (posterior.narrow_range)."""
+        if self.device.type != "cuda":
             return False
         if getattr(self, "_range_ok", None) is None:
             from .posterior import narrow_range

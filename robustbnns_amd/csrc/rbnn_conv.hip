@@ -630,7 +630,10 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
             for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (pt * 16 + li < NPOS_) my[(4 * lg + r) * NPOS_ + pt * 16 + li] = acc[ht][pt][r] * out_scale + bias[r];
+                    if (pt * 16 + li < NPOS_) {
+                        const float pre = acc[ht][pt][r] * out_scale + bias[r];   // sigmoid / tanh are pooled on their VALUES, as torch does
+                        my[(4 * lg + r) * NPOS_ + pt * 16 + li] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+                    }
             // four consecutive pooled cells per lane: one 16-byte store of Q2 and one 4-byte store of the stash (the tile's 16 x NP2
             // cells are contiguous in both)
             for (int i4 = lane; i4 < 16 * NP2_ / 4 && live; i4 += 64) {
@@ -644,7 +647,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
                     if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
                     if (my[base + O2W_] > best) { best = my[base + O2W_]; arg = 2; }
                     if (my[base + O2W_ + 1] > best) { best = my[base + O2W_ + 1]; arg = 3; }
-                    q[j] = act_fwd<ACT>(best);
+                    q[j] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
                     stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
                 }
                 const long long o = sn * F + (long long)hcb * NP2_ + 4 * i4;           // a multiple of 4
@@ -804,7 +807,6 @@ int rbnn_conv_forward_triple(const rbnn_conv_posterior* net, const void* K2_trip
                              int32_t S, int32_t out_kind, const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);
     if (rc) return rc;
-    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
     if (!K2_triple || !X || !ws || !ws->P || !ws->P1 || !ws->st1 || !ws->Q2 || !ws->st2) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || ldx < net->in_channels * net->in_width * net->in_width) return RBNN_ERR_SHAPE;
     if (k2_exp < -100 || k2_exp > 100 || p1_exp < -100 || p1_exp > 100) return RBNN_ERR_SHAPE;
@@ -821,8 +823,7 @@ int rbnn_conv_forward_triple(const rbnn_conv_posterior* net, const void* K2_trip
     return for_geometry(net, [&](auto g) {
         using G = decltype(g);
         a.NP2 = G::NP2;
-        if (net->activation == RBNN_ACT_RELU) return launch_conv_forward_x3<RBNN_ACT_RELU, G>(a, x, st);
-        return launch_conv_forward_x3<RBNN_ACT_LEAKY, G>(a, x, st);
+        return for_activation(net->activation, [&](auto act) { return launch_conv_forward_x3<decltype(act)::value, G>(a, x, st); });
     });
 }
 
@@ -1229,7 +1230,7 @@ __global__ void __launch_bounds__(256, 2) conv_bwd_split_kernel(const ConvBwdArg
 #ifndef RBNN_CONVBWD_X3_UNROLL
 #define RBNN_CONVBWD_X3_UNROLL 0      // 1: the 13-step loop fully unrolled (one basic block per chunk) — measured SLOWER: 18.1 -> 19.6 ms (1x28x28), 31.8 -> 38.2 (3x32x32)
 #endif
-template <class G> struct ConvBwdX3Lds {
+template <class G, bool SMOOTH = false> struct ConvBwdX3Lds {
     static constexpr int HCH = 16;
     static constexpr int IPB = (G::O2W + 8) * G::PITCH + 8;              // positions of a wave's padded image
     static constexpr int PLANE = IPB * HCH * 2;                           // bytes of one piece plane
@@ -1242,13 +1243,14 @@ template <class G> struct ConvBwdX3Lds {
 #ifndef RBNN_CONVBWD_X3_NWB_SMALL
 #define RBNN_CONVBWD_X3_NWB_SMALL 6
 #endif
-    static constexpr int NWB = G::NPT1 <= 9 ? RBNN_CONVBWD_X3_NWB_SMALL : 4;
+    static constexpr int NWB = (G::NPT1 <= 9 && !SMOOTH) ? RBNN_CONVBWD_X3_NWB_SMALL : 4;   // (sigmoid / tanh: their read-modify-write epilogue spills at 256 registers)
     static_assert(NWB * WAVE <= 160 * 1024, "LDS");
 };
 
 template <int ACT, class G>
-__global__ void __launch_bounds__(64 * ConvBwdX3Lds<G>::NWB, (ConvBwdX3Lds<G>::NWB + 3) / 4) conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp, float fw_l1) {
-    using L = ConvBwdX3Lds<G>;
+__global__ void __launch_bounds__((64 * ConvBwdX3Lds<G, smooth_act<ACT>()>::NWB), ((ConvBwdX3Lds<G, smooth_act<ACT>()>::NWB + 3) / 4))
+conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp, float fw_l1) {
+    using L = ConvBwdX3Lds<G, smooth_act<ACT>()>;
     constexpr int HCH = L::HCH, NPT = G::NPT1, PLANE = L::PLANE, NSTEP = 13, NFL = L::NFL, NWB = L::NWB;
     constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, PITCH = G::PITCH;
     static_assert(PITCH == P1W_ && PLANE % 16 == 0 && L::WAVE % 16 == 0, "shared-border image; 16-byte clears");
@@ -1351,7 +1353,8 @@ __global__ void __launch_bounds__(64 * ConvBwdX3Lds<G>::NWB, (ConvBwdX3Lds<G>::N
                     float v = 0.f;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (wok[g][q] && (st[j][q] & 3) == q) v += (st[j][q] & 4) ? dq[j][q] : dq[j][q] * slope;
+                        if (wok[g][q] && (st[j][q] & 3) == q)             // smooth activations: act' is already folded into dQ2
+                            v += (smooth_act<ACT>() || (st[j][q] & 4)) ? dq[j][q] : dq[j][q] * slope;
                     _Float16 e0, e1, e2;
                     conv_split3(v * in_scale, e0, e1, e2);
                     q0[h4 >> 3].v[(h4 & 4) + j] = e0; q1[h4 >> 3].v[(h4 & 4) + j] = e1; q2[h4 >> 3].v[(h4 & 4) + j] = e2;
@@ -1432,7 +1435,9 @@ __global__ void __launch_bounds__(64 * ConvBwdX3Lds<G>::NWB, (ConvBwdX3Lds<G>::N
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (16 * pt + li >= P1W_ * P1W_) continue;
-                a.dP1[sn * G::P1SZ + (16 * ct + 4 * lg + r) * (P1W_ * P1W_) + 16 * pt + li] = tot[ct][pt][r] * out_scale;
+                float* const dst = a.dP1 + sn * G::P1SZ + (16 * ct + 4 * lg + r) * (P1W_ * P1W_) + 16 * pt + li;
+                const float v = tot[ct][pt][r] * out_scale;              // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+                *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
             }
 }
 
@@ -1663,7 +1668,6 @@ extern "C" int rbnn_conv_input_grad_triple(const rbnn_conv_posterior* net, const
                                            const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);
     if (rc) return rc;
-    if (net->activation != RBNN_ACT_RELU && net->activation != RBNN_ACT_LEAKY) return RBNN_ERR_UNSUPPORTED;
     if (!K2_bwd || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
     if (!aligned16(K2_bwd) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
@@ -1673,14 +1677,14 @@ extern "C" int rbnn_conv_input_grad_triple(const rbnn_conv_posterior* net, const
     hipStream_t st = (hipStream_t)stream;
     return for_geometry(net, [&](auto g) {
         using G = decltype(g);
-        using L = ConvBwdX3Lds<G>;
         a.NP2 = G::NP2;
         return for_activation(net->activation, [&](auto actc) {
-            constexpr int ACT = (decltype(actc)::value == RBNN_ACT_RELU) ? RBNN_ACT_RELU : RBNN_ACT_LEAKY;   // sigmoid / tanh were refused above
+            constexpr int ACT = decltype(actc)::value;
+            using L = ConvBwdX3Lds<G, smooth_act<ACT>()>;
             int rc2;
             {
                 const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
-                hipLaunchKernelGGL((conv_fc_bwd_kernel<false, RBNN_ACT_LEAKY>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+                hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
                 if ((rc2 = launch_status())) return rc2;
             }
             constexpr int LDSB = L::NWB * L::WAVE;

@@ -90,8 +90,8 @@ class AttackEngine:
         # takes it wherever it applies and falls back to the fp32 MFMA ("exact") elsewhere.
         tri = bool(getattr(self.post, "triple_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)
         if want == "triple" and not tri:
-            raise _hip.HipError("precision='triple' covers fc / fc2 posteriors with hidden % 128 == 0 and classes <= 10, and the conv "
-                                "architecture with relu / leaky, on the GPU")
+            raise _hip.HipError("precision='triple' covers fc / fc2 posteriors with hidden % 128 == 0 and classes <= 10 and the conv "
+                                "architecture, on the GPU, for weight tensors of ordinary dynamic range (posterior.narrow_range)")
         if want == "triple" or (want == "auto" and tri):
             return "triple"
         ok = bool(getattr(self.post, "split_supported", lambda: False)()) and isinstance(self.k, _hip.HipKernels)

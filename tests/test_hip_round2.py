@@ -534,6 +534,8 @@ CONV_CASES = [  # act, shape, C, Hc, S, N, std, precision
     ("relu", (1, 28, 28), 10, 64, 3, 71, 0.05, "triple"), ("leaky", (1, 28, 28), 4, 272, 1, 9, 0.03, "triple"),
     ("leaky", (3, 32, 32), 10, 16, 2, 9, 0.05, "triple"), ("relu", (3, 32, 32), 10, 512, 2, 64, 0.02, "triple"),
     ("leaky", (3, 32, 32), 10, 272, 1, 5, 0.03, "triple"),
+    ("sigm", (1, 28, 28), 10, 32, 2, 21, 0.05, "triple"), ("tanh", (1, 28, 28), 10, 64, 3, 33, 0.05, "triple"),
+    ("tanh", (3, 32, 32), 7, 32, 2, 18, 0.05, "triple"), ("sigm", (3, 32, 32), 10, 16, 1, 4, 0.05, "triple"),
 ]
 
 
@@ -589,7 +591,7 @@ def test_conv_golden_smooth_activations(golden, name):
     fixtures through the reference's call surface."""
     from robustbnns_amd import adversarialAttacks as A, _hip
     g = golden(name); m = g.meta; bnn = _bnn(g); x, y = g.t("x"), g.t("y")
-    assert type(bnn._engine).__name__ == "ConvEngine" and bnn._engine.precision == "exact"
+    assert type(bnn._engine).__name__ == "ConvEngine" and bnn._engine.precision == "triple"      # auto: the triple conv2 kernels cover sigmoid / tanh too
     assert rel_err(bnn.forward(x.to(DEV), n_samples=m["S"]).cpu(), g.t("forward_probs")) < TOL
     assert rel_err(bnn.forward(x.to(DEV), n_samples=1).cpu(), g.t("forward_probs_s1")) < TOL
     eng = bnn._engine

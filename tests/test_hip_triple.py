@@ -191,8 +191,11 @@ def test_triple_is_refused_where_it_does_not_apply():
         AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), 10, 64, post, DEV), precision="triple")
     from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
     cpost = O.synthetic_posterior("conv", 784, 16, 10, 1, 0.05, in_ch=1, head=49 * 16)
+    cpost["model.3.weight"][0, 1, 2, 3, 4] = 1.0e4                                        # wild dynamic range -> fp32 MFMA
+    csp = ConvStackedPosterior("leaky", (1, 28, 28), 10, 16, cpost, DEV)
+    assert not csp.triple_supported() and ConvEngine(csp).precision == "exact"
     with pytest.raises(_hip.HipError):
-        ConvEngine(ConvStackedPosterior("tanh", (1, 28, 28), 10, 16, cpost, DEV), precision="triple")
+        ConvEngine(csp, precision="triple")
 
 
 # ------------------------------------------------------------------ golden fixtures through the reference's call surface
