@@ -318,6 +318,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         }
         const int hw0 = hc0 + (wave_h * HTW) * 16;
         unsigned mine[NTW];
+        unsigned keep[LAYER2 ? 1 : NTW][6];                    // fc2 layer 1: the even tile's pieces, until the odd tile completes the stage
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) mine[nt] = 0u;
 #pragma unroll
@@ -353,24 +354,33 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
                 } else {
-                    // the three pieces of the lane's four units = 8 bytes per plane; lanes lg (even) and lg + 1 hold the two halves of a
-                    // 16-byte chunk: swap so that the even lane stores the whole p0 and p2 chunks and the odd lane the whole p1 chunk
+                    // the three pieces of the lane's four units = 8 bytes per plane.  A 16-unit tile is HALF of a 32-unit stage of the
+                    // image row (192 B = [piece][32 units]): the even tile's pieces wait in registers for the odd tile, then both go through a
+                    // per-wave 3-KiB LDS tile (16 points x 192 B, in the stage buffer every wave has left) and out as WHOLE 192-byte runs,
+                    // consecutive lanes on consecutive 16-byte chunks (the direct store wrote 16-byte fragments at a 3-KB stride: layer 1
+                    // took 5.8 ms against 3.5 for the same GEMM without the image)
                     union { _Float16 h[4]; unsigned w[2]; } q0, q1, q2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) split3(hv[r] * hid_scale, q0.h[r], q1.h[r], q2.h[r]);
-                    const bool odd = lg & 1;
-                    const unsigned s0 = odd ? q0.w[0] : q1.w[0], s1 = odd ? q0.w[1] : q1.w[1];
-                    const unsigned r0 = __shfl_xor(s0, 16), r1 = __shfl_xor(s1, 16);      // even gets the partner's p0, odd the partner's p1
-                    const unsigned t0 = __shfl_xor(q2.w[0], 16), t1 = __shfl_xor(q2.w[1], 16);
-                    if (n < a.N) {
-                        // row n of sample s: stage hrow / 32 = 192 B = [plane][4 chunks of 16 B]; this pair's chunk = (hrow % 32) / 8
-                        char* const row = a.hid + ((long long)s * a.N + n) * a.H * 6 + (hrow >> 5) * 192 + ((hrow & 31) >> 3) * 16;
-                        if (!odd) {
-                            *(uint4*)(row) = make_uint4(q0.w[0], q0.w[1], r0, r1);
-                            *(uint4*)(row + 128) = make_uint4(q2.w[0], q2.w[1], t0, t1);
-                        } else {
-                            *(uint4*)(row + 64) = make_uint4(r0, r1, q1.w[0], q1.w[1]);
+                    if (!(ht & 1)) {
+                        keep[nt][0] = q0.w[0]; keep[nt][1] = q0.w[1]; keep[nt][2] = q1.w[0]; keep[nt][3] = q1.w[1]; keep[nt][4] = q2.w[0]; keep[nt][5] = q2.w[1];
+                    } else {
+                        char* const scr = ldsb + buf * TILEB + wave * 3072;
+                        char* const mine_row = scr + li * 192 + (lg >> 1) * 16 + (lg & 1) * 8;      // tile 0: chunks 0, 1 of each piece; tile 1: chunks 2, 3
+                        asm volatile("" ::: "memory");
+                        *(uint2*)(mine_row) = make_uint2(keep[nt][0], keep[nt][1]);        *(uint2*)(mine_row + 32) = make_uint2(q0.w[0], q0.w[1]);
+                        *(uint2*)(mine_row + 64) = make_uint2(keep[nt][2], keep[nt][3]);   *(uint2*)(mine_row + 96) = make_uint2(q1.w[0], q1.w[1]);
+                        *(uint2*)(mine_row + 128) = make_uint2(keep[nt][4], keep[nt][5]);  *(uint2*)(mine_row + 160) = make_uint2(q2.w[0], q2.w[1]);
+                        asm volatile("" ::: "memory");
+                        const int nrow0 = n0 + (wave_n * NTW + nt) * 16;
+                        char* const img = a.hid + ((long long)s * a.N) * a.H * 6 + ((hrow - 16) >> 5) * 192;   // stage of this tile pair
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int q = lane + 64 * k, rr = q / 12, cc = q - 12 * rr;        // 16-byte chunk q of the 3-KiB tile: row rr, chunk cc
+                            const uint4 v = *(const uint4*)(scr + q * 16);
+                            if (nrow0 + rr < a.N) *(uint4*)(img + (long long)(nrow0 + rr) * a.H * 6 + cc * 16) = v;
                         }
+                        asm volatile("" ::: "memory");
                     }
                 }
             }
@@ -382,6 +392,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                 if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * HW + (hw0 >> 5) + lg) * mask_ld(a.N) + n] = mine[nt];
             }
         }
+        if (!LAYER2) __syncthreads();                          // the image staging tiles live in the stage buffer that the next stage's DMA refills
     }
     if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
