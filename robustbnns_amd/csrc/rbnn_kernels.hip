@@ -22,6 +22,9 @@
 // The k <-> memory-index map of a K step is free as long as A and B agree; both kernels use
 // "step r of a 16-wide k block: k = lg  <->  index 4*lg + r", so one 16-byte load feeds four K steps.
 #include "rbnn_common.hpp"
+#ifndef RBNN_FWD_SB
+#define RBNN_FWD_SB 8                                          // forward: samples per XCD-resident panel of blocks
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -75,9 +78,10 @@ __global__ void __launch_bounds__(64 * WH * WN, (HTW * NTW > 16 ? 2 : (WH * WN) 
 #ifndef RBNN_FWD_ITEM_1D
     int ntile, s;
     {
-        const int full = a.S / 8, per = 8 * a.NT;
-        if (id < full * per) { ntile = (id % per) / 8; s = (id / per) * 8 + id % 8; }
-        else { const int rem = id - full * per, cnt = a.S - full * 8; ntile = rem / cnt; s = full * 8 + rem % cnt; }
+        constexpr int SB = RBNN_FWD_SB;
+        const int full = a.S / SB, per = SB * a.NT;
+        if (id < full * per) { ntile = (id % per) / SB; s = (id / per) * SB + id % SB; }
+        else { const int rem = id - full * per, cnt = a.S - full * SB; ntile = rem / cnt; s = full * SB + rem % cnt; }
     }
 #else
     const int ntile = id % a.NT, s = id / a.NT;
