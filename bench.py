@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — attack-samples/s of the Bayesian attack hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 50 --warmup 5
     python bench.py --gpus N ...           # N > 1 without a torchrun environment: spawns the N ranks itself (child process)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -182,8 +182,8 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)         # C2: 50 x 7.4 ms = 0.37 s timed (the f16-pipe kernels vary by a few % launch to launch)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--shard", default="samples", choices=["samples", "points"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
