@@ -831,6 +831,15 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     }
     if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
+    if (RBNN_ABL & 8) {                                        // diagnostic: keep the accumulators live, skip the epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int dt = 0; dt < TD; ++dt) t += acc[nt][dt][0] + acc[nt][dt][1] + acc[nt][dt][2] + acc[nt][dt][3];
+        if (t == 12345.678f) a.out[tid] = t;
+        return;
+    }
     // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li], un-scaled per point ----
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
