@@ -385,6 +385,18 @@ def test_svi_loss_gradients_are_seeded_and_nested(rng):
     w2 = bnn.draw_posterior(2, [0, 1])
     w1 = bnn.draw_posterior(1, [0])
     assert torch.equal(w2.W1[:1], w1.W1) and torch.equal(w2.W2[:1], w1.W2)
+    # a seeded draw is a pure function of (seeds, guide): the last one is kept (weights, images, workspaces) and reused batch after batch;
+    # other seeds, no seeds (live RNG) or an edited guide draw again
+    e_a = bnn.hot_path(3, seeds=[4, 5, 6])[0]
+    assert bnn.hot_path(3, seeds=[4, 5, 6])[0] is e_a
+    p_a = bnn.forward(x.to(DEV), n_samples=3, seeds=[4, 5, 6])
+    assert torch.equal(p_a, bnn.forward(x.to(DEV), n_samples=3, seeds=[4, 5, 6]))
+    assert bnn.hot_path(3, seeds=[4, 5, 7])[0] is not e_a
+    assert bnn.hot_path(3)[0] is not bnn.hot_path(3)[0]
+    e_b = bnn.hot_path(3, seeds=[4, 5, 6])[0]
+    next(iter(bnn.svi_loc.values())).mul_(1.0001)                           # in-place edit of the guide: version bump -> redrawn
+    e_c = bnn.hot_path(3, seeds=[4, 5, 6])[0]
+    assert e_c is not e_b and not torch.equal(e_c.post.W1, e_b.post.W1)
 
 
 def test_pyro_param_store_file_on_gpu(tmp_path):
