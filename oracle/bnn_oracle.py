@@ -264,6 +264,16 @@ def pgd_params(x, hyperparams):
     return 0.5, torch.full((x.shape[0],) + (1,) * (x.dim() - 1), 2 / 225, dtype=x.dtype), 40
 
 
+def pgd_step(xi, x0, label, post, arch, act, n_samples, epsilon, alpha, kind="bnn"):
+    """ONE iteration of adversarialAttacks.py:95-105 from the iterate xi towards the eps-ball around x0 (alpha: per-image
+    [N,1,..] tensor or a float), in the reference's fp32 operation order."""
+    g = meanprob_gradients(xi, label, post, arch, act, n_samples, kind)
+    a = alpha.to(xi.dtype) if torch.is_tensor(alpha) else alpha
+    pert = xi + a * g.sign()
+    eta = torch.clamp(pert - x0, min=-epsilon, max=epsilon)
+    return torch.clamp(x0 + eta, min=0, max=1)
+
+
 def pgd_attack(x, label, post, arch, act, n_samples, hyperparams=None, kind="bnn", iters=None):
     """adversarialAttacks.py:86-108, all points at once."""
     epsilon, alpha, it = pgd_params(x, hyperparams)
@@ -271,10 +281,7 @@ def pgd_attack(x, label, post, arch, act, n_samples, hyperparams=None, kind="bnn
     x0 = x.clone()
     xi = x.clone()
     for _ in range(it):
-        g = meanprob_gradients(xi, label, post, arch, act, n_samples, kind)
-        pert = xi + alpha.to(xi.dtype) * g.sign()
-        eta = torch.clamp(pert - x0, min=-epsilon, max=epsilon)
-        xi = torch.clamp(x0 + eta, min=0, max=1)
+        xi = pgd_step(xi, x0, label, post, arch, act, n_samples, epsilon, alpha, kind)
     return xi
 
 

@@ -77,7 +77,9 @@ def fgsm_attack(net, image, label, hyperparams=None, n_samples=None, avg_posteri
     if image.is_leaf:
         image.requires_grad = True                         # the reference's visible side effect (:73)
     eng, S, seeds, mode = _hot_path(net, n_samples, avg_posterior)
-    return eng.fgsm(image, label, S, epsilon, seeds=seeds, mode=mode).to(image.device)
+    # the reference's result is image + eps * grad.sign() with image.requires_grad set (:81-82): a tensor that requires grad, and that is
+    # how attack() pickles it (:140-141; tests/golden/files/TESTS/attacks/*.pkl) — pgd_attack's is detached (:105)
+    return eng.fgsm(image, label, S, epsilon, seeds=seeds, mode=mode).to(image.device).requires_grad_(True)
 
 
 def pgd_attack(net, image, label, hyperparams=None, n_samples=None, avg_posterior=False):

@@ -227,10 +227,10 @@ class StackedPosterior:
         """Sample i as an unpadded CPU state_dict with the reference's keys (model_nn.py:77-91)."""
         keys = LAYER_KEYS[self.arch]
         H, D = self.H, self.D
-        sd = {keys[0] + ".weight": self.W1[i, :H, :D], keys[0] + ".bias": self.b1[i, :H],
-              keys[-1] + ".weight": self.W2[i, :, :H], keys[-1] + ".bias": self.b2[i]}
+        sd = {keys[0] + ".weight": self.W1[i, :H, :D], keys[0] + ".bias": self.b1[i, :H]}
         if self.arch == "fc2":
             sd[keys[1] + ".weight"], sd[keys[1] + ".bias"] = self.Wm[i, :H, :H], self.bm[i, :H]
+        sd[keys[-1] + ".weight"], sd[keys[-1] + ".bias"] = self.W2[i, :, :H], self.b2[i]      # network order, as NN.state_dict() lists them
         return {k: v.detach().cpu().clone() for k, v in sd.items()}
 
     def nbytes(self):

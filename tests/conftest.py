@@ -81,3 +81,42 @@ def rel_err(a, b):
     b = torch.as_tensor(b, dtype=torch.float64).reshape(b.shape[0], -1)
     den = b.abs().max(dim=1)[0].clamp_min(1e-300)
     return float(((a - b).abs().max(dim=1)[0] / den).max())
+
+
+def rel_err_points(a, b, den=None):
+    """per-point max |a-b| / max |den| (den defaults to b)."""
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(a.shape[0], -1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(b.shape[0], -1)
+    d = b if den is None else torch.as_tensor(den, dtype=torch.float64).reshape(b.shape[0], -1)
+    return (a - b).abs().max(dim=1)[0] / d.abs().max(dim=1)[0].clamp_min(1e-300)
+
+
+def saturation_noise(x, post, arch, act, n_samples, kind="bnn"):
+    """Per-point fp32 noise floor of the softmax backward for a posterior that classifies confidently.  The backward of a softmax is
+    p * (G - <G, p>): with one class at p = 1 - d the bracket cancels to O(d) while its terms are O(1), so ANY fp32 evaluation (the
+    reference's autograd included) carries a relative error ~ 2^-24 / d on that sample's gradient; a sample's gradient is itself
+    O(d), so over the samples the floor is 2^-24 / mean_s(1 - max_c p_s[c]).  Computed from the fp64 oracle."""
+    from oracle import bnn_oracle as O
+    post64 = O.cast(post, torch.float64)
+    xd = x.double()
+    if kind == "bnn":
+        d = torch.stack([1 - torch.softmax(O.nn_logits(xd, O.select(post64, [s]), arch, act)[0], -1).max(-1)[0] for s in range(n_samples)]).mean(0)
+    else:
+        d = 1 - torch.softmax(O.ensemble_forward(xd, post64, arch, act, n_samples), -1).max(-1)[0]
+    return 2.0 ** -24 / d.clamp_min(1e-300)
+
+
+def assert_close_to_reference(val, ref, truth64, tol=1e-5, noise=None, what=""):
+    """`val` within `tol` of the reference's fp32 result, per point, relative to the point's largest component — except at points where
+    fp32 arithmetic itself is ill-conditioned: where the reference's own result is further than tol/2 from the fp64 evaluation
+    `truth64` of the same formula, or where the saturation noise floor (saturation_noise) exceeds tol/2; there no fp32 evaluation in
+    another operation order can be asked to land nearer, and the bound is twice that distance / floor.  Returns the number of points
+    that needed the relaxed bound."""
+    e_ref = rel_err_points(ref, truth64, den=truth64)
+    e_val = rel_err_points(val, ref, den=truth64)
+    bound = torch.maximum(torch.full_like(e_ref, tol), 2 * e_ref)
+    if noise is not None:
+        bound = torch.maximum(bound, 2 * noise.to(bound))
+    bad = e_val > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())} points beyond the bound, worst {float((e_val / bound).max()):.2f}x at point {int((e_val / bound).argmax())}"
+    return int((bound > tol).sum())
