@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 5
+#define RBNN_ABI_VERSION 6
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {
@@ -417,6 +417,33 @@ int rbnn_fc_forward_triple(const rbnn_posterior *net, const rbnn_triple_images *
 int rbnn_fc_input_grad_triple(const rbnn_posterior *net, const rbnn_triple_images *tp, const int32_t *sample_idx,
                               int32_t n_samples, int32_t n_points, int32_t chunk, const rbnn_workspace *ws,
                               const rbnn_triple_workspace *tws, int32_t *n_slabs_out, void *stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The SVI guide's draw written IN PLACE into a stacked posterior and all of its weight images, one launch, no eps tensor.
+ * Replaces the per-forward pyro.random_module(basenet, Normal(loc, softplus(scale)))() of model_bnn.py:121-136 called S times per
+ * prediction (:222-232): W[s] = loc + softplus(scale_raw) * eps(s) for every tensor of the net, eps = Box-Muller of
+ * Philox4x32-10(counter = (element quad, tensor id, s or 0, draw_id), key = sample_keys[s] or key).  PARITY UNPINNED against
+ * pyro-ppl 1.3.0's RNG stream (the package is not available to check it against).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct rbnn_svi_guide {    /* device pointers to the variational parameters, UNPADDED row-major as the param store holds them */
+    const float *W1_loc, *W1_scale;   /* model.1.weight_loc / _scale  [hidden, in_features]  (raw scale: softplus is applied here)   */
+    const float *b1_loc, *b1_scale;   /* model.1.bias                  [hidden]                                                      */
+    const float *Wm_loc, *Wm_scale;   /* fc2: model.3.weight           [hidden, hidden]                                              */
+    const float *bm_loc, *bm_scale;   /* fc2: model.3.bias             [hidden]                                                      */
+    const float *W2_loc, *W2_scale;   /* output layer weight           [n_classes, hidden]                                           */
+    const float *b2_loc, *b2_scale;   /* output layer bias             [n_classes]                                                   */
+    int32_t hidden;                   /* the net's own hidden size (<= net->hidden: 16 is stored padded to 32, padding stays zero)   */
+    int32_t reserved;
+} rbnn_svi_guide;
+
+/* Writes samples [0, n_samples) of `net`: W1 b1 (Wm bm) W2 b2 — the pointers are const in rbnn_posterior because every other entry
+ * point only reads them; this one writes through them — plus W1_pack4 / Wm_pack4 when non-NULL, plus, when `tp` is non-NULL, the
+ * triple images W1_rows, W1_cols, W2_gen (Wm_rows, Wm_cols) at the scales tp->w1_exp / w2_exp / wm_exp, which the caller fixes per
+ * guide from the bound |w| <= |loc| + RBNN_SVI_EPS_MAX * softplus(scale).  sample_keys: device array of n_samples 64-bit keys (one
+ * seed per sample: model_bnn.py:222-226) or NULL (all samples under `key`, the sample index in the counter).  Asynchronous on `stream`. */
+#define RBNN_SVI_EPS_MAX 6.77f
+int rbnn_svi_draw(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
+                  const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,13 @@ class TripleImages(C.Structure):
                 ("h1_exp", C.c_int32)]
 
 
+class SviGuide(C.Structure):
+    _fields_ = [(k + sfx, _fp) for k in ("W1", "b1", "Wm", "bm", "W2", "b2") for sfx in ("_loc", "_scale")] + \
+               [("hidden", C.c_int32), ("reserved", C.c_int32)]
+
+
+SVI_EPS_MAX = 6.77                                                     # RBNN_SVI_EPS_MAX: Box-Muller on a 32-bit uniform cannot exceed it
+
 TRIPLE_WS_KEYS = ("X_triple", "dZ_gen", "g_scale", "hid_triple")
 
 
@@ -135,6 +142,7 @@ SIGNATURES = {
     "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(TripleWorkspace), _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
     "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(TripleWorkspace),
                                          C.POINTER(_i32), _fp]),
+    "rbnn_svi_draw": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
 }
 
 _lib = None
@@ -155,7 +163,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 5:
+        if lib.rbnn_abi_version() != 6:
             raise HipError("librbnn_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -407,3 +415,11 @@ class HipKernels:
         require_gpu(loc, "loc")
         check(self.lib.rbnn_svi_materialize(ptr(loc), ptr(scale_raw), ptr(eps), loc.numel(), eps.shape[0], ptr(out),
                                             stream_of(loc)), "rbnn_svi_materialize")
+
+    def svi_draw(self, net, images, guide, S, key, draw_id, sample_keys=None):
+        """One launch: samples [0, S) of the stacked posterior `net` and all its weight images redrawn IN PLACE from the guide
+        (robustbnns_amd.posterior.SviGuide).  images: the posterior's TripleImages or None.  sample_keys: int64 device tensor [S]."""
+        require_gpu(net.W1, "W1")
+        check(self.lib.rbnn_svi_draw(C.byref(net.descriptor()), None if images is None else C.byref(images), C.byref(guide.descriptor()), S,
+                                     ptr(sample_keys), C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF),
+                                     stream_of(net.W1)), "rbnn_svi_draw")

@@ -92,6 +92,10 @@ def pgd_attack(net, image, label, hyperparams=None, n_samples=None, avg_posterio
     # "iters" entry of hyperparams is the build-side parameter for that (absent -> 40, the reference's behaviour)
     iters = int(hyperparams.get("iters", PGD_ITERS)) if hyperparams is not None else PGD_ITERS
     if _redraw(net, n_samples, avg_posterior):
+        if net._in_place():                               # fc / fc2: one resident stack, redrawn in place before every iteration
+            eng, S, seeds, mode = _hot_path(net, n_samples, avg_posterior)
+            return eng.pgd(image, label, S, epsilon, alpha=alpha, iters=iters, mode=mode,
+                           before_step=lambda: net.redraw(n_samples)).to(image.device)
         x0, x = image.detach(), image.detach()
         for _ in range(iters):
             eng, S, seeds, mode = _hot_path(net, n_samples, avg_posterior)

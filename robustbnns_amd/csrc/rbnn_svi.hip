@@ -1,0 +1,279 @@
+// rbnn_svi.hip — the SVI guide's weight draw (model_bnn.py:121-136, :222-232) as ONE kernel that writes a whole stacked posterior
+// IN PLACE: W = loc + softplus(scale) * eps with eps generated in registers (Philox4x32-10 + Box-Muller — no eps tensor in HBM),
+// stored as the fp32 stack AND, in the same pass, as every image the two GEMM modes read:
+//
+//      fp32 stack        W1 [S,H,D_pad]  b1  (Wm bm)  W2 [S,C,H]  b2        what rbnn_fc_forward reads
+//      rbnn_pack_rows4   W1_pack4 / Wm_pack4 [S,H/4,cols,4]                  the fp32-MFMA backward's B operand
+//      triple rows       W1_rows / Wm_rows  [S*H, ld/32, 3, 32] halves       rbnn_fc_forward_triple's A operand
+//      triple cols       W1_cols / Wm_cols  [S,H/32,4,3,ld,8] halves         rbnn_fc_input_grad_triple's B operand
+//      W2 generator      W2_gen [S,H/16,2,64,8] halves                       its dA generator
+//
+// The reference draws one net per forward call (pyro.random_module over Normal(loc, softplus(scale)), S calls per prediction); here a
+// redraw of all S samples is one launch into buffers whose addresses never change, so the posterior descriptor, the engine and its
+// workspaces are reused draw after draw (an SVI PGD attack redraws every iteration: adversarialAttacks.py:95-97 -> model_bnn.py:230-232).
+//
+// eps is a pure function of (key, draw id, tensor, sample, element): the same (key, draw) gives the same weights whatever the tiling.
+// PARITY UNPINNED against pyro-ppl 1.3.0's RNG stream (absent here: SURVEY 8c) — the oracle restates THIS generator.
+// The images' power-of-two scales are host integers fixed per guide from the a-priori bound |w| <= |loc| + 6.77 softplus(scale)
+// (Box-Muller on a 32-bit uniform cannot exceed sqrt(-2 ln 2^-33) = 6.764): no abs-max pass, no device->host sync per draw.
+#include "rbnn_common.hpp"
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four standard normals from one Philox block: Box-Muller on (x0, x1) and (x2, x3); u = (x + 0.5) 2^-32 in (0, 1)
+__device__ __forceinline__ void normal4(const uint32_t x[4], float n[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)x[2 * p] + 0.5f) * 2.3283064365386963e-10f;       // fp32: x + 0.5 rounds for x >= 2^24, still in (0, 1]
+        const float u2 = ((float)x[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
+        const float r = sqrtf(-2.f * logf(fminf(u1, 0.99999994f)));
+        float sn, cs;
+        sincospif(2.f * u2, &sn, &cs);
+        n[2 * p] = r * cs; n[2 * p + 1] = r * sn;
+    }
+}
+
+__device__ __forceinline__ float softplus(float sr) { return sr > 20.f ? sr : log1pf(expf(sr)); }   // torch.nn.Softplus(beta=1, threshold=20), model_bnn.py:18
+
+// p0 + p1 + p2 = v exactly (rbnn_triple.hip's split3, plain C: the image builders are not instruction-issue bound)
+__device__ __forceinline__ void split3(float v, _Float16& a, _Float16& b, _Float16& c) {
+    a = (_Float16)v;
+    const float r1 = v - (float)a;
+    b = (_Float16)r1;
+    c = (_Float16)(r1 - (float)b);
+}
+
+struct DrawArgs {
+    rbnn_posterior net;
+    rbnn_triple_images tp;
+    rbnn_svi_guide g;
+    const unsigned long long* sample_keys;
+    unsigned long long key;
+    uint32_t draw_id;
+    int S, has_tp, tiles_w1_d, tiles_wm_d, tiles_per_sample;
+    float w1_scale, wm_scale, w2_scale;
+};
+
+enum { T_W1 = 0, T_B1 = 1, T_WM = 2, T_BM = 3, T_W2 = 4, T_B2 = 5 };
+
+struct Rng {
+    uint32_t k0, k1, c2, c3;
+    __device__ __forceinline__ void quad(int tensor, uint32_t q, float n[4]) const {
+        uint32_t x[4];
+        philox4x32_10(q, (uint32_t)tensor, c2, c3, k0, k1, x);
+        normal4(x, n);
+    }
+};
+
+// one weight of a [rows, cols] row-major guide tensor (quad index = r * ceil(cols/4) + c/4: eps does not depend on the padding)
+__device__ __forceinline__ void draw_quad(const Rng& rng, int tensor, const float* loc, const float* scl, int r, int c4, int cols, float w[4]) {
+    const int Q = (cols + 3) >> 2;
+    float n[4];
+    rng.quad(tensor, (uint32_t)(r * Q + c4), n);
+    const long long base = (long long)r * cols + 4 * c4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = 4 * c4 + j < cols;
+        w[j] = in ? loc[base + j] + softplus(scl[base + j]) * n[j] : 0.f;          // Normal.rsample(): loc + eps * scale (model_bnn.py:127-130)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// A [H, cols] matrix tile of 32 hidden units x 64 columns of sample s: drawn into LDS, then written in every layout.
+// ---------------------------------------------------------------------------------------------------
+__device__ void draw_matrix_tile(const DrawArgs& a, const Rng& rng, int tensor, int s, int hb, int dt, const float* loc, const float* scl,
+                                 int H0, int cols, float* W, int ldw, float* pack4, uint4* rows_img, int ld_rows, uint4* cols_img, int ld_cols,
+                                 float img_scale, float (*tile)[68]) {
+    const int H = a.net.hidden, t = threadIdx.x, d0 = 64 * dt;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = t + 256 * i, hl = q >> 4, dq = q & 15;
+        const int h = 32 * hb + hl, c4 = (d0 >> 2) + dq;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (h < H0 && 4 * c4 < cols) draw_quad(rng, tensor, loc, scl, h, c4, cols, w);
+        *(f32x4*)&tile[hl][4 * dq] = (f32x4){w[0], w[1], w[2], w[3]};
+    }
+    __syncthreads();
+    // (1) fp32 stack [S][H][ldw] and (2) its pack_rows4 image [S][H/4][ldw][4]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = t + 256 * i, hl = q >> 4, dq = q & 15, d = d0 + 4 * dq;
+        if (d < ldw) *(f32x4*)(W + ((long long)s * H + 32 * hb + hl) * ldw + d) = *(const f32x4*)&tile[hl][4 * dq];
+    }
+    if (pack4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = t + 256 * i, hq = q >> 6, dl = q & 63, d = d0 + dl;
+            if (d < ldw)
+                *(f32x4*)(pack4 + (((long long)s * (H / 4) + 8 * hb + hq) * ldw + d) * 4) =
+                    (f32x4){tile[4 * hq][dl], tile[4 * hq + 1][dl], tile[4 * hq + 2][dl], tile[4 * hq + 3][dl]};
+        }
+    }
+    if (rows_img) {
+        // (3) triple rows: row r = s*H + h, stage k of 32 columns = 12 units of 16 B: [plane][4 groups of 8 columns]
+        const int hl = t >> 3, g = t & 7, d = d0 + 8 * g;
+        if (d < ld_rows) {
+            union { f16x8 v; uint4 u; } o[3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 p0, p1, p2;
+                split3(tile[hl][8 * g + j] * img_scale, p0, p1, p2);
+                o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
+            }
+            const long long r = (long long)s * H + 32 * hb + hl;
+            uint4* const out = rows_img + (r * (ld_rows >> 5) + (d >> 5)) * 12 + ((d >> 3) & 3);
+            out[0] = o[0].u; out[4] = o[1].u; out[8] = o[2].u;
+        }
+        // (4) triple cols: out[s][hb][lg][p][d][j] = piece p of W[32 hb + 16 (j>>2) + 4 lg + (j&3)][d]
+        const int lg = t >> 6, dl = t & 63, dc = d0 + dl;
+        if (dc < ld_cols) {
+            union { f16x8 v; uint4 u; } o[3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 p0, p1, p2;
+                split3(tile[16 * (j >> 2) + 4 * lg + (j & 3)][dl] * img_scale, p0, p1, p2);
+                o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
+            }
+            const long long base = ((((long long)s * (H / 32) + hb) * 4 + lg) * 3) * ld_cols;
+            cols_img[base + dc] = o[0].u;
+            cols_img[base + ld_cols + dc] = o[1].u;
+            cols_img[base + 2LL * ld_cols + dc] = o[2].u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The small tensors of sample s: b1, (bm), b2, and the output layer W2 [C, H] + its dA-generator image.
+// ---------------------------------------------------------------------------------------------------
+__device__ void draw_small(const DrawArgs& a, const Rng& rng, int s, float* w2l /* [C][H] dynamic LDS */) {
+    const int H = a.net.hidden, H0 = a.g.hidden, C = a.net.n_classes, t = threadIdx.x;
+    float* const b1 = const_cast<float*>(a.net.b1) + (long long)s * H;
+    for (int q = t; 4 * q < H; q += 256) {
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (4 * q < H0) draw_quad(rng, T_B1, a.g.b1_loc, a.g.b1_scale, 0, q, H0, w);
+        *(f32x4*)(b1 + 4 * q) = (f32x4){w[0], w[1], w[2], w[3]};
+    }
+    if (a.net.arch == RBNN_ARCH_FC2) {
+        float* const bm = const_cast<float*>(a.net.bm) + (long long)s * H;
+        for (int q = t; 4 * q < H; q += 256) {
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (4 * q < H0) draw_quad(rng, T_BM, a.g.bm_loc, a.g.bm_scale, 0, q, H0, w);
+            *(f32x4*)(bm + 4 * q) = (f32x4){w[0], w[1], w[2], w[3]};
+        }
+    }
+    if (t < (C + 3) / 4) {
+        float w[4];
+        draw_quad(rng, T_B2, a.g.b2_loc, a.g.b2_scale, 0, t, C, w);
+        float* const b2 = const_cast<float*>(a.net.b2) + (long long)s * C;
+        for (int j = 0; j < 4; ++j)
+            if (4 * t + j < C) b2[4 * t + j] = w[j];
+    }
+    float* const W2 = const_cast<float*>(a.net.W2) + (long long)s * C * H;
+    const int Q = H / 4;
+    for (int i = t; i < C * Q; i += 256) {
+        const int c = i / Q, q = i % Q;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (4 * q < H0) draw_quad(rng, T_W2, a.g.W2_loc, a.g.W2_scale, c, q, H0, w);
+        *(f32x4*)(W2 + (long long)c * H + 4 * q) = (f32x4){w[0], w[1], w[2], w[3]};
+        *(f32x4*)(w2l + c * H + 4 * q) = (f32x4){w[0], w[1], w[2], w[3]};
+    }
+    if (!a.has_tp) return;
+    __syncthreads();
+    // W2 generator image (rbnn_triple.hip triple_w2gen_kernel's slot plan): out[s][tile][k][lane][8]
+    uint4* const gen = (uint4*)const_cast<void*>(a.tp.W2_gen) + (long long)s * (H / 16) * 128;
+    for (int i = t; i < (H / 16) * 128; i += 256) {
+        const int lane = i & 63, li = lane & 15, lg = lane >> 4, k = (i >> 6) & 1, tl = i >> 7;
+        _Float16 w[3][10];
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const float v = (c < C) ? w2l[c * H + 16 * tl + li] * a.w2_scale : 0.f;
+            split3(v, w[0][c], w[1][c], w[2][c]);
+        }
+        union { f16x8 v; uint4 u; } o;
+        const _Float16 z = (_Float16)0.f;
+        if (lg < 3) {
+            const int piece = (k == 0) ? (lg == 2 ? 1 : 0) : (lg == 0 ? 1 : (lg == 1 ? 0 : 2));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] = piece == 0 ? w[0][j] : (piece == 1 ? w[1][j] : w[2][j]);
+        } else if (k == 0) {
+            o.v[0] = w[0][8]; o.v[1] = w[0][9]; o.v[2] = w[0][8]; o.v[3] = w[0][9];
+            o.v[4] = w[0][8]; o.v[5] = w[0][9]; o.v[6] = w[1][8]; o.v[7] = w[1][9];
+        } else {
+            o.v[0] = w[2][8]; o.v[1] = w[2][9]; o.v[2] = w[1][8]; o.v[3] = w[1][9];
+            o.v[4] = z; o.v[5] = z; o.v[6] = z; o.v[7] = z;
+        }
+        gen[i] = o.u;
+    }
+}
+
+__global__ void __launch_bounds__(256) svi_draw_kernel(const DrawArgs a) {
+    extern __shared__ float dyn_lds[];
+    const int s = blockIdx.x / a.tiles_per_sample, j = blockIdx.x % a.tiles_per_sample;
+    const unsigned long long key = a.sample_keys ? a.sample_keys[s] : a.key;
+    const Rng rng = {(uint32_t)key, (uint32_t)(key >> 32), a.sample_keys ? 0u : (uint32_t)s, a.draw_id};
+    const int H = a.net.hidden;
+    const int n_w1 = (H / 32) * a.tiles_w1_d, n_wm = (H / 32) * a.tiles_wm_d;
+    float (*tile)[68] = (float (*)[68])dyn_lds;
+    if (j < n_w1) {
+        draw_matrix_tile(a, rng, T_W1, s, j / a.tiles_w1_d, j % a.tiles_w1_d, a.g.W1_loc, a.g.W1_scale, a.g.hidden, a.net.in_features,
+                         const_cast<float*>(a.net.W1), a.net.in_stride, const_cast<float*>(a.net.W1_pack4),
+                         a.has_tp ? (uint4*)const_cast<void*>(a.tp.W1_rows) : nullptr, a.tp.ld_rows,
+                         a.has_tp ? (uint4*)const_cast<void*>(a.tp.W1_cols) : nullptr, a.tp.ld_cols, a.w1_scale, tile);
+    } else if (j < n_w1 + n_wm) {
+        const int jj = j - n_w1;
+        draw_matrix_tile(a, rng, T_WM, s, jj / a.tiles_wm_d, jj % a.tiles_wm_d, a.g.Wm_loc, a.g.Wm_scale, a.g.hidden, a.g.hidden,
+                         const_cast<float*>(a.net.Wm), H, const_cast<float*>(a.net.Wm_pack4),
+                         a.has_tp ? (uint4*)const_cast<void*>(a.tp.Wm_rows) : nullptr, H,
+                         a.has_tp ? (uint4*)const_cast<void*>(a.tp.Wm_cols) : nullptr, H, a.wm_scale, tile);
+    } else {
+        draw_small(a, rng, s, dyn_lds);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
+                  const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, void* stream) {
+    if (!net || !g || !net->W1 || !net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
+    if (!g->W1_loc || !g->W1_scale || !g->b1_loc || !g->b1_scale || !g->W2_loc || !g->W2_scale || !g->b2_loc || !g->b2_scale) return RBNN_ERR_NULL;
+    if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
+    const bool fc2 = net->arch == RBNN_ARCH_FC2;
+    if (fc2 && (!net->Wm || !net->bm || !g->Wm_loc || !g->Wm_scale || !g->bm_loc || !g->bm_scale)) return RBNN_ERR_NULL;
+    const int H = net->hidden, C = net->n_classes;
+    if (n_samples < 1 || n_samples > net->n_stored || H < 32 || (H & 31) || g->hidden < 1 || g->hidden > H || C < 1 || C > 16) return RBNN_ERR_SHAPE;
+    if (net->in_features < 1 || net->in_stride < net->in_features || (net->in_stride & 15)) return RBNN_ERR_SHAPE;
+    DrawArgs a = {};
+    a.net = *net; a.g = *g; a.sample_keys = (const unsigned long long*)sample_keys; a.key = key; a.draw_id = draw_id; a.S = n_samples;
+    int extent = net->in_stride;
+    if (tp) {
+        if (!tp->W1_rows || !tp->W1_cols || !tp->W2_gen || (fc2 && (!tp->Wm_rows || !tp->Wm_cols))) return RBNN_ERR_NULL;
+        if (tp->ld_rows < net->in_features || (tp->ld_rows & 31) || tp->ld_cols != net->in_stride || C > 10 || (H & 127)) return RBNN_ERR_SHAPE;
+        if (tp->w1_exp < -100 || tp->w1_exp > 100 || tp->w2_exp < -100 || tp->w2_exp > 100 || tp->wm_exp < -100 || tp->wm_exp > 100) return RBNN_ERR_SHAPE;
+        a.tp = *tp; a.has_tp = 1;
+        a.w1_scale = ldexpf(1.f, tp->w1_exp); a.w2_scale = ldexpf(1.f, tp->w2_exp); a.wm_scale = ldexpf(1.f, tp->wm_exp);
+        extent = std::max(extent, (int)tp->ld_rows);
+    }
+    a.tiles_w1_d = (extent + 63) / 64;
+    a.tiles_wm_d = fc2 ? (H + 63) / 64 : 0;
+    a.tiles_per_sample = (H / 32) * (a.tiles_w1_d + a.tiles_wm_d) + 1;
+    const size_t lds = std::max((size_t)32 * 68 * sizeof(float), (size_t)C * H * sizeof(float));
+    if (lds > 64 * 1024) return RBNN_ERR_SHAPE;
+    hipLaunchKernelGGL(svi_draw_kernel, dim3((unsigned)((long long)n_samples * a.tiles_per_sample)), dim3(256), lds, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+}  // extern "C"

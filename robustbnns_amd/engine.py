@@ -158,7 +158,9 @@ class AttackEngine:
 
     def workspace(self, N, S, chunk=0, tag=0):
         key = (N, S, chunk, tag)
-        ws = self._ws_cache.get(key)
+        ws = self._ws_cache.pop(key, None)
+        if ws is not None:
+            self._ws_cache[key] = ws            # re-inserted: the dict's order is the order of last use
         if ws is None:
             sizes = self.k.workspace_sizes(self.post, N, S, chunk)
             ws = {"n_slabs": sizes["n_slabs"], "chunk": sizes["chunk"]}
@@ -177,8 +179,8 @@ class AttackEngine:
                 ws["triple"] = {k: torch.empty(max(1, v // 2), dtype=torch.int16, device=self.device) for k, v in tsz.items() if v}
                 ws["triple"]["g_scale"] = ws["triple"]["g_scale"].view(torch.float32)
                 ws.pop("hid1", None)                                # the hidden activations live in the triple image instead
-            if len(self._ws_cache) > 6:
-                self._ws_cache.clear()
+            while len(self._ws_cache) > 6:      # evict the LEAST RECENTLY USED entry only: a sharded step holds at most RBNN_COMM_BLOCKS (<= 6) live
+                self._ws_cache.pop(next(iter(self._ws_cache)))    # workspaces with pending all-reduce handles, all younger than it
             self._ws_cache[key] = ws
         return ws
 
@@ -367,9 +369,11 @@ class AttackEngine:
             self._scales = None
         return self.unpad(X, x)
 
-    def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=LOSS_MEAN_PROB):
+    def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=LOSS_MEAN_PROB, before_step=None):
         """adversarialAttacks.pgd_attack on every row of x (adversarialAttacks.py:86-108).
-        alpha=None: 2/max(image) per image (:89); a float: the same step for all (2/225, :91)."""
+        alpha=None: 2/max(image) per image (:89); a float: the same step for all (2/225, :91).
+        before_step: called before every iteration but the first (an SVI net redraws its resident weights in place there: the
+        reference draws fresh weights at every forward, model_bnn.py:230-232; the caller drew the first set)."""
         sidx, S = self.sample_index(n_samples, seeds)
         labels = to_labels(y, self.device)
         X0 = self.pad_inputs(x, clone=True)
@@ -382,7 +386,13 @@ class AttackEngine:
         step = lambda: self._step(X, X0, labels, sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
         try:
             done = 0
-            if iters >= 3 and self._graph_capturable():
+            if before_step is not None:
+                for it in range(iters):
+                    if it:
+                        before_step()
+                    step()
+                done = iters
+            elif iters >= 3 and self._graph_capturable():
                 # RBNN_HIPGRAPH=1 (opt-in).  One iteration is a fixed sequence of 7-9 launches on fixed buffers (x is updated in
                 # place): run it once eagerly (allocates the workspace), capture it once in a HIP graph, replay it for the other
                 # iterations.  Bit-identical to the eager loop (tests); measured gain on MI355X: none — the asynchronous

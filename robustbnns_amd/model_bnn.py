@@ -4,9 +4,12 @@
 model_bnn.py:198-258, computed for the whole batch and all samples by the HIP kernels:
 
   hmc  the stored chain is one StackedPosterior; `seeds` index it (model_bnn.py:246-252);
-  svi  weights are drawn as loc + softplus(scale) * eps (model_bnn.py:124-130) by rbnn_svi_materialize,
-       then run through the same kernels.  PARITY UNPINNED for the draw itself (pyro-ppl 1.3.0 is not
-       available to check RNG order against); everything downstream of explicit weights is pinned.
+  svi  weights are drawn as loc + softplus(scale) * eps (model_bnn.py:124-130).  fc / fc2 on the GPU: ONE kernel
+       (rbnn_svi_draw: Philox eps in registers) redraws all S samples IN PLACE — fp32 stack, packed and triple images —
+       so the posterior, its engine and its workspaces are reused draw after draw and a redraw contains no device->host
+       sync.  conv, and RBNN_SVI_RNG=host: eps from torch's generators -> rbnn_svi_materialize -> a new stacked posterior.
+       PARITY UNPINNED for the draw itself (pyro-ppl 1.3.0 is not available to check RNG order against); everything
+       downstream of explicit weights is pinned.
 
 Inference (SVI/HMC training, model_bnn.py:260-365) is out of scope: posteriors are inputs here.
 """
@@ -103,6 +106,9 @@ class BNN(nn.Module):
         self.svi_rng = os.environ.get("RBNN_SVI_RNG", "device")
         self._engine = None
         self._drawn = None                    # svi: (key, engine) of the last SEEDED draw (same seeds -> same weights: reused, not redrawn)
+        self._guide = None                    # svi, fc / fc2: posterior.SviGuide of the current parameters (bounds fixed once per guide)
+        self._slots = {}                      # svi: n_samples -> (StackedPosterior.for_guide, engine) redrawn in place by unseeded calls
+        self._draws = 0                       # draw counter (the Philox draw id)
 
     def get_name(self, n_inputs=None):
         """model_bnn.py:90-103"""
@@ -140,6 +146,7 @@ class BNN(nn.Module):
         self.svi_loc = {k: v.detach().to(device, torch.float32).contiguous() for k, v in loc.items()}
         self.svi_scale = {k: v.detach().to(device, torch.float32).contiguous() for k, v in scale.items()}
         self._engine = None
+        self._drawn, self._guide, self._slots = None, None, {}     # nothing drawn from the previous guide may be served for this one
 
     @property
     def posterior_predictive(self):
@@ -230,6 +237,41 @@ class BNN(nn.Module):
             off += n
         return self._make_posterior(stacked, self.device)
 
+    # ------------------------------------------------------------------ svi: in-place redraw (fc / fc2 on the GPU)
+    def _in_place(self):
+        return (self.inference == "svi" and self.basenet.architecture in ("fc", "fc2") and self.svi_rng == "device"
+                and torch.device(self.device).type == "cuda")
+
+    def _new_slot(self, n_samples):
+        from .posterior import StackedPosterior, SviGuide
+        if self._guide is None:
+            self._guide = SviGuide(self.svi_loc, self.svi_scale, self.basenet.architecture, self.device)
+        b = self.basenet
+        post = StackedPosterior.for_guide(self._guide, b.activation, b.input_shape, b.output_size, n_samples)
+        eng = make_engine(post)
+        if eng.precision == "triple":
+            post.triple_images()                          # allocated once; every redraw writes them in the draw kernel itself
+        elif eng.precision == "split":
+            post.split_images()
+        return post, eng
+
+    def _fresh_key(self):
+        """64 bits from torch's global CPU generator — the stream the reference's draws advance (model_bnn.py:230-232 under
+        pyro.set_rng_seed): set_rng_seed(k) makes the following unseeded draws reproducible.  Host arithmetic only."""
+        return int(torch.randint(-(2 ** 63), 2 ** 63 - 1, (1,), dtype=torch.int64).item())
+
+    def redraw(self, n_samples):
+        """Fresh weights for the `n_samples` samples of the resident SVI stack (what every un-seeded forward of the reference does,
+        model_bnn.py:230-232): one kernel launch, nothing allocated, no device->host sync.  Returns the (unchanged) engine."""
+        slot = self._slots.get(n_samples)
+        if slot is None:
+            if len(self._slots) >= 2:                         # e.g. an attack with S samples scored with S' defence samples
+                self._slots.pop(next(iter(self._slots)))
+            slot = self._slots[n_samples] = self._new_slot(n_samples)
+        self._draws += 1
+        slot[0].redraw(self._fresh_key(), self._draws)
+        return slot[1]
+
     # ------------------------------------------------------------------ hot path handles
     def hot_path(self, n_samples, avg_posterior=False, seeds=None):
         """(engine, n_samples, seeds, logits) to run `n_samples` posterior samples through the kernels."""
@@ -242,14 +284,21 @@ class BNN(nn.Module):
             stacked = {k: v.unsqueeze(0) for k, v in self.svi_loc.items()}
             return make_engine(self._make_posterior(stacked, self.device)), 1, None, True
         if not seeds:                                     # the reference draws from the live RNG: fresh weights on every call
+            if self._in_place():
+                return self.redraw(n_samples), n_samples, None, False
             return make_engine(self.draw_posterior(n_samples, seeds)), n_samples, None, False
         # seeded draws are a pure function of (seeds, loc, scale): evaluate(), attack_evaluation() and the drivers call forward() batch
         # after batch with the same seeds — keep the last drawn posterior (weights, packed images, workspaces) instead of re-materialising
-        # it per call.  The key carries the parameter tensors' identity and in-place version, so an edited / reloaded guide is redrawn.
-        params = list(self.svi_loc.values()) + list(self.svi_scale.values())
-        key = (int(n_samples), tuple(int(v) for v in seeds), self.svi_rng, tuple((t.data_ptr(), t._version) for t in params))
+        # it per call.  set_variational_params() drops it, so a reloaded guide can never be served an older guide's draw.
+        key = (int(n_samples), tuple(int(v) for v in seeds), self.svi_rng)
         if self._drawn is None or self._drawn[0] != key:
-            self._drawn = (key, make_engine(self.draw_posterior(n_samples, seeds)))
+            if self._in_place():
+                post, eng = self._new_slot(n_samples)
+                keys = torch.tensor([int(v) for v in seeds], dtype=torch.int64).to(self.device)      # seed i -> Philox key i: the draw for a
+                post.redraw(0, 0, sample_keys=keys)                                                  # seed does not depend on its position
+                self._drawn = (key, eng)
+            else:
+                self._drawn = (key, make_engine(self.draw_posterior(n_samples, seeds)))
         return self._drawn[1], n_samples, None, False
 
     def forward(self, inputs, n_samples=10, avg_posterior=False, seeds=None):

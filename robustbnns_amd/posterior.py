@@ -53,6 +53,54 @@ def scale_exp(max_abs, target=14):
     return max(-100, min(100, target - math.ceil(math.log2(max_abs))))
 
 
+class SviGuide:
+    """The variational parameters of an fc / fc2 guide (model_bnn.py:124-126: `<key>_loc`, `<key>_scale`, raw scale — softplus is
+    applied at the draw) resident on the device, plus everything about them that is fixed ONCE per guide, so that a redraw
+    (rbnn_svi_draw) needs no pass over the drawn weights and no device->host sync:
+
+      bound[k] = max(|loc| + RBNN_SVI_EPS_MAX * softplus(scale))   of W1, W2, Wm: the images' power-of-two scales
+      h1       = (max_h sum_d bound(W1[h,d]), max bound(b1))       the fc2 hidden-activation bound (StackedPosterior.scale_bounds)
+      range_ok = narrow_range on the bound against mean|loc| + 0.8 softplus(scale)  (the guard of the triple mode)
+
+    Box-Muller on a 32-bit uniform cannot exceed 6.764 standard deviations, so these are bounds, not estimates."""
+
+    def __init__(self, loc, scale, arch, device):
+        if arch not in LAYER_KEYS:
+            raise NotImplementedError(f"architecture {arch!r}: the in-place SVI draw covers fc and fc2")
+        self.arch, self.device = arch, torch.device(device)
+        keys = LAYER_KEYS[arch]
+        f = lambda d, k: d[k].detach().to(self.device, torch.float32).contiguous()
+        names = {"W1": keys[0] + ".weight", "b1": keys[0] + ".bias", "W2": keys[-1] + ".weight", "b2": keys[-1] + ".bias"}
+        if arch == "fc2":
+            names.update(Wm=keys[1] + ".weight", bm=keys[1] + ".bias")
+        self.loc = {n: f(loc, k) for n, k in names.items()}
+        self.scale = {n: f(scale, k) for n, k in names.items()}
+        self.hidden = int(self.loc["b1"].numel())
+        self.loc["W1"] = self.loc["W1"].reshape(self.hidden, -1)
+        self.scale["W1"] = self.scale["W1"].reshape(self.hidden, -1)
+        sp = torch.nn.functional.softplus
+        bnd = {n: self.loc[n].abs() + _hip.SVI_EPS_MAX * sp(self.scale[n]) for n in self.loc}
+        typ = {n: self.loc[n].abs() + 0.8 * sp(self.scale[n]) for n in self.loc}                     # ~ E|w|
+        mats = [n for n in ("W1", "W2", "Wm") if n in bnd]
+        rec = torch.stack([bnd[n].max() for n in mats] + [typ[n].double().mean().float() for n in mats] +
+                          [bnd["W1"].sum(-1).max(), bnd["b1"].max()]).cpu().tolist()                   # the one sync, at load
+        k = len(mats)
+        self.bound = dict(zip(mats, rec[:k]))
+        self.h1_bound = (rec[2 * k], rec[2 * k + 1])
+        self.range_ok = all(0.0 < m <= 4096.0 * t and m != float("inf") for m, t in zip(rec[:k], rec[k:2 * k]))
+        self._desc = None
+
+    def descriptor(self):
+        if self._desc is None:
+            d = _hip.SviGuide()
+            for n in ("W1", "b1", "Wm", "bm", "W2", "b2"):
+                setattr(d, n + "_loc", None if n not in self.loc else C.c_void_p(self.loc[n].data_ptr()))
+                setattr(d, n + "_scale", None if n not in self.scale else C.c_void_p(self.scale[n].data_ptr()))
+            d.hidden = self.hidden
+            self._desc = d
+        return self._desc
+
+
 class StackedPosterior:
     def __init__(self, arch, activation, input_shape, n_classes, hidden, stacked, device):
         """`stacked`: dict state_dict-key -> tensor [S, ...] (unpadded, any device, fp32)."""
@@ -92,6 +140,21 @@ class StackedPosterior:
         self._split = None
         self._triple = None
         self._range_ok = None
+        self._guide = None                      # SviGuide: this posterior is a redrawable SVI stack (for_guide / redraw)
+
+    def _abs_max(self, name):
+        """max |tensor| that fixes an image's power-of-two scale: taken from the stored weights (one sync, at load), or, for a
+        redrawable SVI stack, the guide's a-priori bound (no pass over the drawn weights)."""
+        if self._guide is not None:
+            return self._guide.bound[name]
+        return float(getattr(self, name).abs().max())
+
+    def _h1(self):
+        if self._guide is not None:
+            return self._guide.h1_bound
+        if not hasattr(self, "_h1_bound"):
+            self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
+        return self._h1_bound
 
     # ------------------------------------------------------------------ split-half ("f16x3") precision mode
     def split_supported(self):
@@ -105,8 +168,8 @@ class StackedPosterior:
             k = _hip.HipKernels()
             S, H, Dp, D, Cn = self.S, self.Hp, self.Dp, self.D, self.C
             ld = round_up(D, 32)
-            w1_exp = scale_exp(float(self.W1.abs().max()))
-            w2_exp = scale_exp(float(self.W2.abs().max()))
+            w1_exp = scale_exp(self._abs_max("W1"))
+            w2_exp = scale_exp(self._abs_max("W2"))
             rows = torch.empty(S * H, ld * 2, dtype=torch.int16, device=self.device)
             cols = torch.empty(S * (H // 32) * 8 * Dp * 8, dtype=torch.int16, device=self.device)
             gen = torch.empty(S * (H // 16) * 512, dtype=torch.int16, device=self.device)
@@ -118,15 +181,13 @@ class StackedPosterior:
             img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = ld, Dp, w1_exp, w2_exp
             keep = [rows, cols, gen]
             if self.arch == "fc2":                               # forward of the middle layer: Wm as split rows [S*H, H]
-                wm_exp = scale_exp(float(self.Wm.abs().max()))
+                wm_exp = scale_exp(self._abs_max("Wm"))
                 wm_rows = torch.empty(S * H, H * 2, dtype=torch.int16, device=self.device)
                 k.split_rows(self.Wm, H, wm_exp, wm_rows, H)
                 wm_cols = torch.empty(S * (H // 32) * 8 * H * 8, dtype=torch.int16, device=self.device)
                 k.split_cols(self.Wm, H, H, wm_exp, wm_cols, H)
                 img.Wm_rows, img.Wm_cols, img.wm_exp = wm_rows.data_ptr(), wm_cols.data_ptr(), wm_exp
                 keep += [wm_rows, wm_cols]
-                # |h1| <= max_h sum_d |W1[h,d]| * max|x| + max|b1|: the per-call exponent of the hidden image
-                self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
             self._split = (img, keep)                            # the tensors keep the device memory alive
         return self._split[0]
 
@@ -137,7 +198,7 @@ class StackedPosterior:
         if not (self.arch in ("fc", "fc2") and self.Hp % 128 == 0 and self.C <= 10 and self.device.type == "cuda"):
             return False
         if self._range_ok is None:
-            self._range_ok = narrow_range(self.W1, self.W2, self.Wm)
+            self._range_ok = self._guide.range_ok if self._guide is not None else narrow_range(self.W1, self.W2, self.Wm)
         return self._range_ok
 
     def triple_images(self):
@@ -147,8 +208,8 @@ class StackedPosterior:
             k = _hip.HipKernels()
             S, H, Dp, D, Cn = self.S, self.Hp, self.Dp, self.D, self.C
             ld = round_up(D, 32)
-            w1_exp = scale_exp(float(self.W1.abs().max()))
-            w2_exp = scale_exp(float(self.W2.abs().max()))
+            w1_exp = scale_exp(self._abs_max("W1"))
+            w2_exp = scale_exp(self._abs_max("W2"))
             rows = torch.empty(S * H, ld * 3, dtype=torch.int16, device=self.device)
             cols = torch.empty(S * (H // 32) * 12 * Dp * 8, dtype=torch.int16, device=self.device)
             gen = torch.empty(S * (H // 16) * 1024, dtype=torch.int16, device=self.device)
@@ -160,15 +221,13 @@ class StackedPosterior:
             img.ld_rows, img.ld_cols, img.w1_exp, img.w2_exp = ld, Dp, w1_exp, w2_exp
             keep = [rows, cols, gen]
             if self.arch == "fc2":                               # the middle layer: Wm as triple rows [S*H, H] (forward) and triple cols (backward step 1)
-                wm_exp = scale_exp(float(self.Wm.abs().max()))
+                wm_exp = scale_exp(self._abs_max("Wm"))
                 wm_rows = torch.empty(S * H, H * 3, dtype=torch.int16, device=self.device)
                 k.triple_rows(self.Wm, H, wm_exp, wm_rows, H)
                 wm_cols = torch.empty(S * (H // 32) * 12 * H * 8, dtype=torch.int16, device=self.device)
                 k.triple_cols(self.Wm, H, H, wm_exp, wm_cols, H)
                 img.Wm_rows, img.Wm_cols, img.wm_exp = wm_rows.data_ptr(), wm_cols.data_ptr(), wm_exp
                 keep += [wm_rows, wm_cols]
-                # |h1| <= max_h sum_d |W1[h,d]| * max|x| + max|b1|: the per-call exponent of the hidden image (scale_bounds)
-                self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
             self._triple = (img, keep)                           # the tensors keep the device memory alive
         return self._triple[0]
 
@@ -178,9 +237,7 @@ class StackedPosterior:
         |tanh(a)| <= min(|a|, 1); sigmoid <= 1).  fc has no such operand: the record is unused."""
         if self.arch != "fc2":
             return 0.0, 0.0, math.inf
-        if not hasattr(self, "_h1_bound"):
-            self._h1_bound = (float(self.W1.abs().sum(-1).max()), float(self.b1.abs().max()))
-        w_l1, b_max = self._h1_bound
+        w_l1, b_max = self._h1()
         if self.activation == "sigm":
             return 0.0, 1.0, 1.0
         return w_l1, b_max, (1.0 if self.activation == "tanh" else math.inf)
@@ -195,6 +252,41 @@ class StackedPosterior:
             _hip.HipKernels().pack_rows4(W, out)
             return out
         self.W1p, self.Wmp = pack(self.W1), pack(self.Wm)
+
+    # ------------------------------------------------------------------ redrawable SVI stack
+    @classmethod
+    def for_guide(cls, guide, activation, input_shape, n_classes, S):
+        """S (still zero) samples laid out for the kernels, to be filled — again and again, IN PLACE — by redraw().  Buffers,
+        descriptor and images keep their addresses across draws, so the engine and its workspaces are reused."""
+        H, D = guide.hidden, guide.loc["W1"].shape[1]
+        z = lambda *shape: torch.zeros((S,) + shape, dtype=torch.float32)
+        keys = LAYER_KEYS[guide.arch]
+        stacked = {keys[0] + ".weight": z(H, D), keys[0] + ".bias": z(H), keys[-1] + ".weight": z(n_classes, H), keys[-1] + ".bias": z(n_classes)}
+        if guide.arch == "fc2":
+            stacked[keys[1] + ".weight"], stacked[keys[1] + ".bias"] = z(H, H), z(H)
+        post = cls(guide.arch, activation, input_shape, n_classes, H, stacked, guide.device)
+        post._guide = guide
+        return post
+
+    def redraw(self, key, draw_id=0, n_samples=None, sample_keys=None):
+        """W[s] = loc + softplus(scale) * eps(key, draw_id, s) for s < n_samples, written by ONE kernel (rbnn_svi_draw) into the fp32
+        stack, the pack_rows4 images and — once they exist — the triple images.  sample_keys: int64 device tensor, one key per
+        sample (seeded draws, model_bnn.py:222-226).  No device->host sync, no allocation."""
+        if self._guide is None:
+            raise _hip.HipError("redraw() needs a posterior built by StackedPosterior.for_guide")
+        S = self.S if n_samples is None else int(n_samples)
+        tri = self._triple[0] if self._triple is not None else None
+        _hip.HipKernels().svi_draw(self, tri, self._guide, S, int(key), int(draw_id), sample_keys)
+        if self._split is not None:             # the opt-in two-piece mode keeps its own images: rebuilt by its builders (same fixed scales)
+            img, keep = self._split
+            k = _hip.HipKernels()
+            k.split_rows(self.W1, self.D, img.w1_exp, keep[0], img.ld_rows)
+            k.split_cols(self.W1, self.Hp, self.D, img.w1_exp, keep[1], self.Dp)
+            k.split_w2gen(self.W2, self.C, self.Hp, img.w2_exp, keep[2])
+            if self.arch == "fc2":
+                k.split_rows(self.Wm, self.Hp, img.wm_exp, keep[3], self.Hp)
+                k.split_cols(self.Wm, self.Hp, self.Hp, img.wm_exp, keep[4], self.Hp)
+        return self
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -244,6 +336,8 @@ class StackedPosterior:
         for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
             t = getattr(self, name)
             setattr(out, name, None if t is None else t[lo:hi].contiguous())
-        out.S, out._desc, out._split, out._triple, out._range_ok = hi - lo, None, None, None, None
+        # the dynamic-range guard is decided ONCE, on the full posterior: every rank (and the single-process run) picks the same mode
+        out.S, out._desc, out._split, out._triple, out._range_ok = hi - lo, None, None, None, self.triple_supported() and self._range_ok
+        out._guide = None
         out._pack()
         return out

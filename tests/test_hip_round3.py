@@ -1,0 +1,227 @@
+"""GPU parity tests (-m gpu), round 3: TRAINED posteriors, the reference's own PGD iterates, files written by the reference.
+
+  trained     tests/golden/trained_*.npz — networks trained by the reference's NN.train (make_golden_trained.py), attacked and scored by
+              the reference's attack / attack_evaluation / build_eps_attacks_df: clean accuracy 90-99 %, adversarial accuracy walking
+              down with eps.  HIP attack -> HIP evaluation must give the reference's (orig_acc, adv_acc) and softmax_rob to 1e-5, in every
+              precision mode that covers the posterior (auto included).
+  trajectory  adversarialAttacks.py:95-105 one step at a time: from the reference's iterate k the HIP step must land on its iterate k+1,
+              zero non-marginal pixels over all 40 steps.
+  files       BNN.load reads the reference's BNN.save output and reproduces its forward_probs.
+"""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_to_reference, rel_err, saturation_noise
+from oracle import bnn_oracle as O
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
+TOL = 1e-5
+TAU = 1e-3
+DEV = "cuda:0"
+HALFMOONS = ["trained_halfmoons_fc_h32_m10", "trained_halfmoons_fc2_h32_m10"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from robustbnns_amd import _hip
+    _hip.load()
+
+
+def make_bnn(g):
+    from robustbnns_amd.model_bnn import BNN
+    m = g.meta
+    bnn = BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], 0, tuple(m["shape"]), m["n_classes"])
+    bnn.set_posterior_samples(g.posterior(), DEV)
+    return bnn
+
+
+def make_ensemble(g):
+    from robustbnns_amd.model_ensemble import Ensemble_NN
+    from robustbnns_amd.model_nn import NN
+    m = g.meta
+    ens = Ensemble_NN(m["dataset"], m["hidden"], m["act"], m["arch"], 1, 0.01, tuple(m["shape"]), m["n_classes"], m["S"])
+    post = g.posterior()
+    for i in range(m["S"]):
+        net = NN(m["dataset"], tuple(m["shape"]), m["n_classes"], m["hidden"], m["act"], m["arch"], 0.01, 1)
+        net.load_state_dict({k: v[i] for k, v in post.items()})
+        ens.ensemble_models[str(i)] = net
+    ens.device = DEV
+    return ens
+
+
+def marginal_ok(adv, ref, grad, what=""):
+    adv, ref, grad = (torch.as_tensor(v).detach().cpu().reshape(len(ref), -1) for v in (adv, ref, grad))
+    safe = grad.abs() > TAU * grad.abs().max(dim=1, keepdim=True)[0]
+    diff = (adv - ref).abs() > 1e-6
+    assert not (diff & safe).any(), f"{what}: {int((diff & safe).sum())} non-marginal pixels differ"
+    return int(diff.sum())
+
+
+def modes_for(hidden):
+    return ["auto", "exact"] if max(32, hidden) % 128 == 0 else ["auto"]          # below 128 hidden units auto IS the fp32-MFMA mode
+
+
+# ------------------------------------------------------------------------------------------------ trained posteriors
+@pytest.mark.parametrize("name", HALFMOONS)
+@pytest.mark.parametrize("kind", ["bnn", "ens"])
+def test_trained_halfmoons_attack_and_evaluation(golden, name, kind, monkeypatch):
+    from robustbnns_amd import adversarialAttacks as AA
+    g = golden(name); m = g.meta; x, y = g.t("x"), g.t("y"); lab = y.argmax(-1)
+    net = make_bnn(g) if kind == "bnn" else make_ensemble(g)
+    okind = "bnn" if kind == "bnn" else "ensemble"
+    post = g.posterior()
+    relaxed = marg = 0
+    for k, ns in enumerate(m["ns_list"]):
+        ref_g = g.t(kind + "_fgsm_grad")[k]
+        # the gradient whose sign the attack takes, through autograd on the package's forward — as the reference's fgsm_attack does it
+        xg = x.clone().to(DEV).requires_grad_(True)
+        out = net.forward(xg, n_samples=ns)
+        torch.nn.CrossEntropyLoss(reduction="sum")(out, lab.to(DEV)).backward()
+        g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), m["arch"], m["act"], ns, kind=okind)
+        relaxed += assert_close_to_reference(xg.grad.cpu(), ref_g, g64, TOL, saturation_noise(x, post, m["arch"], m["act"], ns, okind), f"{kind} ns={ns}")
+        for e, eps in enumerate(m["eps_list"]):
+            ref_adv = g.t(kind + "_fgsm_adv")[e, k]
+            adv = AA.attack(net=net, x_test=x, y_test=y, dataset_name=m["dataset"], device=DEV, method="fgsm", filename=net.name,
+                            n_samples=ns, hyperparams={"epsilon": eps})
+            n_marg = marginal_ok(adv, ref_adv, ref_g, f"{kind} fgsm eps={eps} ns={ns}")
+            marg += n_marg
+            want = (float(g.arr[kind + "_fgsm_orig_acc"][e, k]), float(g.arr[kind + "_fgsm_adv_acc"][e, k]))
+            # the reference's adversarial set through the HIP evaluation
+            oa, aa, rob = AA.attack_evaluation(net=net, x_test=x, x_attack=ref_adv, y_test=y, device=DEV, n_samples=ns)
+            assert (oa, aa) == want, f"{kind} eps={eps} ns={ns}: {(oa, aa)} vs the reference's {want}"
+            assert float((rob.cpu() - g.t(kind + "_fgsm_rob")[e, k]).abs().max()) < TOL
+            if n_marg == 0:             # end to end: HIP attack -> HIP evaluation
+                oa, aa, rob = AA.attack_evaluation(net=net, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=ns)
+                assert (oa, aa) == want
+                assert float((rob.cpu() - g.t(kind + "_fgsm_rob")[e, k]).abs().max()) < TOL
+    print(f"{name} {kind}: {relaxed} gradient rows at the fp32 saturation floor, {marg} marginal adversarial pixels")
+
+
+@pytest.mark.parametrize("name", HALFMOONS)
+def test_trained_halfmoons_pgd(golden, name):
+    from robustbnns_amd import adversarialAttacks as AA
+    g = golden(name); m = g.meta; x, y = g.t("x"), g.t("y")
+    for kind, eps_l, ns_l in (("bnn", m["pgd_eps"], m["pgd_ns"]), ("ens", m["ens_pgd_eps"], m["ens_pgd_ns"])):
+        net = make_bnn(g) if kind == "bnn" else make_ensemble(g)
+        for e, eps in enumerate(eps_l):
+            for k, ns in enumerate(ns_l):
+                ref_adv = g.t(kind + "_pgd_adv")[e, k]
+                want = (float(g.arr[kind + "_pgd_orig_acc"][e, k]), float(g.arr[kind + "_pgd_adv_acc"][e, k]))
+                oa, aa, rob = AA.attack_evaluation(net=net, x_test=x, x_attack=ref_adv, y_test=y, device=DEV, n_samples=ns)
+                assert (oa, aa) == want
+                assert float((rob.cpu() - g.t(kind + "_pgd_rob")[e, k]).abs().max()) < TOL
+                adv = AA.attack(net=net, x_test=x, y_test=y, dataset_name=m["dataset"], device=DEV, method="pgd", filename=net.name,
+                                n_samples=ns, hyperparams={"epsilon": eps}).cpu()
+                same = (adv - ref_adv).abs().reshape(len(x), -1).max(1)[0] <= 1e-6
+                frac = float(same.double().mean())
+                print(f"{name} {kind} pgd eps={eps} ns={ns}: {100 * frac:.1f} % of the 40-step images identical to the reference's")
+                assert frac > 0.97                                                   # a statistic; the exact statement is the trajectory test
+                oa2, aa2, rob2 = AA.attack_evaluation(net=net, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=ns)
+                assert oa2 == want[0] and abs(aa2 - want[1]) <= 100.0 * float((~same).sum()) / len(x)
+                assert float((rob2.cpu() - g.t(kind + "_pgd_rob")[e, k])[same].abs().max()) < TOL
+
+
+def test_trained_halfmoons_eps_grid_driver(golden, tmp_path, monkeypatch):
+    """plot_eps_attacks.build_eps_attacks_df (plot_eps_attacks.py:9-39) on the trained posterior: the reference's rows."""
+    from robustbnns_amd import plot_eps_attacks
+    g = golden("trained_halfmoons_fc_h32_m10"); m = g.meta
+    bnn = make_bnn(g)
+    assert bnn.name == m["bnn_name"]
+    monkeypatch.chdir(tmp_path)
+    df = plot_eps_attacks.build_eps_attacks_df(bnn=bnn, dataset="half_moons", device=DEV, method="fgsm", x_test=g.t("x"), y_test=g.t("y"),
+                                               epsilon_list=m["eps_list"], n_samples_list=m["ns_list"], savedir=bnn.name)
+    for col in ("epsilon", "test_acc", "adv_acc", "n_samples"):
+        assert np.array_equal(df[col].to_numpy().astype("float64"), g.arr["fgsm_df_" + col]), col
+    assert np.abs(df["softmax_rob"].to_numpy() - g.arr["fgsm_df_softmax_rob"]).max() < TOL
+    assert df["test_acc"].min() > 80 and df["adv_acc"].max() > 75 and df["adv_acc"].min() < 5          # not a degenerate table
+
+
+@pytest.mark.parametrize("precision", ["auto", "exact", "triple"])
+def test_trained_mnist_shaped(golden, precision, monkeypatch):
+    """784 -> 128 -> 10 trained on the synthetic 10-class task: `auto` is the triple mode here (hidden % 128 == 0)."""
+    from robustbnns_amd import adversarialAttacks as AA
+    monkeypatch.setenv("RBNN_PRECISION", precision)
+    g = golden("trained_mnistshaped_fc_h128_m5"); m = g.meta; x, y = g.t("x"), g.t("y"); lab = y.argmax(-1); post = g.posterior()
+    bnn = make_bnn(g)
+    assert bnn._engine.precision == ("exact" if precision == "exact" else "triple")
+    for k, ns in enumerate(m["ns_list"]):
+        sign = g.t("bnn_fgsm_sign")[k].float()
+        g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), "fc", "leaky", ns)
+        for e, eps in enumerate(m["eps_list"]):
+            ref_adv = torch.clamp(x + eps * sign, 0, 1)
+            want = (float(g.arr["bnn_fgsm_orig_acc"][e, k]), float(g.arr["bnn_fgsm_adv_acc"][e, k]))
+            adv = AA.attack(net=bnn, x_test=x, y_test=y, dataset_name="mnist", device=DEV, method="fgsm", filename=bnn.name,
+                            n_samples=ns, hyperparams={"epsilon": eps})
+            n_marg = marginal_ok(adv, ref_adv, g64, f"fgsm eps={eps} ns={ns}")
+            oa, aa, rob = AA.attack_evaluation(net=bnn, x_test=x, x_attack=ref_adv, y_test=y, device=DEV, n_samples=ns)
+            assert (oa, aa) == want, f"eps={eps} ns={ns}: {(oa, aa)} vs the reference's {want}"
+            assert float((rob.cpu() - g.t("bnn_fgsm_rob")[e, k]).abs().max()) < TOL
+            if n_marg == 0:
+                oa, aa, _ = AA.attack_evaluation(net=bnn, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=ns)
+                assert (oa, aa) == want
+    ns = m["ns_list"][-1]
+    xg = x.clone().to(DEV).requires_grad_(True)
+    torch.nn.CrossEntropyLoss(reduction="sum")(bnn.forward(xg, n_samples=ns), lab.to(DEV)).backward()
+    g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), "fc", "leaky", ns)
+    assert_close_to_reference(xg.grad.cpu(), g.t(f"bnn_fgsm_grad_ns{ns}"), g64, TOL, saturation_noise(x, post, "fc", "leaky", ns), "gradient")
+    P = m["pgd_points"]
+    oa, aa, rob = AA.attack_evaluation(net=bnn, x_test=x[:P], x_attack=g.t("bnn_pgd_adv"), y_test=y[:P], device=DEV, n_samples=m["pgd_ns"])
+    assert (oa, aa) == (float(g.arr["bnn_pgd_orig_acc"]), float(g.arr["bnn_pgd_adv_acc"]))
+    assert float((rob.cpu() - g.t("bnn_pgd_rob")).abs().max()) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ PGD, one step at a time
+TRAJ = [("trained_halfmoons_fc_h32_m10", "auto"), ("trained_mnistshaped_fc_h128_m5", "auto"), ("trained_mnistshaped_fc_h128_m5", "exact"),
+        ("pgd_traj_mnist_fc_h512_s8_n8", "auto"), ("pgd_traj_mnist_fc_h512_s8_n8", "exact")]
+
+
+@pytest.mark.parametrize("name,precision", TRAJ)
+def test_pgd_single_steps_along_the_reference_trajectory(golden, name, precision):
+    """From the reference's iterate k, AttackEngine.pgd_continue must land on the reference's iterate k+1: zero non-marginal pixels
+    (|g_k| >= tau * max|g_k|) over all 40 steps.  The 40-step comparison of whole attacks is then only a reported statistic."""
+    from robustbnns_amd.factory import make_engine, posterior_from_stacked
+    g = golden(name); m = g.meta
+    traj, tg = g.t("traj"), g.t("traj_grad")
+    P = traj.shape[1]
+    x0, y = traj[0], g.t("y")[:P]
+    post = posterior_from_stacked(m["arch"], m["act"], tuple(m["shape"]), m["n_classes"], m["hidden"], g.posterior(), DEV)
+    eng = make_engine(post, precision=precision)
+    marginal = 0
+    for k in range(40):
+        nxt = eng.pgd_continue(traj[k].to(DEV), x0.to(DEV), y, m["traj_ns"], m["traj_eps"])
+        marginal += marginal_ok(nxt, traj[k + 1], tg[k], f"step {k}")
+    print(f"{name} [{eng.precision}]: {marginal} marginal pixels differ over 40 steps x {P} points")
+    # and the whole 40-step attack from x_0, as a statistic
+    adv = eng.pgd(x0.to(DEV), y, m["traj_ns"], m["traj_eps"]).cpu()
+    print(f"   whole attack: {float(((adv - traj[40]).abs() > 1e-6).double().mean()) * 100:.3f} % of the pixels differ after 40 steps")
+
+
+# ------------------------------------------------------------------------------------------------ reference-written files
+def test_bnn_load_reads_reference_files_and_reproduces_forward():
+    from robustbnns_amd.model_bnn import BNN
+    files = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "files")
+    d = np.load(os.path.join(files, "expected.npz"))
+    m = ast.literal_eval(str(d["meta"]))
+    bnn = BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], m["warmup"], tuple(m["shape"]), m["n_classes"])
+    bnn.load(DEV, rel_path=os.path.join(files, "posterior") + "/")
+    x = torch.from_numpy(d["x"])
+    p = bnn.forward(x, n_samples=m["S"]).cpu()
+    assert rel_err(p, torch.from_numpy(d["forward_probs"])) < TOL
+    from robustbnns_amd import adversarialAttacks as AA, lossGradients
+    from torch.utils.data import DataLoader
+    y = torch.from_numpy(d["y"])
+    lg = lossGradients.loss_gradients(net=bnn, data_loader=DataLoader(list(zip(x, y)), batch_size=5), device=DEV, filename=bnn.name,
+                                      savedir="grads/", n_samples=m["S"])
+    assert lg.dtype == d["loss_gradients"].dtype and lg.shape == d["loss_gradients"].shape
+    assert rel_err(torch.from_numpy(lg), torch.from_numpy(d["loss_gradients"])) < TOL
+    adv = AA.attack(net=bnn, x_test=x, y_test=y, dataset_name="half_moons", device=DEV, method="fgsm", filename=bnn.name, savedir="attacks",
+                    hyperparams={"epsilon": m["eps"]}, n_samples=m["S"])
+    assert adv.requires_grad and adv.dtype == torch.float32
+    stacked = {k: torch.stack([bnn.posterior.state_dict(i)[k] for i in range(m["S"])]) for k in bnn.posterior.state_dict(0)}
+    gm = O.meanprob_gradients(x.double(), y.argmax(-1), O.cast(stacked, torch.float64), m["arch"], m["act"], m["S"])
+    marginal_ok(adv, torch.from_numpy(d["fgsm"]), gm, "fgsm")
