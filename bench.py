@@ -14,6 +14,13 @@ attack-samples = points x posterior samples x iterations (1 for FGSM).  Other wo
 S=500), c4 (the per-GPU share of S=2000 sharded 8-way: loss_gradients + FGSM per step), c5 (CIFAR-shaped conv-BNN, PGD
 T=100 over eps in {2,4,8}/255; build-defined shapes, parity unpinned), conv, fc2.
 
+Posterior (`--posterior`, default `config` = what BASELINE.json names for the workload): c2 and c1 say "SVI" — the weights are then a
+variational guide (loc ~ N(0, std^2), raw scale -3: SURVEY 8d) and EVERY STEP REDRAWS all S samples inside the timed region, in place,
+with one kernel (rbnn_svi_draw: Philox eps in registers -> fp32 stack + packed + triple images; the reference draws fresh weights at
+every forward, model_bnn.py:230-232); the line's `svi` record carries the draw's own time and write rate, and the same workload on
+stored samples is the `stored_posterior_mode` sub-record.  c3 says "HMC" (stored samples); c4 names neither (stored); c5 / conv say
+SVI but the in-place draw covers fc / fc2 only: they run on stored samples and say so.
+
 N GPUs: one process per GPU; the posterior is SAMPLE-sharded (each rank holds its own S samples, so the job has S*N
 samples: weak scaling) and each step all-reduces sum_s p_s [N,16] and the summed gradients [N,784] over RCCL/xGMI
 (north star).  `--shard points` replicates the samples and splits points instead (no collective).
@@ -107,6 +114,25 @@ def make_problem(w, rank, device):
     return x, y, post
 
 
+def make_guide(w, rank):
+    """SVI-style posterior of SURVEY 8d: loc ~ N(0, std^2) per tensor (distinct per rank), raw scale -3 (softplus = 0.0486)."""
+    D = w["shape"][0] * w["shape"][1] * w["shape"][2]
+    g = torch.Generator().manual_seed(200 + rank)
+    std = 0.5 if D < 16 else 0.05
+    H, C = w["H"], w["C"]
+    shapes = {"model.1.weight": (H, D), "model.1.bias": (H,)}
+    if w["arch"] == "fc2":
+        shapes.update({"model.3.weight": (H, H), "model.3.bias": (H,), "model.5.weight": (C, H), "model.5.bias": (C,)})
+    else:
+        shapes.update({"model.3.weight": (C, H), "model.3.bias": (C,)})
+    loc = {k: torch.randn(*shp, generator=g) * std for k, shp in shapes.items()}
+    scale = {k: torch.full(shp, -3.0) for k, shp in shapes.items()}
+    return loc, scale
+
+
+SVI_NAMED = {"c1", "c2", "c5", "conv"}      # BASELINE.json configs that say "SVI" (conv / c5: the in-place draw does not cover conv)
+
+
 def cpu_baseline(w, x, y, post, budget_s):
     """The reference's loop nest (batch 1, autograd) on this host: bounded sample, linear in points."""
     from oracle import bnn_oracle as O
@@ -197,6 +223,10 @@ def main():
                          "six exact product terms, f32 accumulate) where those kernels cover the workload, else exact (fp32 MFMA); the other "
                          "modes are reported as sub-records")
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision modes at N=1")
+    ap.add_argument("--posterior", default="config", choices=["config", "svi", "stored"],
+                    help="svi: a variational guide, all S samples redrawn in place every step inside the timed region; stored: S stored samples "
+                         "(HMC-style); config (default): what BASELINE.json names for the workload (c1, c2: svi; c3, c4: stored; conv / c5: stored, "
+                         "the in-place draw covers fc / fc2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -230,12 +260,22 @@ def main():
     D = x[0].numel()
     from robustbnns_amd.factory import make_engine, posterior_from_stacked
     sp = posterior_from_stacked(w["arch"], w["act"], w["shape"], w["C"], w["H"], post, device)
+    posterior_kind = args.posterior
+    if posterior_kind == "config":
+        posterior_kind = "svi" if (args.workload in SVI_NAMED and w["arch"] != "conv") else "stored"
+    if posterior_kind == "svi" and w["arch"] == "conv":
+        raise SystemExit("--posterior svi: the in-place draw covers fc / fc2 (conv SVI nets are drawn through rbnn_svi_materialize, not benchmarked)")
+    sp_svi = None
+    if posterior_kind == "svi" or (world == 1 and w["arch"] != "conv"):
+        from robustbnns_amd.posterior import StackedPosterior, SviGuide
+        loc, scale = make_guide(w, rank if args.shard == "samples" else 0)
+        sp_svi = StackedPosterior.for_guide(SviGuide(loc, scale, w["arch"], device), w["act"], w["shape"], w["C"], w["S"])
 
     class TimedKernels(_hip.HipKernels):
         """HIP events around the two GEMM kernels, on the stream they are launched on (torch's current stream)."""
         def __init__(self):
             super().__init__()
-            self.ev = {"fc_forward": [], "fc_input_grad": []} if w["arch"] != "conv" else {"conv_forward": [], "conv_input_grad": []}
+            self.ev = {"fc_forward": [], "fc_input_grad": [], "lowdim": []} if w["arch"] != "conv" else {"conv_forward": [], "conv_input_grad": []}
             self.on = False
 
         def _timed(self, name, fn, *a, **kw):
@@ -247,6 +287,9 @@ def main():
             e1.record()
             self.ev[name].append((e0, e1))
             return r
+
+        def lowdim_run(self, *a, **kw):                                   # in_features <= 16: the whole pass (all iterations) is this one launch
+            return self._timed("lowdim", super().lowdim_run, *a, **kw)
 
         def fc_forward(self, *a, **kw):
             return self._timed("fc_forward", super().fc_forward, *a, **kw)
@@ -298,16 +341,39 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    def run(precision):
-        """warmup, then EXACTLY --steps timed steps between barrier + synchronize; returns (engine precision, seconds, kernel events)."""
+    def run(precision, kind=None):
+        """warmup, then EXACTLY --steps timed steps between barrier + synchronize; returns (engine precision, seconds, kernel events).
+        kind "svi": every step first redraws all S samples of the resident stack in place (PGD: before every iteration)."""
+        kind = kind or posterior_kind
         kern = TimedKernels()
+        post_ = sp_svi if kind == "svi" else sp
         if args.shard == "samples":
-            eng = make_engine(sp, kernels=kern, group=group, total_samples=w["S"] * world, precision=precision)
+            eng = make_engine(post_, kernels=kern, group=group, total_samples=w["S"] * world, precision=precision)
             eng._S_total = w["S"] * world
         else:
-            eng = make_engine(sp, kernels=kern, precision=precision)
+            eng = make_engine(post_, kernels=kern, precision=precision)
+        draws = [0]
+        draw_ev = []
+        if kind == "svi":
+            if eng.precision == "triple":
+                post_.triple_images()
+            elif eng.precision == "split":
+                post_.split_images()
+
+        def redraw():
+            draws[0] += 1
+            if kern.on:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                post_.redraw(0x5EED0000 + rank, draws[0])
+                e1.record()
+                draw_ev.append((e0, e1))
+            else:
+                post_.redraw(0x5EED0000 + rank, draws[0])
 
         def step():
+            if kind == "svi":
+                redraw()
             if "lossgrad" in w["method"]:
                 eng.loss_gradients(xs, labels, w["S"])
             if "fgsm" in w["method"]:
@@ -315,7 +381,7 @@ def main():
                     eng.fgsm(xs, labels, w["S"], e)
             if w["method"] == "pgd":
                 for e in eps_list:
-                    eng.pgd(xs, labels, w["S"], e, alpha=None, iters=w["iters"])
+                    eng.pgd(xs, labels, w["S"], e, alpha=None, iters=w["iters"], before_step=redraw if kind == "svi" else None)
 
         for _ in range(args.warmup):
             step()
@@ -336,7 +402,17 @@ def main():
             tt = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return getattr(eng, "precision", "exact"), dt, kern.ev
+        svi = None
+        if kind == "svi":
+            ms = sum(a.elapsed_time(b) for a, b in draw_ev) / max(1, len(draw_ev))
+            n_par = sum(int(v.numel()) for v in sp_svi._guide.loc.values())
+            # bytes one draw writes: the fp32 stack and its pack_rows4 image (4 + 4 B per matrix weight), and in the triple mode the rows and
+            # cols images (6 + 6 B); reads are the guide's loc + scale (8 B per parameter, once per sample, L2-resident)
+            wr = w["S"] * n_par * (8.0 + (12.0 if eng.precision == "triple" else 0.0))
+            svi = {"draws": len(draw_ev), "draws_per_step": len(draw_ev) / max(1, args.steps), "draw_ms": ms, "kernel": "svi_draw_kernel (1 launch per draw)",
+                   "bytes_written_per_draw": wr, "write_gbs": wr / (ms * 1e-3) / 1e9 if ms else None, "hbm_frac": wr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
+                   "guide": "loc ~ N(0, std^2), raw scale -3 (softplus 0.0486): SURVEY 8d", "rng": "Philox4x32-10 + Box-Muller in registers, no eps tensor"}
+        return getattr(eng, "precision", "exact"), dt, kern.ev, svi
 
     # per-launch algorithmic flops of each GEMM kernel: half of SURVEY 8(d)'s 4*(D*H + H*C) per attack-sample
     per_launch = 2.0 * (D * w["H"] + w["H"] * w["C"]) * w["N"] * w["S"]
@@ -356,6 +432,7 @@ def main():
                         "conv_forward": "conv2_pool_kernel (+ conv1_pool, conv_fc)", "conv_input_grad": "conv_bwd_kernel (+ conv_fc_bwd, conv1_bwd)"},
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
+    KNAMES["lowdim"] = {"lowdim": "lowdim_kernel (forward, loss, input gradient and step of ALL iterations in one launch; fp32 FMA)"}
     KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel",
                         "conv_forward": "conv2_pool_x3_kernel (+ conv1_pool, conv_fc)",
                         "conv_input_grad": "conv_bwd_x3_kernel (+ conv_fc_bwd, conv1_bwd)"}
@@ -374,6 +451,13 @@ def main():
         kernels = {}
         passes_timed = args.steps * passes * w["iters"]
         for name, evs in evs_by_name.items():
+            if not evs:
+                continue
+            if name == "lowdim":        # one launch = `iters` passes, forward AND backward (the backward's recomputed pre-activations not counted)
+                ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
+                kernels[name] = {"launches": len(evs), "launches_per_pass": 1.0 / w["iters"], "avg_ms": ms,
+                                 "tflops": 2 * per_launch * w["iters"] / (ms * 1e-3) / 1e12 if ms else None}
+                continue
             ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
             # launches per hot-path pass: 1, or the number of point blocks when the sample-sharded step is pipelined over blocks
             # (each launch then covers 1/blocks of the points) or a conv job is cut into point blocks
@@ -392,7 +476,7 @@ def main():
         fp32_eq = kernels[dom]["tflops"]
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
              "traffic_source": traffic_src,      # PMC counters cannot be read inside this run: a committed rocprofv3 --pmc pass of the same command
-             "flop_per_launch": per_launch / kernels[dom]["launches_per_pass"], "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
+             "flop_per_launch": (2 if dom == "lowdim" else 1) * per_launch / kernels[dom]["launches_per_pass"], "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
         if dom in F16_KERNELS.get(mode, ()):
             # matrix-pipe work of the split / triple mode: 3 / 6 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
             np_ = PRODUCTS[mode]
@@ -406,7 +490,8 @@ def main():
                               "(frac there is against 157.3 TFLOP/s)" % (np_, F16_MFMA_SUSTAINED_FRAC)})
         else:
             r.update({"achieved": fp32_eq, "peak": FP32_MFMA_PEAK_TFLOPS, "frac": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
-                      "pipe": "v_mfma_f32_16x16x4_f32"})
+                      "pipe": "v_mfma_f32_16x16x4_f32" if mode != "lowdim" else
+                              "v_fma_f32 (fp32 vector peak = the fp32 MFMA peak on this chip); this workload is launch-latency bound, not pipe bound"})
         ms_per_pass = ms_per_step / (passes * w["iters"])
         r["whole_step_tflops"] = 2 * per_launch / (1e-3 * ms_per_pass) / 1e12
         # HBM side (BASELINE.json configs[4] asks for per-GPU HBM GB/s): algorithmic bytes of one pass over its duration, and the
@@ -415,15 +500,18 @@ def main():
                     "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes / (1e-3 * ms_per_pass) / 1e9 / HBM_PEAK_GBS}
         return r
 
-    DTYPES = {"exact": "f32",
+    DTYPES = {"exact": "f32", "lowdim": "f32",
               "triple": "f32 (full-width operands as three f16 pieces: 6 exact f16 MFMA product terms per fp32 product, f32 accumulate)",
               "split": "f32 carried as f16 hi+lo pairs: 3 f16 MFMA products per fp32 product, f32 accumulate (2^-22 per product)"}
     SUBKEY = {"exact": "exact_fp32_mode", "triple": "triple_f16x6_mode", "split": "split_f16x3_mode"}
-    mode, dt, evs = run(args.precision)
+    mode, dt, evs, svi_rec = run(args.precision)
+    other_kind = None
+    if world == 1 and not args.no_other_mode and sp_svi is not None:      # the same workload on the other kind of posterior
+        other_kind = run(args.precision, "stored" if posterior_kind == "svi" else "svi")
     others = []
     if world == 1 and not args.no_other_mode:
         for want in ("exact", "triple", "split"):                         # the other precision modes on the same workload
-            if want == mode:
+            if want == mode or (mode == "lowdim" and want != "exact"):
                 continue
             try:
                 o = run(want)
@@ -445,9 +533,21 @@ def main():
             "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
             "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job,
                        "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none",
+                       "posterior": ("svi: variational guide, all S samples redrawn in place (rbnn_svi_draw) every step — PGD: every iteration — inside "
+                                     "the timed region" if posterior_kind == "svi" else
+                                     "stored samples (HMC-style)" + ("; BASELINE names SVI for this workload, the in-place draw covers fc / fc2 only"
+                                                                     if args.workload in SVI_NAMED else "")),
                        "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters)) if v}},
             "roofline": roofline(mode, evs, ms_per_step),
         }
+        if svi_rec is not None:
+            out["svi"] = svi_rec
+        if other_kind is not None:
+            k_ms = 1e3 * other_kind[1] / args.steps
+            rec = {"value": units / other_kind[1], "ms_per_step": k_ms, "precision_mode": other_kind[0]}
+            if other_kind[3] is not None:
+                rec["svi"] = other_kind[3]
+            out["stored_posterior_mode" if posterior_kind == "svi" else "svi_posterior_mode"] = rec
         for other in others:
             o_ms = 1e3 * other[1] / args.steps
             out[SUBKEY[other[0]]] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],

@@ -445,6 +445,26 @@ typedef struct rbnn_svi_guide {    /* device pointers to the variational paramet
 int rbnn_svi_draw(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
                   const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Low-dimensional fc nets (in_features <= 16, n_classes <= 10, arch fc; half-moons: 2 -> H -> 2) — the WHOLE hot path in one launch.
+ * One call = what a sequence of rbnn_fc_forward, rbnn_reduce_samples, rbnn_loss_dlogits, rbnn_fc_input_grad, rbnn_sum_slabs(_norms),
+ * rbnn_pgd_alpha and `iters` x rbnn_attack_step computes, i.e. for every point the loop nest adversarialAttacks.py:118 -> :95 ->
+ * model_bnn.py:251 (attack), lossGradients.py:20-40 (gradient) or model_bnn.py:243-258 (forward), in fp32 FMA arithmetic.
+ *   op RBNN_LOWDIM_FORWARD   out[N, ldo]  = out_scale * sum_s (probabilities | logits per out_kind) of the samples
+ *   op RBNN_LOWDIM_GRADIENT  out[N, ldo]  = out_scale * sum_s dL_s/dx for loss_mode (MEAN_PROB, PER_SAMPLE, MEAN_LOGIT; inv_S as
+ *                            rbnn_loss_dlogits), linf / l2 (nullable): the per-point norms of that gradient (lossGradients.py:91-105)
+ *   op RBNN_LOWDIM_ATTACK    out[N, ldo]  = the iterate after `iters` steps from X towards the eps-ball around X0 (project != 0) or one
+ *                            FGSM step (project == 0); step size alpha[n], or 2 / max(X0[n]) when alpha_per_image
+ *                            (adversarialAttacks.py:89), or alpha_scalar
+ * P_scratch: [n_samples, n_points, 16] floats (required for MEAN_PROB gradients / attacks).  sample_idx as rbnn_fc_forward.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef enum rbnn_lowdim_op { RBNN_LOWDIM_FORWARD = 0, RBNN_LOWDIM_GRADIENT = 1, RBNN_LOWDIM_ATTACK = 2 } rbnn_lowdim_op;
+int rbnn_lowdim_supported(const rbnn_posterior *net);      /* 1 when rbnn_lowdim_run covers this posterior */
+int rbnn_lowdim_run(const rbnn_posterior *net, int32_t op, int32_t loss_mode, int32_t out_kind, const float *X, const float *X0,
+                    int32_t ldx, int32_t n_points, const int32_t *sample_idx, int32_t n_samples, const int32_t *labels, float inv_S,
+                    float out_scale, float eps, const float *alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project,
+                    int32_t iters, float *P_scratch, float *out, int32_t ldo, float *linf, float *l2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

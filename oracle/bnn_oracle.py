@@ -314,6 +314,60 @@ def svi_materialize(loc, scale_raw, eps):
     return {k: loc[k].unsqueeze(0) + F.softplus(scale_raw[k]).unsqueeze(0) * eps[k] for k in loc}
 
 
+# The in-place draw (robustbnns_amd/csrc/rbnn_svi.hip, rbnn_svi_draw) generates eps itself: Philox4x32-10 + Box-Muller.  Restated
+# here in numpy so that the kernel is checked element by element (generator, counter layout, Box-Muller pairing, the padding rule).
+# PARITY UNPINNED against pyro-ppl 1.3.0 / torch 1.4.0's own stream, like everything about the draw.
+SVI_TENSOR_IDS = {"W1": 0, "b1": 1, "Wm": 2, "bm": 3, "W2": 4, "b2": 5}
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """numpy uint32 arrays (broadcastable) -> four uint32 arrays; Random123's Philox4x32 with 10 rounds."""
+    import numpy as np
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+    c0, c1, c2, c3, k0, k1 = (np.asarray(v, dtype=np.uint32) for v in np.broadcast_arrays(c0, c1, c2, c3, k0, k1))
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0, p1 = M0 * c0.astype(np.uint64), M1 * c2.astype(np.uint64)
+            hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+            hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0, k1 = k0 + W0, k1 + W1
+    return c0, c1, c2, c3
+
+
+def philox_normals(key, draw_id, tensor_id, sample, rows, cols, sample_is_key=False):
+    """eps [rows, cols] of one tensor of one sample, as rbnn_svi_draw generates it: element (r, c) is component c % 4 of the Philox
+    block with counter (r * ceil(cols/4) + c // 4, tensor_id, sample — or 0 when the key IS the sample's seed —, draw_id) under the
+    64-bit key; components (0,1) and (2,3) are Box-Muller pairs of u = (x + 0.5) 2^-32: sqrt(-2 ln u1) * (cos, sin)(2 pi u2)."""
+    import numpy as np
+    Q = (cols + 3) // 4
+    q = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(Q) + np.arange(Q, dtype=np.uint64)[None, :]).astype(np.uint32)
+    key = int(key) & 0xFFFFFFFFFFFFFFFF
+    x = philox4x32_10(q, np.uint32(tensor_id), np.uint32(0 if sample_is_key else sample), np.uint32(draw_id & 0xFFFFFFFF),
+                      np.uint32(key & 0xFFFFFFFF), np.uint32(key >> 32))
+    u = [np.minimum((xi.astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -32), np.float32(1.0)).astype(np.float64) for xi in x]
+    u[0], u[2] = np.minimum(u[0], 0.99999994), np.minimum(u[2], 0.99999994)
+    r01, r23 = np.sqrt(-2.0 * np.log(u[0])), np.sqrt(-2.0 * np.log(u[2]))
+    n = np.stack([r01 * np.cos(2 * np.pi * u[1]), r01 * np.sin(2 * np.pi * u[1]),
+                  r23 * np.cos(2 * np.pi * u[3]), r23 * np.sin(2 * np.pi * u[3])], axis=-1)            # [rows, Q, 4]
+    return n.reshape(rows, 4 * Q)[:, :cols]
+
+
+def svi_draw_philox(loc, scale_raw, key, draw_id, n_samples, sample_keys=None):
+    """The stacked weights rbnn_svi_draw writes: loc / scale_raw: dict name in SVI_TENSOR_IDS -> tensor (matrices [rows, cols], vectors
+    [n]); returns dict name -> float64 tensor [S, ...] and the eps used (same layout)."""
+    import numpy as np
+    W, E = {}, {}
+    for name, l in loc.items():
+        l64, sp = l.double(), F.softplus(scale_raw[name].double())
+        rows, cols = (l.shape if l.dim() == 2 else (1, l.numel()))
+        eps = np.stack([philox_normals(sample_keys[s] if sample_keys is not None else key, draw_id, SVI_TENSOR_IDS[name], s, rows, cols,
+                                       sample_is_key=sample_keys is not None) for s in range(n_samples)])
+        E[name] = torch.from_numpy(eps).reshape((n_samples,) + tuple(l.shape))
+        W[name] = l64.unsqueeze(0) + sp.unsqueeze(0) * E[name]
+    return W, E
+
+
 # =====================================================================================
 # Loop-structured port: the reference's nest, batch 1, autograd.  CPU baseline for bench.py.
 # =====================================================================================

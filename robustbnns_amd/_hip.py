@@ -142,6 +142,9 @@ SIGNATURES = {
     "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(TripleWorkspace), _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
     "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(TripleWorkspace),
                                          C.POINTER(_i32), _fp]),
+    "rbnn_lowdim_supported": (_i32, [_PP]),
+    "rbnn_lowdim_run": (_i32, [_PP, _i32, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _fp, _f32, _f32, _f32, _fp, _f32, _i32, _i32, _i32,
+                               _fp, _fp, _i32, _fp, _fp, _fp]),
     "rbnn_svi_draw": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
 }
 
@@ -423,3 +426,16 @@ class HipKernels:
         check(self.lib.rbnn_svi_draw(C.byref(net.descriptor()), None if images is None else C.byref(images), C.byref(guide.descriptor()), S,
                                      ptr(sample_keys), C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF),
                                      stream_of(net.W1)), "rbnn_svi_draw")
+
+    # -- low-dimensional fc nets: the whole hot path in one launch (rbnn_lowdim.hip) -------------------------
+    LOWDIM_FORWARD, LOWDIM_GRADIENT, LOWDIM_ATTACK = 0, 1, 2
+
+    def lowdim_supported(self, net):
+        return bool(self.lib.rbnn_lowdim_supported(C.byref(net.descriptor())))
+
+    def lowdim_run(self, net, op, loss_mode, out_kind, X, X0, sidx, S, labels, inv_S, out_scale, eps, alpha, alpha_scalar, alpha_per_image,
+                   project, iters, P, out, linf=None, l2=None):
+        require_gpu(X, "X")
+        check(self.lib.rbnn_lowdim_run(C.byref(net.descriptor()), op, loss_mode, out_kind, ptr(X), ptr(X0), X.stride(0), X.shape[0], ptr(sidx), S,
+                                       ptr(labels), inv_S, out_scale, eps, ptr(alpha), alpha_scalar, int(alpha_per_image), int(project), iters,
+                                       ptr(P), ptr(out), out.stride(0), ptr(linf), ptr(l2), stream_of(X)), "rbnn_lowdim_run")

@@ -121,11 +121,15 @@ class ConvStackedPosterior:
         return cls(activation, input_shape, n_classes, hidden, stacked, device)
 
     def scale_bounds(self):
-        """(mul, add, cap) of rbnn_input_scales' record 1: |P1| <= max_c(sum_taps |K1w_c|) * max|x| + max|K1b| bounds the pooled
-        conv1 activations (relu / leaky: |act(a)| <= |a|)."""
+        """(mul, add, cap) of rbnn_input_scales' record 1, the bound of the pooled conv1 ACTIVATIONS that fixes their fp16-piece scale:
+        relu / leaky: |act(a)| <= |a| <= max_c(sum_taps |K1w_c|) * max|x| + max|K1b|; tanh: additionally <= 1; sigmoid lies in (0, 1)
+        whatever the pre-activation — with tiny conv1 weights or all-zero images the |a| bound would be far BELOW sigmoid(a) ~ 0.5 and the
+        scaled activations would overflow fp16 — so its bound is the constant 1, as in StackedPosterior.scale_bounds."""
+        if self.activation == "sigm":
+            return 0.0, 1.0, 1.0
         if not hasattr(self, "_p1_bound"):
             self._p1_bound = (float(self.K1w.abs().sum(-1).max()), float(self.K1b.abs().max()))
-        return self._p1_bound[0], self._p1_bound[1], float("inf")
+        return self._p1_bound[0], self._p1_bound[1], (1.0 if self.activation == "tanh" else float("inf"))
 
     def descriptor(self):
         if self._desc is None:

@@ -1,0 +1,389 @@
+// rbnn_lowdim.hip — the whole hot path of a LOW-DIMENSIONAL fc net (half-moons: 2 -> H -> 2; in_features <= 16, classes <= 10) in ONE
+// launch: forward over all samples -> mean over samples -> loss -> hand-rolled input gradient -> sum over samples -> sign / project /
+// clamp, for ALL PGD iterations, with the iterate resident in registers.
+//
+// Why a second implementation: with D = 2 the "GEMMs" of rbnn_kernels.hip are 16-column MFMA tiles that are 7/8 zero padding, and a
+// BASELINE C1 pass (N = 100, S = 10, H = 64: 0.5 MFLOP) is nothing but the launch floor of its 7 kernels (90 us per FGSM pass, 40 passes
+// per PGD attack, one attack per cell of the reference's grid search, grid_search_halfMoons.py:133-169).  Here the nest
+// adversarialAttacks.py:118 -> :95 -> model_bnn.py:251 becomes:
+//
+//   block  = PB points x SL sample lanes (PB * SL <= 256); thread (j, p) owns point p and samples j, j + SL, j + 2 SL, ...
+//   pass 1   per owned sample: a_h = b1[h] + W1[h,:] . x, act, z_c += W2[c,h] act(a_h); softmax; P[s,n,:] -> scratch; partial sum
+//            -> LDS -> every thread of the point adds the SL partials in lane order  (= rbnn_reduce_samples)
+//   loss     dL/d(mean output) exactly as rbnn_loss_dlogits (double softmax for a BNN, adversarialAttacks.py:74-76)
+//   pass 2   per owned sample: dZ_s from P[s,n,:]; a_h recomputed (cheaper than a stash: D + 1 FMAs); dA_h = act'(a_h) sum_c W2[c,h] dZ_c;
+//            g += dA_h W1[h,:]                                                      (= rbnn_fc_input_grad, fp32 FMA instead of MFMA)
+//            -> LDS -> summed in lane order by every thread of the point            (= rbnn_sum_slabs)
+//   step     x <- clamp(x0 + clamp(x + alpha sign(g) - x0, -eps, eps), 0, 1)         (= rbnn_attack_step; every lane of a point keeps
+//            an identical copy of x: same operands, same order)
+//
+// All samples of a point live in one block, so no grid-wide synchronisation exists and every block runs its T iterations on its own.
+// Weights are read straight from the stacked posterior (lanes of a wave share the sample: one request per load); a whole posterior of
+// this kind is tens of KB per sample and stays in L2.  Everything is fp32 FMA in a fixed order: results are deterministic.
+#include "rbnn_common.hpp"
+#include <algorithm>
+
+namespace {
+
+enum { OP_FORWARD = 0, OP_GRADIENT = 1, OP_ATTACK = 2 };
+
+struct LowArgs {
+    rbnn_posterior net;
+    const float *X, *X0;           // start iterate and clean inputs [N, ldx] (X0 == X for a fresh attack)
+    const int* sidx;
+    const int* labels;
+    const float* alpha;
+    float *P, *out, *linf, *l2;
+    int ldx, N, S, op, loss, out_kind, ldo, iters, project, alpha_per_image, SL, PB;
+    int cache_stride;              // > 0: floats per sample of the LDS weight cache (all S samples of the call fit)
+    float inv_S, out_scale, eps, alpha_scalar;
+};
+
+template <int ACT> __device__ __forceinline__ float act_deriv(float a, float hv) {
+    if (ACT == RBNN_ACT_RELU)  return a > 0.f ? 1.f : 0.f;
+    if (ACT == RBNN_ACT_LEAKY) return a > 0.f ? 1.f : LEAKY_SLOPE;
+    return act_grad_from_value<ACT>(hv);
+}
+
+// One sample's weights: straight from the stacked posterior, or from the block's LDS cache (compact: W1 [H][4 DQ], b1 [H], W2 [C][H], b2 [C]).
+struct SampleW {
+    const float *W1, *b1, *W2, *b2;
+    int ldw;
+};
+
+template <int DQ> __device__ __forceinline__ SampleW sample_view(const LowArgs& a, const float* cache, int s) {
+    const int H = a.net.hidden, C = a.net.n_classes;
+    SampleW v;
+    if (cache) {
+        const float* const base = cache + (long long)s * a.cache_stride;
+        v.W1 = base; v.ldw = 4 * DQ; v.b1 = base + H * 4 * DQ; v.W2 = v.b1 + H; v.b2 = v.W2 + C * H;
+    } else {
+        const int sw = a.sidx ? a.sidx[s] : s;
+        v.W1 = a.net.W1 + (long long)sw * H * a.net.in_stride; v.ldw = a.net.in_stride; v.b1 = a.net.b1 + (long long)sw * H;
+        v.W2 = a.net.W2 + (long long)sw * C * H; v.b2 = a.net.b2 + (long long)sw * C;
+    }
+    return v;
+}
+
+// logits of one sample at x
+template <int ACT, int DQ, int CM>
+__device__ __forceinline__ void forward_sample(const SampleW& w_, int H, int C, const float (&x)[4 * DQ], float (&z)[CM]) {
+    const float* const W1 = w_.W1; const float* const b1 = w_.b1; const float* const W2 = w_.W2;
+    const int ldw = w_.ldw;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) z[c] = (c < C) ? w_.b2[c] : 0.f;
+    for (int h = 0; h < H; h += 4) {
+        const f32x4 bq = *(const f32x4*)(b1 + h);
+        float hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = bq[r];
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                const f32x4 w = *(const f32x4*)(W1 + (long long)(h + r) * ldw + 4 * q);
+                a = fmaf(w[0], x[4 * q], a); a = fmaf(w[1], x[4 * q + 1], a); a = fmaf(w[2], x[4 * q + 2], a); a = fmaf(w[3], x[4 * q + 3], a);
+            }
+            hv[r] = act_fwd<ACT>(a);
+        }
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                const f32x4 w2 = *(const f32x4*)(W2 + (long long)c * H + h);
+                z[c] = fmaf(w2[0], hv[0], z[c]); z[c] = fmaf(w2[1], hv[1], z[c]); z[c] = fmaf(w2[2], hv[2], z[c]); z[c] = fmaf(w2[3], hv[3], z[c]);
+            }
+        }
+    }
+}
+
+// gx += sum_h act'(a_h) (sum_c W2[c,h] dz_c) W1[h,:]   (a_h recomputed)
+template <int ACT, int DQ, int CM>
+__device__ __forceinline__ void backward_sample(const SampleW& w_, int H, int C, const float (&x)[4 * DQ], const float (&dz)[CM],
+                                                float (&gx)[4 * DQ]) {
+    const float* const W1 = w_.W1; const float* const b1 = w_.b1; const float* const W2 = w_.W2;
+    const int ldw = w_.ldw;
+    for (int h = 0; h < H; h += 4) {
+        const f32x4 bq = *(const f32x4*)(b1 + h);
+        float da[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                const f32x4 w2 = *(const f32x4*)(W2 + (long long)c * H + h);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) da[r] = fmaf(w2[r], dz[c], da[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            f32x4 w[DQ];
+            float a = bq[r];
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                w[q] = *(const f32x4*)(W1 + (long long)(h + r) * ldw + 4 * q);
+                a = fmaf(w[q][0], x[4 * q], a); a = fmaf(w[q][1], x[4 * q + 1], a); a = fmaf(w[q][2], x[4 * q + 2], a); a = fmaf(w[q][3], x[4 * q + 3], a);
+            }
+            const float d = da[r] * act_deriv<ACT>(a, act_fwd<ACT>(a));
+#pragma unroll
+            for (int q = 0; q < DQ; ++q) {
+                gx[4 * q] = fmaf(d, w[q][0], gx[4 * q]); gx[4 * q + 1] = fmaf(d, w[q][1], gx[4 * q + 1]);
+                gx[4 * q + 2] = fmaf(d, w[q][2], gx[4 * q + 2]); gx[4 * q + 3] = fmaf(d, w[q][3], gx[4 * q + 3]);
+            }
+        }
+    }
+}
+
+template <int CM> __device__ __forceinline__ void softmax_inplace(float (&v)[CM], int C) {
+    float m = -INFINITY, den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) if (c < C) m = fmaxf(m, v[c]);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) { v[c] = (c < C) ? expf(v[c] - m) : 0.f; den += v[c]; }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) v[c] = v[c] / den;
+}
+
+// dL/d(what the loss saw), as rbnn_loss_dlogits: softmax(t) - onehot(y), times inv_S
+template <int CM> __device__ __forceinline__ void loss_grad(const float (&t)[CM], int C, int y, float inv_S, float (&g)[CM]) {
+    float e[CM], m = -INFINITY, den = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) if (c < C) m = fmaxf(m, t[c]);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) { e[c] = (c < C) ? expf(t[c] - m) : 0.f; den += e[c]; }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+}
+
+template <int ACT, int DQ, int CM>
+__global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [SL][PB][RW] reduction slots, then (cache_stride > 0) the weight cache
+    constexpr int DW = 4 * DQ, RW = DW > CM ? DW : CM;
+    const int t = threadIdx.x, PB = a.PB, SL = a.SL;
+    const int H = a.net.hidden;
+    const float* cache = nullptr;
+    if (a.cache_stride > 0) {
+        // Small posteriors (C1: 10 samples x 1.8 KB): every block first copies ALL the call's samples into LDS, compact, in one round of
+        // independent loads — the per-hidden-unit loop then waits on ds_read latency, not on a chain of dependent L2 round trips (which
+        // is all a 4-block launch has to hide them with).
+        float* const cw = red + ((a.SL * a.PB * RW + 3) & ~3);
+        const int Cn = a.net.n_classes, SS = a.cache_stride, n1 = H * DW, n2 = n1 + H, n3 = n2 + Cn * H;
+        for (int e = t; e < a.S * SS; e += 256) {
+            const int sl = e / SS, r = e - sl * SS;
+            const int sw = a.sidx ? a.sidx[sl] : sl;
+            float v = 0.f;
+            if (r < n1) v = a.net.W1[((long long)sw * H + r / DW) * a.net.in_stride + r % DW];
+            else if (r < n2) v = a.net.b1[(long long)sw * H + (r - n1)];
+            else if (r < n3) v = a.net.W2[(long long)sw * Cn * H + (r - n2)];
+            else if (r < n3 + Cn) v = a.net.b2[(long long)sw * Cn + (r - n3)];
+            cw[e] = v;
+        }
+        cache = cw;
+        __syncthreads();
+    }
+    const int j = t / PB, p = t - j * PB;
+    const int n = blockIdx.x * PB + p;
+    const bool live = j < SL && n < a.N;
+    const int C = a.net.n_classes, D = a.net.in_features, S = a.S, N = a.N;
+    float x[DW], x0[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) {
+        x[d] = (live && d < D) ? a.X[(long long)n * a.ldx + d] : 0.f;
+        x0[d] = (live && d < D && a.op == OP_ATTACK) ? a.X0[(long long)n * a.ldx + d] : x[d];
+    }
+    const int y = (live && a.labels) ? a.labels[n] : 0;
+    float step = a.alpha_scalar;
+    if (a.op == OP_ATTACK && live) {
+        if (a.alpha) step = a.alpha[n];
+        else if (a.alpha_per_image) {                                 // adversarialAttacks.py:89: alpha = 2 / image.max(), from the CLEAN image
+            float m = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < DW; ++d) if (d < D) m = fmaxf(m, x0[d]);
+            step = 2.f / m;
+        }
+    }
+    float* const slot = red + ((long long)j * PB + p) * RW;
+    const float* const col = red + (long long)p * RW;                 // lane jj of this point: col + jj * PB * RW
+    const int iters = a.op == OP_ATTACK ? a.iters : 1;
+    const bool need_mean = a.op == OP_FORWARD || a.loss != RBNN_LOSS_PER_SAMPLE;
+    const bool probs = a.op == OP_FORWARD ? a.out_kind == RBNN_OUT_PROBS : a.loss != RBNN_LOSS_MEAN_LOGIT;
+    for (int it = 0; it < iters; ++it) {
+        float tot[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) tot[c] = 0.f;
+        if (need_mean) {                                              // ---- pass 1: every sample's output at x, and their sum
+            float acc[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) acc[c] = 0.f;
+            if (live)
+                for (int s = j; s < S; s += SL) {
+                    float z[CM];
+                    forward_sample<ACT, DQ, CM>(sample_view<DQ>(a, cache, s), H, C, x, z);
+                    if (probs) softmax_inplace<CM>(z, C);
+                    if (a.op != OP_FORWARD && a.loss == RBNN_LOSS_MEAN_PROB) {
+                        float* const ps = a.P + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+                        for (int c = 0; c < CM; ++c) if (c < C) ps[c] = z[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < CM; ++c) acc[c] += z[c];
+                }
+            if (j < SL) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) slot[c] = acc[c];
+            }
+            __syncthreads();
+            for (int jj = 0; jj < SL; ++jj) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) tot[c] += col[(long long)jj * PB * RW + c];
+            }
+            __syncthreads();
+        }
+        if (a.op == OP_FORWARD) {
+            if (live && j == 0) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) if (c < C) a.out[(long long)n * a.ldo + c] = tot[c] * a.out_scale;
+            }
+            return;
+        }
+        float g[CM];                                                  // ---- loss (mean-prob / mean-logit: one gradient for all samples)
+        if (need_mean) {
+            float tm[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) tm[c] = tot[c] * a.inv_S;
+            loss_grad<CM>(tm, C, y, a.inv_S, g);
+        }
+        float gx[DW];                                                 // ---- pass 2: input gradient of every owned sample
+#pragma unroll
+        for (int d = 0; d < DW; ++d) gx[d] = 0.f;
+        if (live)
+            for (int s = j; s < S; s += SL) {
+                const SampleW sv = sample_view<DQ>(a, cache, s);
+                float dz[CM];
+                if (a.loss == RBNN_LOSS_MEAN_LOGIT) {
+#pragma unroll
+                    for (int c = 0; c < CM; ++c) dz[c] = g[c];
+                } else {
+                    float ps[CM];
+                    if (a.loss == RBNN_LOSS_PER_SAMPLE) {             // lossGradients.py:29-40: CE of THIS sample's probabilities
+                        forward_sample<ACT, DQ, CM>(sv, H, C, x, ps);
+                        softmax_inplace<CM>(ps, C);
+                        loss_grad<CM>(ps, C, y, a.inv_S, g);
+                    } else {
+                        const float* const pp = a.P + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+                        for (int c = 0; c < CM; ++c) ps[c] = (c < C) ? pp[c] : 0.f;
+                    }
+                    float dot = 0.f;                                  // softmax backward: (g - <g,p>) p
+#pragma unroll
+                    for (int c = 0; c < CM; ++c) if (c < C) dot += g[c] * ps[c];
+#pragma unroll
+                    for (int c = 0; c < CM; ++c) dz[c] = (c < C) ? (g[c] - dot) * ps[c] : 0.f;
+                }
+                backward_sample<ACT, DQ, CM>(sv, H, C, x, dz, gx);
+            }
+        if (j < SL) {
+#pragma unroll
+            for (int d = 0; d < DW; ++d) slot[d] = gx[d];
+        }
+        __syncthreads();
+        float G[DW];
+#pragma unroll
+        for (int d = 0; d < DW; ++d) G[d] = 0.f;
+        for (int jj = 0; jj < SL; ++jj) {
+#pragma unroll
+            for (int d = 0; d < DW; ++d) G[d] += col[(long long)jj * PB * RW + d];
+        }
+        __syncthreads();
+        if (a.op == OP_GRADIENT) {
+            if (live && j == 0) {
+                float m = 0.f, ss = 0.f;
+#pragma unroll
+                for (int d = 0; d < DW; ++d) {
+                    if (d < D) {
+                        const float v = G[d] * a.out_scale;
+                        a.out[(long long)n * a.ldo + d] = v;
+                        m = fmaxf(m, fabsf(v)); ss = fmaf(v, v, ss);
+                    }
+                }
+                if (a.linf) a.linf[n] = m;
+                if (a.l2) a.l2[n] = sqrtf(ss);
+            }
+            return;
+        }
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {                                // ---- step: rbnn_attack_step's operation order
+            const float sgn = (G[d] > 0.f) ? 1.f : ((G[d] < 0.f) ? -1.f : 0.f);
+            float pert = x[d] + step * sgn;
+            if (a.project) pert = x0[d] + fminf(fmaxf(pert - x0[d], -a.eps), a.eps);
+            x[d] = (d < D) ? fminf(fmaxf(pert, 0.f), 1.f) : 0.f;
+        }
+    }
+    if (live && j == 0) {
+#pragma unroll
+        for (int d = 0; d < DW; ++d) if (d < D) a.out[(long long)n * a.ldo + d] = x[d];
+    }
+}
+
+template <int ACT, int DQ, int CM> int launch_low(const LowArgs& a, hipStream_t st) {
+    constexpr int RW = (4 * DQ > CM) ? 4 * DQ : CM;
+    LowArgs b = a;
+    const size_t red_floats = ((size_t)a.SL * a.PB * RW + 3) & ~(size_t)3;
+    const int H = a.net.hidden, C = a.net.n_classes;
+    const size_t ss = ((size_t)H * (4 * DQ + 1 + C) + C + 3) & ~(size_t)3;             // compact floats per sample
+    // the cache pays when a block is short of work to hide L2 latency with (few owned samples per thread) and fits the default 64 KB of
+    // dynamic LDS; big posteriors keep reading through L1 / L2, where many resident waves hide the latency
+    b.cache_stride = ((red_floats + ss * a.S) * sizeof(float) <= 60 * 1024) ? (int)ss : 0;
+    const size_t lds = (red_floats + (b.cache_stride ? ss * a.S : 0)) * sizeof(float);
+    hipLaunchKernelGGL((lowdim_kernel<ACT, DQ, CM>), dim3((unsigned)((a.N + a.PB - 1) / a.PB)), dim3(256), lds, st, b);
+    return launch_status();
+}
+
+template <int ACT> int launch_low_act(const LowArgs& a, hipStream_t st) {
+    const bool small_d = a.net.in_features <= 4, small_c = a.net.n_classes <= 2;
+    if (small_d) return small_c ? launch_low<ACT, 1, 2>(a, st) : launch_low<ACT, 1, 10>(a, st);
+    return small_c ? launch_low<ACT, 4, 2>(a, st) : launch_low<ACT, 4, 10>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rbnn_lowdim_supported(const rbnn_posterior* net) {
+    return net && net->arch == RBNN_ARCH_FC && net->in_features >= 1 && net->in_features <= 16 && net->n_classes >= 1 && net->n_classes <= 10 &&
+           net->hidden >= 32 && (net->hidden & 31) == 0 && net->in_stride >= 16 && (net->in_stride & 15) == 0;
+}
+
+int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, int32_t out_kind, const float* X, const float* X0, int32_t ldx,
+                    int32_t n_points, const int32_t* sample_idx, int32_t n_samples, const int32_t* labels, float inv_S, float out_scale,
+                    float eps, const float* alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project, int32_t iters,
+                    float* P_scratch, float* out, int32_t ldo, float* linf, float* l2, void* stream) {
+    if (!net || !X || !out || !net->W1 || !net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
+    if (!rbnn_lowdim_supported(net)) return RBNN_ERR_UNSUPPORTED;
+    if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
+    if (op < OP_FORWARD || op > OP_ATTACK || n_points < 1 || n_samples < 1 || ldx < net->in_features) return RBNN_ERR_SHAPE;
+    if (op == OP_FORWARD ? ldo < net->n_classes : ldo < net->in_features) return RBNN_ERR_SHAPE;
+    if (op != OP_FORWARD) {
+        if (!labels) return RBNN_ERR_NULL;
+        if (loss_mode != RBNN_LOSS_MEAN_PROB && loss_mode != RBNN_LOSS_PER_SAMPLE && loss_mode != RBNN_LOSS_MEAN_LOGIT) return RBNN_ERR_UNSUPPORTED;
+        if (loss_mode == RBNN_LOSS_MEAN_PROB && !P_scratch) return RBNN_ERR_NULL;
+    }
+    if (op == OP_ATTACK && (iters < 1 || (project && !X0))) return RBNN_ERR_SHAPE;
+    if (!aligned16(net->W1) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
+    LowArgs a = {};
+    a.net = *net; a.X = X; a.X0 = X0 ? X0 : X; a.sidx = sample_idx; a.labels = labels; a.alpha = alpha; a.P = P_scratch; a.out = out;
+    a.linf = linf; a.l2 = l2; a.ldx = ldx; a.N = n_points; a.S = n_samples; a.op = op; a.loss = loss_mode; a.out_kind = out_kind; a.ldo = ldo;
+    a.iters = iters; a.project = project; a.alpha_per_image = alpha_per_image; a.inv_S = inv_S; a.out_scale = out_scale; a.eps = eps;
+    a.alpha_scalar = alpha_scalar;
+    // sample lanes per point: enough threads to fill the chip (256 CUs x 2 x 256) when N is small, one lane per point when N is large
+    long long want = (131072 + (long long)n_points - 1) / n_points;
+    a.SL = (int)std::max(1LL, std::min<long long>(std::min<long long>(n_samples, 256), want));
+    a.PB = 256 / a.SL;
+    hipStream_t st = (hipStream_t)stream;
+    switch (net->activation) {
+        case RBNN_ACT_RELU:  return launch_low_act<RBNN_ACT_RELU>(a, st);
+        case RBNN_ACT_LEAKY: return launch_low_act<RBNN_ACT_LEAKY>(a, st);
+        case RBNN_ACT_SIGM:  return launch_low_act<RBNN_ACT_SIGM>(a, st);
+        case RBNN_ACT_TANH:  return launch_low_act<RBNN_ACT_TANH>(a, st);
+    }
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -18,6 +18,8 @@ f16 MFMA pipe, fp32 accumulation (rbnn_fc_forward_triple / rbnn_fc_input_grad_tr
 "auto" (default) = triple where those kernels cover the posterior, else exact; "split" (opt-in) = error-compensated half
 pairs on the f16 MFMA pipe (rbnn_fc_forward_split / rbnn_fc_input_grad_split: 2^-22 per product, ~2.7x faster, same 1e-5
 parity bar, operands narrower than fp32); "fast" = split where the split kernels cover the posterior, else exact.
+Low-dimensional fc nets (in_features <= 16: half-moons) run NONE of the above: "auto" resolves to "lowdim", where a forward, an expected
+gradient or a whole T-iteration attack is ONE launch of rbnn_lowdim_run (rbnn_lowdim.hip; fp32 FMA, the iterate resident in registers).
 torch supplies device memory, the current HIP stream and torch.distributed (RCCL); all arithmetic is
 in the HIP kernels behind `kernels` (robustbnns_amd._hip.HipKernels — there is no other backend in
 this package; tests inject a CPU fake to exercise the multi-process orchestration under gloo).
@@ -82,8 +84,18 @@ class AttackEngine:
         same 1e-5 parity bar, and the same adversarial accuracy in the split-vs-exact tests) — OPT-IN, raises where the split
         kernels do not cover the posterior.  fast: split where it applies, else exact.  RBNN_PRECISION sets the default."""
         want = (precision or os.environ.get("RBNN_PRECISION") or "auto").lower()
-        if want not in ("auto", "exact", "triple", "split", "fast"):
-            raise ValueError(f"precision={want!r}: expected 'auto', 'exact', 'triple', 'split' or 'fast'")
+        if want not in ("auto", "exact", "triple", "split", "fast", "lowdim"):
+            raise ValueError(f"precision={want!r}: expected 'auto', 'exact', 'triple', 'split', 'fast' or 'lowdim'")
+        # lowdim: in_features <= 16 (half-moons).  The contractions are then a few FMAs per hidden unit and a pass is bound by the launch
+        # floor of the 7 kernels above: one kernel does the forward / the expected gradient / ALL iterations of an attack in fp32 FMA
+        # arithmetic (rbnn_lowdim.hip).  Single process only (the sample-sharded step needs its all-reduces between the phases); calls it
+        # does not cover (autograd hooks with an upstream gradient) run the fp32-MFMA kernels.
+        low = (isinstance(self.k, _hip.HipKernels) and self.world == 1 and getattr(self.post, "arch", None) == "fc"
+               and self.device.type == "cuda" and self.k.lowdim_supported(self.post))
+        if want == "lowdim" and not low:
+            raise _hip.HipError("precision='lowdim' covers fc posteriors with in_features <= 16 and classes <= 10 on one GPU")
+        if want == "lowdim" or (want == "auto" and low):
+            return "lowdim"
         # triple: full-width fp32 operands as three fp16 pieces, six exact product terms on the f16 matrix pipe, fp32 accumulation
         # (rbnn_triple.hip).  Nothing is narrower than fp32 — the only rounding left is the fp32 accumulation, as on the fp32 MFMA; its
         # measured error against fp64 is BELOW the fp32-MFMA kernels' (tests/test_hip_triple.py) — and it is ~1.7x faster, so "auto"
@@ -140,6 +152,14 @@ class AttackEngine:
 
     def unpad(self, Xp, like):
         return Xp[:, :self.post.D].reshape(like.shape).clone()
+
+    def _flat(self, x):
+        """[N, *input_shape] -> contiguous fp32 [N, D] on the device, UNPADDED and without a copy when x already is that: what the
+        lowdim kernel reads (any row stride >= D; the MFMA kernels need the D_pad image of pad_inputs)."""
+        xf = x.detach().reshape(x.shape[0], -1).to(self.device, torch.float32).contiguous()
+        if xf.shape[1] != self.post.D:
+            raise ValueError(f"inputs flatten to {xf.shape[1]} features, posterior expects {self.post.D}")
+        return xf
 
     def sample_index(self, n_samples, seeds=None):
         """model_bnn.py:200-202,246-252: first n_samples stored samples, or `seeds` as indices."""
@@ -220,10 +240,14 @@ class AttackEngine:
     def forward_padded(self, Xp, sidx, S, out_kind=OUT_PROBS, out=None):
         """mean over samples of P (probabilities or logits) -> [N, 16] buffer (columns >= C are zero)."""
         N = Xp.shape[0]
-        ws = self.workspace(N, S)
-        self._forward_kernels(Xp, sidx, S, out_kind, ws)
         if out is None:
             out = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
+        if self.precision == "lowdim":
+            self.k.lowdim_run(self.post, self.k.LOWDIM_FORWARD, 0, out_kind, Xp, None, sidx, S, None, 1.0, 1.0 / S, 0.0, None, 0.0, False, False,
+                              1, None, out)
+            return out
+        ws = self.workspace(N, S)
+        self._forward_kernels(Xp, sidx, S, out_kind, ws)
         if self.world == 1:
             self.k.reduce_samples(ws["P"], S, N, self.post.C, 1.0 / S, out)         # model_bnn.py:257
         else:       # sample-sharded: every rank scales its partial sum by 1 / (samples over all ranks); the all-reduce finishes the mean
@@ -237,7 +261,8 @@ class AttackEngine:
             # callers that differentiate the forward themselves (the reference's own fgsm_attack does:
             # adversarialAttacks.py:73-79): the backward is the HIP input-gradient path with the upstream dL/dout
             return _DifferentiableForward.apply(x, self, sidx, S, bool(logits))
-        out = self.forward_padded(self.pad_inputs(x), sidx, S, OUT_LOGITS if logits else OUT_PROBS)
+        xin = self._flat(x) if self.precision == "lowdim" else self.pad_inputs(x)
+        out = self.forward_padded(xin, sidx, S, OUT_LOGITS if logits else OUT_PROBS)
         return out[:, :self.post.C]
 
     def vjp(self, x, grad_out, sidx, S, logits):
@@ -278,6 +303,12 @@ class AttackEngine:
     def gradient(self, Xp, labels, sidx, S, mode, G_up=None, norms=None):
         """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad].  norms = (linf [N], l2 [N]) device
         buffers: filled with the per-point norms of that gradient in the same pass as the slab sum (rbnn_sum_slabs_norms)."""
+        if self.precision == "lowdim" and G_up is None and mode in (LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_MEAN_LOGIT):
+            ws = self.workspace(Xp.shape[0], S)
+            per = mode == LOSS_PER_SAMPLE
+            self.k.lowdim_run(self.post, self.k.LOWDIM_GRADIENT, mode, 0, Xp, None, sidx, S, labels, 1.0 if per else 1.0 / S, 1.0 / S if per else 1.0,
+                              0.0, None, 0.0, False, False, 1, ws["P"], ws["G"], None if norms is None else norms[0], None if norms is None else norms[1])
+            return ws["G"]
         ws, n_slabs, S_tot = self.gradient_slabs(Xp, labels, sidx, S, mode, G_up)
         scale = 1.0 / S_tot if mode == LOSS_PER_SAMPLE else 1.0
         N, p = Xp.shape[0], self.post
@@ -301,7 +332,8 @@ class AttackEngine:
         if norms:
             nb = (torch.empty(x.shape[0], dtype=torch.float32, device=self.device),
                   torch.empty(x.shape[0], dtype=torch.float32, device=self.device))
-        G = self.gradient(self.pad_inputs(x), to_labels(y, self.device), sidx, S, LOSS_PER_SAMPLE, norms=nb)
+        xin = self._flat(x) if self.precision == "lowdim" else self.pad_inputs(x)
+        G = self.gradient(xin, to_labels(y, self.device), sidx, S, LOSS_PER_SAMPLE, norms=nb)
         return (self.unpad(G, x), nb[0], nb[1]) if norms else self.unpad(G, x)
 
     # ------------------------------------------------------------------ attacks
@@ -331,7 +363,11 @@ class AttackEngine:
         Every rank does the same blocks in the same order; each block has its own workspace."""
         p, N, C = self.post, X.shape[0], self.post.C
         nb = self._comm_blocks(N)
-        bounds = [N * i // nb for i in range(nb + 1)]
+        # block boundaries on multiples of 256 points (the gradient kernels' point tile; the forward's is 128): the blocks together then
+        # launch exactly the tiles of the unsplit step — an even split of 10 000 points would add a nearly empty tile to every kernel
+        bounds = [0] + [min(N, (N * i // nb + 255) // 256 * 256) for i in range(1, nb)] + [N]
+        bounds = sorted(set(bounds))
+        nb = len(bounds) - 1
         S_tot = self.total_samples(S)
         need_psum = mode in (LOSS_MEAN_PROB, LOSS_MEAN_LOGIT)
         inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
@@ -361,6 +397,9 @@ class AttackEngine:
     def fgsm(self, x, y, n_samples, epsilon=0.3, seeds=None, mode=LOSS_MEAN_PROB):
         """adversarialAttacks.fgsm_attack on every row of x (adversarialAttacks.py:69-83)."""
         sidx, S = self.sample_index(n_samples, seeds)
+        if self.precision == "lowdim":          # one launch; the inputs are read where they are, the result is a fresh tensor
+            out = self._lowdim_attack(self._flat(x), None, to_labels(y, self.device), sidx, S, mode, None, 0.0, False, float(epsilon), False, 1)
+            return out.reshape(x.shape)
         X = self.pad_inputs(x, clone=True)
         self._scales = self._input_scales(X, iterates=False)
         try:
@@ -376,6 +415,17 @@ class AttackEngine:
         reference draws fresh weights at every forward, model_bnn.py:230-232; the caller drew the first set)."""
         sidx, S = self.sample_index(n_samples, seeds)
         labels = to_labels(y, self.device)
+        if self.precision == "lowdim":          # all `iters` iterations in ONE launch (an SVI net redraws in between: one launch per iteration)
+            a = 0.0 if alpha is None else float(alpha)
+            X0 = self._flat(x)
+            if before_step is None:
+                return self._lowdim_attack(X0, X0, labels, sidx, S, mode, None, a, alpha is None, float(epsilon), True, iters).reshape(x.shape)
+            X = X0
+            for it in range(iters):
+                if it:
+                    before_step()
+                X = self._lowdim_attack(X, X0, labels, sidx, S, mode, None, a, alpha is None, float(epsilon), True, 1)
+            return X.reshape(x.shape)
         X0 = self.pad_inputs(x, clone=True)
         X = X0.clone()
         alpha_t = None
@@ -411,6 +461,17 @@ class AttackEngine:
             self._scales = None
         return self.unpad(X, x)
 
+    def _lowdim_attack(self, X, X0, labels, sidx, S, mode, alpha_t, alpha_scalar, alpha_per_image, eps, project, iters):
+        """rbnn_lowdim_run(ATTACK): `iters` iterations from X (around X0) in one launch -> a new [N, D_pad] tensor.  FGSM: project False,
+        the step is eps itself."""
+        ws = self.workspace(X.shape[0], S)
+        out = torch.empty_like(X)               # the kernel writes every column d < D of every row; X is the unpadded [N, D] view
+        if not project:
+            alpha_scalar, alpha_per_image = eps, False
+        self.k.lowdim_run(self.post, self.k.LOWDIM_ATTACK, mode, 0, X, X0, sidx, S, labels, 1.0 / S, 1.0, eps, alpha_t, alpha_scalar, alpha_per_image,
+                          project, iters, ws["P"], out)
+        return out
+
     graph_safe = True                       # ConvEngine (per-call point blocking) turns this off
 
     def _graph_capturable(self):
@@ -433,6 +494,10 @@ class AttackEngine:
     def pgd_continue(self, x, x0, y, n_samples, epsilon, alpha=None, mode=LOSS_MEAN_PROB):
         """ONE PGD iteration from x towards the eps-ball around x0 (SVI: the caller redraws weights between iterations)."""
         sidx, S = self.sample_index(n_samples)
+        if self.precision == "lowdim":
+            out = self._lowdim_attack(self._flat(x), self._flat(x0), to_labels(y, self.device), sidx, S, mode, None,
+                                      0.0 if alpha is None else float(alpha), alpha is None, float(epsilon), True, 1)
+            return out.reshape(x.shape)
         X0 = self.pad_inputs(x0, clone=True)
         X = self.pad_inputs(x, clone=True)
         alpha_t = None
@@ -448,8 +513,9 @@ class AttackEngine:
         sidx, S = self.sample_index(n_samples)
         kind = OUT_LOGITS if logits else OUT_PROBS
         labels = to_labels(y, self.device)
-        o = self.forward_padded(self.pad_inputs(x), sidx, S, kind)
-        a = self.forward_padded(self.pad_inputs(x_attack), sidx, S, kind)
+        prep = self._flat if self.precision == "lowdim" else self.pad_inputs
+        o = self.forward_padded(prep(x), sidx, S, kind)
+        a = self.forward_padded(prep(x_attack), sidx, S, kind)
         counts = torch.zeros(2, dtype=torch.int32, device=self.device)
         rob = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
         self.k.eval_metrics(o, a, labels, self.post.C, counts, rob)

@@ -108,7 +108,7 @@ class BNN(nn.Module):
         self._drawn = None                    # svi: (key, engine) of the last SEEDED draw (same seeds -> same weights: reused, not redrawn)
         self._guide = None                    # svi, fc / fc2: posterior.SviGuide of the current parameters (bounds fixed once per guide)
         self._slots = {}                      # svi: n_samples -> (StackedPosterior.for_guide, engine) redrawn in place by unseeded calls
-        self._draws = 0                       # draw counter (the Philox draw id)
+        self._draws = 0                       # number of in-place redraws so far
 
     def get_name(self, n_inputs=None):
         """model_bnn.py:90-103"""
@@ -269,7 +269,7 @@ class BNN(nn.Module):
                 self._slots.pop(next(iter(self._slots)))
             slot = self._slots[n_samples] = self._new_slot(n_samples)
         self._draws += 1
-        slot[0].redraw(self._fresh_key(), self._draws)
+        slot[0].redraw(self._fresh_key(), 0)                  # the key alone identifies the draw: reproducible under set_rng_seed
         return slot[1]
 
     # ------------------------------------------------------------------ hot path handles
@@ -283,6 +283,9 @@ class BNN(nn.Module):
         if avg_posterior is True:                         # model_bnn.py:206-216: logits of the mean weights
             stacked = {k: v.unsqueeze(0) for k, v in self.svi_loc.items()}
             return make_engine(self._make_posterior(stacked, self.device)), 1, None, True
+        ver = tuple(t._version for t in list(self.svi_loc.values()) + list(self.svi_scale.values()))
+        if ver != getattr(self, "_guide_ver", None):       # the guide was edited in place: its bounds, stacks and seeded draws are stale
+            self._guide_ver, self._drawn, self._guide, self._slots = ver, None, None, {}
         if not seeds:                                     # the reference draws from the live RNG: fresh weights on every call
             if self._in_place():
                 return self.redraw(n_samples), n_samples, None, False

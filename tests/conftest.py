@@ -120,3 +120,15 @@ def assert_close_to_reference(val, ref, truth64, tol=1e-5, noise=None, what=""):
     bad = e_val > bound
     assert not bad.any(), f"{what}: {int(bad.sum())} points beyond the bound, worst {float((e_val / bound).max()):.2f}x at point {int((e_val / bound).argmax())}"
     return int((bound > tol).sum())
+
+
+def assert_close_to_truth(val, truth64, tol=1e-5, noise=None, what="", rows=None):
+    """`val` (an fp32 result) within `tol` of the fp64 evaluation, per point relative to the point's largest component — or within twice
+    the fp32 saturation noise floor of the point (saturation_noise) where that is larger.  rows: boolean mask of the points to check."""
+    e = rel_err_points(val, truth64)
+    bound = torch.full_like(e, tol) if noise is None else torch.maximum(torch.full_like(e, tol), 2 * noise.to(e))
+    bad = e > bound
+    if rows is not None:
+        bad = bad & rows
+    assert not bad.any(), f"{what}: {int(bad.sum())} points beyond the bound, worst {float((e / bound)[bad].max()):.2f}x"
+    return int((bound > tol).sum())

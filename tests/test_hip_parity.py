@@ -493,7 +493,9 @@ def test_full_size_properties(full_size):
 
 
 def test_svi_materialize_and_forward():
-    """rbnn_svi_materialize (parity unpinned vs pyro; pinned here against the oracle restatement)."""
+    """Seeded SVI forwards, both RNG modes (parity unpinned vs pyro; pinned here against the oracle restatements): "device" = the in-place
+    draw kernel rbnn_svi_draw with the seed as the sample's Philox key (oracle: svi_draw_philox); "host" = a CPU restatement of the
+    guide's draw order -> rbnn_svi_materialize (oracle: svi_materialize on the same eps)."""
     from robustbnns_amd.model_bnn import BNN
     C, H, S, N = 10, 32, 5, 16
     bnn = BNN("mnist", H, "leaky", "fc", "svi", 1, 0.01, None, None, (1, 28, 28), C)
@@ -503,7 +505,20 @@ def test_svi_materialize_and_forward():
     scale["model.1.bias"][:4] = 25.0                                       # softplus threshold branch
     bnn.set_variational_params(loc, scale, DEV)
     x, _ = O.synthetic_inputs(N, (1, 28, 28), C, seed=2)
-    seeds = list(range(S))
+    seeds = [3, 0, 4, 1, 2]
+    assert bnn.svi_rng == "device"
+    out = bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu()
+    role = lambda d: {"W1": d["model.1.weight"].reshape(H, -1), "b1": d["model.1.bias"], "W2": d["model.3.weight"], "b2": d["model.3.bias"]}
+    W, _ = O.svi_draw_philox(role(loc), role(scale), None, 0, S, sample_keys=seeds)
+    post = {"model.1.weight": W["W1"], "model.1.bias": W["b1"], "model.3.weight": W["W2"], "model.3.bias": W["b2"]}
+    assert rel_err(out, O.bnn_forward(x.double(), post, "fc", "leaky", S)) < TOL
+    out2 = bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu()
+    assert torch.equal(out, out2)                                          # same seeds, same draws
+    avg = bnn.forward(x.to(DEV), n_samples=S, avg_posterior=True).cpu()    # logits of the mean weights (model_bnn.py:206-216)
+    assert rel_err(avg, O.nn_logits(x, {k: v[None] for k, v in loc.items()}, "fc", "leaky")[0]) < TOL
+    # host RNG mode: eps from torch's CPU generator in the guide's order, materialised by rbnn_svi_materialize
+    bnn.svi_rng = "host"
+    bnn.set_variational_params(loc, scale, DEV)
     out = bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu()
     eps = bnn._svi_eps(S, seeds).cpu()
     keys = list(loc); off = 0; epsd = {}
@@ -511,10 +526,7 @@ def test_svi_materialize_and_forward():
         n = loc[k].numel(); epsd[k] = eps[:, off:off + n].reshape((S,) + tuple(loc[k].shape)); off += n
     post = O.svi_materialize(loc, scale, epsd)
     assert rel_err(out, O.bnn_forward(x, post, "fc", "leaky", S)) < TOL
-    out2 = bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu()
-    assert torch.equal(out, out2)                                          # same seeds, same draws
-    avg = bnn.forward(x.to(DEV), n_samples=S, avg_posterior=True).cpu()    # logits of the mean weights (model_bnn.py:206-216)
-    assert rel_err(avg, O.nn_logits(x, {k: v[None] for k, v in loc.items()}, "fc", "leaky")[0]) < TOL
+    assert torch.equal(out, bnn.forward(x.to(DEV), n_samples=S, seeds=seeds).cpu())
 
 
 def test_autograd_through_forward(golden):

@@ -392,7 +392,12 @@ def test_svi_loss_gradients_are_seeded_and_nested(rng):
     p_a = bnn.forward(x.to(DEV), n_samples=3, seeds=[4, 5, 6])
     assert torch.equal(p_a, bnn.forward(x.to(DEV), n_samples=3, seeds=[4, 5, 6]))
     assert bnn.hot_path(3, seeds=[4, 5, 7])[0] is not e_a
-    assert bnn.hot_path(3)[0] is not bnn.hot_path(3)[0]
+    if rng == "device":         # un-seeded: ONE resident stack redrawn in place (same engine, new weights); host mode builds a new posterior
+        e_u = bnn.hot_path(3)[0]
+        w_u = e_u.post.W1.clone()
+        assert bnn.hot_path(3)[0] is e_u and not torch.equal(e_u.post.W1, w_u) and e_u is not e_a
+    else:
+        assert bnn.hot_path(3)[0] is not bnn.hot_path(3)[0]
     e_b = bnn.hot_path(3, seeds=[4, 5, 6])[0]
     next(iter(bnn.svi_loc.values())).mul_(1.0001)                           # in-place edit of the guide: version bump -> redrawn
     e_c = bnn.hot_path(3, seeds=[4, 5, 6])[0]

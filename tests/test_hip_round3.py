@@ -225,3 +225,46 @@ def test_bnn_load_reads_reference_files_and_reproduces_forward():
     stacked = {k: torch.stack([bnn.posterior.state_dict(i)[k] for i in range(m["S"])]) for k in bnn.posterior.state_dict(0)}
     gm = O.meanprob_gradients(x.double(), y.argmax(-1), O.cast(stacked, torch.float64), m["arch"], m["act"], m["S"])
     marginal_ok(adv, torch.from_numpy(d["fgsm"]), gm, "fgsm")
+
+
+# ------------------------------------------------------------------------------------------------ conv: smooth activations, tiny pre-activations
+@pytest.mark.parametrize("act", ["sigm", "tanh"])
+@pytest.mark.parametrize("precision", ["triple", "exact"])
+def test_conv_smooth_activation_with_vanishing_preactivations(act, precision):
+    """All-zero images and conv1 weights of ~1e-3: the |a|-bound of the pooled conv1 image (L1(K1w) * max|x| + max|K1b|) is ~1e-3 while
+    sigmoid(a) ~ 0.5 — the image's fp16-piece scale must come from the activation's own range (ConvStackedPosterior.scale_bounds:
+    sigmoid <= 1, |tanh| <= 1), or the scaled activations overflow fp16 and the probabilities turn NaN."""
+    from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
+    C, Hc, S, N = 10, 32, 2, 6
+    post = O.synthetic_posterior("conv", 784, Hc, C, S, 0.05)
+    post["model.0.weight"] = post["model.0.weight"] * 0.02
+    post["model.0.bias"] = post["model.0.bias"] * 0.02
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=3)
+    x[:4] = 0.0                                                      # four all-zero images, two ordinary ones
+    sp = ConvStackedPosterior(act, (1, 28, 28), C, Hc, post, DEV)
+    mul, add, cap = sp.scale_bounds()
+    assert cap == 1.0 and (act == "tanh" or (mul, add) == (0.0, 1.0))
+    eng = ConvEngine(sp, precision=precision)
+    assert eng.precision == precision
+    p64 = O.cast(post, torch.float64)
+    p = eng.forward(x, S).cpu()
+    assert torch.isfinite(p).all() and rel_err(p, O.bnn_forward(x.double(), p64, "conv", act, S)) < TOL
+    # gradients against the fp64 oracle with the kernels' own pooling decisions (tests/test_hip_round2.py: with conv1 this small the four
+    # candidates of a pooling window differ by ~1e-8 relative, so which one is the maximum is within fp32 rounding for many windows)
+    from test_hip_round2 import conv_pinned_oracle, conv_stashes, per_point_err
+    from robustbnns_amd import _hip
+    lab = y.argmax(-1)
+    for mode, hip_mode in (("mean_prob", _hip.LOSS_MEAN_PROB), ("per_sample", _hip.LOSS_PER_SAMPLE)):
+        G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, hip_mode).cpu().reshape(x.shape).clone()
+        assert torch.isfinite(G).all()
+        st1, st2 = conv_stashes(eng, N, S, Hc)
+        pinned, worst, n_diff = conv_pinned_oracle(x, lab, post, act, S, st1, st2, mode)
+        err = per_point_err(G, pinned)
+        print(f"[conv {act} {precision} {mode}] pinned: max {float(err.max()):.2e}; decisions differing from fp64 on {int((n_diff > 0).sum())}/{N} points, "
+              f"farthest from a tie {worst:.1e}")
+        assert float(err.max()) < TOL and worst < 2e-6
+        # an all-zero image makes every pooling window an EXACT tie (conv1 = its bias at every position in any arithmetic; conv2 of a
+        # constant image is constant over positions in the kernels' fixed summation order): torch's max_pool2d keeps the FIRST candidate
+        # (strict >), and so must the kernels — MNIST's zero background is full of such windows.  (The plain fp64 oracle is no yardstick
+        # here: its conv2 outputs differ across positions in the last bit — "farthest from a tie 1e-17" above — and it routes by that.)
+        assert int((st1[:, :4] & 3).max()) == 0 and int((st2[:, :4] & 3).max()) == 0

@@ -103,5 +103,6 @@ for key, d in tr.items():
 if tr:
     print("\n== traffic json ==")
     print(json.dumps(tr))
-    json.dump({workload: tr, "source": f"{out}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {workload} workload)"},
+    rel = "profiles/" + out.split("gpurun_out/")[-1] if "gpurun_out/" in out else out      # the copy that is committed, not the scratch path
+    json.dump({workload: tr, "source": f"{rel}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {workload} workload)"},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
