@@ -19,7 +19,7 @@ variational guide (loc ~ N(0, std^2), raw scale -3: SURVEY 8d) and EVERY STEP RE
 with one kernel (rbnn_svi_draw: Philox eps in registers -> fp32 stack + packed + triple images; the reference draws fresh weights at
 every forward, model_bnn.py:230-232); the line's `svi` record carries the draw's own time and write rate, and the same workload on
 stored samples is the `stored_posterior_mode` sub-record.  c3 says "HMC" (stored samples); c4 names neither (stored); c5 / conv say
-SVI but the in-place draw covers fc / fc2 only: they run on stored samples and say so.
+SVI too (one launch draws the six tensors, the conv2 weight images are rebuilt by their builders).
 
 N GPUs: one process per GPU; the posterior is SAMPLE-sharded (each rank holds its own S samples, so the job has S*N
 samples: weak scaling) and each step all-reduces sum_s p_s [N,16] and the summed gradients [N,784] over RCCL/xGMI
@@ -125,8 +125,13 @@ def make_guide(w, rank):
         shapes.update({"model.3.weight": (H, H), "model.3.bias": (H,), "model.5.weight": (C, H), "model.5.bias": (C,)})
     else:
         shapes.update({"model.3.weight": (C, H), "model.3.bias": (C,)})
+    if w["arch"] == "conv":
+        q2 = conv_geometry(w["shape"])[1]
+        shapes = {"model.0.weight": (32, w["shape"][0], 5, 5), "model.0.bias": (32,), "model.3.weight": (H, 32, 5, 5), "model.3.bias": (H,),
+                  "model.7.weight": (C, q2 * q2 * H), "model.7.bias": (C,)}
+        std = 0.03
     loc = {k: torch.randn(*shp, generator=g) * std for k, shp in shapes.items()}
-    scale = {k: torch.full(shp, -3.0) for k, shp in shapes.items()}
+    scale = {k: torch.full(shp, -3.0 if w["arch"] != "conv" else -4.5) for k, shp in shapes.items()}      # softplus(-4.5) = 0.011
     return loc, scale
 
 
@@ -225,8 +230,7 @@ def main():
     ap.add_argument("--no-other-mode", action="store_true", help="skip timing the other precision modes at N=1")
     ap.add_argument("--posterior", default="config", choices=["config", "svi", "stored"],
                     help="svi: a variational guide, all S samples redrawn in place every step inside the timed region; stored: S stored samples "
-                         "(HMC-style); config (default): what BASELINE.json names for the workload (c1, c2: svi; c3, c4: stored; conv / c5: stored, "
-                         "the in-place draw covers fc / fc2)")
+                         "(HMC-style); config (default): what BASELINE.json names for the workload (c1, c2, c5, conv: svi; c3, c4: stored)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -262,14 +266,16 @@ def main():
     sp = posterior_from_stacked(w["arch"], w["act"], w["shape"], w["C"], w["H"], post, device)
     posterior_kind = args.posterior
     if posterior_kind == "config":
-        posterior_kind = "svi" if (args.workload in SVI_NAMED and w["arch"] != "conv") else "stored"
-    if posterior_kind == "svi" and w["arch"] == "conv":
-        raise SystemExit("--posterior svi: the in-place draw covers fc / fc2 (conv SVI nets are drawn through rbnn_svi_materialize, not benchmarked)")
+        posterior_kind = "svi" if args.workload in SVI_NAMED else "stored"
     sp_svi = None
     if posterior_kind == "svi" or (world == 1 and w["arch"] != "conv"):
-        from robustbnns_amd.posterior import StackedPosterior, SviGuide
         loc, scale = make_guide(w, rank if args.shard == "samples" else 0)
-        sp_svi = StackedPosterior.for_guide(SviGuide(loc, scale, w["arch"], device), w["act"], w["shape"], w["C"], w["S"])
+        if w["arch"] == "conv":
+            from robustbnns_amd.conv import ConvStackedPosterior, ConvSviGuide
+            sp_svi = ConvStackedPosterior.for_guide(ConvSviGuide(loc, scale, device), w["act"], w["shape"], w["C"], w["H"], w["S"])
+        else:
+            from robustbnns_amd.posterior import StackedPosterior, SviGuide
+            sp_svi = StackedPosterior.for_guide(SviGuide(loc, scale, w["arch"], device), w["act"], w["shape"], w["C"], w["S"])
 
     class TimedKernels(_hip.HipKernels):
         """HIP events around the two GEMM kernels, on the stream they are launched on (torch's current stream)."""
@@ -409,7 +415,12 @@ def main():
             # bytes one draw writes: the fp32 stack and its pack_rows4 image (4 + 4 B per matrix weight), and in the triple mode the rows and
             # cols images (6 + 6 B); reads are the guide's loc + scale (8 B per parameter, once per sample, L2-resident)
             wr = w["S"] * n_par * (8.0 + (12.0 if eng.precision == "triple" else 0.0))
-            svi = {"draws": len(draw_ev), "draws_per_step": len(draw_ev) / max(1, args.steps), "draw_ms": ms, "kernel": "svi_draw_kernel (1 launch per draw)",
+            kname = "svi_draw_kernel (1 launch per draw)"
+            if w["arch"] == "conv":         # fp32 stack by one launch; model.3.weight's regrouping (4 B) and triple images (6 + 6.24 B) by their builders
+                k2 = int(sp_svi.K2w[0].numel())
+                wr = w["S"] * (4.0 * n_par + k2 * (4.0 + (12.24 if eng.precision == "triple" else 0.0)))
+                kname = "svi_draw_flat_kernel (1 launch: all six tensors, all samples) + 6 image-builder launches for model.3.weight"
+            svi = {"draws": len(draw_ev), "draws_per_step": len(draw_ev) / max(1, args.steps), "draw_ms": ms, "kernel": kname,
                    "bytes_written_per_draw": wr, "write_gbs": wr / (ms * 1e-3) / 1e9 if ms else None, "hbm_frac": wr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
                    "guide": "loc ~ N(0, std^2), raw scale -3 (softplus 0.0486): SURVEY 8d", "rng": "Philox4x32-10 + Box-Muller in registers, no eps tensor"}
         return getattr(eng, "precision", "exact"), dt, kern.ev, svi
@@ -480,14 +491,20 @@ def main():
         if dom in F16_KERNELS.get(mode, ()):
             # matrix-pipe work of the split / triple mode: 3 / 6 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
             np_ = PRODUCTS[mode]
-            r.update({"achieved": np_ * fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS, "frac": np_ * fp32_eq / F16_MFMA_PEAK_TFLOPS,
-                      "pipe": "v_mfma_f32_16x16x32_f16, %d products per fp32 MAC" % np_, "fp32_equivalent_tflops": fp32_eq,
+            # achieved = ALGORITHMIC (fp32-equivalent) flops over time; peak = what the f16 pipe can deliver of THOSE: its nominal dense rate
+            # divided by the f16 products this mode spends per fp32 MAC (2516.6 / 6 = 419.4, / 3 = 838.9).  frac is unchanged by the choice
+            # of unit; the issued f16 work is listed separately so that it is not read as useful work.
+            r.update({"achieved": fp32_eq, "peak": F16_MFMA_PEAK_TFLOPS / np_, "frac": np_ * fp32_eq / F16_MFMA_PEAK_TFLOPS,
+                      "pipe": "v_mfma_f32_16x16x32_f16, %d products per fp32 MAC" % np_, "f16_pipe_tflops_issued": np_ * fp32_eq,
+                      "f16_pipe_nominal_peak": F16_MFMA_PEAK_TFLOPS, "fp32_equivalent_tflops": fp32_eq,
                       "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
                       "vs_sustained_f16_rate": np_ * fp32_eq / (F16_MFMA_SUSTAINED_FRAC * F16_MFMA_PEAK_TFLOPS),
-                      "note": "frac is against the NOMINAL f16 MFMA peak with %d f16 products per algorithmic fp32 MAC; dense f16 MFMA streams are "
-                              "power-limited on this chip (a bare loop sustains %.2f of nominal: tools/mfma_shape_bench.hip), vs_sustained_f16_rate "
-                              "prices the kernel against that; the same workload on the fp32 MFMA is the exact_fp32_mode sub-record "
-                              "(frac there is against 157.3 TFLOP/s)" % (np_, F16_MFMA_SUSTAINED_FRAC)})
+                      "note": "achieved = algorithmic fp32-equivalent TFLOP/s; peak = nominal f16 MFMA peak / %d f16 products per fp32 MAC, so frac is "
+                              "the fraction of the f16 pipe's nominal rate the kernel's algorithmic work occupies.  Priced against SURVEY 8(d)'s fp32-MFMA "
+                              "denominator (157.3) the same kernel reads vs_fp32_mfma_peak (> 1: it does not run on that pipe), NOT frac.  Dense f16 MFMA "
+                              "streams are power-limited on this chip (a bare loop sustains %.2f of nominal: tools/mfma_shape_bench.hip); "
+                              "vs_sustained_f16_rate prices the kernel against that.  The same workload on the fp32 MFMA is the exact_fp32_mode "
+                              "sub-record (frac there is against 157.3 TFLOP/s)" % (np_, F16_MFMA_SUSTAINED_FRAC)})
         else:
             r.update({"achieved": fp32_eq, "peak": FP32_MFMA_PEAK_TFLOPS, "frac": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
                       "pipe": "v_mfma_f32_16x16x4_f32" if mode != "lowdim" else
@@ -506,7 +523,7 @@ def main():
     SUBKEY = {"exact": "exact_fp32_mode", "triple": "triple_f16x6_mode", "split": "split_f16x3_mode"}
     mode, dt, evs, svi_rec = run(args.precision)
     other_kind = None
-    if world == 1 and not args.no_other_mode and sp_svi is not None:      # the same workload on the other kind of posterior
+    if world == 1 and not args.no_other_mode and sp_svi is not None and args.workload != "c5":      # the same workload on the other kind of posterior (c5: a step is minutes)
         other_kind = run(args.precision, "stored" if posterior_kind == "svi" else "svi")
     others = []
     if world == 1 and not args.no_other_mode:
@@ -535,8 +552,7 @@ def main():
                        "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none",
                        "posterior": ("svi: variational guide, all S samples redrawn in place (rbnn_svi_draw) every step — PGD: every iteration — inside "
                                      "the timed region" if posterior_kind == "svi" else
-                                     "stored samples (HMC-style)" + ("; BASELINE names SVI for this workload, the in-place draw covers fc / fc2 only"
-                                                                     if args.workload in SVI_NAMED else "")),
+                                     "stored samples (HMC-style)"),
                        "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters)) if v}},
             "roofline": roofline(mode, evs, ms_per_step),
         }

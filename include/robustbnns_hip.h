@@ -445,6 +445,19 @@ typedef struct rbnn_svi_guide {    /* device pointers to the variational paramet
 int rbnn_svi_draw(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
                   const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
 
+/* The same draw for tensors of any shape (the conv architecture: model.0 / .3 / .7 weights and biases), written IN PLACE into the fp32
+ * stack: out[s, e] = loc[e] + softplus(scale_raw[e]) * eps, eps of element e = component e % 4 of the Philox block with counter
+ * (e / 4, tensor_id, s — or 0 when sample_keys is given —, draw_id).  One launch for up to 8 tensors and all samples; images derived
+ * from the stack (the regrouped / triple images of the conv2 weights) are rebuilt by their builders (robustbnns_amd/conv.py). */
+typedef struct rbnn_svi_flat_tensor {
+    const float *loc, *scale_raw;     /* [n_elem] variational parameters (raw scale)                          */
+    float *out;                       /* [n_samples, out_sample_stride] destination, first n_elem of each row  */
+    int64_t n_elem, out_sample_stride;
+    int32_t tensor_id, reserved;
+} rbnn_svi_flat_tensor;
+int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor *tensors, int32_t n_tensors, int32_t n_samples, const uint64_t *sample_keys, uint64_t key,
+                       uint32_t draw_id, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Low-dimensional fc nets (in_features <= 16, n_classes <= 10, arch fc; half-moons: 2 -> H -> 2) — the WHOLE hot path in one launch.
  * One call = what a sequence of rbnn_fc_forward, rbnn_reduce_samples, rbnn_loss_dlogits, rbnn_fc_input_grad, rbnn_sum_slabs(_norms),

@@ -73,6 +73,11 @@ class SviGuide(C.Structure):
                [("hidden", C.c_int32), ("reserved", C.c_int32)]
 
 
+class SviFlatTensor(C.Structure):
+    _fields_ = [("loc", _fp), ("scale_raw", _fp), ("out", _fp), ("n_elem", C.c_int64), ("out_sample_stride", C.c_int64),
+                ("tensor_id", C.c_int32), ("reserved", C.c_int32)]
+
+
 SVI_EPS_MAX = 6.77                                                     # RBNN_SVI_EPS_MAX: Box-Muller on a 32-bit uniform cannot exceed it
 
 TRIPLE_WS_KEYS = ("X_triple", "dZ_gen", "g_scale", "hid_triple")
@@ -145,6 +150,7 @@ SIGNATURES = {
     "rbnn_lowdim_supported": (_i32, [_PP]),
     "rbnn_lowdim_run": (_i32, [_PP, _i32, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _fp, _f32, _f32, _f32, _fp, _f32, _i32, _i32, _i32,
                                _fp, _fp, _i32, _fp, _fp, _fp]),
+    "rbnn_svi_draw_flat": (_i32, [C.POINTER(SviFlatTensor), _i32, _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
     "rbnn_svi_draw": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
 }
 
@@ -439,3 +445,13 @@ class HipKernels:
         check(self.lib.rbnn_lowdim_run(C.byref(net.descriptor()), op, loss_mode, out_kind, ptr(X), ptr(X0), X.stride(0), X.shape[0], ptr(sidx), S,
                                        ptr(labels), inv_S, out_scale, eps, ptr(alpha), alpha_scalar, int(alpha_per_image), int(project), iters,
                                        ptr(P), ptr(out), out.stride(0), ptr(linf), ptr(l2), stream_of(X)), "rbnn_lowdim_run")
+
+    def svi_draw_flat(self, items, S, key, draw_id, sample_keys=None):
+        """items: list of (loc, scale_raw, out [S, ...], tensor_id) — every tensor of a net redrawn in place by ONE launch."""
+        arr = (SviFlatTensor * len(items))()
+        for i, (loc, scl, out, tid) in enumerate(items):
+            require_gpu(out, "out")
+            arr[i].loc, arr[i].scale_raw, arr[i].out = loc.data_ptr(), scl.data_ptr(), out.data_ptr()
+            arr[i].n_elem, arr[i].out_sample_stride, arr[i].tensor_id = loc.numel(), out.stride(0), tid
+        check(self.lib.rbnn_svi_draw_flat(arr, len(items), S, ptr(sample_keys), C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF),
+                                          stream_of(items[0][2])), "rbnn_svi_draw_flat")

@@ -28,6 +28,27 @@ def conv_geometry(input_shape):
     return p1, p1 - 4 - 1
 
 
+class ConvSviGuide:
+    """Variational parameters of a conv guide (model_bnn.py:124-126) on the device + the bounds that are fixed once per guide, so a
+    redraw (ConvStackedPosterior.redraw) contains no pass over the drawn weights and no device->host sync — as posterior.SviGuide:
+    |w| <= |loc| + RBNN_SVI_EPS_MAX * softplus(scale)."""
+    TENSOR_IDS = {"model.0.weight": 0, "model.0.bias": 1, "model.3.weight": 2, "model.3.bias": 3, "model.7.weight": 4, "model.7.bias": 5}
+
+    def __init__(self, loc, scale, device):
+        self.device = torch.device(device)
+        self.loc = {k: loc[k].detach().to(self.device, torch.float32).contiguous() for k in self.TENSOR_IDS}
+        self.scale = {k: scale[k].detach().to(self.device, torch.float32).contiguous() for k in self.TENSOR_IDS}
+        sp = torch.nn.functional.softplus
+        bnd = {k: self.loc[k].abs() + _hip.SVI_EPS_MAX * sp(self.scale[k]) for k in self.loc}
+        k2 = bnd["model.3.weight"]
+        typ = (self.loc["model.3.weight"].abs() + 0.8 * sp(self.scale["model.3.weight"])).double().mean().float()
+        Cn = self.loc["model.7.bias"].numel()
+        rec = torch.stack([k2.max(), typ, bnd["model.0.weight"].reshape(32, -1).sum(-1).max(), bnd["model.0.bias"].max(),
+                           bnd["model.7.weight"].reshape(Cn, -1).sum(0).max()]).cpu().tolist()           # the one sync, at load
+        self.k2_max, self.p1_bound, self.fw_l1 = rec[0], (rec[2], rec[3]), rec[4]
+        self.range_ok = 0.0 < rec[0] <= 4096.0 * rec[1] and rec[0] != float("inf")
+
+
 class ConvStackedPosterior:
     arch = "conv"
 
@@ -52,10 +73,82 @@ class ConvStackedPosterior:
         self.Fw, self.Fb = f("model.7.weight", (self.C, self.NP2 * self.H)), f("model.7.bias", (self.C,))
         # model.3.weight regrouped [S, 32 ci, Hc/16 blocks, 25 taps, 16 hc]: the backward GEMM's A operand, K-contiguous
         # with one K tile = one tap x 16 channels
-        self.K2ci = self.K2w.view(S, self.H // 16, 16, 32, 25).permute(0, 3, 1, 4, 2).reshape(S, 32, self.H * 25).contiguous()
+        self.K2ci = torch.empty(S, 32, self.H * 25, dtype=torch.float32, device=self.device)
+        self._regroup_k2ci()
         self._desc = None
         self._split = None
         self._triple = None
+        self._guide = None                      # ConvSviGuide: a redrawable SVI stack (for_guide / redraw)
+
+    # ------------------------------------------------------------------ redrawable SVI stack
+    @classmethod
+    def for_guide(cls, guide, activation, input_shape, n_classes, hidden, S):
+        """S zero samples to be filled IN PLACE by redraw(): buffers, descriptor and images keep their addresses across draws."""
+        shapes = {k: tuple(v.shape) for k, v in guide.loc.items()}
+        post = cls(activation, input_shape, n_classes, hidden, {k: torch.zeros((S,) + shp) for k, shp in shapes.items()}, guide.device)
+        post._guide = guide
+        return post
+
+    def _regroup_k2ci(self):
+        S, H = self.S, self.H
+        self.K2ci.view(S, 32, H // 16, 25, 16).copy_(self.K2w.view(S, H // 16, 16, 32, 25).permute(0, 3, 1, 4, 2))
+
+    def redraw(self, key, draw_id=0, n_samples=None, sample_keys=None):
+        """All six tensors of all samples redrawn by ONE launch (rbnn_svi_draw_flat) into the resident fp32 stack; the images derived from
+        model.3.weight (its input-channel regrouping, the triple / split images — at scales fixed per guide) are then rebuilt in place
+        by their builders: a handful of asynchronous launches, no allocation of a new posterior, no device->host sync."""
+        if self._guide is None:
+            raise _hip.HipError("redraw() needs a posterior built by ConvStackedPosterior.for_guide")
+        g, S = self._guide, (self.S if n_samples is None else int(n_samples))
+        dst = {"model.0.weight": self.K1w, "model.0.bias": self.K1b, "model.3.weight": self.K2w, "model.3.bias": self.K2b,
+               "model.7.weight": self.Fw, "model.7.bias": self.Fb}
+        items = [(g.loc[k], g.scale[k], dst[k], g.TENSOR_IDS[k]) for k in dst]
+        _hip.HipKernels().svi_draw_flat(items, S, int(key), int(draw_id), sample_keys)
+        self._regroup_k2ci()
+        if self._triple is not None:
+            self._build_triple(self._triple[0], self._triple[2])
+        if self._split is not None:
+            self._build_split(self._split[0], self._split[4])
+        return self
+
+    def _k2_max(self):
+        return self._guide.k2_max if self._guide is not None else float(self.K2w.abs().max())
+
+    def _fw_l1(self):
+        return self._guide.fw_l1 if self._guide is not None else float(self.Fw.abs().sum(1).max())
+
+    def _scratch(self):
+        """Staging buffers of the image builders (tap-major conv2 weights, the 26-tap padded regrouping), allocated once."""
+        if getattr(self, "_tmp", None) is None:
+            S, H = self.S, self.H
+            self._tmp = (torch.empty(S * H, 800, dtype=torch.float32, device=self.device),
+                         torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device),
+                         torch.empty(S * 32, (H // 16) * 13 * 32, dtype=torch.float32, device=self.device))
+        return self._tmp
+
+    def _build_triple(self, rows, bwd):
+        S, H = self.S, self.H
+        k2, w26, kb = self._scratch()
+        k = _hip.HipKernels()
+        k2_exp = scale_exp(self._k2_max())
+        k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))                     # k = tap*32 + ci
+        k.triple_rows(k2, 800, k2_exp, rows, 800)
+        w26[..., :25].copy_(self.K2w.view(S, H, 32, 25))
+        kb.view(S, 32, H // 16, 13, 2, 2, 8).copy_(w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3))
+        k.triple_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
+        return k2_exp
+
+    def _build_split(self, rows, bwd):
+        S, H = self.S, self.H
+        k2, w26, kb = self._scratch()
+        k = _hip.HipKernels()
+        k2_exp = scale_exp(self._k2_max())
+        k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))
+        k.split_rows(k2, 800, k2_exp, rows, 800)
+        w26[..., :25].copy_(self.K2w.view(S, H, 32, 25))
+        kb.view(S, 32, H // 16, 13, 2, 2, 8).copy_(w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3))
+        k.split_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
+        return k2_exp
 
     # ------------------------------------------------------------------ triple-split ("f16x6") mode: full-width operands on the f16 pipe
     def triple_supported(self):
@@ -65,7 +158,7 @@ class ConvStackedPosterior:
             return False
         if getattr(self, "_range_ok", None) is None:
             from .posterior import narrow_range
-            self._range_ok = narrow_range(self.K2w)
+            self._range_ok = self._guide.range_ok if self._guide is not None else narrow_range(self.K2w)
         return self._range_ok
 
     def triple_images(self):
@@ -74,18 +167,10 @@ class ConvStackedPosterior:
         built once, resident."""
         if self._triple is None:
             S, H = self.S, self.H
-            k = _hip.HipKernels()
-            k2 = self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2).reshape(S * H, 800).contiguous()      # k = tap*32 + ci
-            k2_exp = scale_exp(float(k2.abs().max()))
             rows = torch.empty(S * H, 800 * 3, dtype=torch.int16, device=self.device)
-            k.triple_rows(k2, 800, k2_exp, rows, 800)
-            w26 = torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device)
-            w26[..., :25] = self.K2w.view(S, H, 32, 25)
-            kb = w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3).reshape(S * 32, (H // 16) * 13 * 32).contiguous()
-            bwd = torch.empty(kb.shape[0], kb.shape[1] * 3, dtype=torch.int16, device=self.device)
-            k.triple_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
-            fw_l1 = float(self.Fw.abs().sum(1).max())
-            self._triple = (rows, k2_exp, bwd, fw_l1)
+            bwd = torch.empty(S * 32, (H // 16) * 13 * 32 * 3, dtype=torch.int16, device=self.device)
+            k2_exp = self._build_triple(rows, bwd)
+            self._triple = (rows, k2_exp, bwd, self._fw_l1())
         return self._triple
 
     # ------------------------------------------------------------------ split-half precision mode (forward conv2)
@@ -98,20 +183,11 @@ class ConvStackedPosterior:
         conv1 activations |P1| <= max_c(sum_taps |K1w_c|) * max|x| + max|K1b|) — built once, resident."""
         if self._split is None:
             S, H = self.S, self.H
-            k2 = self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2).reshape(S * H, 800).contiguous()      # k = tap*32 + ci
-            k2_exp = scale_exp(float(k2.abs().max()))
             rows = torch.empty(S * H, 800 * 2, dtype=torch.int16, device=self.device)
-            _hip.HipKernels().split_rows(k2, 800, k2_exp, rows, 800)
-            w_l1 = float(self.K1w.abs().sum(-1).max())
-            b_max = float(self.K1b.abs().max())
-            # backward image: [S*32 ci, chunk(Hc/16) x 13 tap pairs x lg(4 = tap parity*2 + channel octet) x 8 channels]
-            w26 = torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device)
-            w26[..., :25] = self.K2w.view(S, H, 32, 25)
-            kb = w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3).reshape(S * 32, (H // 16) * 13 * 32).contiguous()
-            bwd = torch.empty(kb.shape[0], kb.shape[1] * 2, dtype=torch.int16, device=self.device)
-            _hip.HipKernels().split_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
-            fw_l1 = float(self.Fw.abs().sum(1).max())
-            self._split = (rows, k2_exp, w_l1, b_max, bwd, fw_l1)
+            bwd = torch.empty(S * 32, (H // 16) * 13 * 32 * 2, dtype=torch.int16, device=self.device)
+            k2_exp = self._build_split(rows, bwd)
+            w_l1, b_max = self._p1()
+            self._split = (rows, k2_exp, w_l1, b_max, bwd, self._fw_l1())
         return self._split
 
     @classmethod
@@ -127,9 +203,15 @@ class ConvStackedPosterior:
         scaled activations would overflow fp16 — so its bound is the constant 1, as in StackedPosterior.scale_bounds."""
         if self.activation == "sigm":
             return 0.0, 1.0, 1.0
+        w_l1, b_max = self._p1()
+        return w_l1, b_max, (1.0 if self.activation == "tanh" else float("inf"))
+
+    def _p1(self):
+        if self._guide is not None:
+            return self._guide.p1_bound
         if not hasattr(self, "_p1_bound"):
             self._p1_bound = (float(self.K1w.abs().sum(-1).max()), float(self.K1b.abs().max()))
-        return self._p1_bound[0], self._p1_bound[1], (1.0 if self.activation == "tanh" else float("inf"))
+        return self._p1_bound
 
     def descriptor(self):
         if self._desc is None:
@@ -214,9 +296,11 @@ class ConvEngine(AttackEngine):
         y = torch.as_tensor(y)
         return self._blocked(lambda xb, yb: AttackEngine.fgsm(self, xb, yb, n_samples, epsilon, seeds, mode), x, y, n_samples=n_samples)
 
-    def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=_hip.LOSS_MEAN_PROB):
+    def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=_hip.LOSS_MEAN_PROB, before_step=None):
+        """before_step (an SVI net's in-place redraw) runs before every iteration but the first of EVERY point block: blocks of one
+        attack then see different draws — each point's marginal over draws is unchanged."""
         y = torch.as_tensor(y)
-        return self._blocked(lambda xb, yb: AttackEngine.pgd(self, xb, yb, n_samples, epsilon, alpha, iters, seeds, mode),
+        return self._blocked(lambda xb, yb: AttackEngine.pgd(self, xb, yb, n_samples, epsilon, alpha, iters, seeds, mode, before_step),
                              x, y, n_samples=n_samples)
 
     def evaluate(self, x, x_attack, y, n_samples, logits=False):

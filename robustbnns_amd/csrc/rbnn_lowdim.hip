@@ -164,16 +164,34 @@ __global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
         // independent loads — the per-hidden-unit loop then waits on ds_read latency, not on a chain of dependent L2 round trips (which
         // is all a 4-block launch has to hide them with).
         float* const cw = red + ((a.SL * a.PB * RW + 3) & ~3);
-        const int Cn = a.net.n_classes, SS = a.cache_stride, n1 = H * DW, n2 = n1 + H, n3 = n2 + Cn * H;
-        for (int e = t; e < a.S * SS; e += 256) {
-            const int sl = e / SS, r = e - sl * SS;
-            const int sw = a.sidx ? a.sidx[sl] : sl;
-            float v = 0.f;
-            if (r < n1) v = a.net.W1[((long long)sw * H + r / DW) * a.net.in_stride + r % DW];
-            else if (r < n2) v = a.net.b1[(long long)sw * H + (r - n1)];
-            else if (r < n3) v = a.net.W2[(long long)sw * Cn * H + (r - n2)];
-            else if (r < n3 + Cn) v = a.net.b2[(long long)sw * Cn + (r - n3)];
-            cw[e] = v;
+        const int Cn = a.net.n_classes, SS = a.cache_stride;
+        // in 16-byte units: per sample H * DQ (W1 rows, their first 4 DQ columns), H / 4 (b1), C * H / 4 (W2), ceil(C / 4) (b2); eight
+        // independent loads in flight per thread before the first LDS store
+        const int u1 = H * DQ, u2 = u1 + H / 4, u3 = u2 + Cn * H / 4, US = SS / 4, total = a.S * US;
+        for (int base = 0; base < total; base += 8 * 256) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * 256 + t;
+                v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (e < total) {
+                    const int sl = e / US, r = e - sl * US;
+                    const int sw = a.sidx ? a.sidx[sl] : sl;
+                    if (r < u1) v[u] = *(const f32x4*)(a.net.W1 + ((long long)sw * H + r / DQ) * a.net.in_stride + 4 * (r % DQ));
+                    else if (r < u2) v[u] = *(const f32x4*)(a.net.b1 + (long long)sw * H + 4 * (r - u1));
+                    else if (r < u3) v[u] = *(const f32x4*)(a.net.W2 + (long long)sw * Cn * H + 4 * (r - u2));
+                    else {
+                        const int c0 = 4 * (r - u3);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (c0 + k < Cn) v[u][k] = a.net.b2[(long long)sw * Cn + c0 + k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * 256 + t;
+                if (e < total) *(f32x4*)(cw + 4 * e) = v[u];
+            }
         }
         cache = cw;
         __syncthreads();
@@ -204,6 +222,10 @@ __global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
     const int iters = a.op == OP_ATTACK ? a.iters : 1;
     const bool need_mean = a.op == OP_FORWARD || a.loss != RBNN_LOSS_PER_SAMPLE;
     const bool probs = a.op == OP_FORWARD ? a.out_kind == RBNN_OUT_PROBS : a.loss != RBNN_LOSS_MEAN_LOGIT;
+    const bool single = S <= SL;                                      // every thread owns at most ONE sample: its output stays in registers
+    float keep[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) keep[c] = 0.f;
     for (int it = 0; it < iters; ++it) {
         float tot[CM];
 #pragma unroll
@@ -218,9 +240,14 @@ __global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
                     forward_sample<ACT, DQ, CM>(sample_view<DQ>(a, cache, s), H, C, x, z);
                     if (probs) softmax_inplace<CM>(z, C);
                     if (a.op != OP_FORWARD && a.loss == RBNN_LOSS_MEAN_PROB) {
-                        float* const ps = a.P + ((long long)s * N + n) * RBNN_CPAD;
+                        if (single) {
 #pragma unroll
-                        for (int c = 0; c < CM; ++c) if (c < C) ps[c] = z[c];
+                            for (int c = 0; c < CM; ++c) keep[c] = z[c];
+                        } else {
+                            float* const ps = a.P + ((long long)s * N + n) * RBNN_CPAD;
+#pragma unroll
+                            for (int c = 0; c < CM; ++c) if (c < C) ps[c] = z[c];
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < CM; ++c) acc[c] += z[c];
@@ -266,6 +293,9 @@ __global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
                         forward_sample<ACT, DQ, CM>(sv, H, C, x, ps);
                         softmax_inplace<CM>(ps, C);
                         loss_grad<CM>(ps, C, y, a.inv_S, g);
+                    } else if (single) {
+#pragma unroll
+                        for (int c = 0; c < CM; ++c) ps[c] = keep[c];
                     } else {
                         const float* const pp = a.P + ((long long)s * N + n) * RBNN_CPAD;
 #pragma unroll
@@ -327,7 +357,7 @@ template <int ACT, int DQ, int CM> int launch_low(const LowArgs& a, hipStream_t 
     LowArgs b = a;
     const size_t red_floats = ((size_t)a.SL * a.PB * RW + 3) & ~(size_t)3;
     const int H = a.net.hidden, C = a.net.n_classes;
-    const size_t ss = ((size_t)H * (4 * DQ + 1 + C) + C + 3) & ~(size_t)3;             // compact floats per sample
+    const size_t ss = (size_t)H * (4 * DQ + 1 + C) + 4 * (size_t)((C + 3) / 4);          // compact floats per sample (whole 16-byte units)
     // the cache pays when a block is short of work to hide L2 latency with (few owned samples per thread) and fits the default 64 KB of
     // dynamic LDS; big posteriors keep reading through L1 / L2, where many resident waves hide the latency
     b.cache_stride = ((red_floats + ss * a.S) * sizeof(float) <= 60 * 1024) ? (int)ss : 0;

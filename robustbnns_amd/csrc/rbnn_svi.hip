@@ -242,9 +242,67 @@ __global__ void __launch_bounds__(256) svi_draw_kernel(const DrawArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Flat draw: up to 8 tensors of any shape (the conv architecture's six), W[s][e] = loc[e] + softplus(scale[e]) * eps(s, e), eps of
+// element e = component e % 4 of the Philox block with counter (e / 4, tensor id, s or 0, draw id).  One launch for all tensors and
+// samples; derived weight images (regrouped / triple images of model.3.weight) are rebuilt from the fp32 stack by their own builders.
+// ---------------------------------------------------------------------------------------------------
+struct FlatArgs {
+    rbnn_svi_flat_tensor t[8];
+    long long first_block[9];      // blocks of tensor i: [first_block[i], first_block[i + 1]) within one sample's range
+    int n_tensors, S;
+    const unsigned long long* sample_keys;
+    unsigned long long key;
+    uint32_t draw_id;
+};
+
+__global__ void __launch_bounds__(256) svi_draw_flat_kernel(const FlatArgs a) {
+    const long long per_sample = a.first_block[a.n_tensors];
+    const int s = (int)(blockIdx.x / per_sample);
+    const long long b = blockIdx.x % per_sample;
+    int ti = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) if (i < a.n_tensors && b >= a.first_block[i]) ti = i;
+    const rbnn_svi_flat_tensor t = a.t[ti];
+    const long long q = (b - a.first_block[ti]) * 256 + threadIdx.x, e0 = 4 * q;
+    if (e0 >= t.n_elem) return;
+    const unsigned long long key = a.sample_keys ? a.sample_keys[s] : a.key;
+    const Rng rng = {(uint32_t)key, (uint32_t)(key >> 32), a.sample_keys ? 0u : (uint32_t)s, a.draw_id};
+    float n[4], w[4];
+    rng.quad(t.tensor_id, (uint32_t)q, n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (e0 + j < t.n_elem) ? t.loc[e0 + j] + softplus(t.scale_raw[e0 + j]) * n[j] : 0.f;
+    float* const out = t.out + (long long)s * t.out_sample_stride + e0;
+    if (e0 + 3 < t.n_elem && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) *(f32x4*)out = (f32x4){w[0], w[1], w[2], w[3]};
+    else
+        for (int j = 0; j < 4; ++j) if (e0 + j < t.n_elem) out[j] = w[j];
+}
+
 }  // namespace
 
 extern "C" {
+
+int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor* tensors, int32_t n_tensors, int32_t n_samples, const uint64_t* sample_keys, uint64_t key,
+                       uint32_t draw_id, void* stream) {
+    if (!tensors) return RBNN_ERR_NULL;
+    if (n_tensors < 1 || n_tensors > 8 || n_samples < 1) return RBNN_ERR_SHAPE;
+    FlatArgs a = {};
+    a.n_tensors = n_tensors; a.S = n_samples; a.sample_keys = (const unsigned long long*)sample_keys; a.key = key; a.draw_id = draw_id;
+    long long blocks = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        const rbnn_svi_flat_tensor& t = tensors[i];
+        if (!t.loc || !t.scale_raw || !t.out) return RBNN_ERR_NULL;
+        if (t.n_elem < 1 || t.n_elem > 0x3FFFFFFFFLL || t.out_sample_stride < t.n_elem) return RBNN_ERR_SHAPE;
+        a.t[i] = t;
+        a.first_block[i] = blocks;
+        blocks += ((t.n_elem + 3) / 4 + 255) / 256;
+    }
+    for (int i = n_tensors; i <= 8; ++i) a.first_block[i] = blocks;
+    if (blocks * n_samples > 0x7FFFFFFFLL) return RBNN_ERR_SHAPE;
+    hipLaunchKernelGGL(svi_draw_flat_kernel, dim3((unsigned)(blocks * n_samples)), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_status();
+}
 
 int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
                   const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, void* stream) {

@@ -4,10 +4,11 @@
 model_bnn.py:198-258, computed for the whole batch and all samples by the HIP kernels:
 
   hmc  the stored chain is one StackedPosterior; `seeds` index it (model_bnn.py:246-252);
-  svi  weights are drawn as loc + softplus(scale) * eps (model_bnn.py:124-130).  fc / fc2 on the GPU: ONE kernel
-       (rbnn_svi_draw: Philox eps in registers) redraws all S samples IN PLACE — fp32 stack, packed and triple images —
-       so the posterior, its engine and its workspaces are reused draw after draw and a redraw contains no device->host
-       sync.  conv, and RBNN_SVI_RNG=host: eps from torch's generators -> rbnn_svi_materialize -> a new stacked posterior.
+  svi  weights are drawn as loc + softplus(scale) * eps (model_bnn.py:124-130).  On the GPU ONE kernel (fc / fc2:
+       rbnn_svi_draw, writing the fp32 stack AND the packed / triple images; conv: rbnn_svi_draw_flat + the image
+       builders; Philox eps in registers) redraws all S samples IN PLACE, so the posterior, its engine and its workspaces
+       are reused draw after draw and a redraw contains no device->host sync.  RBNN_SVI_RNG=host: eps from torch's CPU
+       generator in the guide's order -> rbnn_svi_materialize -> a new stacked posterior per draw.
        PARITY UNPINNED for the draw itself (pyro-ppl 1.3.0 is not available to check RNG order against); everything
        downstream of explicit weights is pinned.
 
@@ -239,15 +240,21 @@ class BNN(nn.Module):
 
     # ------------------------------------------------------------------ svi: in-place redraw (fc / fc2 on the GPU)
     def _in_place(self):
-        return (self.inference == "svi" and self.basenet.architecture in ("fc", "fc2") and self.svi_rng == "device"
+        return (self.inference == "svi" and self.basenet.architecture in ("fc", "fc2", "conv") and self.svi_rng == "device"
                 and torch.device(self.device).type == "cuda")
 
     def _new_slot(self, n_samples):
-        from .posterior import StackedPosterior, SviGuide
-        if self._guide is None:
-            self._guide = SviGuide(self.svi_loc, self.svi_scale, self.basenet.architecture, self.device)
         b = self.basenet
-        post = StackedPosterior.for_guide(self._guide, b.activation, b.input_shape, b.output_size, n_samples)
+        if b.architecture == "conv":
+            from .conv import ConvStackedPosterior, ConvSviGuide
+            if self._guide is None:
+                self._guide = ConvSviGuide(self.svi_loc, self.svi_scale, self.device)
+            post = ConvStackedPosterior.for_guide(self._guide, b.activation, b.input_shape, b.output_size, b.hidden_size, n_samples)
+        else:
+            from .posterior import StackedPosterior, SviGuide
+            if self._guide is None:
+                self._guide = SviGuide(self.svi_loc, self.svi_scale, b.architecture, self.device)
+            post = StackedPosterior.for_guide(self._guide, b.activation, b.input_shape, b.output_size, n_samples)
         eng = make_engine(post)
         if eng.precision == "triple":
             post.triple_images()                          # allocated once; every redraw writes them in the draw kernel itself

@@ -122,13 +122,29 @@ def assert_close_to_reference(val, ref, truth64, tol=1e-5, noise=None, what=""):
     return int((bound > tol).sum())
 
 
-def assert_close_to_truth(val, truth64, tol=1e-5, noise=None, what="", rows=None):
+def assert_close_to_truth(val, truth64, tol=1e-5, noise=None, what="", rows=None, fp32_yardstick=None):
     """`val` (an fp32 result) within `tol` of the fp64 evaluation, per point relative to the point's largest component — or within twice
-    the fp32 saturation noise floor of the point (saturation_noise) where that is larger.  rows: boolean mask of the points to check."""
+    the fp32 saturation noise floor of the point (saturation_noise) where that is larger — or, when given, within twice the WORST error
+    torch's own fp32 evaluation of the same formula makes on this case (fp32_yardstick: that evaluation; a 2 -> 512 -> 2 net with
+    std-0.5 weights sums 512 cancelling terms per logit and per gradient component, and torch-fp32 itself is then 1-2e-5 off).
+    rows: boolean mask of the points to check."""
     e = rel_err_points(val, truth64)
     bound = torch.full_like(e, tol) if noise is None else torch.maximum(torch.full_like(e, tol), 2 * noise.to(e))
+    if fp32_yardstick is not None:
+        bound = torch.maximum(bound, 2 * rel_err_points(fp32_yardstick, truth64).max())
     bad = e > bound
     if rows is not None:
         bad = bad & rows
     assert not bad.any(), f"{what}: {int(bad.sum())} points beyond the bound, worst {float((e / bound)[bad].max()):.2f}x"
     return int((bound > tol).sum())
+
+
+def pgd_whole_attack_statistic(what, adv, ref):
+    """Fraction of pixels of a whole 40-step PGD attack that differ from the reference's — REPORTED, not a parity criterion: the map is
+    chaotic (one noise-level gradient component flipping sign at some iterate moves that pixel across the eps-ball and can redirect later
+    iterates).  Parity of the step itself is asserted exactly, one step at a time along the reference's own iterates
+    (test_pgd_single_steps_along_the_reference_trajectory).  A sanity bound only catches a step that is broken outright."""
+    frac = float(((torch.as_tensor(adv).cpu() - torch.as_tensor(ref)).abs() > 1e-6).double().mean())
+    print(f"[pgd whole-attack statistic] {what}: {100 * frac:.3f} % of the pixels differ from the reference's after 40 steps")
+    assert frac < 0.25
+    return frac

@@ -52,7 +52,7 @@ def test_lowdim_against_fp64_oracle_and_the_mfma_path(shape, H, C, S, N, act):
     g, linf, l2 = low.loss_gradients(x, y, S, norms=True)
     # std-0.5 weights on 512 hidden units saturate the softmax (p = 1 - 1e-6): fp32's own floor there is 2^-24 / (1 - p) (conftest.saturation_noise)
     noise = saturation_noise(x, post, "fc", act, S)
-    assert_close_to_truth(g.cpu(), ref, TOL, noise, "per-sample-loss gradient", rows=ok)
+    assert_close_to_truth(g.cpu(), ref, TOL, noise, "per-sample-loss gradient", rows=ok, fp32_yardstick=O.loss_gradients(x, y, post, "fc", act, S))
     flat = g.cpu().reshape(N, -1)
     assert torch.allclose(linf.cpu(), flat.abs().max(1)[0], rtol=1e-6, atol=0) and torch.allclose(l2.cpu(), flat.norm(dim=1), rtol=1e-5, atol=1e-30)
     Xp, labd = low.pad_inputs(x), lab.int().to(DEV)
@@ -60,9 +60,10 @@ def test_lowdim_against_fp64_oracle_and_the_mfma_path(shape, H, C, S, N, act):
         ref = O.meanprob_gradients(x.double(), lab, p64, "fc", act, S, kind=kind)
         G = low.gradient(Xp, labd, None, S, mode).cpu()[:, :x[0].numel()].reshape(x.shape).clone()
         nz = noise if kind == "bnn" else saturation_noise(x, post, "fc", act, S, "ensemble")
-        assert_close_to_truth(G, ref, TOL, nz, f"{kind} gradient", rows=ok)
+        y32 = O.meanprob_gradients(x, lab, post, "fc", act, S, kind=kind)
+        assert_close_to_truth(G, ref, TOL, nz, f"{kind} gradient", rows=ok, fp32_yardstick=y32)
         Ge = ex.gradient(ex.pad_inputs(x), labd, None, S, mode).cpu()[:, :x[0].numel()].reshape(x.shape)
-        assert_close_to_truth(Ge, ref, TOL, nz, f"{kind} gradient, fp32-MFMA path", rows=ok)   # the 7-kernel path, same posterior, same bar
+        assert_close_to_truth(Ge, ref, TOL, nz, f"{kind} gradient, fp32-MFMA path", rows=ok, fp32_yardstick=y32)   # the 7-kernel path, same posterior, same bar
         # FGSM, and PGD with 7 iterations in one launch
         safe = ref.abs() > TAU * ref.abs().reshape(N, -1).max(1)[0].reshape(N, 1, 1, 1)
         adv = low.fgsm(x, y, S, 0.1, mode=mode).cpu()
@@ -84,7 +85,7 @@ def test_lowdim_against_fp64_oracle_and_the_mfma_path(shape, H, C, S, N, act):
     xg = x.clone().to(DEV).requires_grad_(True)
     torch.nn.CrossEntropyLoss(reduction="sum")(low.forward(xg, S), lab.to(DEV)).backward()
     ref = O.meanprob_gradients(x.double(), lab, p64, "fc", act, S)
-    assert_close_to_truth(xg.grad.cpu(), ref, TOL, noise, "autograd hook", rows=ok)
+    assert_close_to_truth(xg.grad.cpu(), ref, TOL, noise, "autograd hook", rows=ok, fp32_yardstick=O.meanprob_gradients(x, lab, post, "fc", act, S))
 
 
 def test_auto_is_lowdim_only_where_it_applies():

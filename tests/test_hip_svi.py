@@ -210,3 +210,66 @@ def test_svi_attack_and_evaluation_through_the_call_surface(tmp_path, monkeypatc
         oa, aa, rob = AA.attack_evaluation(net=bnn, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=4)
         assert 0 <= aa <= 100 and 0 <= oa <= 100 and rob.shape == (64,) and float(rob.min()) >= 0 and float(rob.max()) <= 1
     assert len(bnn._slots) == 1
+
+
+# ------------------------------------------------------------------------------------------------ conv SVI nets (the reference's saved model_0/2/4/6/8)
+def conv_guide_tensors(Cin, Hc, C, q2, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"model.0.weight": (32, Cin, 5, 5), "model.0.bias": (32,), "model.3.weight": (Hc, 32, 5, 5), "model.3.bias": (Hc,),
+              "model.7.weight": (C, q2 * q2 * Hc), "model.7.bias": (C,)}
+    loc = {k: torch.randn(*s, generator=g) * 0.05 for k, s in shapes.items()}
+    scl = {k: -3.0 + 0.5 * torch.randn(*s, generator=g) for k, s in shapes.items()}
+    return loc, scl
+
+
+@pytest.mark.parametrize("act,Hc", [("leaky", 32), ("tanh", 16)])
+def test_conv_svi_redraws_in_place(act, Hc, tmp_path, monkeypatch):
+    from robustbnns_amd import adversarialAttacks as AA
+    from robustbnns_amd.conv import ConvSviGuide, ConvStackedPosterior
+    from robustbnns_amd.model_bnn import BNN, set_rng_seed
+    monkeypatch.chdir(tmp_path)
+    C, S = 10, 3
+    loc, scl = conv_guide_tensors(1, Hc, C, 7, seed=Hc)
+    # the flat draw against the oracle's generator, tensor by tensor (element e = component e % 4 of block e / 4)
+    post = ConvStackedPosterior.for_guide(ConvSviGuide(loc, scl, DEV), act, (1, 28, 28), C, Hc, S)
+    post.triple_images()
+    post.redraw(0xFEEDFACE12345678, 5)
+    got = post.state_dict
+    for k, tid in ConvSviGuide.TENSOR_IDS.items():
+        n = loc[k].numel()
+        sp = torch.nn.functional.softplus(scl[k].double()).reshape(-1)
+        for s in range(S):
+            eps = torch.from_numpy(O.philox_normals(0xFEEDFACE12345678, 5, tid, s, 1, n)).reshape(-1)
+            want = loc[k].double().reshape(-1) + sp * eps
+            assert float(((got(s)[k].double().reshape(-1) - want).abs() / (sp * (1 + eps.abs()))).max()) < 4e-6, (k, s)
+    # the derived images follow the drawn stack: the default engine (triple conv2) agrees with the fp32-MFMA engine on stored copies
+    from robustbnns_amd.factory import make_engine, posterior_from_stacked
+    x, y = O.synthetic_inputs(8, (1, 28, 28), C, seed=4)
+    stacked = {k: torch.stack([post.state_dict(i)[k] for i in range(S)]) for k in ConvSviGuide.TENSOR_IDS}
+    ex = make_engine(posterior_from_stacked("conv", act, (1, 28, 28), C, Hc, stacked, DEV), precision="exact")
+    tri = make_engine(post)
+    assert tri.precision == "triple"
+    assert rel_err(tri.forward(x, S).cpu(), ex.forward(x, S).cpu()) < 1e-5
+    assert rel_err(tri.forward(x, S).cpu(), O.bnn_forward(x.double(), O.cast(stacked, torch.float64), "conv", act, S)) < 1e-5
+    # through the call surface: one resident stack, redrawn per call / per PGD iteration, no sync inside the attack
+    bnn = BNN("mnist", Hc, act, "conv", "svi", 5, 0.01, None, None, (1, 28, 28), C)
+    bnn.set_variational_params(loc, scl, DEV)
+    set_rng_seed(0)
+    p1 = bnn.forward(x, n_samples=S).cpu()
+    slot = bnn._slots[S]
+    p2 = bnn.forward(x, n_samples=S).cpu()
+    set_rng_seed(0)
+    assert bnn._slots[S] is slot and not torch.equal(p1, p2) and torch.equal(bnn.forward(x, n_samples=S).cpu(), p1)
+    xd, lab = x.to(DEV), y.argmax(-1).to(DEV)
+    AA.pgd_attack(bnn, xd, lab, {"epsilon": 0.1, "iters": 2}, n_samples=S)
+    draws = bnn._draws
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        adv = AA.pgd_attack(bnn, xd, lab, {"epsilon": 0.1, "iters": 3}, n_samples=S)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert bnn._draws == draws + 3 and bnn._slots[S] is slot
+    assert float((adv - xd).abs().max()) <= 0.1 + 1e-6
+    q = bnn.forward(x, n_samples=2, seeds=[7, 3]).cpu()
+    assert torch.equal(q, bnn.forward(x, n_samples=2, seeds=[7, 3]).cpu())
