@@ -503,9 +503,29 @@ __device__ __forceinline__ void conv_split3(float v, _Float16& p0, _Float16& p1,
     p2 = (_Float16)r;
 }
 
+#ifndef RBNN_CONVX3_OLD_IMG
+#define RBNN_CONVX3_OLD_IMG 0                                            // 1: the round-2 image layout (pitch = P1W, chunk swizzle by (pos >> 2) & 1 only)
+#endif
+// Image layout of conv2_pool_x3_kernel: position (y, x) of the pooled conv1 image is a 64-B record (32 channels) at index y * IPITCH + x;
+// 16-B channel octet o is stored at o ^ x3_img_swz(index, y).  A ds_read_b128 is served in four 16-lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}, +32 (rbnn_common.hpp); lane (li, lg) gathers octet lg of the position of output li + a tap offset.  Enumerating
+// every (tap, position tile, group) (tools/conv_x3_swizzle_search.py): with IPITCH = P1W and the swizzle ((idx >> 2) & 1) << 1 alone
+// EVERY gather is a 2-way conflict at 1x28x28 (2.0 LDS passes per read; PMC round 2: 36 % of the LDS cycles) and 2.9 passes at
+// 3x32x32 (43 %, the 12 idle lanes of the last tile all re-reading position 0 included).  1x28x28: XOR-ing the row parity into octet
+// bit 0 makes all of them conflict-free (1.0).  3x32x32: rows of 10 outputs do not tile the 4-position period; a pitch of 18 (48 KB
+// per point instead of 37) with the idle lanes spread over positions 0..11 brings it to 1.14.
+template <class G> struct ConvX3Img {
+    static constexpr bool MNIST = G::P1W == 12;
+    static constexpr int IPITCH = RBNN_CONVX3_OLD_IMG ? G::P1W : (MNIST ? 12 : 18);
+    static constexpr int ROWX = (!RBNN_CONVX3_OLD_IMG && MNIST) ? 1 : 0;
+};
+template <class G> __device__ __forceinline__ int x3_img_swz(int idx, int y) {
+    return ((((idx >> 2) & 1) << 1) ^ (ConvX3Img<G>::ROWX * (y & 1)));
+}
+
 template <class G, int WROWS> struct ConvX3Lds {
     static constexpr int PLANEW = WROWS * 64, TILEW = 3 * PLANEW;        // one tap's weight tile: 3 planes of WROWS 64-B rows
-    static constexpr int IPOS = G::P1W * G::P1W, IMGP = IPOS * 64, IMGB = 3 * IMGP;   // one point's image: 3 planes of IPOS 64-B position records
+    static constexpr int IPOS = G::P1W * ConvX3Img<G>::IPITCH, IMGP = IPOS * 64, IMGB = 3 * IMGP;   // one point's image: 3 planes of IPOS 64-B position records
     static constexpr int SCR = 8 * 16 * G::NPOS * 4;                     // the eight waves' pooling tiles (epilogue; alias the weight buffers)
     static constexpr int WBUF = (2 * TILEW > SCR ? 2 * TILEW : SCR);
     static constexpr int BYTES = WBUF + 2 * IMGB;
@@ -540,17 +560,19 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
     const float out_scale = x.p1_ds ? ldexpf(1.f, -x.k2_exp) * x.p1_ds->inv_scale : ldexpf(1.f, -(x.k2_exp + x.p1_exp));
 
     // both points' fp32 images [32 ci][IPOS] -> three piece planes, channel-last, in LDS: one (position, channel octet) per thread-item
-    for (int i = tid; i < 2 * L::IPOS * 4; i += 512) {
-        const int pt2 = i / (L::IPOS * 4), rem = i % (L::IPOS * 4), pos = rem >> 2, o = rem & 3;
-        const float* const src = a.P1 + ((long long)s * a.N + min(nb0 + pt2, a.N - 1)) * G::P1SZ + (8 * o) * L::IPOS + pos;
+    constexpr int IPITCH = ConvX3Img<G>::IPITCH, NSRC = P1W_ * P1W_;
+    for (int i = tid; i < 2 * NSRC * 4; i += 512) {
+        const int pt2 = i / (NSRC * 4), rem = i % (NSRC * 4), pos = rem >> 2, o = rem & 3;
+        const float* const src = a.P1 + ((long long)s * a.N + min(nb0 + pt2, a.N - 1)) * G::P1SZ + (8 * o) * NSRC + pos;
         union { f16x8 v; uint4 u; } q0, q1, q2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             _Float16 e0, e1, e2;
-            conv_split3(src[j * L::IPOS] * p1_scale, e0, e1, e2);
+            conv_split3(src[j * NSRC] * p1_scale, e0, e1, e2);
             q0.v[j] = e0; q1.v[j] = e1; q2.v[j] = e2;
         }
-        char* const dst = imgs + pt2 * L::IMGB + pos * 64 + ((o ^ (((pos >> 2) & 1) << 1)) * 16);
+        const int iy = pos / P1W_, idx = iy * IPITCH + pos % P1W_;
+        char* const dst = imgs + pt2 * L::IMGB + idx * 64 + ((o ^ x3_img_swz<G>(idx, iy)) * 16);
         *(uint4*)dst = q0.u;
         *(uint4*)(dst + L::IMGP) = q1.u;
         *(uint4*)(dst + 2 * L::IMGP) = q2.u;
@@ -559,9 +581,14 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
     const unsigned src_off = (unsigned)(((lane & 3) ^ swz(prow)) * 16);
     const int foff = li * 64 + ((lg ^ swz(li)) * 16);
     // image position of output position 16pt + li (tap 0,0); positions past NPOS read (0,0), never stored
-    int pbase[NPT];
+    int pbase[NPT], ybase[NPT];
 #pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) { const int pos = pt * 16 + li; pbase[pt] = pos < NPOS_ ? (pos / O2W_) * P1W_ + pos % O2W_ : 0; }
+    for (int pt = 0; pt < NPT; ++pt) {
+        int pos = pt * 16 + li;
+        if (pos >= NPOS_) pos = RBNN_CONVX3_OLD_IMG ? 0 : pos - NPOS_;  // idle lanes of the last tile: distinct valid positions (never stored)
+        ybase[pt] = pos / O2W_;
+        pbase[pt] = ybase[pt] * IPITCH + pos % O2W_;
+    }
     const char* const img = imgs + wp * L::IMGB;
     unsigned wrow[WPP];
 #pragma unroll
@@ -589,12 +616,12 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
             const int buf = tap & 1;
             if (tap + 1 < 25) stage(tap + 1, buf ^ 1);
             const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 16 * 64 + foff;
-            const int toff = (tap / 5) * P1W_ + (tap % 5);
+            const int ky = tap / 5, toff = ky * IPITCH + (tap % 5);
             f16x8 b0[NPT], b1[NPT], b2[NPT];
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
                 const int p = pbase[pt] + toff;
-                const char* const src = img + p * 64 + ((lg ^ (((p >> 2) & 1) << 1)) * 16);
+                const char* const src = img + p * 64 + ((lg ^ x3_img_swz<G>(p, ybase[pt] + ky)) * 16);
                 b0[pt] = *(const f16x8*)src;
                 b1[pt] = *(const f16x8*)(src + L::IMGP);
                 b2[pt] = *(const f16x8*)(src + 2 * L::IMGP);

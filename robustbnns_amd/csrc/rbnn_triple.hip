@@ -24,6 +24,7 @@
 // Lane maps as in rbnn_split.hip (v_mfma_f32_16x16x32_f16): a[j] = A[li][8*lg + j], b[j] = B[8*lg + j][li], acc[r] = D[4*lg + r][li].
 #include "rbnn_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 #ifndef RBNN_X3_FWD_SB
 #define RBNN_X3_FWD_SB 4                                      // forward: samples per XCD-resident group of blocks
@@ -628,12 +629,17 @@ struct GradX3Args {
 };
 enum { X3_FC = 0, X3_FC2_STEP1 = 1, X3_FC2_STEP2 = 2 };
 
-template <int ACT, int TD, int MODE>
-__global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) {
+template <int ACT, int TD, int MODE, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args a) {
     constexpr bool GEN = MODE != X3_FC2_STEP2;                 // dA generated from dZ, or read from memory
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);   // act' from the 1-bit stash, or an fp32 stream (sigmoid / tanh)
     constexpr bool STREAM = !GEN || !BITMASK;                  // a per-lane fp32 operand (A itself, or act') is prefetched from memory
-    constexpr int NTW = 4, NW = 4, BM = 256, LD = TD * 16;
+    // NW = 4 (default): 4 waves x (64 points x TD*16 columns), two blocks per CU.  NW = 8 ("wide": TD = 14): 8 waves x (32 points x 224
+    // columns), one block per CU — the same 28 accumulator tiles per wave and the same 256-point block, but a column group is twice as
+    // wide, so the dA generator + split (a quarter of this kernel: every column group re-derives dA) runs for 4 groups instead of 7 at
+    // D = 784, at the price of twice the B-fragment LDS reads per MFMA (a fragment feeds 2 point tiles instead of 4).
+    constexpr int NTW = 16 / NW, BM = 256, LD = TD * 16;
+    static_assert(NW == 4 || NW == 8, "256-point blocks of 4 or 8 waves");
     constexpr int W1B = 12 * LD * 16;                          // bytes: [4 lg][3 pieces][LD columns][16 B]
     constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + NW - 1) / NW;
     constexpr int BUFB = W1B + 4096 + 1024;                    // + 2 generator tiles of 2 KiB + 256 stash words
@@ -673,7 +679,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     auto dz_issue = [&](int s) {                                // this wave's 64 points x 64 B of sample s -> its own region of dzl
         const char* const src = a.dzg + ((long long)s * a.n_pad + nb) * 64;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16((const float*)(src + j * 1024 + loff), (float*)(dzl + wave * 4096 + j * 1024));
+        for (int j = 0; j < NTW; ++j) glds16((const float*)(src + j * 1024 + loff), (float*)(dzl + wave * (NTW * 1024) + j * 1024));
     };
     // The DMA pieces of a stage, per wave: 0 .. PPW-1 its W1 pieces, PPW its generator-tile piece (tiles 2*hb, 2*hb + 1 of the sample
     // are 4 KiB contiguous: one piece per wave), PPW + 1 the stash words (the block's 256 points = 1 KiB; last wave only).
@@ -693,7 +699,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
         if (i < PPW) {
             if (wave + NW * i < NPIECE) glds16((const float*)(q.W + goff[i < PPW ? i : 0]), (float*)(q.B + (wave + NW * i) * 1024));
         } else if (i == PPW) {
-            glds16((const float*)(q.G + loff), (float*)(q.B + W1B + wave * 1024));
+            if (NW == 4 || wave < 4) glds16((const float*)(q.G + loff), (float*)(q.B + W1B + wave * 1024));   // the two generator tiles are 4 pieces
         } else if (BITMASK && i == PPW + 1) {
             if (wave == NW - 1) glds16((const float*)(q.M + loff), (float*)(q.B + W1B + 4096));
         }
@@ -727,7 +733,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
     const unsigned cn_bits = (ACT == RBNN_ACT_RELU) ? 0u : __float_as_uint(LEAKY_SLOPE * ldexpf(1.f, GEN_Q3));
     const int dzc1 = (lg == 2 ? 0 : lg), dzc2 = (lg == 0 ? 1 : (lg == 1 ? 2 : (lg == 2 ? 0 : 3)));   // dZ chunk of MFMA 1 / 2 for this lane group
     const int sz = dz_swz3(li);
-    const char* const dzw = dzl + wave * 4096 + li * 64;
+    const char* const dzw = dzl + wave * (NTW * 1024) + li * 64;
     f16x8 da0[NTW], da1[NTW], da2[NTW];                        // A operand of the main MFMA: this wave's 4 point tiles, one stage
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1, hb = st % HS;
@@ -867,24 +873,36 @@ __global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) 
         }
 }
 
-template <int ACT, int TD, int MODE>
+template <int ACT, int TD, int MODE, int NW = 4>
 int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
     constexpr int LDSB = 2 * (12 * TD * 16 * 16 + 5120) + 256 * 64;
-    static_assert(2 * LDSB <= 160 * 1024, "two blocks per CU");
+    static_assert((NW == 4 ? 2 : 1) * LDSB <= 160 * 1024, "two 4-wave blocks or one 8-wave block per CU");
     a.NT = (a.N + 255) / 256;
     a.ND = (a.Dt + TD - 1) / TD;
-    auto kern = fc_grad_x3_kernel<ACT, TD, MODE>;
+    auto kern = fc_grad_x3_kernel<ACT, TD, MODE, NW>;
     static unsigned long long attr_done = 0;
     if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, st, a);
     return launch_status();
 }
+
+// fc (MODE X3_FC), relu / leaky: 8 waves x (32 points x 224 columns) where that saves column groups.  MEASURED SLOWER at C2 (round 3, same
+// box, alternating runs): gradient kernel 3.98 / 4.14 ms wide vs 3.75 / 3.69 ms narrow — the generator + split work it saves (4 column
+// groups instead of 7) is smaller than what the doubled B-fragment LDS traffic per MFMA costs.  Compiled in only with -DRBNN_X3_GRAD_WIDE=1
+// (then switchable with the environment variable RBNN_X3_GRAD_WIDE=0|1).
+#ifndef RBNN_X3_GRAD_WIDE
+#define RBNN_X3_GRAD_WIDE 0
+#endif
 
 // 7 or 4 column tiles per block: every group pays the dA generator (or the A-operand reads) again, so fewer groups win — 7 wherever
 // that saves a group (a partial last group skips its missing tiles' MFMAs)
 template <int ACT, int MODE>
 int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
+    if constexpr (RBNN_X3_GRAD_WIDE && MODE == X3_FC && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {
+        static const bool wide = [] { const char* e = getenv("RBNN_X3_GRAD_WIDE"); return !e || e[0] != '0'; }();
+        if (wide && (a.Dt + 13) / 14 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 14, MODE, 8>(a, st);
+    }
     if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7, MODE>(a, st);
     return launch_grad_x3_cfg<ACT, 4, MODE>(a, st);
 }

@@ -5,7 +5,7 @@ tensors, so the whole sharded step — every rank's forward / backward kernels t
 sum_s p_s and of the summed gradients, pipelined over point blocks — runs here across two processes and must reproduce the
 single-process result on the full posterior: gradients to 1e-5 (the partial sums are added in a different order), FGSM images equal
 except noise-level gradient components, identical replicas on both ranks.  Runs in the package's default precision (auto = triple at
-H = 512) and on the fp32 MFMA."""
+H = 512) and on the fp32 MFMA, and for the conv architecture (ConvEngine: the plain, un-pipelined sharded sequence)."""
 import os
 import socket
 import sys
@@ -21,36 +21,52 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, precision, q):
+def _problem(arch, dev):
+    """(full posterior, this-rank builder, x, y, D, S, N, PGD points) for the fc-512 case and a small conv net."""
+    from oracle import bnn_oracle as O
+    if arch == "fc":
+        from robustbnns_amd.posterior import StackedPosterior
+        D, H, C, S, N = 784, 512, 10, 6, 1100
+        post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
+        full = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, dev)
+        x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=5)
+        return full, (lambda r, w: full.shard(r, w)), x, y, D, S, N, 600
+    from robustbnns_amd.conv import ConvStackedPosterior
+    D, Hc, C, S, N = 784, 32, 10, 4, 48
+    post = O.synthetic_posterior("conv", D, Hc, C, S, 0.05)
+    full = ConvStackedPosterior("leaky", (1, 28, 28), C, Hc, post, dev)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=6)
+    part = lambda r, w: ConvStackedPosterior("leaky", (1, 28, 28), C, Hc, {k: v[r * S // w:(r + 1) * S // w] for k, v in post.items()}, dev)
+    return full, part, x, y, D, S, N, 16
+
+
+def _worker(rank, world, port, precision, q, arch="fc"):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["RBNN_COMM_BLOCKS"], os.environ["RBNN_COMM_MIN_POINTS"] = "2", "256"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from oracle import bnn_oracle as O
         from robustbnns_amd import _hip
-        from robustbnns_amd.engine import AttackEngine
-        from robustbnns_amd.posterior import StackedPosterior
+        from robustbnns_amd.factory import make_engine
         dev = "cuda:0"
-        D, H, C, S, N = 784, 512, 10, 6, 1100
-        post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
-        x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=5)
-        full = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, dev)
-        eng = AttackEngine(full.shard(rank, world), group=dist.group.WORLD, total_samples=S, precision=precision)
-        assert eng.world == 2 and eng._comm_blocks(N) == 2 and eng.post.S == S // world
+        full, part, x, y, D, S, N, NP = _problem(arch, dev)
+        eng = make_engine(part(rank, world), group=dist.group.WORLD, total_samples=S, precision=precision)
+        assert eng.world == 2 and eng.post.S == S // world
+        if arch == "fc":
+            assert eng._comm_blocks(N) == 2                     # pipelined over two point blocks; ConvEngine keeps the plain sequence
         lab = y.argmax(-1).int().to(dev)
         out = {"probs": eng.forward(x, eng.post.S).cpu(), "lg": eng.loss_gradients(x, y, eng.post.S).cpu(),
                "gm": eng.gradient(eng.pad_inputs(x), lab, None, eng.post.S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().clone(),
-               "fgsm": eng.fgsm(x, y, eng.post.S, 0.3).cpu(), "pgd": eng.pgd(x[:600], y[:600], eng.post.S, 0.3, iters=4).cpu()}
+               "fgsm": eng.fgsm(x, y, eng.post.S, 0.3).cpu(), "pgd": eng.pgd(x[:NP], y[:NP], eng.post.S, 0.3, iters=4).cpu()}
         torch.cuda.synchronize()
         t = out["fgsm"].clone()                                  # every rank holds the same (replicated) adversarial images
         dist.broadcast(t, src=0)
         assert torch.equal(t, out["fgsm"])
         if rank == 0:
-            single = AttackEngine(full, precision=precision)
+            single = make_engine(full, precision=precision)
             ref = {"probs": single.forward(x, S).cpu(), "lg": single.loss_gradients(x, y, S).cpu(),
                    "gm": single.gradient(single.pad_inputs(x), lab, None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().clone(),
-                   "fgsm": single.fgsm(x, y, S, 0.3).cpu(), "pgd": single.pgd(x[:600], y[:600], S, 0.3, iters=4).cpu()}
+                   "fgsm": single.fgsm(x, y, S, 0.3).cpu(), "pgd": single.pgd(x[:NP], y[:NP], S, 0.3, iters=4).cpu()}
             errs = {"mode": eng.precision}
             for k in ("probs", "lg", "gm"):
                 a, b = out[k].reshape(N, -1).double(), ref[k].reshape(N, -1).double()
@@ -67,15 +83,15 @@ def _worker(rank, world, port, precision, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", ["auto", "exact"])
-def test_two_ranks_real_kernels_match_single_process(precision):
+@pytest.mark.parametrize("arch,precision", [("fc", "auto"), ("fc", "exact"), ("conv", "auto")])
+def test_two_ranks_real_kernels_match_single_process(arch, precision):
     assert torch.cuda.is_available(), "this test needs the MI355X"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q, arch)) for r in range(2)]
     for p in procs:
         p.start()
     errs = q.get(timeout=600)

@@ -1,29 +1,34 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): the GPU test tier, smoke, every bench workload, rocprofv3 kernel-trace stats and PMC passes.
-# usage: tools/profile_round.sh <tag> [quick]       -> gpurun_out/<tag>/...   (copy what should be judged into profiles/<tag>/)
+# Run on the GPU box (via gpurun): usage: tools/profile_round.sh <tag> <stage>       -> gpurun_out/<tag>/...   (copy what should be judged into profiles/<tag>/)
+#   stage tests : the GPU test tier (-s: statistics printed), smoke()
+#   stage bench : every bench workload (JSON lines) + the 1-rank forced-collectives run
+#   stage prof  : rocprofv3 --kernel-trace --stats and the separate --pmc passes of c2 (+ c5, conv unless QUICK=1)
+# (a gpurun call is limited to 20 minutes: one stage per call)
 set -u
-TAG=${1:-r02}
-QUICK=${2:-}
+TAG=${1:-r03}
+STAGE=${2:-bench}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-if [ -z "$QUICK" ]; then
-  (timeout 2400 python -m pytest tests -m gpu -q -s 2>&1 | grep -vE "^(Saving|Loading|Producing|Evaluating|test accuracy|avg softmax|vanishing|increasing|null|image_idx| === |min = |$)" | tail -400) > $OUT/pytest_gpu.log
+if [ "$STAGE" = "tests" ]; then
+  (timeout 1100 python -m pytest tests -m gpu -q -s 2>&1 | grep -vE "^(Saving|Loading|Producing|Evaluating|test accuracy|avg softmax|vanishing|increasing|null|image_idx| === |min = |$)" | tail -600) > $OUT/pytest_gpu.log
   tail -2 $OUT/pytest_gpu.log
   python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 fi
-python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json
-if [ -z "$QUICK" ]; then
+if [ "$STAGE" = "bench" ]; then
+  python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 300 $OUT/bench.json
   python bench.py --workload c3 --steps 2 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_c3.json
   python bench.py --workload c4 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_c4.json
   python bench.py --workload c5 --points 1024 --iters 10 --steps 1 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_c5_n1024_t10.json
   python bench.py --workload conv --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_conv.json
   python bench.py --workload fc2 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_fc2.json
-  python bench.py --workload c1 --steps 50 --warmup 5 --cpu-seconds 5 2>/dev/null | tail -1 > $OUT/bench_c1.json
+  python bench.py --workload c1 --steps 200 --warmup 20 --cpu-seconds 5 2>/dev/null | tail -1 > $OUT/bench_c1.json
   RBNN_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 > $OUT/bench_c2_torchrun_1rank_forced_collectives.json
+  for f in $OUT/bench*.json; do python3 -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$(basename $f)', d['precision_mode'], '%.4g' % d['value'], '%.4g ms' % d['ms_per_step'])"; done
 fi
+if [ "$STAGE" = "prof" ]; then
 cd /tmp
 prof() {   # prof <subdir> <workload> <extra bench args...>
   local sub=$1 wl=$2; shift 2
@@ -39,7 +44,7 @@ prof() {   # prof <subdir> <workload> <extra bench args...>
   head -30 $OUT/$sub/summary.txt
 }
 prof c2 c2 --steps 5 --warmup 2
-if [ -z "$QUICK" ]; then
+if [ -z "${QUICK:-}" ]; then
   prof c5 c5 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
   prof conv conv --steps 3 --warmup 1
 fi
@@ -54,3 +59,4 @@ for f in sorted(glob.glob("$OUT/*/pmc_traffic.json")):
 json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
 print(sorted(k for k in out if k != "source"))
 PY
+fi

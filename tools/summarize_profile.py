@@ -25,7 +25,7 @@ MAIN = [("fc_forward_x3_kernel", "fc_forward_triple"), ("fc_grad_x3_kernel", "fc
         ("conv_bwd_split_kernel", "conv_input_grad_split"),
         ("conv2_pool_kernel", "conv_forward"), ("conv1_pool_kernel", "conv_forward"), ("conv_fc_kernel", "conv_forward"),
         ("conv_bwd_kernel", "conv_input_grad"), ("conv_fc_bwd_kernel", "conv_input_grad"), ("conv1_bwd_mfma_kernel", "conv_input_grad")]
-SHORT = [k for k, _ in MAIN] + ["triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
+SHORT = [k for k, _ in MAIN] + ["svi_draw_flat_kernel", "svi_draw_kernel", "lowdim_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
                                 "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"]
 
 
