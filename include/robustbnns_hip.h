@@ -421,12 +421,13 @@ int rbnn_fc_input_grad_triple(const rbnn_posterior *net, const rbnn_triple_image
 /* ------------------------------------------------------------------------------------------------------------
  * The SVI guide's draw written IN PLACE into a stacked posterior and all of its weight images, one launch, no eps tensor.
  * Replaces the per-forward pyro.random_module(basenet, Normal(loc, softplus(scale)))() of model_bnn.py:121-136 called S times per
- * prediction (:222-232): W[s] = loc + softplus(scale_raw) * eps(s) for every tensor of the net, eps = Box-Muller of
+ * prediction (:222-232): W[s] = loc + sigma * eps(s) for every tensor of the net (sigma = softplus(raw scale)), eps = Box-Muller of
  * Philox4x32-10(counter = (element quad, tensor id, s or 0, draw_id), key = sample_keys[s] or key).  PARITY UNPINNED against
  * pyro-ppl 1.3.0's RNG stream (the package is not available to check it against).
  * ------------------------------------------------------------------------------------------------------------ */
-typedef struct rbnn_svi_guide {    /* device pointers to the variational parameters, UNPADDED row-major as the param store holds them */
-    const float *W1_loc, *W1_scale;   /* model.1.weight_loc / _scale  [hidden, in_features]  (raw scale: softplus is applied here)   */
+typedef struct rbnn_svi_guide {    /* device pointers to the variational parameters, UNPADDED row-major as the param store holds them;     */
+                                   /* *_scale = the STANDARD DEVIATION softplus(raw `<key>_scale`) (model_bnn.py:127), taken once per guide */
+    const float *W1_loc, *W1_scale;   /* model.1.weight_loc, softplus(model.1.weight_scale)  [hidden, in_features]                   */
     const float *b1_loc, *b1_scale;   /* model.1.bias                  [hidden]                                                      */
     const float *Wm_loc, *Wm_scale;   /* fc2: model.3.weight           [hidden, hidden]                                              */
     const float *bm_loc, *bm_scale;   /* fc2: model.3.bias             [hidden]                                                      */
@@ -439,18 +440,18 @@ typedef struct rbnn_svi_guide {    /* device pointers to the variational paramet
 /* Writes samples [0, n_samples) of `net`: W1 b1 (Wm bm) W2 b2 — the pointers are const in rbnn_posterior because every other entry
  * point only reads them; this one writes through them — plus W1_pack4 / Wm_pack4 when non-NULL, plus, when `tp` is non-NULL, the
  * triple images W1_rows, W1_cols, W2_gen (Wm_rows, Wm_cols) at the scales tp->w1_exp / w2_exp / wm_exp, which the caller fixes per
- * guide from the bound |w| <= |loc| + RBNN_SVI_EPS_MAX * softplus(scale).  sample_keys: device array of n_samples 64-bit keys (one
+ * guide from the bound |w| <= |loc| + RBNN_SVI_EPS_MAX * sigma.  sample_keys: device array of n_samples 64-bit keys (one
  * seed per sample: model_bnn.py:222-226) or NULL (all samples under `key`, the sample index in the counter).  Asynchronous on `stream`. */
 #define RBNN_SVI_EPS_MAX 6.77f
 int rbnn_svi_draw(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
                   const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
 
 /* The same draw for tensors of any shape (the conv architecture: model.0 / .3 / .7 weights and biases), written IN PLACE into the fp32
- * stack: out[s, e] = loc[e] + softplus(scale_raw[e]) * eps, eps of element e = component e % 4 of the Philox block with counter
+ * stack: out[s, e] = loc[e] + sigma[e] * eps, eps of element e = component e % 4 of the Philox block with counter
  * (e / 4, tensor_id, s — or 0 when sample_keys is given —, draw_id).  One launch for up to 8 tensors and all samples; images derived
  * from the stack (the regrouped / triple images of the conv2 weights) are rebuilt by their builders (robustbnns_amd/conv.py). */
 typedef struct rbnn_svi_flat_tensor {
-    const float *loc, *scale_raw;     /* [n_elem] variational parameters (raw scale)                          */
+    const float *loc, *sigma;         /* [n_elem] variational mean and standard deviation softplus(raw scale) */
     float *out;                       /* [n_samples, out_sample_stride] destination, first n_elem of each row  */
     int64_t n_elem, out_sample_stride;
     int32_t tensor_id, reserved;

@@ -74,7 +74,7 @@ class SviGuide(C.Structure):
 
 
 class SviFlatTensor(C.Structure):
-    _fields_ = [("loc", _fp), ("scale_raw", _fp), ("out", _fp), ("n_elem", C.c_int64), ("out_sample_stride", C.c_int64),
+    _fields_ = [("loc", _fp), ("sigma", _fp), ("out", _fp), ("n_elem", C.c_int64), ("out_sample_stride", C.c_int64),
                 ("tensor_id", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -447,11 +447,11 @@ class HipKernels:
                                        ptr(P), ptr(out), out.stride(0), ptr(linf), ptr(l2), stream_of(X)), "rbnn_lowdim_run")
 
     def svi_draw_flat(self, items, S, key, draw_id, sample_keys=None):
-        """items: list of (loc, scale_raw, out [S, ...], tensor_id) — every tensor of a net redrawn in place by ONE launch."""
+        """items: list of (loc, sigma = softplus(raw scale), out [S, ...], tensor_id) — every tensor of a net redrawn in place by ONE launch."""
         arr = (SviFlatTensor * len(items))()
         for i, (loc, scl, out, tid) in enumerate(items):
             require_gpu(out, "out")
-            arr[i].loc, arr[i].scale_raw, arr[i].out = loc.data_ptr(), scl.data_ptr(), out.data_ptr()
+            arr[i].loc, arr[i].sigma, arr[i].out = loc.data_ptr(), scl.data_ptr(), out.data_ptr()
             arr[i].n_elem, arr[i].out_sample_stride, arr[i].tensor_id = loc.numel(), out.stride(0), tid
         check(self.lib.rbnn_svi_draw_flat(arr, len(items), S, ptr(sample_keys), C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF),
                                           stream_of(items[0][2])), "rbnn_svi_draw_flat")

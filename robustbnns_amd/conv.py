@@ -38,10 +38,10 @@ class ConvSviGuide:
         self.device = torch.device(device)
         self.loc = {k: loc[k].detach().to(self.device, torch.float32).contiguous() for k in self.TENSOR_IDS}
         self.scale = {k: scale[k].detach().to(self.device, torch.float32).contiguous() for k in self.TENSOR_IDS}
-        sp = torch.nn.functional.softplus
-        bnd = {k: self.loc[k].abs() + _hip.SVI_EPS_MAX * sp(self.scale[k]) for k in self.loc}
+        self.sigma = {k: torch.nn.functional.softplus(v).contiguous() for k, v in self.scale.items()}     # once per guide (as posterior.SviGuide)
+        bnd = {k: self.loc[k].abs() + _hip.SVI_EPS_MAX * self.sigma[k] for k in self.loc}
         k2 = bnd["model.3.weight"]
-        typ = (self.loc["model.3.weight"].abs() + 0.8 * sp(self.scale["model.3.weight"])).double().mean().float()
+        typ = (self.loc["model.3.weight"].abs() + 0.8 * self.sigma["model.3.weight"]).double().mean().float()
         Cn = self.loc["model.7.bias"].numel()
         rec = torch.stack([k2.max(), typ, bnd["model.0.weight"].reshape(32, -1).sum(-1).max(), bnd["model.0.bias"].max(),
                            bnd["model.7.weight"].reshape(Cn, -1).sum(0).max()]).cpu().tolist()           # the one sync, at load
@@ -102,7 +102,7 @@ class ConvStackedPosterior:
         g, S = self._guide, (self.S if n_samples is None else int(n_samples))
         dst = {"model.0.weight": self.K1w, "model.0.bias": self.K1b, "model.3.weight": self.K2w, "model.3.bias": self.K2b,
                "model.7.weight": self.Fw, "model.7.bias": self.Fb}
-        items = [(g.loc[k], g.scale[k], dst[k], g.TENSOR_IDS[k]) for k in dst]
+        items = [(g.loc[k], g.sigma[k], dst[k], g.TENSOR_IDS[k]) for k in dst]
         _hip.HipKernels().svi_draw_flat(items, S, int(key), int(draw_id), sample_keys)
         self._regroup_k2ci()
         if self._triple is not None:

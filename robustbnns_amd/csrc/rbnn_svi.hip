@@ -1,5 +1,5 @@
 // rbnn_svi.hip — the SVI guide's weight draw (model_bnn.py:121-136, :222-232) as ONE kernel that writes a whole stacked posterior
-// IN PLACE: W = loc + softplus(scale) * eps with eps generated in registers (Philox4x32-10 + Box-Muller — no eps tensor in HBM),
+// IN PLACE: W = loc + sigma * eps (sigma = softplus(raw scale), taken once per guide by the caller) with eps generated in registers (Philox4x32-10 + Box-Muller — no eps tensor in HBM),
 // stored as the fp32 stack AND, in the same pass, as every image the two GEMM modes read:
 //
 //      fp32 stack        W1 [S,H,D_pad]  b1  (Wm bm)  W2 [S,C,H]  b2        what rbnn_fc_forward reads
@@ -38,14 +38,12 @@ __device__ __forceinline__ void normal4(const uint32_t x[4], float n[4]) {
     for (int p = 0; p < 2; ++p) {
         const float u1 = ((float)x[2 * p] + 0.5f) * 2.3283064365386963e-10f;       // fp32: x + 0.5 rounds for x >= 2^24, still in (0, 1]
         const float u2 = ((float)x[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
-        const float r = sqrtf(-2.f * logf(fminf(u1, 0.99999994f)));
-        float sn, cs;
-        sincospif(2.f * u2, &sn, &cs);
-        n[2 * p] = r * cs; n[2 * p + 1] = r * sn;
+        // the hardware transcendentals: v_log_f32 (log2, 1 ulp) and v_sin_f32 / v_cos_f32, whose argument is in REVOLUTIONS — sin(2 pi u2)
+        // is one instruction.  (libm's logf + sincospif cost ~25 vector instructions per weight and made this kernel ALU-bound.)
+        const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u1, 0.99999994f)));   // sqrt(-2 ln u1), ln = log2 * ln 2
+        n[2 * p] = r * __builtin_amdgcn_cosf(u2); n[2 * p + 1] = r * __builtin_amdgcn_sinf(u2);
     }
 }
-
-__device__ __forceinline__ float softplus(float sr) { return sr > 20.f ? sr : log1pf(expf(sr)); }   // torch.nn.Softplus(beta=1, threshold=20), model_bnn.py:18
 
 // p0 + p1 + p2 = v exactly (rbnn_triple.hip's split3, plain C: the image builders are not instruction-issue bound)
 __device__ __forceinline__ void split3(float v, _Float16& a, _Float16& b, _Float16& c) {
@@ -86,7 +84,7 @@ __device__ __forceinline__ void draw_quad(const Rng& rng, int tensor, const floa
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool in = 4 * c4 + j < cols;
-        w[j] = in ? loc[base + j] + softplus(scl[base + j]) * n[j] : 0.f;          // Normal.rsample(): loc + eps * scale (model_bnn.py:127-130)
+        w[j] = in ? fmaf(scl[base + j], n[j], loc[base + j]) : 0.f;              // Normal.rsample(): loc + eps * scale (model_bnn.py:127-130); scl = softplus(raw scale), applied ONCE per guide by the caller
     }
 }
 
@@ -244,7 +242,7 @@ __global__ void __launch_bounds__(256) svi_draw_kernel(const DrawArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
-// Flat draw: up to 8 tensors of any shape (the conv architecture's six), W[s][e] = loc[e] + softplus(scale[e]) * eps(s, e), eps of
+// Flat draw: up to 8 tensors of any shape (the conv architecture's six), W[s][e] = loc[e] + sigma[e] * eps(s, e) (sigma = softplus(raw scale)), eps of
 // element e = component e % 4 of the Philox block with counter (e / 4, tensor id, s or 0, draw id).  One launch for all tensors and
 // samples; derived weight images (regrouped / triple images of model.3.weight) are rebuilt from the fp32 stack by their own builders.
 // ---------------------------------------------------------------------------------------------------
@@ -272,7 +270,7 @@ __global__ void __launch_bounds__(256) svi_draw_flat_kernel(const FlatArgs a) {
     float n[4], w[4];
     rng.quad(t.tensor_id, (uint32_t)q, n);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = (e0 + j < t.n_elem) ? t.loc[e0 + j] + softplus(t.scale_raw[e0 + j]) * n[j] : 0.f;
+    for (int j = 0; j < 4; ++j) w[j] = (e0 + j < t.n_elem) ? fmaf(t.sigma[e0 + j], n[j], t.loc[e0 + j]) : 0.f;
     float* const out = t.out + (long long)s * t.out_sample_stride + e0;
     if (e0 + 3 < t.n_elem && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) *(f32x4*)out = (f32x4){w[0], w[1], w[2], w[3]};
     else
@@ -292,7 +290,7 @@ int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor* tensors, int32_t n_tensors, i
     long long blocks = 0;
     for (int i = 0; i < n_tensors; ++i) {
         const rbnn_svi_flat_tensor& t = tensors[i];
-        if (!t.loc || !t.scale_raw || !t.out) return RBNN_ERR_NULL;
+        if (!t.loc || !t.sigma || !t.out) return RBNN_ERR_NULL;
         if (t.n_elem < 1 || t.n_elem > 0x3FFFFFFFFLL || t.out_sample_stride < t.n_elem) return RBNN_ERR_SHAPE;
         a.t[i] = t;
         a.first_block[i] = blocks;

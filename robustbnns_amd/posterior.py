@@ -78,9 +78,11 @@ class SviGuide:
         self.hidden = int(self.loc["b1"].numel())
         self.loc["W1"] = self.loc["W1"].reshape(self.hidden, -1)
         self.scale["W1"] = self.scale["W1"].reshape(self.hidden, -1)
-        sp = torch.nn.functional.softplus
-        bnd = {n: self.loc[n].abs() + _hip.SVI_EPS_MAX * sp(self.scale[n]) for n in self.loc}
-        typ = {n: self.loc[n].abs() + 0.8 * sp(self.scale[n]) for n in self.loc}                     # ~ E|w|
+        # the standard deviation softplus(raw scale) (model_bnn.py:18,127) is the same for every draw: taken ONCE here (the draw kernel was
+        # ALU-bound while it re-evaluated expf + log1pf for each of the S x P weights)
+        self.sigma = {n: torch.nn.functional.softplus(v).contiguous() for n, v in self.scale.items()}
+        bnd = {n: self.loc[n].abs() + _hip.SVI_EPS_MAX * self.sigma[n] for n in self.loc}
+        typ = {n: self.loc[n].abs() + 0.8 * self.sigma[n] for n in self.loc}                         # ~ E|w|
         mats = [n for n in ("W1", "W2", "Wm") if n in bnd]
         rec = torch.stack([bnd[n].max() for n in mats] + [typ[n].double().mean().float() for n in mats] +
                           [bnd["W1"].sum(-1).max(), bnd["b1"].max()]).cpu().tolist()                   # the one sync, at load
@@ -95,7 +97,7 @@ class SviGuide:
             d = _hip.SviGuide()
             for n in ("W1", "b1", "Wm", "bm", "W2", "b2"):
                 setattr(d, n + "_loc", None if n not in self.loc else C.c_void_p(self.loc[n].data_ptr()))
-                setattr(d, n + "_scale", None if n not in self.scale else C.c_void_p(self.scale[n].data_ptr()))
+                setattr(d, n + "_scale", None if n not in self.sigma else C.c_void_p(self.sigma[n].data_ptr()))
             d.hidden = self.hidden
             self._desc = d
         return self._desc

@@ -67,7 +67,7 @@ def test_draw_kernel_matches_the_oracle_generator_and_the_image_builders(arch, s
         got.update(Wm=post.Wm[:, :H, :H], bm=post.bm[:, :H])
     for name, w in got.items():
         sp = torch.nn.functional.softplus(by_role(scl, arch)[name].double())
-        tol = 4e-6 * sp.unsqueeze(0) * (1 + E[name].abs()) + 1e-7 * W64[name].abs()     # logf / sincospif vs numpy's double precision
+        tol = 2e-5 * sp.unsqueeze(0) * (1 + E[name].abs()) + 1e-7 * W64[name].abs()     # v_log_f32 / v_sin_f32 / v_cos_f32 vs numpy's double precision
         assert bool(((w.cpu().double() - W64[name]).abs() <= tol).all()), name
     # padding stays zero (hidden 16 -> 32 rows, D -> D_pad columns)
     assert float(post.W1[:, H:, :].abs().max() if Hp > H else 0.0) == 0.0 and float(post.W1[:, :, D:].abs().max() if post.Dp > D else 0.0) == 0.0
@@ -105,7 +105,7 @@ def test_seeded_draws_do_not_depend_on_position_and_draw_ids_differ():
     b.redraw(0, 0, sample_keys=torch.tensor([2, 5], dtype=torch.int64, device=DEV))
     assert torch.equal(a.W1[0], b.W1[1]) and torch.equal(a.W1[2], b.W1[0]) and torch.equal(a.W2[2], b.W2[0]) and torch.equal(a.b1[0], b.b1[1])
     W64, _ = O.svi_draw_philox(by_role(loc, "fc"), by_role(scl, "fc"), None, 0, 3, sample_keys=[5, 9, 2])
-    assert float((a.W1[:, :, :784].cpu().double() - W64["W1"]).abs().max()) < 1e-5
+    assert float((a.W1[:, :, :784].cpu().double() - W64["W1"]).abs().max()) < 5e-5
     w0 = a.W1.clone()
     a.redraw(77, 1)
     w1 = a.W1.clone()
@@ -241,7 +241,7 @@ def test_conv_svi_redraws_in_place(act, Hc, tmp_path, monkeypatch):
         for s in range(S):
             eps = torch.from_numpy(O.philox_normals(0xFEEDFACE12345678, 5, tid, s, 1, n)).reshape(-1)
             want = loc[k].double().reshape(-1) + sp * eps
-            assert float(((got(s)[k].double().reshape(-1) - want).abs() / (sp * (1 + eps.abs()))).max()) < 4e-6, (k, s)
+            assert float(((got(s)[k].double().reshape(-1) - want).abs() / (sp * (1 + eps.abs()))).max()) < 2e-5, (k, s)
     # the derived images follow the drawn stack: the default engine (triple conv2) agrees with the fp32-MFMA engine on stored copies
     from robustbnns_amd.factory import make_engine, posterior_from_stacked
     x, y = O.synthetic_inputs(8, (1, 28, 28), C, seed=4)
