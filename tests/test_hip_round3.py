@@ -268,3 +268,43 @@ def test_conv_smooth_activation_with_vanishing_preactivations(act, precision):
         # (strict >), and so must the kernels — MNIST's zero background is full of such windows.  (The plain fp64 oracle is no yardstick
         # here: its conv2 outputs differ across positions in the last bit — "farthest from a tie 1e-17" above — and it routes by that.)
         assert int((st1[:, :4] & 3).max()) == 0 and int((st2[:, :4] & 3).max()) == 0
+
+
+# ------------------------------------------------------------------------------------------------ the reference's half-moons grid, timed
+def test_half_moons_grid_drivers_over_the_reference_grid(tmp_path, monkeypatch):
+    """grid_search_halfMoons.main (:159-169): fc2 / HMC, hidden in {32, 128, 256, 512}, 250 posterior samples, FGSM + loss_gradients on
+    100 test points per model.  Synthetic chains of that shape are written in the reference's file layout, then the two drivers run over
+    the hidden-size axis exactly as the reference's main calls them; the wall time per (model, driver) cell is printed (the reference
+    spreads these cells over 10 joblib processes on the CPU)."""
+    import time
+    from robustbnns_amd import grid_search_halfMoons as G
+    monkeypatch.chdir(tmp_path)
+    hidden, S, N = [32, 128, 256, 512], 250, 100
+    x, y = O.synthetic_inputs(N, (1, 2, 1), 2, seed=9)
+    rel = str(tmp_path) + "/"
+    for h in hidden:
+        bnn = G.MoonsBNN(h, "leaky", "fc2", "hmc", None, None, S, 100, 5000, (1, 2, 1), 2)
+        bnn.set_posterior_samples(O.synthetic_posterior("fc2", 2, h, 2, S, 0.3), "cpu")
+        bnn.save(rel_path=rel)
+    axes = (hidden, ["leaky"], ["fc2"], ["hmc"], [None], [None], [S], [100], [5000])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    adv = G.grid_attack("fgsm", *axes, [S], x, y, device=DEV, rel_path=rel)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    grads = G.serial_compute_grads(*axes, [S], rel, x, y, device=DEV)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    assert len(adv) == len(grads) == 4
+    for (name, s), a in adv.items():
+        assert s == S and a.shape == x.shape and float((a.cpu() - x).abs().max()) <= 0.3 + 1e-6
+    for (name, s), g_ in grads.items():
+        assert g_.shape == (N, 2) and np.isfinite(g_).all()
+    # one cell against the fp64 oracle
+    h = 128
+    post = O.synthetic_posterior("fc2", 2, h, 2, S, 0.3)
+    name = [k for k in grads if f"hid={h}_" in k[0]][0]
+    ref = O.loss_gradients(x.double(), y, O.cast(post, torch.float64), "fc2", "leaky", S).reshape(N, 2)
+    assert rel_err(torch.from_numpy(grads[name]), ref) < 1e-4                     # std-0.3 chains of 250 samples: see test_hip_lowdim's yardstick
+    print(f"[half-moons grid: 4 models (fc2, hidden 32..512) x S=250 x N=100] grid_attack {1e3 * (t1 - t0):.1f} ms, serial_compute_grads "
+          f"{1e3 * (t2 - t1):.1f} ms — incl. loading 1000 .pt files from disk, PNG + pickle side effects")
