@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    python tests/golden/make_golden_trained.py [trained|mnist|traj|files]
+    python tests/golden/make_golden_trained.py [trained|mnist|mnist2|traj|files]
 
 Everything here is produced by the reference's own functions, imported unmodified from /root/reference behind the inert
 keras / pyro stubs of make_golden.py (neither package is touched by these code paths):
@@ -212,15 +212,18 @@ def synth_digits(n, seed, noise=0.35, amp=0.17):
     return x, y
 
 
-def run_trained_mnist_shaped(name):
-    hidden, M, N, shape, C = 128, 5, 200, (1, 28, 28), 10
+def run_trained_mnist_shaped(name, arch="fc", hidden=128, M=5, N=200, epochs=2, lr=0.001, seed0=2000, ns_list=(1, 3, 5), pgd_points=48, traj_points=4):
+    """M nets of one architecture trained by the reference's NN.train on the synthetic 10-class task, attacked (FGSM over an eps x n_samples
+    grid, PGD on a prefix) and scored by the reference.  fc 784-128-10 (the triple kernels' smallest hidden size), fc2 784-128-128-10,
+    conv (hidden 16: the reference's conv on 1x28x28)."""
+    shape, C = (1, 28, 28), 10
     x_train, y_train = synth_digits(3000, 1)
     x, y = synth_digits(N, 2)
-    nets = train_members("fc", hidden, M, x_train.numpy(), y_train.numpy(), shape, C, "mnist", n_sub=1500, epochs=2, lr=0.001, seed0=2000)
+    nets = train_members(arch, hidden, M, x_train.numpy(), y_train.numpy(), shape, C, "mnist", n_sub=1500, epochs=epochs, lr=lr, seed0=seed0)
     out = {"x": x.numpy(), "y": y.numpy()}
     out.update(MG.state_arrays(nets))
-    bnn = as_bnn(nets, "mnist", "fc", hidden, shape, C)
-    eps_list, ns_list = [0.01, 0.02, 0.04, 0.06, 0.1], [1, 3, 5]
+    bnn = as_bnn(nets, "mnist", arch, hidden, shape, C)
+    eps_list, ns_list = [0.01, 0.02, 0.04, 0.06, 0.1], list(ns_list)
     import adversarialAttacks as AA
     E, K = len(eps_list), len(ns_list)
     oacc, aacc, rob = np.zeros((E, K)), np.zeros((E, K)), np.zeros((E, K, N), dtype="float32")
@@ -240,20 +243,20 @@ def run_trained_mnist_shaped(name):
             assert torch.equal(torch.clamp(x + eps * s, 0, 1), xa.detach()), "fgsm image is not clamp(x + eps*sign(g))"
             sign[k] = s.numpy().astype("int8")
             oacc[e, k], aacc[e, k], rob[e, k] = oa, aa, r.numpy()
-            print(f"  mnist-shaped fgsm eps={eps} ns={ns}: orig {oa:.2f}  adv {aa:.2f}  rob {float(r.mean()):.4f}", flush=True)
+            print(f"  mnist-shaped {arch} fgsm eps={eps} ns={ns}: orig {oa:.2f}  adv {aa:.2f}  rob {float(r.mean()):.4f}", flush=True)
     out["bnn_fgsm_sign"], out["bnn_fgsm_orig_acc"], out["bnn_fgsm_adv_acc"], out["bnn_fgsm_rob"] = sign, oacc, aacc, rob
-    # PGD on the first 48 points, eps 0.04, all 5 members
-    P, p_eps = 48, 0.04
+    # PGD on the first points, eps 0.04, all members
+    P, p_eps = pgd_points, 0.04
     with quiet():
         xa = AA.attack(net=bnn, x_test=x[:P], y_test=y[:P], dataset_name="mnist", device="cpu", method="pgd", filename=bnn.name,
                        n_samples=M, hyperparams={"epsilon": p_eps})
         oa, aa, r = AA.attack_evaluation(net=bnn, x_test=x[:P], n_samples=M, x_attack=xa, y_test=y[:P], device="cpu")
     out["bnn_pgd_adv"], out["bnn_pgd_orig_acc"], out["bnn_pgd_adv_acc"], out["bnn_pgd_rob"] = xa.detach().numpy(), np.float64(oa), np.float64(aa), r.numpy()
-    print(f"  mnist-shaped pgd eps={p_eps} ns={M} on {P} points: orig {oa:.2f}  adv {aa:.2f}", flush=True)
-    out["traj"], out["traj_grad"] = record_pgd_trajectory(bnn, x[:4], y[:4], p_eps, M)
-    meta = dict(dataset="mnist", shape=list(shape), n_classes=C, hidden=hidden, act="leaky", arch="fc", S=M, N=N, eps_list=eps_list,
-                ns_list=ns_list, pgd_points=P, pgd_eps=p_eps, pgd_ns=M, traj_eps=p_eps, traj_ns=M, traj_points=4,
-                trained="NN.train (model_nn.py:175-219), 2 epochs Adam lr 0.001 on 1500-image subsets of synth_digits(3000, 1), seeds 2000+i / i")
+    print(f"  mnist-shaped {arch} pgd eps={p_eps} ns={M} on {P} points: orig {oa:.2f}  adv {aa:.2f}", flush=True)
+    out["traj"], out["traj_grad"] = record_pgd_trajectory(bnn, x[:traj_points], y[:traj_points], p_eps, M)
+    meta = dict(dataset="mnist", shape=list(shape), n_classes=C, hidden=hidden, act="leaky", arch=arch, S=M, N=N, eps_list=eps_list,
+                ns_list=ns_list, pgd_points=P, pgd_eps=p_eps, pgd_ns=M, traj_eps=p_eps, traj_ns=M, traj_points=traj_points,
+                trained=f"NN.train (model_nn.py:175-219), {epochs} epochs Adam lr {lr} on 1500-image subsets of synth_digits(3000, 1), seeds {seed0}+i / i")
     out["meta"] = np.array(repr(meta))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
@@ -361,6 +364,11 @@ def main():
                               pgd_eps=[0.1], pgd_ns=[10])
     if only in (None, "mnist"):
         run_trained_mnist_shaped("trained_mnistshaped_fc_h128_m5")
+    if only in (None, "mnist2"):
+        run_trained_mnist_shaped("trained_mnistshaped_fc2_h128_m3", arch="fc2", hidden=128, M=3, N=100, seed0=3000, ns_list=(1, 3), pgd_points=24,
+                                 traj_points=2)
+        run_trained_mnist_shaped("trained_mnistshaped_conv_h16_m3", arch="conv", hidden=16, M=3, N=100, epochs=3, seed0=3000, ns_list=(1, 3),
+                                 pgd_points=16, traj_points=2)
     if only in (None, "traj"):
         run_traj_fc512("pgd_traj_mnist_fc_h512_s8_n8")
     if only in (None, "files"):
