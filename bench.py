@@ -330,6 +330,9 @@ def main():
         def conv_input_grad_triple(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad_triple, *a, **kw)
 
+        def conv_input_grad_dense(self, *a, **kw):
+            return self._timed("conv_input_grad", super().conv_input_grad_dense, *a, **kw)
+
         def conv_input_grad_split(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad_split, *a, **kw)
 
@@ -446,7 +449,7 @@ def main():
     KNAMES["lowdim"] = {"lowdim": "lowdim_kernel (forward, loss, input gradient and step of ALL iterations in one launch; fp32 FMA)"}
     KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel",
                         "conv_forward": "conv2_pool_x3_kernel (+ conv1_pool, conv_fc)",
-                        "conv_input_grad": "conv_bwd_x3_kernel (+ conv_fc_bwd, conv1_bwd)"}
+                        "conv_input_grad": "conv_bwd_dense_x3_kernel at 1x28x28 / conv_bwd_x3_kernel at 3x32x32 (+ conv_fc_bwd, conv1_bwd)"}
     # which C-ABI calls run on the f16 pipe in each mode (the rest of that mode's calls are the fp32-MFMA kernels)
     F16_KERNELS = {"split": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"},
                    "triple": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}}

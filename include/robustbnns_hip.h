@@ -273,6 +273,14 @@ int rbnn_conv_input_grad_triple(const rbnn_conv_posterior *net, const void *K2_b
                                 const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
                                 const rbnn_conv_workspace *ws, void *stream);
 
+/* rbnn_conv_input_grad_triple's arithmetic in the DENSE form (1x28x28 only): conv2^T as one GEMM per tap over the 64 conv2 OUTPUT positions
+ * (T[tap][ci][pos] = sum_hc W[hc][ci][tap] * dO2[hc][pos], every MFMA useful) + a col2im gather, instead of the gather form over the
+ * zero-padded gradient image (36-39 % of whose MFMAs multiply padding).  K2_dense = rbnn_triple_rows image (ld 32) of model.3.weight
+ * regrouped [S_total, ceil(Hc/32) K steps, 25 taps, 32 ci][32 hc] (hc zero-padded to a multiple of 32), holding W * 2^k2_exp.  Same G. */
+int rbnn_conv_input_grad_dense(const rbnn_conv_posterior *net, const void *K2_dense, int32_t k2_exp, float fw_l1,
+                               const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
+                               const rbnn_conv_workspace *ws, void *stream);
+
 /* rbnn_conv_input_grad with conv2^T in split-half precision.  K2_bwd = rbnn_split_rows image of model.3.weight regrouped
  * [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8]: element (ci; chunk, t, lg, j) = W[hc = 16*chunk + 8*(lg&1) + j, ci,
  * tap = 2t + (lg>>1)] * 2^k2_exp (0 for the padded 26th tap); fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed

@@ -130,6 +130,7 @@ SIGNATURES = {
     "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                        C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_input_grad_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
+    "rbnn_conv_input_grad_dense": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                         C.POINTER(ConvWorkspace), _fp]),
     "rbnn_input_scales": (_i32, [_fp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _fp, _fp]),
@@ -406,6 +407,12 @@ class HipKernels:
         w = self._conv_ws(ws)
         check(self.lib.rbnn_conv_input_grad_triple(C.byref(net.descriptor()), ptr(K2_bwd), k2_exp, fw_l1, ptr(sidx), S, N, C.byref(w),
                                                    stream_of(ws["dZ"])), "rbnn_conv_input_grad_triple")
+        return S
+
+    def conv_input_grad_dense(self, net, K2_dense, k2_exp, fw_l1, sidx, S, N, ws):
+        w = self._conv_ws(ws)
+        check(self.lib.rbnn_conv_input_grad_dense(C.byref(net.descriptor()), ptr(K2_dense), k2_exp, fw_l1, ptr(sidx), S, N, C.byref(w),
+                                                  stream_of(ws["dZ"])), "rbnn_conv_input_grad_dense")
         return S
 
     def conv_input_grad_split(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):

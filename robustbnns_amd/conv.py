@@ -79,6 +79,7 @@ class ConvStackedPosterior:
         self._split = None
         self._triple = None
         self._guide = None                      # ConvSviGuide: a redrawable SVI stack (for_guide / redraw)
+        self._dense = None                      # triple mode, 1x28x28: model.3.weight image of the dense conv2^T kernel
 
     # ------------------------------------------------------------------ redrawable SVI stack
     @classmethod
@@ -107,6 +108,8 @@ class ConvStackedPosterior:
         self._regroup_k2ci()
         if self._triple is not None:
             self._build_triple(self._triple[0], self._triple[2])
+            if getattr(self, "_dense", None) is not None:
+                self._build_dense(self._dense)
         if self._split is not None:
             self._build_split(self._split[0], self._split[4])
         return self
@@ -125,6 +128,22 @@ class ConvStackedPosterior:
                          torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device),
                          torch.empty(S * 32, (H // 16) * 13 * 32, dtype=torch.float32, device=self.device))
         return self._tmp
+
+    def dense_supported(self):
+        """The dense conv2^T kernel (rbnn_conv_input_grad_dense) is built for the 1x28x28 geometry."""
+        return self.input_shape == (1, 28, 28) and os.environ.get("RBNN_CONV_BWD_DENSE", "1") != "0"
+
+    def _build_dense(self, dense):
+        """model.3.weight regrouped [S, K steps of 32 hc, 25 taps, 32 ci][32 hc] (hc zero-padded) as a triple-rows image."""
+        S, H = self.S, self.H
+        KS = (H + 31) // 32
+        if getattr(self, "_dense_tmp", None) is None:
+            self._dense_tmp = (torch.zeros(S, KS * 32, 32, 25, dtype=torch.float32, device=self.device),
+                               torch.empty(S * KS * 25 * 32, 32, dtype=torch.float32, device=self.device))
+        pad, rows = self._dense_tmp
+        pad[:, :H].copy_(self.K2w.view(S, H, 32, 25))
+        rows.view(S, KS, 25, 32, 32).copy_(pad.view(S, KS, 32, 32, 25).permute(0, 1, 4, 3, 2))         # [s, ks, tap, ci, hc]
+        _hip.HipKernels().triple_rows(rows, 32, scale_exp(self._k2_max()), dense, 32)
 
     def _build_triple(self, rows, bwd):
         S, H = self.S, self.H
@@ -171,6 +190,9 @@ class ConvStackedPosterior:
             bwd = torch.empty(S * 32, (H // 16) * 13 * 32 * 3, dtype=torch.int16, device=self.device)
             k2_exp = self._build_triple(rows, bwd)
             self._triple = (rows, k2_exp, bwd, self._fw_l1())
+            if self.dense_supported():
+                self._dense = torch.empty(S * ((H + 31) // 32) * 25 * 32, 32 * 3, dtype=torch.int16, device=self.device)
+                self._build_dense(self._dense)
         return self._triple
 
     # ------------------------------------------------------------------ split-half precision mode (forward conv2)
@@ -329,6 +351,8 @@ class ConvEngine(AttackEngine):
     def _grad_kernels(self, sidx, S, N, ws):
         if self.precision == "triple" and os.environ.get("RBNN_CONV_BWD_EXACT") != "1":
             _, k2_exp, bwd, fw_l1 = self.post.triple_images()
+            if self.post._dense is not None and self.post.dense_supported():      # 1x28x28: GEMM per tap over the conv2 outputs + col2im
+                return self.k.conv_input_grad_dense(self.post, self.post._dense, k2_exp, fw_l1, sidx, S, N, ws)
             return self.k.conv_input_grad_triple(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)
         if self.precision != "split" or os.environ.get("RBNN_CONV_BWD_EXACT") == "1":
             return self.k.conv_input_grad(self.post, sidx, S, N, ws)

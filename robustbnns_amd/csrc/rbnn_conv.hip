@@ -1691,6 +1691,291 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
     return launch_conv1_backward<RBNN_ACT_RELU, GeoMnist>(a, st);
 }
 
+// =====================================================================================================
+// conv2^T, DENSE form (triple-split arithmetic), 1x28x28: a GEMM per tap over the conv2 OUTPUT positions + col2im, instead of the
+// gather form of conv_bwd_x3_kernel, whose zero-padded gradient image makes 36-39 % of its MFMAs multiply padding:
+//
+//     T[tap][ci][pos2] = sum_hc W[hc][ci][tap] * dO2[hc][pos2]          pos2 over the 8 x 8 conv2 outputs: M = 32 ci, N = 64, K = Hc
+//     dP1[ci][y + ky][x + kx] += T[(ky, kx)][ci][(y, x)]                 col2im, once per (sample, point)
+//
+// Every MFMA is useful (25 taps x 2 ci tiles x 4 position tiles x 6 product terms per 32 channels: 1200, against ~1970 issued by the
+// gather form).  One block = one (sample, point), 8 waves = 2 input-channel tiles x 4 tap groups (7 + 6 + 6 + 6 taps; the 7-tap groups
+// of the two channel tiles sit on different SIMDs): a wave holds T for its taps in <= 28 accumulator tiles over the WHOLE Hc loop.  Per
+// K step of 32 channels the block (a) routes the pooled gradients of those channels through the pool-2 argmax / activation derivative
+// into a dense channel-last image [64 positions][32 hc] of three fp16 piece planes (12 KB; the staging of dQ2 / stash rows by 4-byte
+// LDS-DMA and the image are double-buffered: one barrier per K step), (b) reads its B fragments ONCE (12 ds_read_b128: a fragment
+// feeds 7 taps = 42 MFMAs, against 12 in the gather form, which was LDS-bandwidth bound) and its A fragments — model.3.weight regrouped
+// [K step][tap][ci][32 hc] as a triple-rows image — straight from memory (L2: 2.4 MB per block, as the gather form).
+// Epilogue: the T tiles of one channel tile go to LDS ([25 taps][16 ci][64 pos] floats, aliasing the loop buffers) and every thread gathers
+// its dP1 outputs as a fixed-order sum of <= 25 terms (deterministic, no atomics); twice (two channel tiles).
+// =====================================================================================================
+#ifndef RBNN_CONV_BWD_DENSE
+#define RBNN_CONV_BWD_DENSE 1
+#endif
+template <class G> struct ConvBwdDenseLds {
+    static constexpr int NPOSP = G::NPT2 * 16;                            // positions, padded to whole MFMA tiles
+    static constexpr int PLANE = NPOSP * 64, IMG = 3 * PLANE;             // one piece plane: NPOSP records of 32 hc halves
+    static constexpr int NFL = 32 * G::NP2;                               // pooled cells of one K step
+    static constexpr int STG = (NFL * 5 + 15) / 16 * 16;                  // staging: NFL dQ2 floats + NFL stash bytes
+    static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
+    static constexpr int AOFF = 2 * IMG + 2 * STG;                        // the eight waves' rings follow the image / staging buffers
+    static constexpr int LOOP = AOFF + 8 * RING * SLOT;
+    static constexpr int EPI = 25 * 16 * NPOSP * 4;
+    static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
+    static_assert(BYTES <= 160 * 1024, "LDS");
+};
+
+template <int ACT, class G>
+__global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2d, int k2_exp, float fw_l1) {
+    using L = ConvBwdDenseLds<G>;
+    constexpr int NPT = G::NPT2, P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, NFL = L::NFL;
+    static_assert(NPOS_ == 64 && NPT == 4, "built for the 1x28x28 geometry (64 conv2 output positions = one per lane of the routing)");
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* const lds = (char*)lds_f;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave >> 2, q = wave & 3;
+    // taps of this wave: 7 for q == ct (waves 0 and 5: SIMDs 0 and 1), 6 for the others, in tap order
+    const int ntap = 6 + (q == ct ? 1 : 0);
+    const int tap0 = 6 * q + (q > ct ? 1 : 0);
+
+    int id;
+    if (!item_of_block(blockIdx.x, a.N * a.S, id)) return;
+    const int s = id / a.N, n = id % a.N;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const long long sn = (long long)s * a.N + n;
+    const int F = a.Hc * NP2_, KS = (a.Hc + 31) / 32;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+
+    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1 (as conv_bwd_x3_kernel)
+    float dzmax = fabsf(a.dZ[sn * RBNN_CPAD + li]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
+    const float bound = 4.f * dzmax * fw_l1;
+    int e = 0;
+    if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
+    const float in_scale = ldexpf(1.f, e), out_scale = ldexpf(1.f, -(e + k2_exp));
+
+    // routing role of this thread: position gp = lane (gy, gx) of the 8 x 8 gradient map, channel quad qd = wave of the K step's 32
+    const int gy = lane / O2W_, gx = lane % O2W_, qd = wave;
+    int woff[4];
+    bool wok[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
+        const int py = gy - (w >> 1), px = gx - (w & 1);
+        wok[w] = py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+        woff[w] = wok[w] ? py * P2W_ + px : 0;
+    }
+    const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
+
+    auto dma4 = [&](const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
+    };
+    auto stage_issue = [&](int ks, int buf) {                               // rows of channels 32ks .. of dQ2 and of the stash: contiguous in memory
+        char* const S = lds + 2 * L::IMG + buf * L::STG;
+        const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
+        const long long fb = sn * F + (long long)ks * NFL;
+#pragma unroll
+        for (int i = 0; i < (NFL + 511) / 512; ++i) {
+            const int b = 512 * i + 64 * wave;                              // wave-uniform destination base
+            if (b + lane < nvalid) dma4(a.dQ2 + fb + b + lane, (float*)S + b);
+        }
+        const int d = 64 * wave;                                            // stash: one dword (4 cells) per lane
+        if (4 * (d + lane) < nvalid) dma4(a.st2 + fb + 4 * (d + lane), S + NFL * 4 + 4 * d);
+    };
+    // routing of ONE channel (j of this thread's quad) of K step ks from staging buffer sbuf: pool-2 argmax + activation derivative (gather
+    // form), scaled, split into the three pieces.  Called between the MFMA groups of the previous K step so that its LDS reads and
+    // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
+    union Q { _Float16 h[4]; uint2 u; };
+    auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
+        const float* const sdq = (const float*)(lds + 2 * L::IMG + sbuf * L::STG);
+        const unsigned char* const sst = (const unsigned char*)(lds + 2 * L::IMG + sbuf * L::STG + NFL * 4);
+        const int hl = 4 * qd + j, fb = hl * NP2_;
+        const bool live = 32 * ks + hl < a.Hc;                             // channels past Hc (and the step past the last): zeros
+        int st[4];
+        float dq[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { st[w] = sst[fb + woff[w]]; dq[w] = sdq[fb + woff[w]]; }   // eight independent LDS reads, then straight-line selects
+        // window w routes here iff its stashed argmax is w; act' = 1 or the slope by bit 2 of the stash (folding act' into dQ2 in
+        // conv_fc_bwd_kernel instead was measured: that kernel went from 1.1 to 2.35 ms on its byte loads of the stash)
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float g = (smooth_act<ACT>() || (st[w] & 4)) ? dq[w] : dq[w] * slope;   // smooth: act' already folded into dQ2
+            const unsigned keep = 0u - (unsigned)((int)live & (int)wok[w] & (int)((st[w] & 3) == w));
+            v += __uint_as_float(__float_as_uint(g) & keep);
+        }
+        conv_split3(v * in_scale, p0.h[j], p1.h[j], p2.h[j]);
+    };
+    auto route_store = [&](int ibuf, const Q& p0, const Q& p1, const Q& p2) {
+        char* const I = lds + ibuf * L::IMG;
+        *(uint2*)(I + rec) = p0.u;
+        *(uint2*)(I + L::PLANE + rec) = p1.u;
+        *(uint2*)(I + 2 * L::PLANE + rec) = p2.u;
+    };
+
+    f32x4 acc[7][NPT];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
+    // private ring of RING slots, three 1-KiB pieces per tile (one per plane: lane p lands at row p >> 2, physical chunk p & 3 and
+    // fetches logical chunk (p & 3) ^ swz(row)), issued THREE taps ahead of their use: an L2 round trip (500+ cycles) is far longer than
+    // the 24 MFMAs of a tap, and registers for a deeper prefetch do not exist (112 accumulators + 48 B-fragment registers).  The
+    // wave's running tap index g = ks * ntap + i names the slot g & 3; nothing but this wave touches its ring (no barrier involved).
+    const int prow = lane >> 2;
+    const unsigned a_lane = (unsigned)(prow * 192 + (((lane & 3) ^ swz(prow)) * 16));   // per-lane part of a piece's source address
+    const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
+    char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
+    const int G_ = KS * ntap;                                              // tiles this wave consumes
+    int iks = 0, itap = 0, ig = 0;                                         // (K step, tap, running index) of the next tile to issue
+    auto a_issue = [&]() {
+        if (ig < G_) {
+            const char* const src = Awave + ((long long)iks * 25 + tap0 + itap) * (32 * 192);
+            char* const dst = ring + (ig & (L::RING - 1)) * L::SLOT;
+            glds16((const float*)(src + a_lane), (float*)dst);
+            glds16((const float*)(src + 64 + a_lane), (float*)(dst + 1024));
+            glds16((const float*)(src + 128 + a_lane), (float*)(dst + 2048));
+            ++ig;
+            if (++itap == ntap) { itap = 0; ++iks; }
+        }
+    };
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // fragment of row li (position / input channel), K chunk lg
+
+    stage_issue(0, 0);
+    a_issue(); a_issue(); a_issue();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
+    __syncthreads();
+    {
+        Q p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) route_one(0, 0, j, p0, p1, p2);
+        route_store(0, p0, p1, p2);
+    }
+    if (KS > 1) stage_issue(1, 1);
+    f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
+    int g = 0;                                                             // running tile index of this wave
+    for (int ks = 0; ks < KS; ++ks) {
+        // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
+        // vector-memory operations — the ring tiles issued since — may still be in flight
+        if (ks == 0) __builtin_amdgcn_s_waitcnt(VMCNT(0));                 // (nothing has been issued behind the prologue's staging piece yet)
+        else __builtin_amdgcn_s_waitcnt(VMCNT(9));
+        __syncthreads();                                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
+        if (ks + 2 < KS) stage_issue(ks + 2, ks & 1);
+        const char* const I = lds + (ks & 1) * L::IMG + foff;
+        f16x8 b0[NPT], b1[NPT], b2[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            b0[pt] = *(const f16x8*)(I + pt * 1024);
+            b1[pt] = *(const f16x8*)(I + L::PLANE + pt * 1024);
+            b2[pt] = *(const f16x8*)(I + 2 * L::PLANE + pt * 1024);
+        }
+        Q p0, p1, p2;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            if (t < 6 || ntap == 7) {                                      // taps 0..5 unconditionally; the 7th is wave-uniform
+                a_issue();                                                 // tile g + 3 -> slot (g + 3) & 3 = the slot of tile g - 1: consumed
+                // tile g + 1 has landed once all but the 6 youngest operations (tiles g + 2, g + 3; at a step's first tap the staging
+                // pieces instead of tile g + 2, which is then older and complete as well) are done
+                asm volatile("" ::: "memory");
+                if (g + 3 < G_) __builtin_amdgcn_s_waitcnt(VMCNT(6));
+                else __builtin_amdgcn_s_waitcnt(VMCNT(0));                 // the last three tiles: nothing younger is issued behind them
+                asm volatile("" ::: "memory");
+                const char* const nx = ring + ((g + 1) & (L::RING - 1)) * L::SLOT + foff;
+                // The six product groups, ordered by the piece of A they read — a2 | a1 a1 | a0 a0 a0 — so that each piece of the NEXT tile
+                // is loaded IN PLACE right behind the last MFMA that reads the current one (an MFMA reads its operands when it issues):
+                // no copies, and every reload has >= 12 MFMAs before its first use.  (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and
+                // a0*b1 the 2^-11 ones: apart from a0*b2, still small terms first.)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a2, b0[pt], acc[t][pt]);
+                a2 = *(const f16x8*)(nx + 2048);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a1, b1[pt], acc[t][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a1, b0[pt], acc[t][pt]);
+                a1 = *(const f16x8*)(nx + 1024);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a0, b2[pt], acc[t][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a0, b1[pt], acc[t][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a0, b0[pt], acc[t][pt]);
+                a0 = *(const f16x8*)nx;
+                ++g;
+            }
+            if (t < 4) route_one(ks + 1, (ks + 1) & 1, t, p0, p1, p2);     // the next K step's image, one channel per tap group
+            if (t == 3) route_store((ks + 1) & 1, p0, p1, p2);
+        }
+    }
+    // ---- col2im: two rounds (input-channel tiles), T of a round in LDS as [25 taps][16 ci][64 pos] floats ----
+    float* const T = lds_f;
+    for (int round = 0; round < 2; ++round) {
+        __syncthreads();                                                   // the loop buffers / the previous round's T are free
+        if (ct == round) {
+#pragma unroll
+            for (int t = 0; t < 7; ++t)
+                if (t < ntap) {
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T[(tap0 + t) * 1024 + (4 * lg + r) * 64 + 16 * pt + li] = acc[t][pt][r];
+                }
+        }
+        __syncthreads();
+        // thread = one output position (Y, X) and every third channel: the valid taps of a position are the same for all channels, and
+        // T[(ky*5 + kx)*1024 + cl*64 + (Y - ky)*O2W + (X - kx)] is linear in (ky, kx): two strided loops of 11 terms on average
+        constexpr int NPP = P1W_ * P1W_;
+        if (tid < 3 * NPP) {
+            const int cg = tid / NPP, pp = tid % NPP, Y = pp / P1W_, X = pp % P1W_;
+            const int ky0 = max(0, Y - (O2W_ - 1)), ky1 = min(4, Y), kx0 = max(0, X - (O2W_ - 1)), kx1 = min(4, X);
+            const float* const T0 = T + Y * O2W_ + X + ky0 * (5 * 1024 - O2W_) + kx0 * (1024 - 1);
+            for (int cl = cg; cl < 16; cl += 3) {
+                float sum = 0.f;
+                const float* row = T0 + cl * 64;
+                for (int ky = ky0; ky <= ky1; ++ky, row += 5 * 1024 - O2W_) {
+                    const float* q = row;
+                    for (int kx = kx0; kx <= kx1; ++kx, q += 1024 - 1) sum += *q;
+                }
+                float* const dst = a.dP1 + sn * G::P1SZ + (16 * round + cl) * NPP + pp;
+                const float v = sum * out_scale;                           // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+                *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+            }
+        }
+    }
+}
+
+extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const void* K2_dense, int32_t k2_exp, float fw_l1,
+                                          const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (net->in_channels != 1 || net->in_width != 28) return RBNN_ERR_UNSUPPORTED;
+    if (!K2_dense || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
+    if (!aligned16(K2_dense) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
+    ConvBwdArgs a = {};
+    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = nullptr; a.Fw = net->Fw;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
+    hipStream_t st = (hipStream_t)stream;
+    using G = GeoMnist;
+    a.NP2 = G::NP2;
+    return for_activation(net->activation, [&](auto actc) {
+        constexpr int ACT = decltype(actc)::value;
+        int rc2;
+        {
+            const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+            hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+            if ((rc2 = launch_status())) return rc2;
+        }
+        constexpr int LDSB = ConvBwdDenseLds<G>::BYTES;
+        static unsigned long long attr = 0;
+        if (!ensure_dynamic_lds((const void*)conv_bwd_dense_x3_kernel<ACT, G>, LDSB, attr)) return (int)RBNN_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv_bwd_dense_x3_kernel<ACT, G>), dim3(grid_for_items((long long)N * S)), dim3(512), LDSB, st, a, (const char*)K2_dense, k2_exp, fw_l1);
+        if ((rc2 = launch_status())) return rc2;
+        return launch_conv1_backward<ACT, G>(a, st);
+    });
+}
+
 extern "C" int rbnn_conv_input_grad_triple(const rbnn_conv_posterior* net, const void* K2_bwd, int32_t k2_exp, float fw_l1,
                                            const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);
