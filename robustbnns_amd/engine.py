@@ -352,8 +352,17 @@ class AttackEngine:
 
     pipelined_comm = True                   # ConvEngine (one cached workspace) keeps the plain sequence
 
-    def _comm_blocks(self, N):
-        want = int(os.environ.get("RBNN_COMM_BLOCKS", "2"))
+    def _comm_blocks(self, N, S=None):
+        """Point blocks of the sample-sharded step.  Pipelining hides at most the exchange of all blocks but the last under compute, and
+        costs 2-7 % by itself (half-size launches: measured on one rank with the collectives forced, profiles/r03t, r03u).  The exchange
+        is 8 D_pad bytes per point against 4 S (D H + H C) flops per point of compute: about 2200 / (S H) of the step at xGMI / MI355X
+        rates — 4 % at C2 (S H = 51 200), where one block (the exchange exposed) is cheaper than two; below S H = 16 384 (exchange > 13 %)
+        the step is cut in two.  RBNN_COMM_BLOCKS overrides."""
+        env = os.environ.get("RBNN_COMM_BLOCKS")
+        if env is not None:
+            want = int(env)
+        else:
+            want = 2 if (S is not None and S * getattr(self.post, "Hp", 1 << 30) < 16384) else 1
         return max(1, min(want, N // max(1, int(os.environ.get("RBNN_COMM_MIN_POINTS", "512")))))
 
     def _step_sharded(self, X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project):
@@ -362,7 +371,7 @@ class AttackEngine:
         [n,D_pad] before the step) run on RCCL's stream while block b+1's forward / backward kernels run on ours.
         Every rank does the same blocks in the same order; each block has its own workspace."""
         p, N, C = self.post, X.shape[0], self.post.C
-        nb = self._comm_blocks(N)
+        nb = self._comm_blocks(N, S)
         # block boundaries on multiples of 256 points (the gradient kernels' point tile; the forward's is 128): the blocks together then
         # launch exactly the tiles of the unsplit step — an even split of 10 000 points would add a nearly empty tile to every kernel
         bounds = [0] + [min(N, (N * i // nb + 255) // 256 * 256) for i in range(1, nb)] + [N]
