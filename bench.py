@@ -369,16 +369,32 @@ def main():
             elif eng.precision == "split":
                 post_.split_images()
 
+        # RBNN_SVI_PREFETCH=1 (opt-in, fc / fc2): the draw of step k + 1 is started on a side stream at the beginning of step k and runs under
+        # its GEMM kernels (StackedPosterior.prefetch / flip: a second buffer set).  Measured (profiles/r03a/svi_prefetch_ab.txt): 7.85 vs 7.88 ms
+        # per C2 step — the forward kernel slows down by what the hidden draw took — so the default draws between the steps
+        pipe = (kind == "svi" and getattr(post_, "can_prefetch", lambda: False)() and os.environ.get("RBNN_SVI_PREFETCH", "0") == "1")
+        key = 0x5EED0000 + rank
+
+        timed = [0]
+
         def redraw():
             draws[0] += 1
+            timed[0] += 1 if kern.on else 0
+            if pipe:
+                if getattr(post_, "_prefetched", False):
+                    post_.flip()
+                else:
+                    post_.redraw(key, draws[0])
+                post_.prefetch(key, draws[0] + 1)
+                return
             if kern.on:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                post_.redraw(0x5EED0000 + rank, draws[0])
+                post_.redraw(key, draws[0])
                 e1.record()
                 draw_ev.append((e0, e1))
             else:
-                post_.redraw(0x5EED0000 + rank, draws[0])
+                post_.redraw(key, draws[0])
 
         def step():
             if kind == "svi":
@@ -394,6 +410,15 @@ def main():
 
         for _ in range(args.warmup):
             step()
+        if pipe:                                                          # the draw's own duration: stand-alone launches, outside the timed region
+            torch.cuda.synchronize()
+            for i in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                post_.redraw(key, 1000 + i)
+                e1.record()
+                draw_ev.append((e0, e1))
+            post_._prefetched = False                                     # (those overwrote the front set: start the timed region with a fresh draw)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -423,7 +448,10 @@ def main():
                 k2 = int(sp_svi.K2w[0].numel())
                 wr = w["S"] * (4.0 * n_par + k2 * (4.0 + (12.24 if eng.precision == "triple" else 0.0)))
                 kname = "svi_draw_flat_kernel (1 launch: all six tensors, all samples) + 6 image-builder launches for model.3.weight"
-            svi = {"draws": len(draw_ev), "draws_per_step": len(draw_ev) / max(1, args.steps), "draw_ms": ms, "kernel": kname,
+            svi = {"draws": timed[0], "draws_per_step": timed[0] / max(1, args.steps),
+                   "overlap": ("the draw of step k + 1 runs on a side stream under the GEMM kernels of step k (second buffer set); draw_ms = the same launch timed "
+                               "stand-alone outside the timed region" if pipe else "none: the draw runs between the steps on the same stream"),
+                   "draw_ms": ms, "kernel": kname,
                    "bytes_written_per_draw": wr, "write_gbs": wr / (ms * 1e-3) / 1e9 if ms else None, "hbm_frac": wr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
                    "guide": "loc ~ N(0, std^2), raw scale -3 (softplus 0.0486): SURVEY 8d", "rng": "Philox4x32-10 + Box-Muller in registers, no eps tensor"}
         return getattr(eng, "precision", "exact"), dt, kern.ev, svi

@@ -143,6 +143,7 @@ class StackedPosterior:
         self._triple = None
         self._range_ok = None
         self._guide = None                      # SviGuide: this posterior is a redrawable SVI stack (for_guide / redraw)
+        self._back = None                       # second buffer set of enable_prefetch()
 
     def _abs_max(self, name):
         """max |tensor| that fixes an image's power-of-two scale: taken from the stored weights (one sync, at load), or, for a
@@ -290,6 +291,72 @@ class StackedPosterior:
                 k.split_cols(self.Wm, self.Hp, self.Hp, img.wm_exp, keep[4], self.Hp)
         return self
 
+    # ------------------------------------------------------------------ redraw overlapped with compute (second buffer set + side stream)
+    _SETS = ("W1", "b1", "Wm", "bm", "W2", "b2", "W1p", "Wmp")
+
+    def can_prefetch(self):
+        """The next draw can be prepared while the kernels still read the current one: needs the resident SVI stack of for_guide and
+        not the opt-in split mode (whose images are rebuilt by separate builders from the fp32 stack)."""
+        return self._guide is not None and self._split is None and self.device.type == "cuda"
+
+    def enable_prefetch(self):
+        """A second ("back") set of every buffer rbnn_svi_draw writes — fp32 stack, pack_rows4 images, triple images — plus a side stream
+        and two events.  prefetch(key) draws into the back set on the side stream, ordered after everything enqueued so far on the current
+        stream (the last readers of those buffers); flip() makes the current stream wait for that draw and swaps the sets.  An SVI PGD
+        attack redraws before every iteration (model_bnn.py:230-232): with this the draw of iteration t + 1 — HBM-write-bound — runs
+        under the compute-bound GEMM kernels of iteration t instead of between them."""
+        if getattr(self, "_back", None) is not None:
+            return
+        back = {n: (None if getattr(self, n) is None else torch.empty_like(getattr(self, n))) for n in self._SETS}
+        self._back = {"bufs": back, "triple": None, "desc": None}
+        self._side = torch.cuda.Stream(device=self.device)
+        self._ev_main, self._ev_drawn = torch.cuda.Event(), torch.cuda.Event()
+        self._prefetched = False
+
+    def _back_triple(self):
+        """The back set's triple images, allocated when the front set has them (they may be built after enable_prefetch)."""
+        if self._triple is not None and self._back["triple"] is None:
+            img, keep = self._triple
+            keep2 = [torch.empty_like(t) for t in keep]
+            img2 = _hip.TripleImages()
+            C.memmove(C.byref(img2), C.byref(img), C.sizeof(img))
+            img2.W1_rows, img2.W1_cols, img2.W2_gen = keep2[0].data_ptr(), keep2[1].data_ptr(), keep2[2].data_ptr()
+            if self.arch == "fc2":
+                img2.Wm_rows, img2.Wm_cols = keep2[3].data_ptr(), keep2[4].data_ptr()
+            self._back["triple"] = (img2, keep2)
+
+    def _swap_sets(self):
+        b = self._back
+        for n in self._SETS:
+            cur = getattr(self, n)
+            setattr(self, n, b["bufs"][n])
+            b["bufs"][n] = cur
+        self._triple, b["triple"] = b["triple"], self._triple
+        self._desc, b["desc"] = b["desc"], self._desc
+
+    def prefetch(self, key, draw_id=0, sample_keys=None):
+        """Start the draw of the NEXT weight set into the back buffers on the side stream; returns at once."""
+        self.enable_prefetch()
+        self._back_triple()
+        self._ev_main.record(torch.cuda.current_stream(self.device))
+        self._swap_sets()                       # the draw kernel writes through `self`: aim it at the back set ...
+        try:
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(self._ev_main)
+                self.redraw(key, draw_id, sample_keys=sample_keys)
+                self._ev_drawn.record(self._side)
+        finally:
+            self._swap_sets()                   # ... and leave the front set in place for the kernels about to be launched
+        self._prefetched = True
+
+    def flip(self):
+        """Make the prefetched weight set current: the current stream waits for its draw, then every later launch reads it."""
+        if not getattr(self, "_prefetched", False):
+            raise _hip.HipError("flip() without a prefetch()")
+        torch.cuda.current_stream(self.device).wait_event(self._ev_drawn)
+        self._swap_sets()
+        self._prefetched = False
+
     # ------------------------------------------------------------------ constructors
     @classmethod
     def from_state_dicts(cls, state_dicts, arch, activation, input_shape, n_classes, hidden, device):
@@ -340,6 +407,6 @@ class StackedPosterior:
             setattr(out, name, None if t is None else t[lo:hi].contiguous())
         # the dynamic-range guard is decided ONCE, on the full posterior: every rank (and the single-process run) picks the same mode
         out.S, out._desc, out._split, out._triple, out._range_ok = hi - lo, None, None, None, self.triple_supported() and self._range_ok
-        out._guide = None
+        out._guide, out._back = None, None
         out._pack()
         return out

@@ -273,3 +273,53 @@ def test_conv_svi_redraws_in_place(act, Hc, tmp_path, monkeypatch):
     assert float((adv - xd).abs().max()) <= 0.1 + 1e-6
     q = bnn.forward(x, n_samples=2, seeds=[7, 3]).cpu()
     assert torch.equal(q, bnn.forward(x, n_samples=2, seeds=[7, 3]).cpu())
+
+
+def test_prefetched_draws_equal_sequential_draws(monkeypatch):
+    """StackedPosterior.prefetch / flip (the next draw on a side stream into a second buffer set, under the current iteration's kernels)
+    gives bit for bit what redraw() between the iterations gives for the same keys; an SVI PGD attack through the call surface uses it."""
+    from robustbnns_amd import adversarialAttacks as AA
+    from robustbnns_amd.engine import AttackEngine
+    from robustbnns_amd.model_bnn import set_rng_seed
+    from robustbnns_amd.posterior import StackedPosterior, SviGuide
+    loc, scl = guide_tensors("fc", 784, 512, 10, seed=21)
+    x, y = O.synthetic_inputs(300, (1, 28, 28), 10, seed=3)
+    keys = [11, 22, 33, 44]
+
+    def run(prefetch):
+        post = StackedPosterior.for_guide(SviGuide(loc, scl, "fc", DEV), "leaky", (1, 28, 28), 10, 6)
+        eng = AttackEngine(post)
+        post.triple_images()
+        post.redraw(keys[0], 0)
+        it = iter(keys[1:])
+        if prefetch:
+            post.prefetch(next(it))
+
+            def before():
+                post.flip()
+                k = next(it, None)
+                if k is not None:
+                    post.prefetch(k)
+        else:
+            before = lambda: post.redraw(next(it), 0)
+        adv = eng.pgd(x, y, 6, 0.1, iters=4, before_step=before).cpu()
+        return adv, post.W1.clone(), eng.forward(x, 6).cpu()
+
+    a1, w1, p1 = run(False)
+    a2, w2, p2 = run(True)
+    assert torch.equal(a1, a2) and torch.equal(w1, w2) and torch.equal(p1, p2)
+    # the call surface (opt-in: RBNN_SVI_PREFETCH=1): same generator state -> same attack, prefetched or not
+    monkeypatch.setenv("RBNN_SVI_PREFETCH", "1")
+    bnn, _, _ = make_svi_bnn("fc", 512)
+    xd, lab = x.to(DEV), y.argmax(-1).to(DEV)
+    set_rng_seed(5)
+    adv_a = AA.pgd_attack(bnn, xd, lab, {"epsilon": 0.1, "iters": 4}, n_samples=5)
+    post = bnn._slots[5][0]
+    assert post._back is not None and not post._prefetched
+    set_rng_seed(5)
+    adv_b = AA.pgd_attack(bnn, xd, lab, {"epsilon": 0.1, "iters": 4}, n_samples=5)
+    assert torch.equal(adv_a, adv_b)
+    set_rng_seed(5)
+    monkeypatch.setenv("RBNN_SVI_PREFETCH", "0")                        # the default, sequential path: redraw between the iterations
+    adv_c = AA.pgd_attack(bnn, xd, lab, {"epsilon": 0.1, "iters": 4}, n_samples=5)
+    assert torch.equal(adv_a, adv_c)
