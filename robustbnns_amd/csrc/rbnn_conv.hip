@@ -62,20 +62,25 @@ struct ConvArgs {
 // broadcasts: ~16 FMAs per LDS read).  The first version (one thread per pooled output, patch and weights re-read from memory
 // by every thread: 1.6 FMAs per load) took 7.9 ms per pass at the CIFAR-shaped c5 bench.  Same accumulation order
 // (input channel, ky, kx), so the results are bit-identical to it.
+// Two threads per pooled position (16 channels each): 144 / 196 positions alone left 44 % / 23 % of a 256-thread block's lanes idle in
+// the FMA loop (0.52 -> see profiles/r03a/conv_small_kernels.txt).  Each output is still produced by one thread in the same order.
+template <class G> constexpr int conv1_threads() { return (2 * G::P1W * G::P1W + 63) / 64 * 64; }
 template <int ACT, class G>
-__global__ void __launch_bounds__(256) conv1_pool_kernel(const ConvArgs a) {
-    constexpr int NPP = G::P1W * G::P1W, IW = G::IW;
-    static_assert(NPP <= 256, "one thread per pooled position");
-    __shared__ float wsh[C1 * G::K1];                                     // [c][ci*25 + ky*5 + kx]
+__global__ void __launch_bounds__(conv1_threads<G>()) conv1_pool_kernel(const ConvArgs a) {
+    constexpr int NPP = G::P1W * G::P1W, IW = G::IW, NTH = conv1_threads<G>();
+    // [c][ci][28: ky*5 + kx, 3 pad]: a tap row is 7 aligned float4; channels 16.. sit 4 floats further on, so that the one wave holding
+    // threads of both channel halves reads its two rows from different banks
+    __shared__ __attribute__((aligned(16))) float wsh[C1 * G::CIN * 28 + 4];
     __shared__ float xsh[G::DIN];
     const long long sn = blockIdx.x;
     const int n = (int)(sn % a.N), s = (int)(sn / a.N), tid = threadIdx.x;
     const int sw = a.sidx ? a.sidx[s] : s;
-    for (int e = tid; e < C1 * G::K1; e += 256) wsh[e] = a.K1w[(long long)sw * C1 * G::K1 + e];
-    for (int e = tid; e < G::DIN; e += 256) xsh[e] = a.X[(long long)n * a.ldx + e];
+    for (int e = tid; e < C1 * G::K1; e += NTH) wsh[(e / 25) * 28 + e % 25 + (e >= C1 * G::K1 / 2 ? 4 : 0)] = a.K1w[(long long)sw * C1 * G::K1 + e];
+    for (int e = tid; e < G::DIN; e += NTH) xsh[e] = a.X[(long long)n * a.ldx + e];
     __syncthreads();
-    if (tid >= NPP) return;
-    const int py = tid / G::P1W, px = tid % G::P1W;
+    if (tid >= 2 * NPP) return;
+    const int pos = tid % NPP, c0 = (tid / NPP) * (C1 / 2);
+    const int py = pos / G::P1W, px = pos % G::P1W;
     float patch[G::CIN][6][6];
 #pragma unroll
     for (int ci = 0; ci < G::CIN; ++ci)
@@ -83,24 +88,25 @@ __global__ void __launch_bounds__(256) conv1_pool_kernel(const ConvArgs a) {
         for (int y = 0; y < 6; ++y)
 #pragma unroll
             for (int xx = 0; xx < 6; ++xx) patch[ci][y][xx] = xsh[ci * (IW * IW) + (2 * py + y) * IW + 2 * px + xx];
-    float* const p1 = a.P1 + sn * G::P1SZ + tid;                         // dense [S][N][32][P1W][P1W]
-    uint8_t* const st = a.st1 + sn * G::P1SZ + tid;
+    float* const p1 = a.P1 + sn * G::P1SZ + pos;                         // dense [S][N][32][P1W][P1W]
+    uint8_t* const st = a.st1 + sn * G::P1SZ + pos;
 #pragma unroll 1
-    for (int c = 0; c < C1; ++c) {
-        const float* const w = wsh + c * G::K1;
+    for (int c = c0; c < c0 + C1 / 2; ++c) {
         float v4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ci = 0; ci < G::CIN; ++ci)                               // channel-major accumulation, taps in (ky, kx) order
+        for (int ci = 0; ci < G::CIN; ++ci) {                             // channel-major accumulation, taps in (ky, kx) order
+            float wk[28];
+#pragma unroll
+            for (int v = 0; v < 7; ++v) *(f32x4*)(wk + 4 * v) = *(const f32x4*)(wsh + (c * G::CIN + ci) * 28 + (c0 ? 4 : 0) + 4 * v);
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx) {
-                    const float wk = w[ci * 25 + ky * 5 + kx];
+                for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) v4[dy * 2 + dx] = fmaf(wk, patch[ci][dy + ky][dx + kx], v4[dy * 2 + dx]);
-                }
+                        for (int dx = 0; dx < 2; ++dx) v4[dy * 2 + dx] = fmaf(wk[ky * 5 + kx], patch[ci][dy + ky][dx + kx], v4[dy * 2 + dx]);
+        }
         const float b = a.K1b[(long long)sw * C1 + c];
         float best = 0.f, best_pre = 0.f;
         int arg = 0;
@@ -689,7 +695,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 template <int ACT, class G>
 int launch_conv_forward_x3(const ConvArgs& a, const ConvX3Args& x, hipStream_t st) {
     constexpr int WROWS = (G::CIN == 1 ? 256 : 128);
-    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(conv1_threads<G>()), 0, st, a);
     int rc = launch_status();
     if (rc) return rc;
     constexpr int LDSB = ConvX3Lds<G, WROWS>::BYTES;
@@ -737,7 +743,7 @@ template <class F> int for_activation(int act, F&& f) {
 
 template <int ACT, class G>
 int launch_conv_forward(const ConvArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv1_pool_kernel<ACT, G>), dim3((unsigned)((long long)a.S * a.N)), dim3(conv1_threads<G>()), 0, st, a);
     int rc = launch_status();
     if (rc) return rc;
     constexpr int LDSB = conv2_lds_floats<G>() * 4;
@@ -1515,11 +1521,15 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
 // fp32 MFMA product whose B operand is built in registers from the stash bytes and pooled gradients of pooled row Ya/2 — keeps the
 // last five rows of T in an LDS ring, and emits output row Y = Ya as a 25-term gather  dX[Y][X] = sum_tap T[tap][Y - ky][X - kx].
 // With Cin > 1 the pass is repeated per input channel (the routed B operand is rebuilt from L2-resident data; the ring stays 62.5 KiB).
+template <class G> constexpr int conv1_bwd_ts() { return G::O1 % 8 == 0 ? G::O1 + 2 : G::O1; }
 template <int ACT, class G>
-__global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
-    constexpr int RING = 5, TROW = 25 * 32;                              // floats per ring row: [25 taps][32 Xa]
+__global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <= 160 * 1024 ? 3 : 2)) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
+    // ring row: [25 taps][TS Xa]; TS >= O1 with 4 * TS = 8 or 16 mod 32 (26 for O1 = 24, 28 for O1 = 28) keeps the accumulator stores at the
+    // 2-way minimum of a 64-lane ds_write_b32 (the four tap groups of a store land on different banks) and, at 1x28x28, the ring at 12.7 KiB
+    // per wave: three blocks per CU
     constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW;
-    static_assert(O1 <= 32 && IW <= 64, "a conv1 output row fits two 16-wide MFMA tiles; an input row fits one wave");
+    constexpr int RING = 5, TS = conv1_bwd_ts<G>(), TROW = 25 * TS;
+    static_assert(O1 <= TS && (4 * TS) % 32 != 0 && O1 <= 32 && IW <= 64, "a conv1 output row fits two 16-wide MFMA tiles; an input row fits one wave");
     __shared__ float lds[4 * RING * TROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int NB = (a.N + 3) / 4;
@@ -1531,6 +1541,17 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
     const long long sn = (long long)s * a.N + n;
     float* const T = lds + wave * RING * TROW;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+
+    // this lane's 16 (channel, position) elements of a pooled row: pt = position tile (Xa = 16pt + li), channel c = 16kb + 4lg + r
+    int eoff[2][2][4];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eoff[pt][kb][r] = (16 * kb + 4 * lg + r) * (P1W_ * P1W_) + min((16 * pt + li) >> 1, P1W_ - 1);
+    const uint8_t* const st_sn = a.st1 + sn * G::P1SZ;
+    const float* const d_sn = a.dP1 + sn * G::P1SZ;
 
     for (int ci = 0; ci < G::CIN; ++ci) {
         // A operand: A[i = tap][k = c], K step r of channel block kb is c = 16kb + 4lg + r (one f32x4 per (tap tile, channel block))
@@ -1552,18 +1573,33 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
                 for (int ky = 0; ky < 5; ++ky) {
                     const int Yp = Y - ky;
                     if (Yp < 0 || Yp > O1 - 1) continue;                 // wave-uniform
-                    const float* const row = T + (Yp % RING) * TROW + ky * 5 * 32;
+                    const float* const row = T + (Yp % RING) * TROW + ky * 5 * TS;
 #pragma unroll
                     for (int kx = 0; kx < 5; ++kx) {
                         const int Xp = lane - kx;
-                        if (Xp >= 0 && Xp <= O1 - 1) g += row[kx * 32 + Xp];
+                        if (Xp >= 0 && Xp <= O1 - 1) g += row[kx * TS + Xp];
                     }
                 }
                 Gout[Y * IW + lane] = g;
             }
         };
+        // the stash bytes and pooled gradients of pooled row py + 1 are fetched under the matrix work of row py (the wave has nothing
+        // else in flight: without this every row paid a full memory round trip, 1.24 ms at the conv-512 bench)
+        int stn[2][2][4];
+        float dn[2][2][4];
+        auto fetch = [&](int py) {
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        stn[pt][kb][r] = st_sn[eoff[pt][kb][r] + py * P1W_];
+                        dn[pt][kb][r] = d_sn[eoff[pt][kb][r] + py * P1W_];
+                    }
+        };
+        fetch(0);
         for (int py = 0; py < P1W_; ++py) {
-            // this lane's 16 (channel, position) elements of pooled row py: pt = position tile (Xa = 16pt + li), kb, r as above
             float gv[2][2][4];
             int ar[2][2][4];
 #pragma unroll
@@ -1572,13 +1608,12 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int Xa = 16 * pt + li, c = 16 * kb + 4 * lg + r;
-                        const long long e = sn * G::P1SZ + c * (P1W_ * P1W_) + py * P1W_ + min(Xa >> 1, P1W_ - 1);
-                        const int st = a.st1[e];
-                        const float d = a.dP1[e];
+                        const int Xa = 16 * pt + li, st = stn[pt][kb][r];
+                        const float d = dn[pt][kb][r];
                         gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
                         ar[pt][kb][r] = (st & 3) ^ (Xa & 1);             // == 2*half for the row half that owns the argmax, with the right column parity
                     }
+            if (py + 1 < P1W_) fetch(py + 1);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int Ya = 2 * py + half;
@@ -1607,7 +1642,7 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_mfma_kernel(const ConvBwdArg
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int tap = 16 * mt + 4 * lg + r;        // acc[mt][pt][r] = T[tap][Xa = 16pt + li]
-                            if (tap < 25) row[tap * 32 + 16 * pt + li] = acc[mt][pt][r];
+                            if (tap < 25 && 16 * pt + li < TS) row[tap * TS + 16 * pt + li] = acc[mt][pt][r];
                         }
                 emit_row(Ya);
             }
@@ -1720,7 +1755,7 @@ template <class G> struct ConvBwdDenseLds {
     static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
     static constexpr int AOFF = 2 * IMG + 2 * STG;                        // the eight waves' rings follow the image / staging buffers
     static constexpr int LOOP = AOFF + 8 * RING * SLOT;
-    static constexpr int EPI = 25 * 16 * NPOSP * 4;
+    static constexpr int EPI = 25 * NPOSP * 16 * 4;                       // T of one channel tile: [25 taps][pos][16 ci] floats
     static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
     static_assert(BYTES <= 160 * 1024, "LDS");
 };
@@ -1758,13 +1793,17 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
 
     // routing role of this thread: position gp = lane (gy, gx) of the 8 x 8 gradient map, channel quad qd = wave of the K step's 32
     const int gy = lane / O2W_, gx = lane % O2W_, qd = wave;
-    int woff[4];
-    bool wok[4];
+    // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells), and the stash
+    // code that routes window w here: argmax == w (and, ReLU, the pre-activation positive: bit 2); 15 never matches (window off the map)
+    int adq[4], ast[4], wcode[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
         const int py = gy - (w >> 1), px = gx - (w & 1);
-        wok[w] = py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
-        woff[w] = wok[w] ? py * P2W_ + px : 0;
+        const bool ok = py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+        const int cell = 4 * qd * NP2_ + (ok ? py * P2W_ + px : 0);
+        adq[w] = 4 * cell;
+        ast[w] = NFL * 4 + cell;
+        wcode[w] = ok ? (ACT == RBNN_ACT_RELU ? (w | 4) : w) : 15;
     }
     const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
 
@@ -1788,24 +1827,29 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
     union Q { _Float16 h[4]; uint2 u; };
     auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
-        const float* const sdq = (const float*)(lds + 2 * L::IMG + sbuf * L::STG);
-        const unsigned char* const sst = (const unsigned char*)(lds + 2 * L::IMG + sbuf * L::STG + NFL * 4);
-        const int hl = 4 * qd + j, fb = hl * NP2_;
-        const bool live = 32 * ks + hl < a.Hc;                             // channels past Hc (and the step past the last): zeros
+        const char* const sb = lds + 2 * L::IMG + sbuf * L::STG;
+        const bool live = 32 * ks + 4 * qd + j < a.Hc;                     // wave-uniform; channels past Hc (and the step past the last): zeros
         int st[4];
         float dq[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) { st[w] = sst[fb + woff[w]]; dq[w] = sdq[fb + woff[w]]; }   // eight independent LDS reads, then straight-line selects
+        for (int w = 0; w < 4; ++w) {                                      // eight independent LDS reads, then straight-line selects
+            st[w] = *(const unsigned char*)(sb + ast[w] + j * NP2_);
+            dq[w] = *(const float*)(sb + adq[w] + 4 * j * NP2_);
+        }
         // window w routes here iff its stashed argmax is w; act' = 1 or the slope by bit 2 of the stash (folding act' into dQ2 in
-        // conv_fc_bwd_kernel instead was measured: that kernel went from 1.1 to 2.35 ms on its byte loads of the stash)
+        // conv_fc_bwd_kernel instead was measured: that kernel went from 1.1 to 2.35 ms on its byte loads of the stash).  ReLU: both
+        // tests are one compare of the stash's low three bits (a cell whose pre-activation was <= 0 passes nothing on).
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float g = (smooth_act<ACT>() || (st[w] & 4)) ? dq[w] : dq[w] * slope;   // smooth: act' already folded into dQ2
-            const unsigned keep = 0u - (unsigned)((int)live & (int)wok[w] & (int)((st[w] & 3) == w));
-            v += __uint_as_float(__float_as_uint(g) & keep);
+            if (ACT == RBNN_ACT_RELU) {
+                v += (st[w] & 7) == wcode[w] ? dq[w] : 0.f;
+            } else {
+                const float g = (smooth_act<ACT>() || (st[w] & 4)) ? dq[w] : dq[w] * slope;   // smooth: act' already folded into dQ2
+                v += (st[w] & 3) == wcode[w] ? g : 0.f;
+            }
         }
-        conv_split3(v * in_scale, p0.h[j], p1.h[j], p2.h[j]);
+        conv_split3((live ? v : 0.f) * in_scale, p0.h[j], p1.h[j], p2.h[j]);
     };
     auto route_store = [&](int ibuf, const Q& p0, const Q& p1, const Q& p2) {
         char* const I = lds + ibuf * L::IMG;
@@ -1831,6 +1875,9 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     const int G_ = KS * ntap;                                              // tiles this wave consumes
     int iks = 0, itap = 0, ig = 0;                                         // (K step, tap, running index) of the next tile to issue
     auto a_issue = [&]() {
+#ifdef RBNN_DENSE_ABL_NOA
+        if (ig >= 4) { ++ig; return; }                                     // ablation (timing only): no weight-tile traffic after the prologue
+#endif
         if (ig < G_) {
             const char* const src = Awave + ((long long)iks * 25 + tap0 + itap) * (32 * 192);
             char* const dst = ring + (ig & (L::RING - 1)) * L::SLOT;
@@ -1854,17 +1901,32 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         route_store(0, p0, p1, p2);
     }
     if (KS > 1) stage_issue(1, 1);
+#ifdef RBNN_DENSE_ABL_NOMFMA
+#define DENSE_MFMA(A, B, C) (C)
+#else
+#define DENSE_MFMA(A, B, C) MFMA_H(A, B, C)
+#endif
     f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
     int g = 0;                                                             // running tile index of this wave
+#ifdef RBNN_DENSE_ABL_NOB
+    f16x8 b0[NPT], b1[NPT], b2[NPT];
+#endif
     for (int ks = 0; ks < KS; ++ks) {
         // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
         // vector-memory operations — the ring tiles issued since — may still be in flight
         if (ks == 0) __builtin_amdgcn_s_waitcnt(VMCNT(0));                 // (nothing has been issued behind the prologue's staging piece yet)
         else __builtin_amdgcn_s_waitcnt(VMCNT(9));
+#ifdef RBNN_DENSE_ABL_NOBAR
+        if (ks == 0)
+#endif
         __syncthreads();                                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
         if (ks + 2 < KS) stage_issue(ks + 2, ks & 1);
         const char* const I = lds + (ks & 1) * L::IMG + foff;
+#ifdef RBNN_DENSE_ABL_NOB
+        if (ks == 0)                                                       // ablation (timing only): the B fragments of the first K step serve all
+#else
         f16x8 b0[NPT], b1[NPT], b2[NPT];
+#endif
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             b0[pt] = *(const f16x8*)(I + pt * 1024);
@@ -1879,8 +1941,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 // tile g + 1 has landed once all but the 6 youngest operations (tiles g + 2, g + 3; at a step's first tap the staging
                 // pieces instead of tile g + 2, which is then older and complete as well) are done
                 asm volatile("" ::: "memory");
+#ifndef RBNN_DENSE_ABL_NOA
                 if (g + 3 < G_) __builtin_amdgcn_s_waitcnt(VMCNT(6));
                 else __builtin_amdgcn_s_waitcnt(VMCNT(0));                 // the last three tiles: nothing younger is issued behind them
+#endif
                 asm volatile("" ::: "memory");
                 const char* const nx = ring + ((g + 1) & (L::RING - 1)) * L::SLOT + foff;
                 // The six product groups, ordered by the piece of A they read — a2 | a1 a1 | a0 a0 a0 — so that each piece of the NEXT tile
@@ -1888,28 +1952,54 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 // no copies, and every reload has >= 12 MFMAs before its first use.  (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and
                 // a0*b1 the 2^-11 ones: apart from a0*b2, still small terms first.)
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a2, b0[pt], acc[t][pt]);
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a2, b0[pt], acc[t][pt]);
+#ifndef RBNN_DENSE_ABL_NOAREAD
                 a2 = *(const f16x8*)(nx + 2048);
+#endif
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a1, b1[pt], acc[t][pt]);
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b1[pt], acc[t][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a1, b0[pt], acc[t][pt]);
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b0[pt], acc[t][pt]);
+#ifndef RBNN_DENSE_ABL_NOAREAD
                 a1 = *(const f16x8*)(nx + 1024);
+#endif
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a0, b2[pt], acc[t][pt]);
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b2[pt], acc[t][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a0, b1[pt], acc[t][pt]);
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b1[pt], acc[t][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = MFMA_H(a0, b0[pt], acc[t][pt]);
+                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b0[pt], acc[t][pt]);
+#ifndef RBNN_DENSE_ABL_NOAREAD
                 a0 = *(const f16x8*)nx;
+#endif
                 ++g;
             }
+#ifndef RBNN_DENSE_ABL_NOROUTE
             if (t < 4) route_one(ks + 1, (ks + 1) & 1, t, p0, p1, p2);     // the next K step's image, one channel per tap group
             if (t == 3) route_store((ks + 1) & 1, p0, p1, p2);
+#endif
         }
     }
-    // ---- col2im: two rounds (input-channel tiles), T of a round in LDS as [25 taps][16 ci][64 pos] floats ----
+    // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
+    // registers are four consecutive channels (one ds_write_b128 per tile; the four channel quads of a position are XOR-swizzled by
+    // (pos >> 1) & 3, which spreads eight consecutive positions over all 32 banks), and a gathering thread = one output position (Y, X) x two
+    // channel quads adds up its <= 25 terms in (ky, kx) order with eight independent sums.  (First version: [tap][ci][pos] floats, 112
+    // 4-way-conflicting ds_write_b32 per lane and one serial chain of ~60 dependent LDS reads per thread: 2.0 of the kernel's 11.0 ms,
+    // profiles/r03a/conv_dense_ablations.txt.) ----
     float* const T = lds_f;
+#ifdef RBNN_DENSE_ABL_NOEPI
+    {                                                                      // ablation (timing only): the accumulators stay live, nothing is gathered
+        float sink = 0.f;
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) sink += acc[t][pt][0] + acc[t][pt][1] + acc[t][pt][2] + acc[t][pt][3];
+        if (sink == 1.2345e-30f) a.dP1[sn * G::P1SZ] = sink;
+        return;
+    }
+#endif
+    constexpr int NPP = P1W_ * P1W_;
+    static_assert(2 * NPP <= 512, "one thread per output position and pair of channel quads");
     for (int round = 0; round < 2; ++round) {
         __syncthreads();                                                   // the loop buffers / the previous round's T are free
         if (ct == round) {
@@ -1917,28 +2007,29 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             for (int t = 0; t < 7; ++t)
                 if (t < ntap) {
 #pragma unroll
-                    for (int pt = 0; pt < NPT; ++pt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) T[(tap0 + t) * 1024 + (4 * lg + r) * 64 + 16 * pt + li] = acc[t][pt][r];
+                    for (int pt = 0; pt < NPT; ++pt) {
+                        const int pos = 16 * pt + li;                      // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][pos]
+                        *(f32x4*)(T + ((tap0 + t) * 64 + pos) * 16 + 4 * (lg ^ ((pos >> 1) & 3))) = acc[t][pt];
+                    }
                 }
         }
         __syncthreads();
-        // thread = one output position (Y, X) and every third channel: the valid taps of a position are the same for all channels, and
-        // T[(ky*5 + kx)*1024 + cl*64 + (Y - ky)*O2W + (X - kx)] is linear in (ky, kx): two strided loops of 11 terms on average
-        constexpr int NPP = P1W_ * P1W_;
-        if (tid < 3 * NPP) {
-            const int cg = tid / NPP, pp = tid % NPP, Y = pp / P1W_, X = pp % P1W_;
+        if (tid < 2 * NPP) {
+            const int qp = tid / NPP, pp = tid % NPP, Y = pp / P1W_, X = pp % P1W_;
             const int ky0 = max(0, Y - (O2W_ - 1)), ky1 = min(4, Y), kx0 = max(0, X - (O2W_ - 1)), kx1 = min(4, X);
-            const float* const T0 = T + Y * O2W_ + X + ky0 * (5 * 1024 - O2W_) + kx0 * (1024 - 1);
-            for (int cl = cg; cl < 16; cl += 3) {
-                float sum = 0.f;
-                const float* row = T0 + cl * 64;
-                for (int ky = ky0; ky <= ky1; ++ky, row += 5 * 1024 - O2W_) {
-                    const float* q = row;
-                    for (int kx = kx0; kx <= kx1; ++kx, q += 1024 - 1) sum += *q;
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) {
+                    const int pos = (Y - ky) * O2W_ + (X - kx), sw = (pos >> 1) & 3;
+                    const float* const rowp = T + ((ky * 5 + kx) * 64 + pos) * 16;
+                    s0 += *(const f32x4*)(rowp + 4 * ((2 * qp) ^ sw));
+                    s1 += *(const f32x4*)(rowp + 4 * ((2 * qp + 1) ^ sw));
                 }
-                float* const dst = a.dP1 + sn * G::P1SZ + (16 * round + cl) * NPP + pp;
-                const float v = sum * out_scale;                           // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+            float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * round + 8 * qp) * NPP + pp;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float* const dst = dst0 + r * NPP;
+                const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
                 *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
             }
         }
