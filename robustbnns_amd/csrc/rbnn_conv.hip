@@ -532,7 +532,7 @@ template <class G> __device__ __forceinline__ int x3_img_swz(int idx, int y) {
 template <class G, int WROWS> struct ConvX3Lds {
     static constexpr int PLANEW = WROWS * 64, TILEW = 3 * PLANEW;        // one tap's weight tile: 3 planes of WROWS 64-B rows
     static constexpr int IPOS = G::P1W * ConvX3Img<G>::IPITCH, IMGP = IPOS * 64, IMGB = 3 * IMGP;   // one point's image: 3 planes of IPOS 64-B position records
-    static constexpr int SCR = 8 * 16 * G::NPOS * 4;                     // the eight waves' pooling tiles (epilogue; alias the weight buffers)
+    static constexpr int SCR = 8 * 16 * (G::NPOS + 4) * 4;               // the eight waves' pooling tiles (epilogue; alias the weight buffers)
     static constexpr int WBUF = (2 * TILEW > SCR ? 2 * TILEW : SCR);
     static constexpr int BYTES = WBUF + 2 * IMGB;
 };
@@ -567,7 +567,11 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 
     // both points' fp32 images [32 ci][IPOS] -> three piece planes, channel-last, in LDS: one (position, channel octet) per thread-item
     constexpr int IPITCH = ConvX3Img<G>::IPITCH, NSRC = P1W_ * P1W_;
+#ifdef RBNN_X3FWD_ABL_NOFILL
+    for (int i = tid; i < 2 * NSRC * 4 && a.Hc == 12345; i += 512) {     // ablation (timing only): the images are never filled
+#else
     for (int i = tid; i < 2 * NSRC * 4; i += 512) {
+#endif
         const int pt2 = i / (NSRC * 4), rem = i % (NSRC * 4), pos = rem >> 2, o = rem & 3;
         const float* const src = a.P1 + ((long long)s * a.N + min(nb0 + pt2, a.N - 1)) * G::P1SZ + (8 * o) * NSRC + pos;
         union { f16x8 v; uint4 u; } q0, q1, q2;
@@ -600,6 +604,16 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #pragma unroll
     for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(16 * (wave + NW * i) + prow);
 
+    // epilogue roles: lane handles the four consecutive pooled cells 4 * (lane + 64 it) .. of a 16-channel tile; their offsets in the wave's tile
+    constexpr int CPITCH = NPOS_ + 4, EIT = (16 * NP2_ / 4 + 63) / 64;
+    int pbase_e[EIT][4];
+#pragma unroll
+    for (int it = 0; it < EIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = min(4 * (lane + 64 * it) + j, 16 * NP2_ - 1), hl = idx / NP2_, p = idx % NP2_;
+            pbase_e[it][j] = hl * CPITCH + (p / P2W_) * O2W_ + (p % P2W_);
+        }
     for (int hc0 = 0; hc0 < a.Hc; hc0 += WROWS) {
         f32x4 acc[HTW][NPT];
 #pragma unroll
@@ -652,8 +666,22 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
             ring_wait_barrier<0>();                                      // tap+1's weights landed; everyone is done with this tile
         }
         // epilogue (as conv2_pool_kernel): scale, bias, 2x2 / stride-1 max-pool of the pre-activations through a per-wave LDS tile
-        // (aliases the weight buffers: every wave passed the barrier above), activation, stash
-        float* const my = (float*)ldsb + wave * 16 * NPOS_;
+        // (aliases the weight buffers: every wave passed the barrier above), activation, stash.  The tile's channel pitch CPITCH = NPOS + 4
+        // spreads the four channel groups of a store over the banks, and the cell -> tile offsets of a lane (pbase_e) are computed once per
+        // kernel: the divisions by NP2 / P2W per cell made this epilogue 1.1 of the kernel's 7.9 ms (profiles/r03a/conv_dense_ablations.txt)
+        float* const my = (float*)ldsb + wave * 16 * CPITCH;
+#ifdef RBNN_X3FWD_ABL_NOEPI
+        {                                                                  // ablation (timing only)
+            float sink = 0.f;
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) sink += acc[ht][pt][0] + acc[ht][pt][1] + acc[ht][pt][2] + acc[ht][pt][3];
+            if (sink == 1.2345e-30f) a.Q2[sn * F] = sink;
+            __syncthreads();
+            continue;
+        }
+#endif
 #pragma unroll
         for (int ht = 0; ht < HTW; ++ht) {
             const int hcb = hc0 + (wq * HTW + ht) * 16;                    // wave-uniform
@@ -665,27 +693,31 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
                 for (int r = 0; r < 4; ++r)
                     if (pt * 16 + li < NPOS_) {
                         const float pre = acc[ht][pt][r] * out_scale + bias[r];   // sigmoid / tanh are pooled on their VALUES, as torch does
-                        my[(4 * lg + r) * NPOS_ + pt * 16 + li] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+                        my[(4 * lg + r) * CPITCH + pt * 16 + li] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
                     }
             // four consecutive pooled cells per lane: one 16-byte store of Q2 and one 4-byte store of the stash (the tile's 16 x NP2
             // cells are contiguous in both)
-            for (int i4 = lane; i4 < 16 * NP2_ / 4 && live; i4 += 64) {
-                f32x4 q;
-                unsigned stw = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = 4 * i4 + j, hl = idx / NP2_, p = idx % NP2_, base = hl * NPOS_ + (p / P2W_) * O2W_ + (p % P2W_);
-                    float best = my[base];
-                    int arg = 0;
-                    if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
-                    if (my[base + O2W_] > best) { best = my[base + O2W_]; arg = 2; }
-                    if (my[base + O2W_ + 1] > best) { best = my[base + O2W_ + 1]; arg = 3; }
-                    q[j] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
-                    stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
+            for (int it = 0; it < EIT; ++it) {
+                const int i4 = lane + 64 * it;
+                if (i4 < 16 * NP2_ / 4 && live) {
+                    f32x4 q;
+                    unsigned stw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int base = pbase_e[it][j];
+                        float best = my[base];
+                        int arg = 0;
+                        if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
+                        if (my[base + O2W_] > best) { best = my[base + O2W_]; arg = 2; }
+                        if (my[base + O2W_ + 1] > best) { best = my[base + O2W_ + 1]; arg = 3; }
+                        q[j] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
+                        stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
+                    }
+                    const long long o = sn * F + (long long)hcb * NP2_ + 4 * i4;       // a multiple of 4
+                    *(f32x4*)(a.Q2 + o) = q;
+                    *(unsigned*)(a.st2 + o) = stw;
                 }
-                const long long o = sn * F + (long long)hcb * NP2_ + 4 * i4;           // a multiple of 4
-                *(f32x4*)(a.Q2 + o) = q;
-                *(unsigned*)(a.st2 + o) = stw;
             }
         }
         __syncthreads();                                                 // the pooling tiles alias the weight buffers of the next chunk
@@ -1844,6 +1876,9 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         for (int w = 0; w < 4; ++w) {
             if (ACT == RBNN_ACT_RELU) {
                 v += (st[w] & 7) == wcode[w] ? dq[w] : 0.f;
+            } else if (ACT == RBNN_ACT_LEAKY) {                            // factor 1 / slope / 0 from the same three bits
+                const int m = st[w] & 7;
+                v = fmaf(dq[w], m == (wcode[w] | 4) ? 1.f : (m == wcode[w] ? slope : 0.f), v);
             } else {
                 const float g = (smooth_act<ACT>() || (st[w] & 4)) ? dq[w] : dq[w] * slope;   // smooth: act' already folded into dQ2
                 v += (st[w] & 3) == wcode[w] ? g : 0.f;
@@ -2017,14 +2052,27 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         if (tid < 2 * NPP) {
             const int qp = tid / NPP, pp = tid % NPP, Y = pp / P1W_, X = pp % P1W_;
             const int ky0 = max(0, Y - (O2W_ - 1)), ky1 = min(4, Y), kx0 = max(0, X - (O2W_ - 1)), kx1 = min(4, X);
+            // the five kx terms of a row are read together (ten independent ds_read_b128; terms outside [kx0, kx1] read a clamped position
+            // and add +0): a wave runs as long as its busiest lane, 25 terms for the interior positions, and one read pair per trip made that
+            // 25 dependent LDS round trips
             f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-            for (int ky = ky0; ky <= ky1; ++ky)
-                for (int kx = kx0; kx <= kx1; ++kx) {
-                    const int pos = (Y - ky) * O2W_ + (X - kx), sw = (pos >> 1) & 3;
+            for (int ky = ky0; ky <= ky1; ++ky) {
+                f32x4 u0[5], u1[5];
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int pos = (Y - ky) * O2W_ + min(max(X - kx, 0), O2W_ - 1), sw = (pos >> 1) & 3;
                     const float* const rowp = T + ((ky * 5 + kx) * 64 + pos) * 16;
-                    s0 += *(const f32x4*)(rowp + 4 * ((2 * qp) ^ sw));
-                    s1 += *(const f32x4*)(rowp + 4 * ((2 * qp + 1) ^ sw));
+                    u0[kx] = *(const f32x4*)(rowp + 4 * ((2 * qp) ^ sw));
+                    u1[kx] = *(const f32x4*)(rowp + 4 * ((2 * qp + 1) ^ sw));
                 }
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const float m = (kx >= kx0 && kx <= kx1) ? 1.f : 0.f;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    s0 += m != 0.f ? u0[kx] : z;
+                    s1 += m != 0.f ? u1[kx] : z;
+                }
+            }
             float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * round + 8 * qp) * NPP + pp;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
