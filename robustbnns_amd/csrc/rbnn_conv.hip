@@ -64,7 +64,9 @@ struct ConvArgs {
 // (input channel, ky, kx), so the results are bit-identical to it.
 // Two threads per pooled position (16 channels each): 144 / 196 positions alone left 44 % / 23 % of a 256-thread block's lanes idle in
 // the FMA loop (0.52 -> see profiles/r03a/conv_small_kernels.txt).  Each output is still produced by one thread in the same order.
-template <class G> constexpr int conv1_threads() { return (2 * G::P1W * G::P1W + 63) / 64 * 64; }
+// (3x32x32: 196 positions fill a 256-thread block well enough, and the two-halves form measured slower there: 2.45 -> 2.66 ms at c5)
+template <class G> constexpr int conv1_halves() { return G::CIN == 1 ? 2 : 1; }
+template <class G> constexpr int conv1_threads() { return (conv1_halves<G>() * G::P1W * G::P1W + 63) / 64 * 64; }
 template <int ACT, class G>
 __global__ void __launch_bounds__(conv1_threads<G>()) conv1_pool_kernel(const ConvArgs a) {
     constexpr int NPP = G::P1W * G::P1W, IW = G::IW, NTH = conv1_threads<G>();
@@ -78,8 +80,9 @@ __global__ void __launch_bounds__(conv1_threads<G>()) conv1_pool_kernel(const Co
     for (int e = tid; e < C1 * G::K1; e += NTH) wsh[(e / 25) * 28 + e % 25 + (e >= C1 * G::K1 / 2 ? 4 : 0)] = a.K1w[(long long)sw * C1 * G::K1 + e];
     for (int e = tid; e < G::DIN; e += NTH) xsh[e] = a.X[(long long)n * a.ldx + e];
     __syncthreads();
-    if (tid >= 2 * NPP) return;
-    const int pos = tid % NPP, c0 = (tid / NPP) * (C1 / 2);
+    constexpr int NH = conv1_halves<G>(), CPT = C1 / NH;                  // channels per thread
+    if (tid >= NH * NPP) return;
+    const int pos = tid % NPP, c0 = (tid / NPP) * CPT;
     const int py = pos / G::P1W, px = pos % G::P1W;
     float patch[G::CIN][6][6];
 #pragma unroll
@@ -91,7 +94,7 @@ __global__ void __launch_bounds__(conv1_threads<G>()) conv1_pool_kernel(const Co
     float* const p1 = a.P1 + sn * G::P1SZ + pos;                         // dense [S][N][32][P1W][P1W]
     uint8_t* const st = a.st1 + sn * G::P1SZ + pos;
 #pragma unroll 1
-    for (int c = c0; c < c0 + C1 / 2; ++c) {
+    for (int c = c0; c < c0 + CPT; ++c) {
         float v4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ci = 0; ci < G::CIN; ++ci) {                             // channel-major accumulation, taps in (ky, kx) order
@@ -1369,8 +1372,9 @@ conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp
     // this lane's positions (gy, gx) of the O2W x O2W gradient map: lane, lane + 64, ...; window q = 2dy + dx of the <= 4 stride-1
     // pooling windows containing it routes here iff its stashed argmax == q
     constexpr int NGP = (NPOS_ + 63) / 64;
-    int woff[NGP][4], goff[NGP];
-    bool wok[NGP][4], gok[NGP];
+    // (wcode: the stash code that routes window q here — argmax == q and, ReLU, bit 2 set; 15 for a window off the map: never matches)
+    int woff[NGP][4], goff[NGP], wcode[NGP][4];
+    bool gok[NGP];
 #pragma unroll
     for (int g = 0; g < NGP; ++g) {
         const int gp = lane + 64 * g, gy = gp / O2W_, gx = gp % O2W_;
@@ -1379,8 +1383,9 @@ conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int py = gy - (q >> 1), px = gx - (q & 1);
-            wok[g][q] = gok[g] && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
-            woff[g][q] = wok[g][q] ? py * P2W_ + px : 0;
+            const bool ok = gok[g] && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+            woff[g][q] = ok ? py * P2W_ + px : 0;
+            wcode[g][q] = ok ? (ACT == RBNN_ACT_RELU ? (q | 4) : q) : 15;
         }
     }
     auto dma4 = [&](const void* g, void* l) {
@@ -1417,9 +1422,18 @@ conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp
                 for (int j = 0; j < 4; ++j) {
                     float v = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (wok[g][q] && (st[j][q] & 3) == q)             // smooth activations: act' is already folded into dQ2
-                            v += (smooth_act<ACT>() || (st[j][q] & 4)) ? dq[j][q] : dq[j][q] * slope;
+                    for (int q = 0; q < 4; ++q) {                         // (as conv_bwd_dense_x3_kernel's route_one)
+                        if (L::NWB > 4) {                                  // two waves on a SIMD (256 registers): the stash codes would spill
+                            if (wcode[g][q] != 15 && (st[j][q] & 3) == q) v += (st[j][q] & 4) ? dq[j][q] : dq[j][q] * slope;
+                        } else if (ACT == RBNN_ACT_RELU) {
+                            v += (st[j][q] & 7) == wcode[g][q] ? dq[j][q] : 0.f;
+                        } else if (ACT == RBNN_ACT_LEAKY) {
+                            const int m = st[j][q] & 7;
+                            v = fmaf(dq[j][q], m == (wcode[g][q] | 4) ? 1.f : (m == wcode[g][q] ? slope : 0.f), v);
+                        } else {
+                            v += (st[j][q] & 3) == wcode[g][q] ? dq[j][q] : 0.f;   // smooth activations: act' is already folded into dQ2
+                        }
+                    }
                     _Float16 e0, e1, e2;
                     conv_split3(v * in_scale, e0, e1, e2);
                     q0[h4 >> 3].v[(h4 & 4) + j] = e0; q1[h4 >> 3].v[(h4 & 4) + j] = e1; q2[h4 >> 3].v[(h4 & 4) + j] = e2;
