@@ -43,6 +43,21 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// The three fp16 pieces (rbnn_triple.hip split3: p0 = f16(v), p1 = f16(v - p0), p2 = f16(v - p0 - p1), round-to-nearest-even) of TWO fp32 values,
+// packed [even | odd << 16] per piece: 6 vector instructions per pair (plain C++ compiles to ~12 per value).  `one` must hold 1.0f.
+__device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
+    float re, ro;
+    asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"
+        "v_fma_mix_f32 %[re], %[ve], %[one], -%[d0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[ro], %[vo], %[one], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t"
+        "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro)
+        : [ve] "v"(ve), [vo] "v"(vo), [one] "v"(one));
+}
+
+
 // row stride (in words) of the 1-bit activation stash [S][H/32][N_pad]: padded to the gradient kernel's 256-point block so that
 // a block's words of one row are one aligned 1-KiB LDS-DMA piece
 __host__ __device__ __forceinline__ long long mask_ld(int N) { return ((long long)N + 255) / 256 * 256; }

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(conv1_threads<G>()) conv1_pool_kernel(const Co
         for (int ci = 0; ci < G::CIN; ++ci) {                             // channel-major accumulation, taps in (ky, kx) order
             float wk[28];
 #pragma unroll
-            for (int v = 0; v < 7; ++v) *(f32x4*)(wk + 4 * v) = *(const f32x4*)(wsh + (c * G::CIN + ci) * 28 + (c0 ? 4 : 0) + 4 * v);
+            for (int v = 0; v < 7; ++v) *(f32x4*)(wk + 4 * v) = *(const f32x4*)(wsh + (c * G::CIN + ci) * 28 + (c >= C1 / 2 ? 4 : 0) + 4 * v);
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
@@ -577,13 +577,10 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #endif
         const int pt2 = i / (NSRC * 4), rem = i % (NSRC * 4), pos = rem >> 2, o = rem & 3;
         const float* const src = a.P1 + ((long long)s * a.N + min(nb0 + pt2, a.N - 1)) * G::P1SZ + (8 * o) * NSRC + pos;
-        union { f16x8 v; uint4 u; } q0, q1, q2;
+        union { f16x8 v; uint4 u; unsigned w[4]; } q0, q1, q2;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 e0, e1, e2;
-            conv_split3(src[j * NSRC] * p1_scale, e0, e1, e2);
-            q0.v[j] = e0; q1.v[j] = e1; q2.v[j] = e2;
-        }
+        for (int j = 0; j < 8; j += 2)
+            split3_plain_pair(src[j * NSRC] * p1_scale, src[(j + 1) * NSRC] * p1_scale, 1.f, q0.w[j >> 1], q1.w[j >> 1], q2.w[j >> 1]);
         const int iy = pos / P1W_, idx = iy * IPITCH + pos % P1W_;
         char* const dst = imgs + pt2 * L::IMGB + idx * 64 + ((o ^ x3_img_swz<G>(idx, iy)) * 16);
         *(uint4*)dst = q0.u;
@@ -1407,11 +1404,11 @@ conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp
         // 1. interior of the image for channels 16ch .. 16ch+15: pool-2 routing + activation derivative (gather form), scaled, split
 #pragma unroll
         for (int g = 0; g < NGP; ++g) {
-            union { f16x8 v; uint4 u; } q0[2], q1[2], q2[2];
+            union { f16x8 v; uint4 u; unsigned w[4]; } q0[2], q1[2], q2[2];
 #pragma unroll
             for (int h4 = 0; h4 < HCH; h4 += 4) {
                 int st[4][4];
-                float dq[4][4];
+                float dq[4][4], vr[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int fb = (h4 + j) * NP2_;
@@ -1434,9 +1431,12 @@ conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp
                             v += (st[j][q] & 3) == wcode[g][q] ? dq[j][q] : 0.f;   // smooth activations: act' is already folded into dQ2
                         }
                     }
-                    _Float16 e0, e1, e2;
-                    conv_split3(v * in_scale, e0, e1, e2);
-                    q0[h4 >> 3].v[(h4 & 4) + j] = e0; q1[h4 >> 3].v[(h4 & 4) + j] = e1; q2[h4 >> 3].v[(h4 & 4) + j] = e2;
+                    vr[j] = v * in_scale;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int w = ((h4 & 4) + j) >> 1;
+                    split3_plain_pair(vr[j], vr[j + 1], 1.f, q0[h4 >> 3].w[w], q1[h4 >> 3].w[w], q2[h4 >> 3].w[w]);
                 }
             }
             if (gok[g]) {
@@ -1871,7 +1871,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // routing of ONE channel (j of this thread's quad) of K step ks from staging buffer sbuf: pool-2 argmax + activation derivative (gather
     // form), scaled, split into the three pieces.  Called between the MFMA groups of the previous K step so that its LDS reads and
     // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
-    union Q { _Float16 h[4]; uint2 u; };
+    union Q { unsigned w[2]; uint2 u; };                                    // pieces of the thread's four channels: [j0 | j1 << 16], [j2 | j3 << 16]
+    float vpend = 0.f;                                                     // the even channel of a pair waits for the odd one (split3_plain_pair)
     auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
         const char* const sb = lds + 2 * L::IMG + sbuf * L::STG;
         const bool live = 32 * ks + 4 * qd + j < a.Hc;                     // wave-uniform; channels past Hc (and the step past the last): zeros
@@ -1898,7 +1899,9 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 v += (st[w] & 3) == wcode[w] ? g : 0.f;
             }
         }
-        conv_split3((live ? v : 0.f) * in_scale, p0.h[j], p1.h[j], p2.h[j]);
+        const float vs = (live ? v : 0.f) * in_scale;
+        if (!(j & 1)) vpend = vs;
+        else split3_plain_pair(vpend, vs, 1.f, p0.w[j >> 1], p1.w[j >> 1], p2.w[j >> 1]);
     };
     auto route_store = [&](int ibuf, const Q& p0, const Q& p1, const Q& p2) {
         char* const I = lds + ibuf * L::IMG;

@@ -95,18 +95,7 @@ __device__ __forceinline__ void split3_pair_m(float ge, float go, float me, floa
     else asm volatile(RBNN_X3_PAIRM_BODY RBNN_X3_PAIRM_OPS);
 }
 
-// The same for two plain fp32 values (fc2 step 2: the A operand comes from memory): 6 vector instructions per pair.
-__device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
-    float re, ro;
-    asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"
-        "v_fma_mix_f32 %[re], %[ve], %[one], -%[d0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %[ro], %[vo], %[one], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t"
-        "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro)
-        : [ve] "v"(ve), [vo] "v"(vo), [one] "v"(one));
-}
+// (split3_plain_pair — two plain fp32 values, 6 vector instructions per pair — lives in rbnn_common.hpp: the conv kernels use it too)
 
 // ===================================================================================================
 // fp32 rows -> triple-rows image.  One thread per (row, group of 8 columns): three 16-B stores.
@@ -139,6 +128,9 @@ __global__ void triple_rows_kernel(const float* __restrict__ src, long long rows
 // in 1-KiB pieces of 16 rows; physical 16-B chunk of logical chunk c in row r is c ^ swz(r), applied on the SOURCE address.
 // Epilogue = the exact kernel's (bias, activation, 1-bit stash, skinny H->C layer on the fp32 MFMA, softmax).
 // ===================================================================================================
+#ifndef RBNN_X3_L1_PAIR
+#define RBNN_X3_L1_PAIR 1                                       // fc2 layer 1's hidden image: pieces by split3_plain_pair (6 instructions per pair) / plain C++
+#endif
 struct FwdX3Args {
     const char* X;  int ldx;  int N;                           // triple-rows image of the inputs [N][ldx] (ldx elements, % 32 == 0)
     const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // triple-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
@@ -361,8 +353,13 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                     // consecutive lanes on consecutive 16-byte chunks (the direct store wrote 16-byte fragments at a 3-KB stride: layer 1
                     // took 5.8 ms against 3.5 for the same GEMM without the image)
                     union { _Float16 h[4]; unsigned w[2]; } q0, q1, q2;
+#if RBNN_X3_L1_PAIR
+                    split3_plain_pair(hv[0] * hid_scale, hv[1] * hid_scale, 1.f, q0.w[0], q1.w[0], q2.w[0]);
+                    split3_plain_pair(hv[2] * hid_scale, hv[3] * hid_scale, 1.f, q0.w[1], q1.w[1], q2.w[1]);
+#else
 #pragma unroll
                     for (int r = 0; r < 4; ++r) split3(hv[r] * hid_scale, q0.h[r], q1.h[r], q2.h[r]);
+#endif
                     if (!(ht & 1)) {
                         keep[nt][0] = q0.w[0]; keep[nt][1] = q0.w[1]; keep[nt][2] = q1.w[0]; keep[nt][3] = q1.w[1]; keep[nt][4] = q2.w[0]; keep[nt][5] = q2.w[1];
                     } else {
