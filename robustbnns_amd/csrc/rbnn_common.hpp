@@ -111,6 +111,16 @@ template <int ACT> __device__ __forceinline__ float act_grad_from_value(float h)
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int launch_status() { return hipGetLastError() == hipSuccess ? RBNN_OK : RBNN_ERR_LAUNCH; }
 inline int grid_for_items(long long M) { return (int)(8 * ((M + 7) / 8)); }
+inline int device_cus() {                                      // compute units of the current device (cached per ordinal)
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus[dev];
+}
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: raise it once per (instantiation,
 // device) — `done` is that instantiation's bitmask over device ordinals (a race only repeats an idempotent call).
 inline bool ensure_dynamic_lds(const void* kern, int bytes, unsigned long long& done) {

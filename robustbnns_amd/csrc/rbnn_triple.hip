@@ -609,6 +609,9 @@ __global__ void __launch_bounds__(256) triple_dz_kernel(const float* __restrict_
 // wave's own 64 points (4 KiB per sample) lives in a SINGLE buffer: the wave itself re-fills it for the next sample during
 // the last stage of the current one, after its generator reads (two blocks per CU need <= 80 KB each).
 // ===================================================================================================
+#ifndef RBNN_X3_GRAD_BCOPY
+#define RBNN_X3_GRAD_BCOPY 0
+#endif
 #define GEN_Q3 (-17)                                           // |generator| <= 16 * 2^14 * 2^14 = 2^32  ->  |dA| <= 2^15 < fp16 max
 
 struct GradX3Args {
@@ -805,29 +808,35 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
             dz_issue(s_begin + st / HS + 1);                   // lands under the main MFMAs; the stage barrier's vmcnt(0) covers it
         }
         // ---- main: column-tile major ----
+        // the B fragments of column tile dt + 1 are read into the OTHER of two register sets while tile dt's MFMAs run: the set index is a
+        // compile-time constant of the unrolled loop (a "next" set copied into the current one cost 36 v_mov_b64 per wave-stage, and vector
+        // instructions do not overlap the matrix pipe's time here: profiles/r03a/conv_dense_ablations.txt)
         const char* const Bw = B + (lg * 3 * LD + li) * 16;
-        f16x8 b0 = *(const f16x8*)(Bw), b1 = *(const f16x8*)(Bw + LD * 16), b2 = *(const f16x8*)(Bw + 2 * LD * 16), b0n = b0, b1n = b1, b2n = b2;
+        f16x8 bb[2][3];
+        bb[0][0] = *(const f16x8*)(Bw); bb[0][1] = *(const f16x8*)(Bw + LD * 16); bb[0][2] = *(const f16x8*)(Bw + 2 * LD * 16);
 #pragma unroll
         for (int dt = 0; dt < TD; ++dt) {
             if (dt < ntd) {                                     // block-uniform; the loop stays fully unrolled (acc in registers)
+                f16x8 (&bc)[3] = bb[RBNN_X3_GRAD_BCOPY ? 0 : (dt & 1)];
                 if (dt + 1 < TD) {
-                    b0n = *(const f16x8*)(Bw + (dt + 1) * 256);
-                    b1n = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
-                    b2n = *(const f16x8*)(Bw + 2 * LD * 16 + (dt + 1) * 256);
+                    f16x8 (&bn)[3] = bb[RBNN_X3_GRAD_BCOPY ? 1 : ((dt + 1) & 1)];
+                    bn[0] = *(const f16x8*)(Bw + (dt + 1) * 256);
+                    bn[1] = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
+                    bn[2] = *(const f16x8*)(Bw + 2 * LD * 16 + (dt + 1) * 256);
                 }
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], b2, acc[nt][dt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], bc[2], acc[nt][dt]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da2[nt], b0, acc[nt][dt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da2[nt], bc[0], acc[nt][dt]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da1[nt], b1, acc[nt][dt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da1[nt], bc[1], acc[nt][dt]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da1[nt], b0, acc[nt][dt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da1[nt], bc[0], acc[nt][dt]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], b1, acc[nt][dt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], bc[1], acc[nt][dt]);
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], b0, acc[nt][dt]);
-                b0 = b0n; b1 = b1n; b2 = b2n;
+                for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], bc[0], acc[nt][dt]);
+                if (RBNN_X3_GRAD_BCOPY) { bb[0][0] = bb[1][0]; bb[0][1] = bb[1][1]; bb[0][2] = bb[1][2]; }   // (the round-2 form, kept for A/B runs)
             }
         }
         if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();           // next stage landed; everyone is done with this one
@@ -891,6 +900,14 @@ int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
 #ifndef RBNN_X3_GRAD_WIDE
 #define RBNN_X3_GRAD_WIDE 0
 #endif
+#ifndef RBNN_X3_GRAD_TD9
+#define RBNN_X3_GRAD_TD9 1
+#endif
+
+inline bool x3_grad_td9() {
+    static const bool on = [] { const char* e = getenv("RBNN_X3_GRAD_TD9"); return !e || e[0] != '0'; }();
+    return on;
+}
 
 // 7 or 4 column tiles per block: every group pays the dA generator (or the A-operand reads) again, so fewer groups win — 7 wherever
 // that saves a group (a partial last group skips its missing tiles' MFMAs)
@@ -900,6 +917,14 @@ int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
         static const bool wide = [] { const char* e = getenv("RBNN_X3_GRAD_WIDE"); return !e || e[0] != '0'; }();
         if (wide && (a.Dt + 13) / 14 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 14, MODE, 8>(a, st);
     }
+#if RBNN_X3_GRAD_TD9
+    // 9 column tiles per block (two blocks' LDS = exactly 160 KB): 6 column groups instead of 7 at D = 784, i.e. one generator + split
+    // pass in seven less: 3.71 / 3.68 -> 3.59 / 3.59 ms at C2 (alternating builds, same box).  Environment RBNN_X3_GRAD_TD9=0 switches
+    // back.  (Re-planning the slab size for the 6-group grid — 6 samples per slab instead of 5 — measured slower, 3.75 ms: kept as planned.)
+    if constexpr (MODE == X3_FC && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {   // (fc2 step 2 spills at 9 tiles)
+        if (x3_grad_td9() && (a.Dt + 8) / 9 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 9, MODE>(a, st);
+    }
+#endif
     if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7, MODE>(a, st);
     return launch_grad_x3_cfg<ACT, 4, MODE>(a, st);
 }
