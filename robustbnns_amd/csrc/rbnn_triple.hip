@@ -903,6 +903,9 @@ int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
 #ifndef RBNN_X3_GRAD_TD9
 #define RBNN_X3_GRAD_TD9 1
 #endif
+#ifndef RBNN_X3_GRAD_TD8
+#define RBNN_X3_GRAD_TD8 1
+#endif
 
 inline bool x3_grad_td9() {
     static const bool on = [] { const char* e = getenv("RBNN_X3_GRAD_TD9"); return !e || e[0] != '0'; }();
@@ -923,6 +926,12 @@ int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
     // back.  (Re-planning the slab size for the 6-group grid — 6 samples per slab instead of 5 — measured slower, 3.75 ms: kept as planned.)
     if constexpr (MODE == X3_FC && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {   // (fc2 step 2 spills at 9 tiles)
         if (x3_grad_td9() && (a.Dt + 8) / 9 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 9, MODE>(a, st);
+    }
+#endif
+#if RBNN_X3_GRAD_TD8
+    // 8 column tiles per block where that saves a group over 7 (hidden = 512: fc2 step 1 runs 4 groups instead of 5)
+    if constexpr (MODE != X3_FC2_STEP2 && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {   // (the streamed-operand forms spill at 8 tiles)
+        if (x3_grad_td9() && (a.Dt + 7) / 8 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 8, MODE>(a, st);
     }
 #endif
     if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7, MODE>(a, st);
