@@ -1966,12 +1966,15 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     for (int ks = 0; ks < KS; ++ks) {
         // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
         // vector-memory operations — the ring tiles issued since — may still be in flight
-        if (ks == 0) __builtin_amdgcn_s_waitcnt(VMCNT(0));                 // (nothing has been issued behind the prologue's staging piece yet)
-        else __builtin_amdgcn_s_waitcnt(VMCNT(9));
+        // (a raw s_barrier behind the counted wait: __syncthreads() makes hipcc drain vmcnt to 0 first — the three weight tiles in flight
+        // for the coming taps included)
 #ifdef RBNN_DENSE_ABL_NOBAR
         if (ks == 0)
 #endif
-        __syncthreads();                                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
+        {
+            if (ks == 0) ring_wait_barrier<0>();                           // (nothing has been issued behind the prologue's staging piece yet)
+            else ring_wait_barrier<9>();                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
+        }
         if (ks + 2 < KS) stage_issue(ks + 2, ks & 1);
         const char* const I = lds + (ks & 1) * L::IMG + foff;
 #ifdef RBNN_DENSE_ABL_NOB
