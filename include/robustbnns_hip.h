@@ -391,7 +391,7 @@ typedef struct rbnn_triple_workspace {
     void  *X_triple;               /* [N, ld_rows] triple-rows image of the current inputs (caller fills it with rbnn_triple_rows)  */
     void  *dZ_gen;                 /* [S, N_pad, 64 B] dA-generator image of dZ, written by rbnn_fc_input_grad_triple               */
     float *g_scale;                /* [N_pad] per-point 2^-e(n) of that image                                                       */
-    void  *hid_triple;             /* fc2: [S, N, H] triple-rows image of the hidden activations (6 bytes per element)              */
+    void  *hid_triple;             /* fc2: triple image of the hidden activations, stage-major [S, H/32, N, 3 pieces, 32 units] (6 B/elt) */
 } rbnn_triple_workspace;
 typedef struct rbnn_triple_workspace_sizes { size_t X_triple, dZ_gen, g_scale, hid_triple; } rbnn_triple_workspace_sizes;
 

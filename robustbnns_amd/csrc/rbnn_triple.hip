@@ -138,9 +138,12 @@ struct FwdX3Args {
     const int* sidx;  int S;  int NT;  float out_scale;        // out_scale = 2^-(e_x + e_w)
     float* P;  uint32_t* mask;  float* dact;  int out_kind;
     const rbnn_dev_scale* x_ds;                                // != NULL: out_scale *= x_ds->inv_scale
-    // fc2: layer 1 (!LAYER2) writes the hidden activations as a per-sample triple-rows image [S][N][H] (value * hid_scale = p0 + p1 + p2);
-    // layer 2 reads it as its X operand (x_sample_bytes = N * H * 6)
+    // fc2: layer 1 (!LAYER2) writes the hidden activations as a per-sample STAGE-major triple image [S][H/32][N][3 pieces][32 units]
+    // (value * hid_scale = p0 + p1 + p2); layer 2 reads it as its X operand (x_sample_bytes = N * H * 6)
     long long x_sample_bytes;  char* hid;  float hid_scale;  const rbnn_dev_scale* hid_ds;
+    // X image geometry: bytes between consecutive points of one stage / between consecutive stages of one point.  Point-major images
+    // (rbnn_triple_rows: [N][K/32 stages][192 B]): ldx * 6 and 192.  The hidden image of fc2 is STAGE-major ([S][H/32][N][192 B]): 192 and N * 192
+    unsigned x_row_bytes, x_stage_bytes;
 };
 
 template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     // the h chunk: the chunk's base goes into the uniform part of the address.
     unsigned xrow[XPP], wrow[WPP];
 #pragma unroll
-    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min(n0 + 16 * (wave + NW * i) + prow, a.N - 1) * (unsigned)a.ldx * 6u + src_off;
+    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min(n0 + 16 * (wave + NW * i) + prow, a.N - 1) * a.x_row_bytes + src_off;
 #pragma unroll
     for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(16 * (wave + NW * i) + prow) * (unsigned)a.ldw * 6u + src_off;
 
@@ -209,9 +212,9 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     auto piece = [&](int c, int kt, int buf, int i) {           // chunk c, columns 32 * kt -> buffer buf; i: compile-time constant, plane i / (WPP + XPP)
         char* const T = ldsb + buf * TILEB;
         const int p = i / (WPP + XPP), j = i % (WPP + XPP);
-        const unsigned koff = (unsigned)kt * 192u + 64u * p;
+        const unsigned koff = (unsigned)kt * 192u + 64u * p, xoff = (unsigned)kt * a.x_stage_bytes + 64u * p;
         if (j < WPP) glds16((const float*)(Ws + (long long)c * BH * a.ldw * 6 + (wrow[j < WPP ? j : 0] + koff)), (float*)(T + p * PLANEB + (wave + NW * j) * 1024));
-        else glds16((const float*)(Xs + (xrow[j >= WPP ? j - WPP : 0] + koff)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * (j - WPP)) * 1024));
+        else glds16((const float*)(Xs + (xrow[j >= WPP ? j - WPP : 0] + xoff)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * (j - WPP)) * 1024));
     };
 #pragma unroll
     for (int i = 0; i < PPS; ++i) piece(0, 0, 0, i);
@@ -311,7 +314,6 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         }
         const int hw0 = hc0 + (wave_h * HTW) * 16;
         unsigned mine[NTW];
-        unsigned keep[LAYER2 ? 1 : NTW][6];                    // fc2 layer 1: the even tile's pieces, until the odd tile completes the stage
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) mine[nt] = 0u;
 #pragma unroll
@@ -347,11 +349,6 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
                 } else {
-                    // the three pieces of the lane's four units = 8 bytes per plane.  A 16-unit tile is HALF of a 32-unit stage of the
-                    // image row (192 B = [piece][32 units]): the even tile's pieces wait in registers for the odd tile, then both go through a
-                    // per-wave 3-KiB LDS tile (16 points x 192 B, in the stage buffer every wave has left) and out as WHOLE 192-byte runs,
-                    // consecutive lanes on consecutive 16-byte chunks (the direct store wrote 16-byte fragments at a 3-KB stride: layer 1
-                    // took 5.8 ms against 3.5 for the same GEMM without the image)
                     union { _Float16 h[4]; unsigned w[2]; } q0, q1, q2;
 #if RBNN_X3_L1_PAIR
                     split3_plain_pair(hv[0] * hid_scale, hv[1] * hid_scale, 1.f, q0.w[0], q1.w[0], q2.w[0]);
@@ -360,25 +357,15 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) split3(hv[r] * hid_scale, q0.h[r], q1.h[r], q2.h[r]);
 #endif
-                    if (!(ht & 1)) {
-                        keep[nt][0] = q0.w[0]; keep[nt][1] = q0.w[1]; keep[nt][2] = q1.w[0]; keep[nt][3] = q1.w[1]; keep[nt][4] = q2.w[0]; keep[nt][5] = q2.w[1];
-                    } else {
-                        char* const scr = ldsb + buf * TILEB + wave * 3072;
-                        char* const mine_row = scr + li * 192 + (lg >> 1) * 16 + (lg & 1) * 8;      // tile 0: chunks 0, 1 of each piece; tile 1: chunks 2, 3
-                        asm volatile("" ::: "memory");
-                        *(uint2*)(mine_row) = make_uint2(keep[nt][0], keep[nt][1]);        *(uint2*)(mine_row + 32) = make_uint2(q0.w[0], q0.w[1]);
-                        *(uint2*)(mine_row + 64) = make_uint2(keep[nt][2], keep[nt][3]);   *(uint2*)(mine_row + 96) = make_uint2(q1.w[0], q1.w[1]);
-                        *(uint2*)(mine_row + 128) = make_uint2(keep[nt][4], keep[nt][5]);  *(uint2*)(mine_row + 160) = make_uint2(q2.w[0], q2.w[1]);
-                        asm volatile("" ::: "memory");
-                        const int nrow0 = n0 + (wave_n * NTW + nt) * 16;
-                        char* const img = a.hid + ((long long)s * a.N) * a.H * 6 + ((hrow - 16) >> 5) * 192;   // stage of this tile pair
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const int q = lane + 64 * k, rr = q / 12, cc = q - 12 * rr;        // 16-byte chunk q of the 3-KiB tile: row rr, chunk cc
-                            const uint4 v = *(const uint4*)(scr + q * 16);
-                            if (nrow0 + rr < a.N) *(uint4*)(img + (long long)(nrow0 + rr) * a.H * 6 + cc * 16) = v;
-                        }
-                        asm volatile("" ::: "memory");
+                    // stage-major image [S][H/32][N][piece][32 units]: this lane's four units of tile ht are 8 bytes per piece, at byte
+                    // (ht & 1) * 32 + lg * 8 of the point's 64-byte piece row; the 16 points of a tile are 3 KiB contiguous, so the six
+                    // 8-byte stores of a lane (two tiles x three pieces) fill whole lines between them — no LDS staging, no barrier
+                    // (the point-major image needed a per-wave LDS transposition to write 192-byte runs: layer 1 4.7 ms)
+                    if (n < a.N) {
+                        char* const row = a.hid + (((long long)s * HW + (hrow >> 5)) * a.N + n) * 192 + ((hrow >> 4) & 1) * 32 + lg * 8;
+                        *(uint2*)(row) = make_uint2(q0.w[0], q0.w[1]);
+                        *(uint2*)(row + 64) = make_uint2(q1.w[0], q1.w[1]);
+                        *(uint2*)(row + 128) = make_uint2(q2.w[0], q2.w[1]);
                     }
                 }
             }
@@ -390,7 +377,6 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                 if (lg < HTW / 2 && n < a.N) a.mask[((long long)s * HW + (hw0 >> 5) + lg) * mask_ld(a.N) + n] = mine[nt];
             }
         }
-        if (!LAYER2) __syncthreads();                          // the image staging tiles live in the stage buffer that the next stage's DMA refills
     }
     if (RBNN_ABL & 2) ring_wait_barrier<0>();
 
@@ -1019,7 +1005,7 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
     if (fc2 && (!aligned16(tp->Wm_rows) || !aligned16(tws->hid_triple) || !aligned16(net->bm))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     FwdX3Args a = {};
-    a.X = (const char*)tws->X_triple; a.ldx = ld; a.N = N; a.x_sample_bytes = 0;
+    a.X = (const char*)tws->X_triple; a.ldx = ld; a.N = N; a.x_sample_bytes = 0; a.x_row_bytes = (unsigned)ld * 6u; a.x_stage_bytes = 192u;
     a.W = (const char*)tp->W1_rows; a.w_sample_bytes = (long long)H * ld * 6; a.ldw = ld; a.KT = ld / 32;
     a.b = net->b1; a.W2 = net->W2; a.b2 = net->b2; a.C = net->n_classes; a.H = H;
     a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -((dev_scales ? 0 : x_exp) + tp->w1_exp)); a.x_ds = dev_scales;
@@ -1031,7 +1017,7 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
     int rc = launch_forward_x3<false>(net->activation, a, st);
     if (rc) return rc;
     FwdX3Args b = a;
-    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)N * H * 6;
+    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)N * H * 6; b.x_row_bytes = 192u; b.x_stage_bytes = (unsigned)N * 192u;
     b.W = (const char*)tp->Wm_rows; b.w_sample_bytes = (long long)H * H * 6; b.ldw = H; b.KT = H / 32;
     b.b = net->bm; b.out_scale = ldexpf(1.f, -((dev_scales ? 0 : tp->h1_exp) + tp->wm_exp));
     b.x_ds = dev_scales ? dev_scales + 1 : nullptr; b.hid_ds = nullptr;
