@@ -361,8 +361,16 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                     // (ht & 1) * 32 + lg * 8 of the point's 64-byte piece row; the 16 points of a tile are 3 KiB contiguous, so the six
                     // 8-byte stores of a lane (two tiles x three pieces) fill whole lines between them — no LDS staging, no barrier
                     // (the point-major image needed a per-wave LDS transposition to write 192-byte runs: layer 1 4.7 ms)
+#ifdef RBNN_X3_L1_ABL_NOSTORE
+                    if (n < a.N && q0.w[0] == 0x12345678u) {               // ablation (timing only): pieces computed, never stored
+#else
                     if (n < a.N) {
+#endif
+#ifdef RBNN_X3_L1_ABL_SMALL
+                        char* const row = a.hid + ((((long long)s * HW + (hrow >> 5)) * a.N + n) * 192 & 0xFFFC0) + ((hrow >> 4) & 1) * 32 + lg * 8;   // ablation: all stores into 1 MB
+#else
                         char* const row = a.hid + (((long long)s * HW + (hrow >> 5)) * a.N + n) * 192 + ((hrow >> 4) & 1) * 32 + lg * 8;
+#endif
                         *(uint2*)(row) = make_uint2(q0.w[0], q0.w[1]);
                         *(uint2*)(row + 64) = make_uint2(q1.w[0], q1.w[1]);
                         *(uint2*)(row + 128) = make_uint2(q2.w[0], q2.w[1]);
