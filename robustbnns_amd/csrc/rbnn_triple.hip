@@ -906,6 +906,25 @@ inline bool x3_grad_td9() {
     return on;
 }
 
+// The wider column groups only pay while TWO blocks still share a CU (9 tiles: 2 x 80 KB = every byte of the 160 KB): ask the runtime once
+// per (configuration, device) and fall back to 7 tiles where it says one.
+template <int ACT, int TD, int MODE>
+bool x3_grad_two_blocks() {
+    static int ok[64] = {0};                                   // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!ok[dev]) {
+        constexpr int LDSB = 2 * (12 * TD * 16 * 16 + 5120) + 256 * 64;
+        auto kern = fc_grad_x3_kernel<ACT, TD, MODE, 4>;
+        static unsigned long long attr_done = 0;
+        int nb = 0;
+        const bool fine = ensure_dynamic_lds((const void*)kern, LDSB, attr_done) &&
+                          hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, LDSB) == hipSuccess && nb >= 2;
+        ok[dev] = fine ? 1 : 2;
+    }
+    return ok[dev] == 1;
+}
+
 // 7 or 4 column tiles per block: every group pays the dA generator (or the A-operand reads) again, so fewer groups win — 7 wherever
 // that saves a group (a partial last group skips its missing tiles' MFMAs)
 template <int ACT, int MODE>
@@ -919,13 +938,13 @@ int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
     // pass in seven less: 3.71 / 3.68 -> 3.59 / 3.59 ms at C2 (alternating builds, same box).  Environment RBNN_X3_GRAD_TD9=0 switches
     // back.  (Re-planning the slab size for the 6-group grid — 6 samples per slab instead of 5 — measured slower, 3.75 ms: kept as planned.)
     if constexpr (MODE == X3_FC && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {   // (fc2 step 2 spills at 9 tiles)
-        if (x3_grad_td9() && (a.Dt + 8) / 9 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 9, MODE>(a, st);
+        if (x3_grad_td9() && (a.Dt + 8) / 9 < (a.Dt + 6) / 7 && x3_grad_two_blocks<ACT, 9, MODE>()) return launch_grad_x3_cfg<ACT, 9, MODE>(a, st);
     }
 #endif
 #if RBNN_X3_GRAD_TD8
     // 8 column tiles per block where that saves a group over 7 (hidden = 512: fc2 step 1 runs 4 groups instead of 5)
     if constexpr (MODE != X3_FC2_STEP2 && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {   // (the streamed-operand forms spill at 8 tiles)
-        if (x3_grad_td9() && (a.Dt + 7) / 8 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 8, MODE>(a, st);
+        if (x3_grad_td9() && (a.Dt + 7) / 8 < (a.Dt + 6) / 7 && x3_grad_two_blocks<ACT, 8, MODE>()) return launch_grad_x3_cfg<ACT, 8, MODE>(a, st);
     }
 #endif
     if ((a.Dt + 6) / 7 < (a.Dt + 3) / 4) return launch_grad_x3_cfg<ACT, 7, MODE>(a, st);
