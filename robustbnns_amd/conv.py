@@ -105,14 +105,27 @@ class ConvStackedPosterior:
                "model.7.weight": self.Fw, "model.7.bias": self.Fb}
         items = [(g.loc[k], g.sigma[k], dst[k], g.TENSOR_IDS[k]) for k in dst]
         _hip.HipKernels().svi_draw_flat(items, S, int(key), int(draw_id), sample_keys)
-        self._regroup_k2ci()
+        # images nobody may read before the next draw are only marked stale (each is a 100+ MB permuted copy at Hc = 512): the fp32 kernels'
+        # input-channel regrouping, and the gather-form backward image while the dense conv2^T is what runs (refresh_lazy_images)
+        self._k2ci_stale = True
         if self._triple is not None:
-            self._build_triple(self._triple[0], self._triple[2])
+            dense = getattr(self, "_dense", None) is not None and self.dense_supported()
+            self._build_triple(self._triple[0], self._triple[2], with_bwd=not dense)
+            self._bwd_stale = dense
             if getattr(self, "_dense", None) is not None:
                 self._build_dense(self._dense)
         if self._split is not None:
             self._build_split(self._split[0], self._split[4])
         return self
+
+    def refresh_lazy_images(self, k2ci=False, triple_bwd=False):
+        """Rebuild an image that redraw() only marked stale, right before a kernel that reads it."""
+        if k2ci and getattr(self, "_k2ci_stale", False):
+            self._regroup_k2ci()
+            self._k2ci_stale = False
+        if triple_bwd and getattr(self, "_bwd_stale", False) and self._triple is not None:
+            self._build_triple(self._triple[0], self._triple[2], with_fwd=False)
+            self._bwd_stale = False
 
     def _k2_max(self):
         return self._guide.k2_max if self._guide is not None else float(self.K2w.abs().max())
@@ -145,16 +158,18 @@ class ConvStackedPosterior:
         rows.view(S, KS, 25, 32, 32).copy_(pad.view(S, KS, 32, 32, 25).permute(0, 1, 4, 3, 2))         # [s, ks, tap, ci, hc]
         _hip.HipKernels().triple_rows(rows, 32, scale_exp(self._k2_max()), dense, 32)
 
-    def _build_triple(self, rows, bwd):
+    def _build_triple(self, rows, bwd, with_fwd=True, with_bwd=True):
         S, H = self.S, self.H
         k2, w26, kb = self._scratch()
         k = _hip.HipKernels()
         k2_exp = scale_exp(self._k2_max())
-        k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))                     # k = tap*32 + ci
-        k.triple_rows(k2, 800, k2_exp, rows, 800)
-        w26[..., :25].copy_(self.K2w.view(S, H, 32, 25))
-        kb.view(S, 32, H // 16, 13, 2, 2, 8).copy_(w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3))
-        k.triple_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
+        if with_fwd:
+            k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))                 # k = tap*32 + ci
+            k.triple_rows(k2, 800, k2_exp, rows, 800)
+        if with_bwd:
+            w26[..., :25].copy_(self.K2w.view(S, H, 32, 25))
+            kb.view(S, 32, H // 16, 13, 2, 2, 8).copy_(w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3))
+            k.triple_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
         return k2_exp
 
     def _build_split(self, rows, bwd):
@@ -353,8 +368,10 @@ class ConvEngine(AttackEngine):
             _, k2_exp, bwd, fw_l1 = self.post.triple_images()
             if self.post._dense is not None and self.post.dense_supported():      # 1x28x28: GEMM per tap over the conv2 outputs + col2im
                 return self.k.conv_input_grad_dense(self.post, self.post._dense, k2_exp, fw_l1, sidx, S, N, ws)
+            self.post.refresh_lazy_images(triple_bwd=True)
             return self.k.conv_input_grad_triple(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)
         if self.precision != "split" or os.environ.get("RBNN_CONV_BWD_EXACT") == "1":
+            self.post.refresh_lazy_images(k2ci=True)
             return self.k.conv_input_grad(self.post, sidx, S, N, ws)
         _, k2_exp, _, _, bwd, fw_l1 = self.post.split_images()
         return self.k.conv_input_grad_split(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)
