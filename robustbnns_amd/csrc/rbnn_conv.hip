@@ -1931,11 +1931,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         if (ig >= 4) { ++ig; return; }                                     // ablation (timing only): no weight-tile traffic after the prologue
 #endif
         if (ig < G_) {
-            const char* const src = Awave + ((long long)iks * 25 + tap0 + itap) * (32 * 192);
+            // source = a block-uniform 64-bit base (the sample's image) + ONE 32-bit per-lane offset (tile offset + lane part; a sample's image is
+            // KS * 25 * 6 KiB): hipcc then uses the SGPR-base addressing form instead of a 64-bit vector add per piece
+            const unsigned off = (unsigned)((iks * 25 + tap0 + itap) * (32 * 192)) + a_lane;
             char* const dst = ring + (ig & (L::RING - 1)) * L::SLOT;
-            glds16((const float*)(src + a_lane), (float*)dst);
-            glds16((const float*)(src + 64 + a_lane), (float*)(dst + 1024));
-            glds16((const float*)(src + 128 + a_lane), (float*)(dst + 2048));
+            glds16((const float*)(Awave + off), (float*)dst);
+            glds16((const float*)(Awave + (off + 64u)), (float*)(dst + 1024));
+            glds16((const float*)(Awave + (off + 128u)), (float*)(dst + 2048));
             ++ig;
             if (++itap == ntap) { itap = 0; ++iks; }
         }
