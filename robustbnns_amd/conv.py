@@ -156,7 +156,13 @@ class ConvStackedPosterior:
         pad, rows = self._dense_tmp
         pad[:, :H].copy_(self.K2w.view(S, H, 32, 25))
         rows.view(S, KS, 25, 32, 32).copy_(pad.view(S, KS, 32, 32, 25).permute(0, 1, 4, 3, 2))         # [s, ks, tap, ci, hc]
-        _hip.HipKernels().triple_rows(rows, 32, scale_exp(self._k2_max()), dense, 32)
+        # triple rows ([row][3 pieces][64 B]) into a staging copy, then each 16-row tile piece-major ([3 pieces][16 rows][64 B]) — the order
+        # the kernel's ring slots hold it in, so that a tile's three LDS-DMA pieces differ by the same offset on both sides
+        if getattr(self, "_dense_stage", None) is None:
+            self._dense_stage = torch.empty_like(dense)
+        _hip.HipKernels().triple_rows(rows, 32, scale_exp(self._k2_max()), self._dense_stage, 32)
+        T = dense.shape[0] // 16
+        dense.view(T, 3, 16, 32).copy_(self._dense_stage.view(T, 16, 3, 32).permute(0, 2, 1, 3))
 
     def _build_triple(self, rows, bwd, with_fwd=True, with_bwd=True):
         S, H = self.S, self.H

@@ -1920,8 +1920,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // fetches logical chunk (p & 3) ^ swz(row)), issued THREE taps ahead of their use: an L2 round trip (500+ cycles) is far longer than
     // the 24 MFMAs of a tap, and registers for a deeper prefetch do not exist (112 accumulators + 48 B-fragment registers).  The
     // wave's running tap index g = ks * ntap + i names the slot g & 3; nothing but this wave touches its ring (no barrier involved).
+    // (weight tiles are PLANE-major in memory — [tile][3 pieces][16 ci][64 B], conv.py::_build_dense — exactly as they sit in a ring slot: the
+    // immediate offset of global_load_lds applies to the global AND the LDS address, so a tile's three pieces share one address and one M0)
     const int prow = lane >> 2;
-    const unsigned a_lane = (unsigned)(prow * 192 + (((lane & 3) ^ swz(prow)) * 16));   // per-lane part of a piece's source address
+    const unsigned a_lane = (unsigned)(prow * 64 + (((lane & 3) ^ swz(prow)) * 16));    // per-lane part of a piece's source address
     const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
     char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
     const int G_ = KS * ntap;                                              // tiles this wave consumes
@@ -1935,9 +1937,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             // KS * 25 * 6 KiB): hipcc then uses the SGPR-base addressing form instead of a 64-bit vector add per piece
             const unsigned off = (unsigned)((iks * 25 + tap0 + itap) * (32 * 192)) + a_lane;
             char* const dst = ring + (ig & (L::RING - 1)) * L::SLOT;
-            glds16((const float*)(Awave + off), (float*)dst);
-            glds16((const float*)(Awave + (off + 64u)), (float*)(dst + 1024));
-            glds16((const float*)(Awave + (off + 128u)), (float*)(dst + 2048));
+            const auto gsrc = (const __attribute__((address_space(1))) void*)(Awave + off);
+            const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
             ++ig;
             if (++itap == ntap) { itap = 0; ++iks; }
         }
