@@ -171,7 +171,13 @@ class ConvStackedPosterior:
         k2_exp = scale_exp(self._k2_max())
         if with_fwd:
             k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))                 # k = tap*32 + ci
-            k.triple_rows(k2, 800, k2_exp, rows, 800)
+            # triple rows ([channel][tap][3 pieces][64 B]) into a staging copy, then grouped [16 channels][tap][3 pieces][16 rows][64 B]: the order
+            # a 16-channel group of one tap has in the kernel's stage tile (its three LDS-DMA pieces then differ by 1 KiB on both sides)
+            if getattr(self, "_rows_stage", None) is None:
+                self._rows_stage = torch.empty_like(rows)
+            k.triple_rows(k2, 800, k2_exp, self._rows_stage, 800)
+            G = S * H // 16
+            rows.view(G, 25, 3, 16, 32).copy_(self._rows_stage.view(G, 16, 25, 3, 32).permute(0, 2, 3, 1, 4))
         if with_bwd:
             w26[..., :25].copy_(self.K2w.view(S, H, 32, 25))
             kb.view(S, 32, H // 16, 13, 2, 2, 8).copy_(w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3))

@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
         *(uint4*)(dst + 2 * L::IMGP) = q2.u;
     }
     const int prow = lane >> 2;
-    const unsigned src_off = (unsigned)(((lane & 3) ^ swz(prow)) * 16);
+    const unsigned src_off = (unsigned)(prow * 64 + ((lane & 3) ^ swz(prow)) * 16);   // inside a 1-KiB piece: row prow, logical chunk (lane & 3) ^ swz(row)
     const int foff = li * 64 + ((lg ^ swz(li)) * 16);
     // image position of output position 16pt + li (tap 0,0); positions past NPOS read (0,0), never stored
     int pbase[NPT], ybase[NPT];
@@ -600,10 +600,6 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
         pbase[pt] = ybase[pt] * IPITCH + pos % O2W_;
     }
     const char* const img = imgs + wp * L::IMGB;
-    unsigned wrow[WPP];
-#pragma unroll
-    for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(16 * (wave + NW * i) + prow);
-
     // epilogue roles: lane handles the four consecutive pooled cells 4 * (lane + 64 it) .. of a 16-channel tile; their offsets in the wave's tile
     constexpr int CPITCH = NPOS_ + 4, EIT = (16 * NP2_ / 4 + 63) / 64;
     int pbase_e[EIT][4];
@@ -621,21 +617,26 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         auto stage = [&](int tap, int buf) {
+            // the weight image is grouped [16 channels][tap][3 pieces][16 rows][64 B] (conv.py::_build_triple) and a 16-channel group sits in the
+            // stage tile the same way — [group][3 pieces][1 KiB]: the immediate offset of global_load_lds applies to the global AND the LDS
+            // address, so a group's three pieces share one address register and one M0 write
             char* const T = ldsb + buf * L::TILEW;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int i = 0; i < WPP; ++i) {
-                    const unsigned row = min((unsigned)hc0 + wrow[i], (unsigned)a.Hc - 1u);   // rows past Hc repeat the last channel; never stored
-                    glds16((const float*)(Ws + ((long long)row * (K2 * 6) + tap * 192 + 64 * p + src_off)), (float*)(T + p * L::PLANEW + (wave + NW * i) * 1024));
-                }
+            for (int i = 0; i < WPP; ++i) {
+                const unsigned grp = min((unsigned)(hc0 >> 4) + (unsigned)(wave + NW * i), (unsigned)(a.Hc >> 4) - 1u);   // groups past Hc repeat the last one; never stored
+                const auto gsrc = (const __attribute__((address_space(1))) void*)(Ws + ((grp * 25u + (unsigned)tap) * 3072u + src_off));
+                const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)(T + (wave + NW * i) * 3072);
+                __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
+            }
         };
         stage(0, 0);
         __syncthreads();                                                 // also orders the image fill (first chunk) / the previous chunk's pooling tiles
         for (int tap = 0; tap < 25; ++tap) {
             const int buf = tap & 1;
             if (tap + 1 < 25) stage(tap + 1, buf ^ 1);
-            const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 16 * 64 + foff;
+            const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 3072 + foff;
             const int ky = tap / 5, toff = ky * IPITCH + (tap % 5);
             f16x8 b0[NPT], b1[NPT], b2[NPT];
 #pragma unroll
@@ -648,8 +649,8 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
             }
 #pragma unroll
             for (int ht = 0; ht < HTW; ++ht) {
-                const f16x8 a0 = *(const f16x8*)(Wt + ht * 1024), a1 = *(const f16x8*)(Wt + L::PLANEW + ht * 1024),
-                            a2 = *(const f16x8*)(Wt + 2 * L::PLANEW + ht * 1024);
+                const f16x8 a0 = *(const f16x8*)(Wt + ht * 3072), a1 = *(const f16x8*)(Wt + ht * 3072 + 1024),
+                            a2 = *(const f16x8*)(Wt + ht * 3072 + 2048);
 #pragma unroll
                 for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b2[pt], acc[ht][pt]);
 #pragma unroll
