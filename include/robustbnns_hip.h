@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 6
+#define RBNN_ABI_VERSION 7
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {
@@ -371,7 +371,7 @@ int rbnn_fc_input_grad_split(const rbnn_posterior *net, const rbnn_split_images 
  * Architectures fc and fc2, hidden % 128 == 0, all four activations, <= 10 classes in the input gradient.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct rbnn_triple_images {
-    const void *W1_rows;           /* rbnn_triple_rows image of W1 viewed as [S_total*H, D] rows: [S_total,H,ld_rows/32,3,32] halves */
+    const void *W1_rows;           /* rbnn_triple_rows_grouped image of W1 viewed as [S_total*H, D] rows: [S_total*H/16,ld_rows/32,3,16,32] halves */
     const void *W1_cols;           /* rbnn_triple_cols image of W1 (backward B operand): [S_total,H/32,4,3,ld_cols,8] halves         */
     const void *W2_gen;            /* rbnn_triple_w2gen image of the OUTPUT layer (backward dA generator): [S_total,H/16,2,64,8] halves */
     int32_t ld_rows;               /* columns per row of W1_rows, multiple of 32, >= D                                              */
@@ -379,7 +379,7 @@ typedef struct rbnn_triple_images {
     int32_t w1_exp;                /* W1_rows and W1_cols hold W1 * 2^w1_exp                                                        */
     int32_t w2_exp;                /* W2_gen holds the output layer * 2^w2_exp                                                      */
     /* fc2: */
-    const void *Wm_rows;           /* rbnn_triple_rows image of Wm viewed as [S_total*H, H] rows, holding Wm * 2^wm_exp (forward)    */
+    const void *Wm_rows;           /* rbnn_triple_rows_grouped image of Wm viewed as [S_total*H, H] rows, holding Wm * 2^wm_exp (forward) */
     const void *Wm_cols;           /* rbnn_triple_cols image of Wm [S_total,H/32,4,3,H,8] (backward step 1)                         */
     int32_t wm_exp;
     int32_t h1_exp;                /* layer-1 activations are carried as h * 2^h1_exp = p0 + p1 + p2 in tws->hid_triple; set from the */
@@ -388,10 +388,10 @@ typedef struct rbnn_triple_images {
 
 /* per-problem scratch of the triple mode */
 typedef struct rbnn_triple_workspace {
-    void  *X_triple;               /* [N, ld_rows] triple-rows image of the current inputs (caller fills it with rbnn_triple_rows)  */
+    void  *X_triple;               /* [ceil16(N), ld_rows] grouped triple-rows image of the current inputs (rbnn_triple_rows_grouped) */
     void  *dZ_gen;                 /* [S, N_pad, 64 B] dA-generator image of dZ, written by rbnn_fc_input_grad_triple               */
     float *g_scale;                /* [N_pad] per-point 2^-e(n) of that image                                                       */
-    void  *hid_triple;             /* fc2: triple image of the hidden activations, stage-major [S, H/32, N, 3 pieces, 32 units] (6 B/elt) */
+    void  *hid_triple;             /* fc2: triple image of the hidden activations, [S, H/32 stages, ceil(N/16) groups, 3 pieces, 16 points, 32 units] */
 } rbnn_triple_workspace;
 typedef struct rbnn_triple_workspace_sizes { size_t X_triple, dZ_gen, g_scale, hid_triple; } rbnn_triple_workspace_sizes;
 
@@ -402,6 +402,13 @@ int rbnn_triple_workspace_query(const rbnn_posterior *net, const rbnn_triple_ima
  * (0 past `cols`): the triple-rows image [rows, ld_dst/32, 3, 32] halves.  ld_dst % 32 == 0.  scale_exp / dev_scale as rbnn_split_rows. */
 int rbnn_triple_rows(const float *src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
                      const rbnn_dev_scale *dev_scale, void *dst, int32_t ld_dst, void *stream);
+
+/* The same pieces in the GROUPED order the fc forward kernel reads (W1_rows, Wm_rows, X_triple): 16 consecutive rows share one 3-KiB block
+ * per K stage, dst[r / 16, k, p, r % 16, :] — [rows/16, ld_dst/32, 3, 16, 32] halves.  A 16-row group then sits in memory exactly as in the
+ * kernel's stage tile, so its three LDS-DMA pieces (1 KiB apart on both sides) share one address and one M0 write.  Rows past `rows` in the
+ * last group are left untouched: size dst for ceil(rows / 16) * 16 rows.  Same arguments as rbnn_triple_rows. */
+int rbnn_triple_rows_grouped(const float *src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                             const rbnn_dev_scale *dev_scale, void *dst, int32_t ld_dst, void *stream);
 
 /* Triple-cols image of n_mats row-major [rows, ld_src] matrices (rows % 32 == 0):
  * dst[m, hb, lg, p, d, j] = piece p of W[m, 32*hb + 16*(j>>2) + 4*lg + (j&3), d] * 2^scale_exp.  One-off at posterior load. */
@@ -414,7 +421,7 @@ int rbnn_triple_w2gen(const float *W2, int32_t n_mats, int32_t n_classes, int32_
                       void *stream);
 
 /* rbnn_fc_forward on triple images: same outputs (ws->P, ws->mask1 / ws->dact1; fc2: ws->mask2 / ws->dact2).  tws->X_triple =
- * rbnn_triple_rows(X, N, D, ., x_exp, ., tp->ld_rows); dev_scales != NULL: the two records of rbnn_input_scales — [0] replaces
+ * rbnn_triple_rows_grouped(X, N, D, ., x_exp, ., tp->ld_rows); dev_scales != NULL: the two records of rbnn_input_scales — [0] replaces
  * x_exp, [1] replaces tp->h1_exp (fc2) — read on the device. */
 int rbnn_fc_forward_triple(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_triple_workspace *tws,
                            int32_t x_exp, const rbnn_dev_scale *dev_scales, int32_t n_points, const int32_t *sample_idx,

@@ -143,6 +143,7 @@ SIGNATURES = {
                                         C.POINTER(_i32), _fp]),
     "rbnn_triple_workspace_query": (_i32, [_PP, C.POINTER(TripleImages), _i32, _i32, C.POINTER(TripleWorkspaceSizes)]),
     "rbnn_triple_rows": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
+    "rbnn_triple_rows_grouped": (_i32, [_fp, _i64, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
     "rbnn_triple_cols": (_i32, [_fp, _i64, _i32, _i32, _i32, _i32, _fp, _i32, _fp]),
     "rbnn_triple_w2gen": (_i32, [_fp, _i32, _i32, _i32, _i32, _fp, _fp]),
     "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(TripleWorkspace), _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
@@ -173,7 +174,7 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 6:
+        if lib.rbnn_abi_version() != 7:
             raise HipError("librbnn_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -329,12 +330,14 @@ class HipKernels:
         return n.value
 
     # -- triple-split ("f16x6") mode: full-width fp32 operands on the f16 matrix pipe ---------------------
-    def triple_rows(self, src, cols, scale_exp, out, ld_dst, dev_scale=None):
-        """src: [..., ld_src] fp32 rows -> out: triple-rows image (int16 storage, 3 halves per element)."""
+    def triple_rows(self, src, cols, scale_exp, out, ld_dst, dev_scale=None, grouped=False):
+        """src: [..., ld_src] fp32 rows -> out: triple-rows image (int16 storage, 3 halves per element).  grouped=True: the fc forward's
+        operand order (16-row groups, [3 pieces][16 rows][64 B] per K stage; out sized for ceil16(rows) rows)."""
         require_gpu(src, "src")
         ld_src = src.shape[-1]
-        check(self.lib.rbnn_triple_rows(ptr(src), src.numel() // ld_src, cols, ld_src, scale_exp, ptr(dev_scale), ptr(out), ld_dst,
-                                        stream_of(src)), "rbnn_triple_rows")
+        fn = self.lib.rbnn_triple_rows_grouped if grouped else self.lib.rbnn_triple_rows
+        check(fn(ptr(src), src.numel() // ld_src, cols, ld_src, scale_exp, ptr(dev_scale), ptr(out), ld_dst, stream_of(src)),
+              "rbnn_triple_rows_grouped" if grouped else "rbnn_triple_rows")
 
     def triple_cols(self, W, rows, cols, scale_exp, out, ld_dst):
         require_gpu(W, "W")

@@ -4,7 +4,7 @@
 //
 //      fp32 stack        W1 [S,H,D_pad]  b1  (Wm bm)  W2 [S,C,H]  b2        what rbnn_fc_forward reads
 //      rbnn_pack_rows4   W1_pack4 / Wm_pack4 [S,H/4,cols,4]                  the fp32-MFMA backward's B operand
-//      triple rows       W1_rows / Wm_rows  [S*H, ld/32, 3, 32] halves       rbnn_fc_forward_triple's A operand
+//      triple rows       W1_rows / Wm_rows  [S*H/16, ld/32, 3, 16, 32] halves  rbnn_fc_forward_triple's A operand (grouped rows)
 //      triple cols       W1_cols / Wm_cols  [S,H/32,4,3,ld,8] halves         rbnn_fc_input_grad_triple's B operand
 //      W2 generator      W2_gen [S,H/16,2,64,8] halves                       its dA generator
 //
@@ -120,7 +120,8 @@ __device__ void draw_matrix_tile(const DrawArgs& a, const Rng& rng, int tensor, 
         }
     }
     if (rows_img) {
-        // (3) triple rows: row r = s*H + h, stage k of 32 columns = 12 units of 16 B: [plane][4 groups of 8 columns]
+        // (3) triple rows, GROUPED (rbnn_triple_rows_grouped): row r = s*H + h; block of (16-row group, stage of 32 columns) = 192 units of 16 B:
+        //     [piece][16 rows][4 groups of 8 columns]
         const int hl = t >> 3, g = t & 7, d = d0 + 8 * g;
         if (d < ld_rows) {
             union { f16x8 v; uint4 u; } o[3];
@@ -131,8 +132,8 @@ __device__ void draw_matrix_tile(const DrawArgs& a, const Rng& rng, int tensor, 
                 o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
             }
             const long long r = (long long)s * H + 32 * hb + hl;
-            uint4* const out = rows_img + (r * (ld_rows >> 5) + (d >> 5)) * 12 + ((d >> 3) & 3);
-            out[0] = o[0].u; out[4] = o[1].u; out[8] = o[2].u;
+            uint4* const out = rows_img + (((r >> 4) * (ld_rows >> 5) + (d >> 5)) * 192 + (r & 15) * 4 + ((d >> 3) & 3));
+            out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
         }
         // (4) triple cols: out[s][hb][lg][p][d][j] = piece p of W[32 hb + 16 (j>>2) + 4 lg + (j&3)][d]
         const int lg = t >> 6, dl = t & 63, dc = d0 + dl;

@@ -100,8 +100,11 @@ __device__ __forceinline__ void split3_pair_m(float ge, float go, float me, floa
 // ===================================================================================================
 // fp32 rows -> triple-rows image.  One thread per (row, group of 8 columns): three 16-B stores.
 // ===================================================================================================
+// grouped (rbnn_triple_rows_grouped, the fc forward's operands): 16 consecutive rows share a 3-KiB block per K stage, [3 pieces][16 rows][64 B] —
+// the order a 16-row group has in the forward kernel's stage tile, so that its three LDS-DMA pieces differ by 1 KiB on BOTH sides and share
+// one address register and one M0 write (the immediate offset of global_load_lds applies to the global and the LDS address).
 __global__ void triple_rows_kernel(const float* __restrict__ src, long long rows, int cols, int ld_src, float scale,
-                                   const rbnn_dev_scale* __restrict__ ds, uint4* __restrict__ dst, int groups) {
+                                   const rbnn_dev_scale* __restrict__ ds, uint4* __restrict__ dst, int groups, int grouped) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * groups) return;
     if (ds) scale = ds->scale;
@@ -115,6 +118,11 @@ __global__ void triple_rows_kernel(const float* __restrict__ src, long long rows
         _Float16 a, b, c;
         split3(v, a, b, c);
         o[0].v[j] = a; o[1].v[j] = b; o[2].v[j] = c;
+    }
+    if (grouped) {                                             // 16-B units: block of (row group, stage) = 192 units: [plane][16 rows][4 chunks]
+        uint4* const out = dst + (((r >> 4) * (groups >> 2) + (g >> 2)) * 192 + (r & 15) * 4 + (g & 3));
+        out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
+        return;
     }
     // 16-B units: row r has (groups / 4) stages of 12 units: [plane][4 chunks]
     uint4* const out = dst + (r * (groups >> 2) + (g >> 2)) * 12 + (g & 3);
@@ -132,8 +140,8 @@ __global__ void triple_rows_kernel(const float* __restrict__ src, long long rows
 #define RBNN_X3_L1_PAIR 1                                       // fc2 layer 1's hidden image: pieces by split3_plain_pair (6 instructions per pair) / plain C++
 #endif
 struct FwdX3Args {
-    const char* X;  int ldx;  int N;                           // triple-rows image of the inputs [N][ldx] (ldx elements, % 32 == 0)
-    const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // triple-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
+    const char* X;  int ldx;  int N;                           // grouped triple-rows image of the inputs [ceil16(N)][ldx] (ldx elements, % 32 == 0)
+    const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // grouped triple-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
     const float* b;  const float* W2;  const float* b2;  int C;  int H;
     const int* sidx;  int S;  int NT;  float out_scale;        // out_scale = 2^-(e_x + e_w)
     float* P;  uint32_t* mask;  float* dact;  int out_kind;
@@ -141,9 +149,10 @@ struct FwdX3Args {
     // fc2: layer 1 (!LAYER2) writes the hidden activations as a per-sample STAGE-major triple image [S][H/32][N][3 pieces][32 units]
     // (value * hid_scale = p0 + p1 + p2); layer 2 reads it as its X operand (x_sample_bytes = N * H * 6)
     long long x_sample_bytes;  char* hid;  float hid_scale;  const rbnn_dev_scale* hid_ds;
-    // X image geometry: bytes between consecutive points of one stage / between consecutive stages of one point.  Point-major images
-    // (rbnn_triple_rows: [N][K/32 stages][192 B]): ldx * 6 and 192.  The hidden image of fc2 is STAGE-major ([S][H/32][N][192 B]): 192 and N * 192
-    unsigned x_row_bytes, x_stage_bytes;
+    // X image geometry (grouped rows: 3-KiB blocks [3 pieces][16 rows][64 B] per (16-row group, stage)): bytes between consecutive row groups
+    // of one stage / between consecutive stages of one group.  rbnn_triple_rows_grouped images: KT * 3072 and 3072.  The hidden image of fc2
+    // is stage-major ([S][H/32 stages][N/16 groups][3 KiB]): 3072 and ceil(N/16) * 3072
+    unsigned x_group_bytes, x_stage_bytes;
 };
 
 template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
@@ -187,7 +196,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     // DMA piece = 16 rows x 64 B of one plane: lane p lands at row (p >> 2), physical chunk p & 3, so it fetches logical chunk
     // (p & 3) ^ swz(row); pieces start at multiples of 16 rows, so swz(row) = swz(p >> 2)
     const int prow = lane >> 2;
-    const unsigned src_off = (unsigned)(((lane & 3) ^ swz(prow)) * 16);
+    const unsigned src_off = (unsigned)(prow * 64 + ((lane & 3) ^ swz(prow)) * 16);   // inside a 1-KiB piece of a grouped image: row prow, logical chunk
     // fragment read of row li (any 16-row tile), K chunk lg
     const int foff = li * 64 + ((lg ^ swz(li)) * 16);
 
@@ -195,26 +204,38 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) zacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane row offsets (bytes) of this wave's pieces; 32-bit (the host checks H*ldw*6 and N*ldx*6 < 2^32).  W rows are relative to
-    // the h chunk: the chunk's base goes into the uniform part of the address.
+    // per-lane offsets (bytes) of this wave's 16-row groups; 32-bit (the host checks H*ldw*6 and N*ldx*6 < 2^32).  W groups are relative to
+    // the h chunk: the chunk's base goes into the uniform part of the address.  Point groups past N repeat the last one (never stored).
     unsigned xrow[XPP], wrow[WPP];
 #pragma unroll
-    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min(n0 + 16 * (wave + NW * i) + prow, a.N - 1) * a.x_row_bytes + src_off;
+    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min((n0 >> 4) + wave + NW * i, ((a.N + 15) >> 4) - 1) * a.x_group_bytes + src_off;
 #pragma unroll
-    for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(16 * (wave + NW * i) + prow) * (unsigned)a.ldw * 6u + src_off;
+    for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(wave + NW * i) * (unsigned)a.KT * 3072u + src_off;
 
     // The K stages of all h chunks form ONE software pipeline: stage g = (chunk g / KT, columns 32 * (g % KT)), buffer g & 1; the
     // first stage of the next chunk is in flight while a chunk's epilogue runs.  The pieces of stage g + 1 (PPS per wave) are
     // issued BETWEEN stage g's MFMA groups, not at its top next to the LDS reads (an LDS-DMA instruction costs ~60 cycles among
     // MFMAs against 100-185 there), all within the first two h tiles so that they land before the stage ends.
-    constexpr int PPS = 3 * (WPP + XPP);
+    // A "piece" below is one 16-row GROUP of one stage: three 1-KiB LDS-DMA instructions (the three fp16 pieces) that share their address
+    // register and M0 — a group is [3 pieces][1 KiB] both in the image and in the stage tile.
+    constexpr int PPS = WPP + XPP;
     const int G = (a.H / BH) * a.KT;
-    auto piece = [&](int c, int kt, int buf, int i) {           // chunk c, columns 32 * kt -> buffer buf; i: compile-time constant, plane i / (WPP + XPP)
+    auto piece = [&](int c, int kt, int buf, int j) {           // chunk c, columns 32 * kt -> buffer buf; j: compile-time constant
         char* const T = ldsb + buf * TILEB;
-        const int p = i / (WPP + XPP), j = i % (WPP + XPP);
-        const unsigned koff = (unsigned)kt * 192u + 64u * p, xoff = (unsigned)kt * a.x_stage_bytes + 64u * p;
-        if (j < WPP) glds16((const float*)(Ws + (long long)c * BH * a.ldw * 6 + (wrow[j < WPP ? j : 0] + koff)), (float*)(T + p * PLANEB + (wave + NW * j) * 1024));
-        else glds16((const float*)(Xs + (xrow[j >= WPP ? j - WPP : 0] + xoff)), (float*)(T + p * PLANEB + BH * 64 + (wave + NW * (j - WPP)) * 1024));
+        const char* src;
+        char* dst;
+        if (j < WPP) {
+            src = Ws + (long long)c * BH * a.ldw * 6 + (wrow[j < WPP ? j : 0] + (unsigned)kt * 3072u);
+            dst = T + (wave + NW * j) * 3072;
+        } else {
+            src = Xs + (xrow[j >= WPP ? j - WPP : 0] + (unsigned)kt * a.x_stage_bytes);
+            dst = T + (BH / 16 + wave + NW * (j - WPP)) * 3072;
+        }
+        const auto gsrc = (const __attribute__((address_space(1))) void*)src;
+        const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
+        __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
     };
 #pragma unroll
     for (int i = 0; i < PPS; ++i) piece(0, 0, 0, i);
@@ -232,8 +253,8 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         // next stage; the very last one re-fetches itself into the idle buffer (1 stage in G: keeps the body branch-free)
         const bool wrap = kt + 1 == a.KT, last = g + 1 == G;
         const int ktn = last ? kt : (wrap ? 0 : kt + 1), chn = (wrap && !last) ? ch + 1 : ch;
-        const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 16 * 64 + foff;
-        const char* const Xt = ldsb + buf * TILEB + BH * 64 + (wave_n * NTW) * 16 * 64 + foff;
+        const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 3072 + foff;
+        const char* const Xt = ldsb + buf * TILEB + (BH / 16 + wave_n * NTW) * 3072 + foff;
         f16x8 b0[NTW], b1[NTW], b2[NTW], a0, a1, a2, a0n, a1n, a2n;
         if (!RBNN_X3_SPREAD && !(RBNN_ABL & 1)) {
 #pragma unroll
@@ -241,13 +262,13 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            b0[nt] = *(const f16x8*)(Xt + nt * 1024);
-            b1[nt] = *(const f16x8*)(Xt + PLANEB + nt * 1024);
-            b2[nt] = *(const f16x8*)(Xt + 2 * PLANEB + nt * 1024);
+            b0[nt] = *(const f16x8*)(Xt + nt * 3072);
+            b1[nt] = *(const f16x8*)(Xt + nt * 3072 + 1024);
+            b2[nt] = *(const f16x8*)(Xt + nt * 3072 + 2048);
         }
         a0 = *(const f16x8*)(Wt);
-        a1 = *(const f16x8*)(Wt + PLANEB);
-        a2 = *(const f16x8*)(Wt + 2 * PLANEB);
+        a1 = *(const f16x8*)(Wt + 1024);
+        a2 = *(const f16x8*)(Wt + 2048);
         a0n = a0; a1n = a1; a2n = a2;
         constexpr int PER_HT = (PPS + 1) / 2;                   // pieces issued inside h tile 0 and inside h tile 1
         static_assert(PER_HT <= 6, "one piece after each of an h tile's six product groups at most");
@@ -272,15 +293,15 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                     }
                     if (k == 2 && ht + 1 < HTW) {
                         __builtin_amdgcn_sched_barrier(0);
-                        a0n = *(const f16x8*)(Wt + (ht + 1) * 1024);
-                        a1n = *(const f16x8*)(Wt + PLANEB + (ht + 1) * 1024);
-                        a2n = *(const f16x8*)(Wt + 2 * PLANEB + (ht + 1) * 1024);
+                        a0n = *(const f16x8*)(Wt + (ht + 1) * 3072);
+                        a1n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 1024);
+                        a2n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 2048);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else if (k == 0 && ht + 1 < HTW) {
-                    a0n = *(const f16x8*)(Wt + (ht + 1) * 1024);
-                    a1n = *(const f16x8*)(Wt + PLANEB + (ht + 1) * 1024);
-                    a2n = *(const f16x8*)(Wt + 2 * PLANEB + (ht + 1) * 1024);
+                    a0n = *(const f16x8*)(Wt + (ht + 1) * 3072);
+                    a1n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 1024);
+                    a2n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 2048);
                 }
             }
             a0 = a0n; a1 = a1n; a2 = a2n;
@@ -357,23 +378,24 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) split3(hv[r] * hid_scale, q0.h[r], q1.h[r], q2.h[r]);
 #endif
-                    // stage-major image [S][H/32][N][piece][32 units]: this lane's four units of tile ht are 8 bytes per piece, at byte
-                    // (ht & 1) * 32 + lg * 8 of the point's 64-byte piece row; the 16 points of a tile are 3 KiB contiguous, so the six
-                    // 8-byte stores of a lane (two tiles x three pieces) fill whole lines between them — no LDS staging, no barrier
-                    // (the point-major image needed a per-wave LDS transposition to write 192-byte runs: layer 1 4.7 ms)
+                    // stage-major grouped image [S][H/32 stages][N/16 groups][3 pieces][16 points][32 units]: this lane's four units of tile ht
+                    // are 8 bytes per piece, at byte (ht & 1) * 32 + lg * 8 of its point's 64-byte row; a tile's 16 points are one 3-KiB block, so
+                    // the six 8-byte stores of a lane (two tiles x three pieces) fill whole lines between them — no LDS staging, no barrier
 #ifdef RBNN_X3_L1_ABL_NOSTORE
                     if (n < a.N && q0.w[0] == 0x12345678u) {               // ablation (timing only): pieces computed, never stored
 #else
                     if (n < a.N) {
 #endif
+                        // block of (stage, 16-point group) = [3 pieces][16 points][64 B]: this lane's point is row n & 15 of its group
+                        const long long blk = ((long long)s * HW + (hrow >> 5)) * ((a.N + 15) >> 4) + (n >> 4);
 #ifdef RBNN_X3_L1_ABL_SMALL
-                        char* const row = a.hid + ((((long long)s * HW + (hrow >> 5)) * a.N + n) * 192 & 0xFFFC0) + ((hrow >> 4) & 1) * 32 + lg * 8;   // ablation: all stores into 1 MB
+                        char* const row = a.hid + ((blk * 3072) & 0xFFC00) + (n & 15) * 64 + ((hrow >> 4) & 1) * 32 + lg * 8;   // ablation: all stores into 1 MB
 #else
-                        char* const row = a.hid + (((long long)s * HW + (hrow >> 5)) * a.N + n) * 192 + ((hrow >> 4) & 1) * 32 + lg * 8;
+                        char* const row = a.hid + blk * 3072 + (n & 15) * 64 + ((hrow >> 4) & 1) * 32 + lg * 8;
 #endif
                         *(uint2*)(row) = make_uint2(q0.w[0], q0.w[1]);
-                        *(uint2*)(row + 64) = make_uint2(q1.w[0], q1.w[1]);
-                        *(uint2*)(row + 128) = make_uint2(q2.w[0], q2.w[1]);
+                        *(uint2*)(row + 1024) = make_uint2(q1.w[0], q1.w[1]);
+                        *(uint2*)(row + 2048) = make_uint2(q2.w[0], q2.w[1]);
                     }
                 }
             }
@@ -964,8 +986,8 @@ int launch_grad_x3_act(int act, const GradX3Args& a, hipStream_t st) {
 
 extern "C" {
 
-int rbnn_triple_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
-                     const rbnn_dev_scale* dev_scale, void* dst, int32_t ld_dst, void* stream) {
+static int triple_rows_launch(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                              const rbnn_dev_scale* dev_scale, void* dst, int32_t ld_dst, void* stream, int grouped) {
     if (!src || !dst) return RBNN_ERR_NULL;
     if (rows < 1 || cols < 1 || ld_src < cols || ld_dst < cols || (ld_dst & 31)) return RBNN_ERR_SHAPE;
     if (scale_exp < -100 || scale_exp > 100) return RBNN_ERR_SHAPE;
@@ -973,8 +995,18 @@ int rbnn_triple_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_sr
     const int groups = ld_dst / 8;
     const long long total = (long long)rows * groups;
     hipLaunchKernelGGL(triple_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       src, (long long)rows, cols, ld_src, ldexpf(1.f, scale_exp), dev_scale, (uint4*)dst, groups);
+                       src, (long long)rows, cols, ld_src, ldexpf(1.f, scale_exp), dev_scale, (uint4*)dst, groups, grouped);
     return launch_status();
+}
+
+int rbnn_triple_rows(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                     const rbnn_dev_scale* dev_scale, void* dst, int32_t ld_dst, void* stream) {
+    return triple_rows_launch(src, rows, cols, ld_src, scale_exp, dev_scale, dst, ld_dst, stream, 0);
+}
+
+int rbnn_triple_rows_grouped(const float* src, int64_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
+                             const rbnn_dev_scale* dev_scale, void* dst, int32_t ld_dst, void* stream) {
+    return triple_rows_launch(src, rows, cols, ld_src, scale_exp, dev_scale, dst, ld_dst, stream, 1);
 }
 
 int rbnn_triple_cols(const float* W, int64_t n_mats, int32_t rows, int32_t cols, int32_t ld_src, int32_t scale_exp,
@@ -1005,10 +1037,10 @@ int rbnn_triple_workspace_query(const rbnn_posterior* net, const rbnn_triple_ima
     if (!net || !tp || !out) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || tp->ld_rows < net->in_features || (tp->ld_rows & 31)) return RBNN_ERR_SHAPE;
     rbnn_triple_workspace_sizes z = {};
-    z.X_triple = (size_t)N * tp->ld_rows * 6;
+    z.X_triple = (size_t)((N + 15) / 16 * 16) * tp->ld_rows * 6;          // grouped image: whole 16-row groups
     z.dZ_gen = (size_t)S * mask_ld(N) * 64;
     z.g_scale = (size_t)mask_ld(N) * sizeof(float);
-    z.hid_triple = net->arch == RBNN_ARCH_FC2 ? (size_t)S * N * net->hidden * 6 : 0;
+    z.hid_triple = net->arch == RBNN_ARCH_FC2 ? (size_t)S * ((N + 15) / 16 * 16) * net->hidden * 6 : 0;
     *out = z;
     return RBNN_OK;
 }
@@ -1025,14 +1057,14 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
     if (H < 128 || (H % 128) || ld < net->in_features || (ld & 31)) return RBNN_ERR_SHAPE;
     if (net->n_classes < 1 || net->n_classes > RBNN_CPAD || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     // the kernel addresses a sample's weight image and the input image with 32-bit byte offsets from a 64-bit base
-    if ((long long)H * ld * 6 >= (1LL << 32) || (long long)N * ld * 6 >= (1LL << 32) || (long long)N * H * 6 >= (1LL << 32)) return RBNN_ERR_SHAPE;
+    if ((long long)H * ld * 6 >= (1LL << 32) || ((long long)N + 15) * ld * 6 >= (1LL << 32) || ((long long)N + 15) * H * 6 >= (1LL << 32)) return RBNN_ERR_SHAPE;
     if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
     if (!aligned16(tws->X_triple) || !aligned16(tp->W1_rows) || !aligned16(ws->P) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
     if (fc2 && (!tp->Wm_rows || !net->bm || !tws->hid_triple || (bm ? !ws->mask2 : !ws->dact2))) return RBNN_ERR_NULL;
     if (fc2 && (!aligned16(tp->Wm_rows) || !aligned16(tws->hid_triple) || !aligned16(net->bm))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     FwdX3Args a = {};
-    a.X = (const char*)tws->X_triple; a.ldx = ld; a.N = N; a.x_sample_bytes = 0; a.x_row_bytes = (unsigned)ld * 6u; a.x_stage_bytes = 192u;
+    a.X = (const char*)tws->X_triple; a.ldx = ld; a.N = N; a.x_sample_bytes = 0; a.x_group_bytes = (unsigned)(ld / 32) * 3072u; a.x_stage_bytes = 3072u;
     a.W = (const char*)tp->W1_rows; a.w_sample_bytes = (long long)H * ld * 6; a.ldw = ld; a.KT = ld / 32;
     a.b = net->b1; a.W2 = net->W2; a.b2 = net->b2; a.C = net->n_classes; a.H = H;
     a.sidx = sidx; a.S = S; a.out_scale = ldexpf(1.f, -((dev_scales ? 0 : x_exp) + tp->w1_exp)); a.x_ds = dev_scales;
@@ -1044,7 +1076,8 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
     int rc = launch_forward_x3<false>(net->activation, a, st);
     if (rc) return rc;
     FwdX3Args b = a;
-    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)N * H * 6; b.x_row_bytes = 192u; b.x_stage_bytes = (unsigned)N * 192u;
+    const int NG = (N + 15) / 16;
+    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)NG * 16 * H * 6; b.x_group_bytes = 3072u; b.x_stage_bytes = (unsigned)NG * 3072u;
     b.W = (const char*)tp->Wm_rows; b.w_sample_bytes = (long long)H * H * 6; b.ldw = H; b.KT = H / 32;
     b.b = net->bm; b.out_scale = ldexpf(1.f, -((dev_scales ? 0 : tp->h1_exp) + tp->wm_exp));
     b.x_ds = dev_scales ? dev_scales + 1 : nullptr; b.hid_ds = nullptr;

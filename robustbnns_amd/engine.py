@@ -209,7 +209,7 @@ class AttackEngine:
         if self.precision == "triple":
             img = self.post.triple_images()
             ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
-            self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds)
+            self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds, grouped=True)
             return self.k.fc_forward_triple(self.post, img, ws["triple"], 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
         if self.precision != "split":
             return self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)

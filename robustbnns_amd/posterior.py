@@ -216,7 +216,7 @@ class StackedPosterior:
             rows = torch.empty(S * H, ld * 3, dtype=torch.int16, device=self.device)
             cols = torch.empty(S * (H // 32) * 12 * Dp * 8, dtype=torch.int16, device=self.device)
             gen = torch.empty(S * (H // 16) * 1024, dtype=torch.int16, device=self.device)
-            k.triple_rows(self.W1, D, w1_exp, rows, ld)
+            k.triple_rows(self.W1, D, w1_exp, rows, ld, grouped=True)
             k.triple_cols(self.W1, H, D, w1_exp, cols, Dp)
             k.triple_w2gen(self.W2, Cn, H, w2_exp, gen)
             img = _hip.TripleImages()
@@ -226,7 +226,7 @@ class StackedPosterior:
             if self.arch == "fc2":                               # the middle layer: Wm as triple rows [S*H, H] (forward) and triple cols (backward step 1)
                 wm_exp = scale_exp(self._abs_max("Wm"))
                 wm_rows = torch.empty(S * H, H * 3, dtype=torch.int16, device=self.device)
-                k.triple_rows(self.Wm, H, wm_exp, wm_rows, H)
+                k.triple_rows(self.Wm, H, wm_exp, wm_rows, H, grouped=True)
                 wm_cols = torch.empty(S * (H // 32) * 12 * H * 8, dtype=torch.int16, device=self.device)
                 k.triple_cols(self.Wm, H, H, wm_exp, wm_cols, H)
                 img.Wm_rows, img.Wm_cols, img.wm_exp = wm_rows.data_ptr(), wm_cols.data_ptr(), wm_exp

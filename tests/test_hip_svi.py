@@ -83,11 +83,11 @@ def test_draw_kernel_matches_the_oracle_generator_and_the_image_builders(arch, s
     if tri:
         img, keep = post._triple
         chk = [torch.empty_like(t) for t in keep]
-        k.triple_rows(post.W1, D, img.w1_exp, chk[0], img.ld_rows)
+        k.triple_rows(post.W1, D, img.w1_exp, chk[0], img.ld_rows, grouped=True)
         k.triple_cols(post.W1, Hp, D, img.w1_exp, chk[1], post.Dp)
         k.triple_w2gen(post.W2, C, Hp, img.w2_exp, chk[2])
         if arch == "fc2":
-            k.triple_rows(post.Wm, Hp, img.wm_exp, chk[3], Hp)
+            k.triple_rows(post.Wm, Hp, img.wm_exp, chk[3], Hp, grouped=True)
             k.triple_cols(post.Wm, Hp, Hp, img.wm_exp, chk[4], Hp)
         for i, (a, b) in enumerate(zip(chk, keep)):
             assert torch.equal(a, b), f"triple image {i}"

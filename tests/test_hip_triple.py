@@ -55,6 +55,13 @@ def test_triple_rows_image_is_bit_exact():
     assert torch.equal(rec[big], want[big])                     # bit for bit
     assert float((rec - want).abs().max()) <= 2.0 ** -25
     assert float(img[:, :, 0].abs().max()) <= 2.0 ** 14
+    # the grouped order (the fc forward's operands) holds the same pieces: [row group][stage][piece][16 rows][32]
+    rp = (rows + 15) // 16 * 16
+    outg = torch.zeros(rp, ld * 3, dtype=torch.int16, device=DEV)
+    k.triple_rows(v.to(DEV).contiguous(), cols, e, outg, ld, grouped=True)
+    torch.cuda.synchronize()
+    imgg = _halves(outg).reshape(rp // 16, ld // 32, 3, 16, 32).permute(0, 3, 1, 2, 4).reshape(rp, ld // 32, 3, 32)
+    assert torch.equal(imgg[:rows], img) and float(imgg[rows:].abs().max()) == 0.0      # rows past the last one: untouched
 
 
 def test_triple_cols_and_generator_images():

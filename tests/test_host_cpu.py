@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rbnn_abi_version() == 6
+    assert lib.rbnn_abi_version() == 7
     assert lib.rbnn_strerror(0) == b"ok" and b"NULL" in lib.rbnn_strerror(-1)
 
 
@@ -147,7 +147,7 @@ def test_triple_abi_rejects_bad_arguments():
     net.arch, net.in_features, net.hidden = 1, 784, 512
     img.ld_rows = 800
     assert lib.rbnn_triple_workspace_query(C.byref(net), C.byref(img), 100, 7, C.byref(sizes)) == 0
-    assert (sizes.X_triple, sizes.hid_triple, sizes.g_scale) == (100 * 800 * 6, 7 * 100 * 512 * 6, 256 * 4)
+    assert (sizes.X_triple, sizes.hid_triple, sizes.g_scale) == (112 * 800 * 6, 7 * 112 * 512 * 6, 256 * 4)   # grouped images: whole 16-row groups
     cnet = _hip.ConvPosterior()
     assert lib.rbnn_conv_forward_triple(C.byref(cnet), None, 0, 0, None, None, 784, 4, None, 1, 0, None, None) != 0
     assert lib.rbnn_conv_input_grad_triple(C.byref(cnet), None, 0, 1.0, None, 1, 4, None, None) != 0
