@@ -1389,14 +1389,23 @@ conv_bwd_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2b, int k2_exp
     auto dma4 = [&](const void* g, void* l) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
     };
-    auto stage_chunk = [&](int ch) {                                       // lane p of instruction q lands at byte 256q + 4p of its region
+    // lane p of instruction q lands at byte 256q + 4p of its region — and reads byte 256q + 4p of the chunk's rows: the immediate offset of
+    // global_load_lds applies to both addresses, so up to 16 instructions (offsets 0 .. 3840) share one address register and one M0 write
+    // (one wave per SIMD here: every set-up is time the matrix pipe idles)
+    auto stage_chunk = [&](int ch) {
         const long long fb = sn * F + (long long)ch * NFL;                 // a multiple of 4: the stash dwords are aligned
-#pragma unroll
-        for (int q = 0; q < (NFL + 63) / 64; ++q)
-            if (q * 64 + lane < NFL) dma4(a.dQ2 + fb + q * 64 + lane, sdq + q * 64);
-#pragma unroll
-        for (int q = 0; q < (NFL + 255) / 256; ++q)
-            if (q * 256 + 4 * lane < NFL) dma4(a.st2 + fb + q * 256 + 4 * lane, sst + q * 256);
+        static_for<0, (NFL + 63) / 64>([&](auto Q) {
+            constexpr int q = decltype(Q)::value, q0 = q & ~15;
+            if (q * 64 + lane < NFL)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dQ2 + fb + q0 * 64 + lane),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)(sdq + q0 * 64), 4, (q - q0) * 256, 0);
+        });
+        static_for<0, (NFL + 255) / 256>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            if (q * 256 + 4 * lane < NFL)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.st2 + fb + 4 * lane),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)sst, 4, q * 256, 0);
+        });
     };
     stage_chunk(0);
     for (int ch = 0; ch < NCH; ++ch) {
@@ -1861,11 +1870,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         char* const S = lds + 2 * L::IMG + buf * L::STG;
         const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
         const long long fb = sn * F + (long long)ks * NFL;
-#pragma unroll
-        for (int i = 0; i < (NFL + 511) / 512; ++i) {
-            const int b = 512 * i + 64 * wave;                              // wave-uniform destination base
-            if (b + lane < nvalid) dma4(a.dQ2 + fb + b + lane, (float*)S + b);
-        }
+        static_for<0, (NFL + 511) / 512>([&](auto I) {                       // pieces 2 KiB apart on both sides: pairs share address and M0
+            constexpr int i = decltype(I)::value, i0 = i & ~1;
+            const int b = 512 * i0 + 64 * wave;                             // wave-uniform destination base
+            if (b + 512 * (i - i0) + lane < nvalid)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dQ2 + fb + b + lane),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)((float*)S + b), 4, (i - i0) * 2048, 0);
+        });
         const int d = 64 * wave;                                            // stash: one dword (4 cells) per lane
         if (4 * (d + lane) < nvalid) dma4(a.st2 + fb + 4 * (d + lane), S + NFL * 4 + 4 * d);
     };
