@@ -74,10 +74,12 @@ WORKLOADS = {
     # the grid {2,4,8}/255, 10 000 points.  Shapes are BUILD-DEFINED (3x32x32 -> head 81*Hc; the reference's conv cannot express
     # them, SURVEY 8a note): parity unpinned.  One step = the whole eps grid = 3 x 100 iterations (minutes): profile with
     # --points / --iters overrides, which the line then reports.
-    "c5": dict(shape=(3, 32, 32), H=512, C=10, arch="conv", act="leaky", S=64, N=10000, method="pgd", iters=100,
+    # n_samples = 500 does not divide by 8: rank r holds shard r of the 8-way split (62, 63, 62, 63, ...: floor(500 (r+1) / 8) - floor(500 r / 8)),
+    # so the 8-GPU job runs the config's 500 samples exactly (rounds 2-3 ran 64 per GPU = 512) and per-GPU work stays fixed as GPUs are added
+    "c5": dict(shape=(3, 32, 32), H=512, C=10, arch="conv", act="leaky", S=62, S_split=(500, 8), N=10000, method="pgd", iters=100,
                eps=(2 / 255, 4 / 255, 8 / 255),
                desc="CIFAR-shaped conv-BNN (3x32x32: conv5x5x32 - pool - conv5x5x512 - pool - fc 81*512, leaky; build-defined shapes, parity "
-                    "unpinned), PGD T=100 over eps in {2,4,8}/255, N=10000 points, S=64 samples/GPU (n_samples=500 sharded 8-way)"),
+                    "unpinned), PGD T=100 over eps in {2,4,8}/255, N=10000 points, n_samples=500 sharded 8-way unevenly: 62 / 63 samples per GPU"),
     "c1": dict(shape=(1, 2, 1), H=64, C=2, arch="fc", act="leaky", S=10, N=100, method="fgsm", iters=1, eps=0.3,
                desc="half-moons fc-BNN 2->64->2 (leaky), FGSM eps=0.3, N=100 points, S=10 samples/GPU"),
 }
@@ -223,6 +225,9 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override N (debug)")
     ap.add_argument("--samples", type=int, default=0, help="override S per GPU (debug)")
     ap.add_argument("--iters", type=int, default=0, help="override the PGD iteration count (debug)")
+    ap.add_argument("--samples-total", type=int, default=0,
+                    help="the JOB's posterior samples, split over the ranks as evenly as integers allow (rank r: floor(T (r+1) / G) - floor(T r / G)); "
+                         "c5 defaults to its config's 500 split 8-way (62 / 63 per GPU) whatever --gpus is, so that per-GPU work stays fixed")
     ap.add_argument("--precision", default="auto", choices=["auto", "exact", "triple", "split", "fast"],
                     help="arithmetic of the line's top level.  auto (the package default) = triple (full-width fp32 operands as three f16 pieces, "
                          "six exact product terms, f32 accumulate) where those kernels cover the workload, else exact (fp32 MFMA); the other "
@@ -258,6 +263,16 @@ def main():
         w["S"] = args.samples
     if args.iters:
         w["iters"] = args.iters
+    shard_of = lambda T, ways, r: T * (r + 1) // ways - T * r // ways
+    sr = rank if args.shard == "samples" else 0                           # point-sharded: every rank holds the same (rank 0's) samples
+    S_ranks = [w["S"]] * world
+    if args.samples_total:
+        S_ranks = [shard_of(args.samples_total, world, r if args.shard == "samples" else 0) for r in range(world)]
+    elif "S_split" in w and not args.samples:
+        S_ranks = [shard_of(w["S_split"][0], w["S_split"][1], (r if args.shard == "samples" else 0) % w["S_split"][1]) for r in range(world)]
+    w["S"] = S_ranks[rank]
+    if min(S_ranks) < 1:
+        raise SystemExit(f"--samples-total {args.samples_total}: fewer samples than ranks")
     eps_list = list(w["eps"]) if isinstance(w["eps"], (list, tuple)) else [w["eps"]]
     passes = w.get("passes", len(eps_list))                           # hot-path passes (each N x S x iters attack-samples) per step
     x, y, post = make_problem(w, rank if args.shard == "samples" else 0, device)
@@ -268,7 +283,9 @@ def main():
     if posterior_kind == "config":
         posterior_kind = "svi" if args.workload in SVI_NAMED else "stored"
     sp_svi = None
-    if posterior_kind == "svi" or (world == 1 and w["arch"] != "conv"):
+    # the redrawable SVI stack (a second full posterior + its images) is built only when a run will use it: the line's own kind, or the
+    # "other kind of posterior" sub-record of a single-GPU fc / fc2 line
+    if posterior_kind == "svi" or (world == 1 and w["arch"] != "conv" and not args.no_other_mode):
         loc, scale = make_guide(w, rank if args.shard == "samples" else 0)
         if w["arch"] == "conv":
             from robustbnns_amd.conv import ConvStackedPosterior, ConvSviGuide
@@ -337,7 +354,7 @@ def main():
             return self._timed("conv_input_grad", super().conv_input_grad_split, *a, **kw)
 
     if args.shard == "samples":
-        xs, ys, S_job, N_job = x, y, w["S"] * world, w["N"]
+        xs, ys, S_job, N_job = x, y, sum(S_ranks), w["N"]
     else:
         g = torch.Generator().manual_seed(4321 + rank)                # weak scaling: every rank its own N points
         xs = torch.rand((w["N"],) + w["shape"], generator=g, dtype=torch.float32) if rank else x
@@ -357,8 +374,8 @@ def main():
         kern = TimedKernels()
         post_ = sp_svi if kind == "svi" else sp
         if args.shard == "samples":
-            eng = make_engine(post_, kernels=kern, group=group, total_samples=w["S"] * world, precision=precision)
-            eng._S_total = w["S"] * world
+            eng = make_engine(post_, kernels=kern, group=group, total_samples=S_job, precision=precision)
+            eng._S_total = S_job
         else:
             eng = make_engine(post_, kernels=kern, precision=precision)
         draws = [0]
@@ -507,17 +524,39 @@ def main():
             kernels[name] = {"launches": len(evs), "launches_per_pass": lpp, "avg_ms": ms,
                              "tflops": per_launch / lpp / (ms * 1e-3) / 1e12 if ms else None}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
-        traffic, traffic_src = None, None
+        # PMC counters cannot be read inside this run: profiles/pmc_traffic.json is the committed rocprofv3 --pmc pass of the same workload
+        # (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x 2 on gfx950), keyed by workload, with the
+        # points x samples it ran at.  A conv record taken at another size is scaled by points x samples (the per-(point, sample)
+        # activations are > 95 % of that path's traffic) and says so; an fc record (weights + activations) is used at its own size only.
+        traffic, traffic_src, counter, scaled = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and not args.points and not args.samples:
+        if os.path.exists(pmc):
             rec = json.load(open(pmc))
-            key = dom + ("_" + mode if dom in F16_KERNELS.get(mode, ()) else "")
-            ent = rec.get(args.workload, rec if args.workload == "c2" else {}).get(key, {})
-            traffic = ent.get("hbm_bytes_per_launch")
-            traffic_src = rec.get("source") if traffic is not None else None
+            wl = rec.get(args.workload) or {}
+            tab, scale, scaled = wl.get("kernels", {}), 1.0, None
+            if wl.get("points") and (wl["points"], wl["samples"]) != (w["N"], w["S"]):
+                if w["arch"] == "conv":
+                    scale = w["N"] * w["S"] / float(wl["points"] * wl["samples"])
+                    scaled = "scaled x%.4g from the record's N=%d, S=%d by points x samples" % (scale, wl["points"], wl["samples"])
+                else:
+                    tab = {}
+            sfx = "_" + mode if mode in F16_KERNELS else ""
+            keys = {"fc_forward": ["fc_forward" + sfx], "fc_input_grad": ["fc_input_grad" + sfx], "lowdim": ["lowdim"],
+                    "conv_forward": ["conv_forward" + sfx, "conv_forward_common"], "conv_input_grad": ["conv_input_grad" + sfx, "conv_input_grad_common"]}
+            def tot(names):
+                return sum(tab[n]["hbm_bytes_per_launch"] for n in names) * scale if names and all(n in tab for n in names) else None
+            traffic = tot(keys.get(dom))
+            if traffic is not None:
+                traffic /= kernels[dom]["launches_per_pass"]
+                traffic_src = rec.get("source")
+            calls = [k for k in kernels if k in keys]
+            if calls and all(tot(keys[k]) is not None for k in calls):
+                small = sum(v["hbm_bytes_per_launch"] for v in wl.get("small", {}).values()) * scale
+                counter = {"bytes_per_pass": sum(tot(keys[k]) for k in calls) + small, "small_kernels_bytes": small, "scaled": scaled,
+                           "kernels": {k: tot(keys[k]) for k in calls}}
         fp32_eq = kernels[dom]["tflops"]
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
-             "traffic_source": traffic_src,      # PMC counters cannot be read inside this run: a committed rocprofv3 --pmc pass of the same command
+             "traffic_source": traffic_src, "traffic_scaled": scaled if traffic is not None else None,
              "flop_per_launch": (2 if dom == "lowdim" else 1) * per_launch / kernels[dom]["launches_per_pass"], "avg_launch_ms": kernels[dom]["avg_ms"], "kernels": kernels}
         if dom in F16_KERNELS.get(mode, ()):
             # matrix-pipe work of the split / triple mode: 3 / 6 f16 products per algorithmic fp32 MAC (the dA generator's MFMAs are not counted)
@@ -546,6 +585,15 @@ def main():
         # PMC-counted bytes of the two GEMM kernels (when a committed pass covers this workload) over the same time
         r["hbm"] = {"algorithmic_bytes_per_pass": alg_bytes, "algorithmic_gbs": alg_bytes / (1e-3 * ms_per_pass) / 1e9,
                     "peak_gbs": HBM_PEAK_GBS, "frac": alg_bytes / (1e-3 * ms_per_pass) / 1e9 / HBM_PEAK_GBS}
+        if counter is not None:
+            # per-GPU bytes moved beyond the L2 by ALL kernels of one hot-path pass (FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes)
+            # over this run's pass time: BASELINE.json configs[4]'s "per-GPU HBM GB/s vs roofline"; counter / algorithmic = re-read + spilled
+            # intermediates (part of it served by the 256 MB Infinity Cache: the counters sit between L2 and the fabric)
+            gbs = counter["bytes_per_pass"] / (1e-3 * ms_per_pass) / 1e9
+            r["hbm"].update({"counter_bytes_per_pass": counter["bytes_per_pass"], "counter_gbs": gbs, "counter_frac_of_peak": gbs / HBM_PEAK_GBS,
+                             "counter_over_algorithmic": counter["bytes_per_pass"] / alg_bytes, "counter_bytes_by_call": counter["kernels"],
+                             "counter_small_kernels_bytes": counter["small_kernels_bytes"], "counter_scaled": counter["scaled"],
+                             "counter_source": traffic_src})
         return r
 
     DTYPES = {"exact": "f32", "lowdim": "f32",
@@ -579,12 +627,13 @@ def main():
             "value": units / dt, "unit": "attack-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
-            "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job,
+            "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job, "samples_per_rank": S_ranks,
                        "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none",
                        "posterior": ("svi: variational guide, all S samples redrawn in place (rbnn_svi_draw) every step — PGD: every iteration — inside "
                                      "the timed region" if posterior_kind == "svi" else
                                      "stored samples (HMC-style)"),
-                       "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters)) if v}},
+                       "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters),
+                                                       ("samples_total", args.samples_total)) if v}},
             "roofline": roofline(mode, evs, ms_per_step),
         }
         if svi_rec is not None:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 7
+#define RBNN_ABI_VERSION 8
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {
@@ -103,6 +103,10 @@ typedef struct rbnn_workspace_sizes {  /* bytes; 0 = not needed for this posteri
 } rbnn_workspace_sizes;
 
 int rbnn_abi_version(void);
+/* 0 for a product build.  Bit 0: a translation unit of this library was compiled with a timing-only ablation switch (RBNN_ABL,
+ * RBNN_*_ABL_*, RBNN_FAST_BUILD — csrc/rbnn_common.hpp; such kernels compute WRONG results by design and need -DRBNN_ALLOW_ABLATION
+ * to compile at all).  robustbnns_amd._hip.load() refuses a library whose flags are not 0 unless RBNN_ALLOW_ABLATION=1. */
+int rbnn_build_flags(void);
 const char *rbnn_strerror(int status);
 
 /* Sizes of every workspace buffer for N points x S used samples.  chunk<=0: library picks. [host] */
@@ -460,6 +464,9 @@ typedef struct rbnn_svi_guide {    /* device pointers to the variational paramet
 #define RBNN_SVI_EPS_MAX 6.77f
 int rbnn_svi_draw(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
                   const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
+/* 1 when rbnn_svi_draw covers this posterior (fc / fc2; W2 [n_classes, hidden] fits the 160 KB of LDS it is staged in; with triple
+ * images: n_classes <= 10, hidden % 128 == 0) — the host falls back to rbnn_svi_materialize + a new stack otherwise. */
+int rbnn_svi_draw_supported(const rbnn_posterior *net, int32_t with_triple_images);
 
 /* The same draw for tensors of any shape (the conv architecture: model.0 / .3 / .7 weights and biases), written IN PLACE into the fp32
  * stack: out[s, e] = loc[e] + sigma[e] * eps, eps of element e = component e % 4 of the Philox block with counter

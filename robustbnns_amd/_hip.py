@@ -110,6 +110,7 @@ _PP, _PW, _PS = C.POINTER(Posterior), C.POINTER(Workspace), C.POINTER(WorkspaceS
 # name -> (restype, argtypes): exactly the declarations of include/robustbnns_hip.h
 SIGNATURES = {
     "rbnn_abi_version": (_i32, []),
+    "rbnn_build_flags": (_i32, []),
     "rbnn_strerror": (C.c_char_p, [_i32]),
     "rbnn_workspace_query": (_i32, [_PP, _i32, _i32, _i32, _PS]),
     "rbnn_fc_forward": (_i32, [_PP, _fp, _i32, _i32, _fp, _i32, _i32, _PW, _fp]),
@@ -154,9 +155,11 @@ SIGNATURES = {
                                _fp, _fp, _i32, _fp, _fp, _fp]),
     "rbnn_svi_draw_flat": (_i32, [C.POINTER(SviFlatTensor), _i32, _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
     "rbnn_svi_draw": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
+    "rbnn_svi_draw_supported": (_i32, [_PP, _i32]),
 }
 
 _lib = None
+ABI_VERSION = 8
 
 
 class HipError(RuntimeError):
@@ -174,8 +177,13 @@ def load():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if lib.rbnn_abi_version() != 7:
-            raise HipError("librbnn_hip.so ABI version mismatch")
+        if lib.rbnn_abi_version() != ABI_VERSION:
+            raise HipError(f"librbnn_hip.so ABI version {lib.rbnn_abi_version()} != {ABI_VERSION}: rebuild it (__graft_entry__.build())")
+        flags = lib.rbnn_build_flags()
+        if flags != 0 and os.environ.get("RBNN_ALLOW_ABLATION") != "1":
+            raise HipError(f"librbnn_hip.so was built with timing-only ablation switches (rbnn_build_flags() = {flags}): its kernels compute "
+                           "wrong results by design.  Rebuild it (`python __graft_entry__.py --force`); the scripts under tools/ that build "
+                           "such variants set RBNN_ALLOW_ABLATION=1 for their own runs.")
         _lib = lib
     return _lib
 
@@ -434,6 +442,9 @@ class HipKernels:
         require_gpu(loc, "loc")
         check(self.lib.rbnn_svi_materialize(ptr(loc), ptr(scale_raw), ptr(eps), loc.numel(), eps.shape[0], ptr(out),
                                             stream_of(loc)), "rbnn_svi_materialize")
+
+    def svi_draw_supported(self, net, with_triple_images):
+        return bool(self.lib.rbnn_svi_draw_supported(C.byref(net.descriptor()), int(bool(with_triple_images))))
 
     def svi_draw(self, net, images, guide, S, key, draw_id, sample_keys=None):
         """One launch: samples [0, S) of the stacked posterior `net` and all its weight images redrawn IN PLACE from the guide

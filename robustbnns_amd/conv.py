@@ -142,6 +142,13 @@ class ConvStackedPosterior:
                          torch.empty(S * 32, (H // 16) * 13 * 32, dtype=torch.float32, device=self.device))
         return self._tmp
 
+    def _free_staging(self):
+        """A stored (HMC / ensemble) posterior builds its images ONCE: the builders' staging buffers — a second copy of the triple rows image,
+        three fp32 regroupings, the dense image's two — go back to the allocator (at Hc = 512 they are ~100 MB per 50 samples EACH, i.e. they
+        would double or triple the resident size of the posterior).  A redrawable SVI stack (for_guide) keeps them: it rebuilds per draw."""
+        if self._guide is None:
+            self._tmp = self._dense_tmp = self._dense_stage = self._rows_stage = None
+
     def dense_supported(self):
         """The dense conv2^T kernel (rbnn_conv_input_grad_dense) is built for the 1x28x28 geometry."""
         return self.input_shape == (1, 28, 28) and os.environ.get("RBNN_CONV_BWD_DENSE", "1") != "0"
@@ -220,6 +227,7 @@ class ConvStackedPosterior:
             if self.dense_supported():
                 self._dense = torch.empty(S * ((H + 31) // 32) * 25 * 32, 32 * 3, dtype=torch.int16, device=self.device)
                 self._build_dense(self._dense)
+            self._free_staging()
         return self._triple
 
     # ------------------------------------------------------------------ split-half precision mode (forward conv2)
@@ -237,6 +245,7 @@ class ConvStackedPosterior:
             k2_exp = self._build_split(rows, bwd)
             w_l1, b_max = self._p1()
             self._split = (rows, k2_exp, w_l1, b_max, bwd, self._fw_l1())
+            self._free_staging()
         return self._split
 
     @classmethod

@@ -19,6 +19,18 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef RBNN_ABL
 #define RBNN_ABL 0
 #endif
+// FENCE: every timing-only ablation switch (results wrong by design) needs -DRBNN_ALLOW_ABLATION beside it, and a translation unit built
+// with one plants the (weak) marker rbnn_ablation_build_marker, which rbnn_build_flags() reports: robustbnns_amd._hip.load() refuses such
+// a library unless RBNN_ALLOW_ABLATION=1 is in the environment (the variant scripts under tools/ set it for their own runs only).
+#if (RBNN_ABL != 0) || defined(RBNN_X3FWD_ABL_NOFILL) || defined(RBNN_X3FWD_ABL_NOEPI) || defined(RBNN_DENSE_ABL_NOA) || \
+    defined(RBNN_DENSE_ABL_NOMFMA) || defined(RBNN_DENSE_ABL_NOB) || defined(RBNN_DENSE_ABL_NOBAR) || defined(RBNN_DENSE_ABL_NOAREAD) || \
+    defined(RBNN_DENSE_ABL_NOROUTE) || defined(RBNN_DENSE_ABL_NOEPI) || defined(RBNN_X3_L1_ABL_NOSTORE) || defined(RBNN_X3_L1_ABL_SMALL) || \
+    defined(RBNN_FAST_BUILD)
+#ifndef RBNN_ALLOW_ABLATION
+#error "a timing-only ablation switch (RBNN_ABL / RBNN_*_ABL_* / RBNN_FAST_BUILD) is set: such a build computes wrong results; pass -DRBNN_ALLOW_ABLATION to build it on purpose"
+#endif
+extern "C" __attribute__((weak, visibility("default"))) int rbnn_ablation_build_marker = 1;
+#endif
 // s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14)
 #define VMCNT(n) ((((n) & 15) | (((n) >> 4) << 14)) | 0x0F70)
 #define VMCNT_LGKM0(n) ((((n) & 15) | (((n) >> 4) << 14)) | 0x0070)

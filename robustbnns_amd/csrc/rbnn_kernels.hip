@@ -825,6 +825,10 @@ extern "C" {
 
 int rbnn_abi_version(void) { return RBNN_ABI_VERSION; }
 
+// 0 for a product build; bit 0: some translation unit of this library was compiled with a timing-only ablation switch (rbnn_common.hpp)
+extern __attribute__((weak)) int rbnn_ablation_build_marker;
+int rbnn_build_flags(void) { return (&rbnn_ablation_build_marker != nullptr) ? 1 : 0; }
+
 const char* rbnn_strerror(int status) {
     switch (status) {
         case RBNN_OK: return "ok";

@@ -303,6 +303,18 @@ int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor* tensors, int32_t n_tensors, i
     return launch_status();
 }
 
+// the small-tensor block stages W2 [C, H] in dynamic LDS: C * H * 4 bytes of the CU's 160 KB (hidden 4096 at 10 classes)
+static constexpr size_t SVI_DRAW_LDS_MAX = 160 * 1024;
+
+int rbnn_svi_draw_supported(const rbnn_posterior* net, int32_t with_triple_images) {
+    if (!net || (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2)) return 0;
+    const int H = net->hidden, C = net->n_classes;
+    if (H < 32 || (H & 31) || C < 1 || C > 16 || net->in_features < 1 || net->in_stride < net->in_features || (net->in_stride & 15)) return 0;
+    if ((size_t)C * H * sizeof(float) > SVI_DRAW_LDS_MAX) return 0;
+    if (with_triple_images && (C > 10 || (H & 127))) return 0;
+    return 1;
+}
+
 int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
                   const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, void* stream) {
     if (!net || !g || !net->W1 || !net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
@@ -328,7 +340,9 @@ int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const
     a.tiles_wm_d = fc2 ? (H + 63) / 64 : 0;
     a.tiles_per_sample = (H / 32) * (a.tiles_w1_d + a.tiles_wm_d) + 1;
     const size_t lds = std::max((size_t)32 * 68 * sizeof(float), (size_t)C * H * sizeof(float));
-    if (lds > 64 * 1024) return RBNN_ERR_SHAPE;
+    if (lds > SVI_DRAW_LDS_MAX) return RBNN_ERR_SHAPE;                     // rbnn_svi_draw_supported() says so beforehand
+    static unsigned long long attr = 0;
+    if (lds > 64 * 1024 && !ensure_dynamic_lds((const void*)svi_draw_kernel, (int)SVI_DRAW_LDS_MAX, attr)) return RBNN_ERR_LAUNCH;
     hipLaunchKernelGGL(svi_draw_kernel, dim3((unsigned)((long long)n_samples * a.tiles_per_sample)), dim3(256), lds, (hipStream_t)stream, a);
     return launch_status();
 }

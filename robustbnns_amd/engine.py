@@ -183,6 +183,10 @@ class AttackEngine:
             self._ws_cache[key] = ws            # re-inserted: the dict's order is the order of last use
         if ws is None:
             sizes = self.k.workspace_sizes(self.post, N, S, chunk)
+            if self.precision == "triple":
+                gb = self._fc2_groups(N, S, sizes["chunk"])[1]
+                if gb < S:                                          # fc2, grouped backward: dL/d(pre-activation 1) of gb samples at a time
+                    sizes["dhid1"] = sizes["dhid1"] // S * gb
             ws = {"n_slabs": sizes["n_slabs"], "chunk": sizes["chunk"]}
             for name in _hip.WS_KEYS:
                 if sizes[name]:
@@ -195,10 +199,18 @@ class AttackEngine:
                                "dZ_gen": torch.empty(ssz["dZ_gen"] // 2, dtype=torch.int16, device=self.device),
                                "g_scale": torch.empty(ssz["g_scale"] // 4, dtype=torch.float32, device=self.device)}
             if self.precision == "triple":
+                gf, gb = self._fc2_groups(N, S, ws["chunk"])
                 tsz = self.k.triple_workspace_sizes(self.post, self.post.triple_images(), N, S)
-                ws["triple"] = {k: torch.empty(max(1, v // 2), dtype=torch.int16, device=self.device) for k, v in tsz.items() if v}
+                if gf < S:                                          # fc2, grouped: ONE hidden image of gf samples, reused group after group
+                    tsz["hid_triple"] = tsz["hid_triple"] // S * gf
+                # X_triple / hid_triple are ZEROED once: the forward kernel DMA-reads whole 16-row groups, and rows N .. ceil16(N) - 1 are never
+                # written by the image builders — their products land in accumulator columns that are never stored, but they must not be
+                # stale NaN / Inf halves of another call's data (invariant stated in include/robustbnns_hip.h)
+                ws["triple"] = {k: (torch.zeros if k in ("X_triple", "hid_triple") else torch.empty)(max(1, v // 2), dtype=torch.int16, device=self.device)
+                                for k, v in tsz.items() if v}
                 ws["triple"]["g_scale"] = ws["triple"]["g_scale"].view(torch.float32)
                 ws.pop("hid1", None)                                # the hidden activations live in the triple image instead
+                ws["fc2_groups"] = (gf, gb)
             while len(self._ws_cache) > 6:      # evict the LEAST RECENTLY USED entry only: a sharded step holds at most RBNN_COMM_BLOCKS (<= 6) live
                 self._ws_cache.pop(next(iter(self._ws_cache)))    # workspaces with pending all-reduce handles, all younger than it
             self._ws_cache[key] = ws
@@ -210,7 +222,14 @@ class AttackEngine:
             img = self.post.triple_images()
             ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
             self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds, grouped=True)
-            return self.k.fc_forward_triple(self.post, img, ws["triple"], 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
+            gf = ws.get("fc2_groups", (S, S))[0]
+            if gf >= S:
+                return self.k.fc_forward_triple(self.post, img, ws["triple"], 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
+            for s0 in range(0, S, gf):          # fc2: layer 1 -> layer 2 per group of samples through ONE reused hidden image (_fc2_groups)
+                g = min(gf, S - s0)
+                self.k.fc_forward_triple(self.post, img, ws["triple"], 0, Xp.shape[0], self._sample_slice(sidx, s0, g), g, out_kind,
+                                         self._ws_samples(ws, s0, Xp.shape[0]), dev_scales=ds)
+            return None
         if self.precision != "split":
             return self.k.fc_forward(self.post, Xp, sidx, S, out_kind, ws)
         img = self.post.split_images()
@@ -220,10 +239,62 @@ class AttackEngine:
 
     def _grad_kernels(self, sidx, S, N, ws):
         if self.precision == "triple":
-            return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["triple"])
+            gb = ws.get("fc2_groups", (S, S))[1]
+            if gb >= S:
+                return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["triple"])
+            n_slabs = 0                         # fc2: step 1 -> step 2 per group of samples (a multiple of the slab chunk) through ONE reused dhid1
+            for s0 in range(0, S, gb):
+                g = min(gb, S - s0)
+                n_slabs += self.k.fc_input_grad_triple(self.post, self.post.triple_images(), self._sample_slice(sidx, s0, g), g, N, ws["chunk"],
+                                                       self._ws_samples(ws, s0, N, n_slabs), ws["triple"])
+            return n_slabs
         if self.precision != "split" or (self.post.arch == "fc2" and os.environ.get("RBNN_FC2_BWD_EXACT") == "1"):
             return self.k.fc_input_grad(self.post, sidx, S, N, ws["chunk"], ws)
         return self.k.fc_input_grad_split(self.post, self.post.split_images(), sidx, S, N, ws["chunk"], ws, ws["split"])
+
+    def _fc2_groups(self, N, S, chunk):
+        """(forward, backward) sample-group sizes of the triple-mode fc2 path.  Layer 1 writes the hidden activations of every (sample,
+        point) as a triple image for layer 2 to read back (3 GB at C2's size, S x N x H x 6 B), and the backward does the same with dhid1
+        (fp32, 2 GB).  Run group after group through ONE buffer of g samples, the image a layer reads is the one the layer before it has
+        just written — inside the 256 MB Infinity Cache when g x N x H x 6 B fits — and the workspace shrinks by (S - g) / S.
+        RBNN_FC2_GROUP (both) / RBNN_FC2_GROUP_FWD / RBNN_FC2_GROUP_BWD override (0 = one group of S); the backward's group is rounded
+        to a multiple of the slab chunk (a slab sums the samples of one chunk)."""
+        if getattr(self.post, "arch", None) != "fc2":
+            return S, S
+        both = os.environ.get("RBNN_FC2_GROUP")
+        want_f = os.environ.get("RBNN_FC2_GROUP_FWD", both)
+        want_b = os.environ.get("RBNN_FC2_GROUP_BWD", both)
+        per_sample = (N + 15) // 16 * 16 * self.post.Hp * 6
+        auto = max(1, int(self._FC2_GROUP_BYTES // per_sample)) if self._FC2_GROUP_BYTES else S
+        gf = int(want_f) if want_f not in (None, "") else auto
+        gb = int(want_b) if want_b not in (None, "") else auto
+        gf = S if gf <= 0 else min(S, gf)
+        gb = S if gb <= 0 else min(S, max(chunk, gb // chunk * chunk))
+        return gf, gb
+
+    _FC2_GROUP_BYTES = 0                    # default group = this many bytes of hidden image (0: no grouping); set from the A/B in profiles/r04a
+
+    def _sample_slice(self, sidx, s0, g):
+        """The index buffer of samples [s0, s0 + g) of a call (the kernels take weights AND workspace rows by it / by position)."""
+        if sidx is not None:
+            return sidx[s0:s0 + g]
+        if getattr(self, "_arange", None) is None or self._arange.numel() < s0 + g:
+            self._arange = torch.arange(max(self.post.S, s0 + g), dtype=torch.int32, device=self.device)
+        return self._arange[s0:s0 + g]
+
+    def _ws_samples(self, ws, s0, N, slab0=None):
+        """The workspace as samples [s0, ...) see it: every per-sample buffer advanced by s0 samples (the kernels index them from 0);
+        hid_triple / dhid1 are group-local (not advanced); slabs advanced by the slabs already written."""
+        H = self.post.Hp
+        n_pad = (N + 255) // 256 * 256
+        stride = {"P": N * _hip.CPAD, "dZ": N * _hip.CPAD, "mask1": (H // 32) * n_pad, "mask2": (H // 32) * n_pad, "dact1": N * H, "dact2": N * H}
+        out = dict(ws)
+        for k, st in stride.items():
+            if k in ws:
+                out[k] = ws[k][s0 * st:]
+        if slab0:
+            out["slabs"] = ws["slabs"][slab0 * N * self.post.Dp:]
+        return out
 
     def _input_scales(self, X, iterates):
         """Split mode: the power-of-two scales of the inputs' half-pair image (and of the activations they bound: fc2 hidden

@@ -240,8 +240,14 @@ class BNN(nn.Module):
 
     # ------------------------------------------------------------------ svi: in-place redraw (fc / fc2 on the GPU)
     def _in_place(self):
-        return (self.inference == "svi" and self.basenet.architecture in ("fc", "fc2", "conv") and self.svi_rng == "device"
-                and torch.device(self.device).type == "cuda")
+        ok = (self.inference == "svi" and self.basenet.architecture in ("fc", "fc2", "conv") and self.svi_rng == "device"
+              and torch.device(self.device).type == "cuda")
+        if ok and self.basenet.architecture != "conv":
+            # rbnn_svi_draw stages W2 [C, H] in LDS (160 KB: hidden <= 4096 at 10 classes); a wider net keeps the older path
+            # (draw_posterior: rbnn_svi_materialize into a new stack), which has no such limit
+            b = self.basenet
+            ok = int(b.output_size) * max(32, int(b.hidden_size)) * 4 <= 160 * 1024
+        return ok
 
     def _new_slot(self, n_samples):
         b = self.basenet
@@ -290,8 +296,10 @@ class BNN(nn.Module):
         if avg_posterior is True:                         # model_bnn.py:206-216: logits of the mean weights
             stacked = {k: v.unsqueeze(0) for k, v in self.svi_loc.items()}
             return make_engine(self._make_posterior(stacked, self.device)), 1, None, True
-        ver = tuple(t._version for t in list(self.svi_loc.values()) + list(self.svi_scale.values()))
-        if ver != getattr(self, "_guide_ver", None):       # the guide was edited in place: its bounds, stacks and seeded draws are stale
+        # (identity, version) of every variational tensor: an in-place edit bumps _version, a REPLACED tensor (net.svi_loc[k] = new, version 0
+        # again) changes data_ptr — either way the guide's bounds (hard bounds of the fp16 piece scaling), stacks and seeded draws are stale
+        ver = tuple((t.data_ptr(), t._version) for t in list(self.svi_loc.values()) + list(self.svi_scale.values()))
+        if ver != getattr(self, "_guide_ver", None):
             self._guide_ver, self._drawn, self._guide, self._slots = ver, None, None, {}
         if not seeds:                                     # the reference draws from the live RNG: fresh weights on every call
             if self._in_place():

@@ -139,12 +139,14 @@ def assert_close_to_truth(val, truth64, tol=1e-5, noise=None, what="", rows=None
     return int((bound > tol).sum())
 
 
-def pgd_whole_attack_statistic(what, adv, ref):
-    """Fraction of pixels of a whole 40-step PGD attack that differ from the reference's — REPORTED, not a parity criterion: the map is
-    chaotic (one noise-level gradient component flipping sign at some iterate moves that pixel across the eps-ball and can redirect later
-    iterates).  Parity of the step itself is asserted exactly, one step at a time along the reference's own iterates
-    (test_pgd_single_steps_along_the_reference_trajectory).  A sanity bound only catches a step that is broken outright."""
+def pgd_whole_attack_statistic(what, adv, ref, bound=0.02):
+    """Fraction of pixels of a whole 40-step PGD attack that differ from the reference's: printed AND held to the end-to-end gate of the
+    multi-iteration loop (alpha taken once from x0, projection around x0, the before_step / redraw ordering, the one-launch lowdim loop) —
+    the single-step test along the reference's iterates (test_pgd_single_steps_along_the_reference_trajectory) does not exercise those.
+    The map is chaotic (a noise-level gradient component flipping sign at some iterate moves that pixel across the eps-ball), hence a
+    fraction and not zero; every fixture measures 0.000 % (profiles/r03z/pytest_gpu.log), the bound stays at round 1's 2 %.  A fixture that
+    needs more must say so by passing its own `bound`, with the measured value in a comment."""
     frac = float(((torch.as_tensor(adv).cpu() - torch.as_tensor(ref)).abs() > 1e-6).double().mean())
-    print(f"[pgd whole-attack statistic] {what}: {100 * frac:.3f} % of the pixels differ from the reference's after 40 steps")
-    assert frac < 0.25
+    print(f"[pgd whole-attack statistic] {what}: {100 * frac:.3f} % of the pixels differ from the reference's after 40 steps (bound {100 * bound:.1f} %)")
+    assert frac < bound, f"{what}: {100 * frac:.3f} % of the pixels differ after the whole attack"
     return frac

@@ -336,6 +336,43 @@ def test_fc2_bench_shape_triple_vs_exact():
     assert ev_e[0] == ev_t[0] and ev_e[1] == ev_t[1] and float((ev_e[2] - ev_t[2]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("act,gf,gb", [("leaky", 5, 8), ("tanh", 7, 4), ("leaky", 1, 1)])
+def test_fc2_sample_groups_reproduce_the_ungrouped_pass(act, gf, gb, monkeypatch):
+    """fc2 in the triple mode run group after group through ONE reused hidden image / dhid1 buffer (AttackEngine._fc2_groups): the
+    forward is bit-identical to the one-group pass (a sample's blocks do not depend on the others'); the gradients agree to fp32
+    rounding (the per-point gradient scale e(n) is taken over a group's samples instead of all of them: the pieces stay exact, only
+    sub-2^-39 tails move); a ragged last group, a sample-index call and the workspace's size are covered."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    S, N, Hn, Cn, Dn = 22, 700, 256, 10, 784
+    post = O.synthetic_posterior("fc2", Dn, Hn, Cn, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=72)
+    sp = StackedPosterior("fc2", act, (1, 28, 28), Cn, Hn, post, DEV)
+    lab = y.argmax(-1).int().to(DEV)
+    seeds = [3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8]
+    res = {}
+    for tag, env in (("one", ("0", "0")), ("grouped", (str(gf), str(gb)))):
+        monkeypatch.setenv("RBNN_FC2_GROUP_FWD", env[0])
+        monkeypatch.setenv("RBNN_FC2_GROUP_BWD", env[1])
+        eng = AttackEngine(sp, precision="triple")
+        ws = eng.workspace(N, S)
+        res[tag] = dict(groups=ws["fc2_groups"], hid=ws["triple"]["hid_triple"].numel(), dhid=ws["dhid1"].numel(), chunk=ws["chunk"],
+                        probs=eng.forward(x, S).cpu(), G=eng.gradient(eng.pad_inputs(x), lab, None, S, _hip.LOSS_MEAN_PROB)[:, :Dn].cpu().clone(),
+                        Gl=eng.loss_gradients(x, y, S).cpu(), adv=eng.fgsm(x, y, S, 0.3).cpu(),
+                        ps=eng.forward(x, len(seeds), seeds=seeds).cpu(), gs=eng.fgsm(x, y, len(seeds), 0.1, seeds=seeds).cpu())
+    one, grp = res["one"], res["grouped"]
+    assert one["groups"] == (S, S) and grp["groups"][0] == gf and grp["groups"][1] % grp["chunk"] == 0 and grp["groups"][1] < S
+    assert grp["hid"] * S == one["hid"] * gf and grp["dhid"] * S == one["dhid"] * grp["groups"][1]     # the workspace shrinks with the group
+    assert torch.equal(one["probs"], grp["probs"]) and torch.equal(one["ps"], grp["ps"])
+    assert rel_err(grp["G"], one["G"]) < 2e-6 and rel_err(grp["Gl"], one["Gl"]) < 2e-6
+    safe = one["G"].abs() > TAU * one["G"].abs().max(1, keepdim=True)[0]
+    assert int((((one["adv"] - grp["adv"]).abs().reshape(N, -1) > 1e-6) & safe).sum()) == 0
+    assert float(((one["gs"] - grp["gs"]).abs() > 1e-6).float().mean()) < 1e-4
+    p64 = O.cast(post, torch.float64)
+    g64 = O.meanprob_gradients(x[:64].double(), y[:64].argmax(-1), p64, "fc2", act, S).reshape(64, -1)
+    far = O.kink_margin(x[:64].double(), p64, "fc2", act, S) > KINK if act == "leaky" else torch.ones(64, dtype=torch.bool)
+    assert int(far.sum()) >= 8 and rel_err(grp["G"][:64][far], g64[far]) < TOL
+
+
 @pytest.mark.parametrize("shape,N,S", [((1, 28, 28), 300, 3), ((3, 32, 32), 150, 2)])
 def test_conv_bench_shape_triple_vs_exact(shape, N, S):
     """conv-512 on both geometries at a few hundred points: the triple conv2 forward / conv2^T backward against the fp32-MFMA kernels on

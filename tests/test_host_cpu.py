@@ -30,8 +30,44 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rbnn_abi_version() == 7
+    assert lib.rbnn_abi_version() == _hip.ABI_VERSION == 8
+    assert lib.rbnn_build_flags() == 0                       # a product build: no timing-only ablation switch in any translation unit
     assert lib.rbnn_strerror(0) == b"ok" and b"NULL" in lib.rbnn_strerror(-1)
+
+
+def test_ablation_switches_are_fenced(tmp_path):
+    """The timing-only switches compiled into the product kernels (RBNN_ABL, RBNN_*_ABL_*, RBNN_FAST_BUILD: wrong results by design)
+    do not compile without -DRBNN_ALLOW_ABLATION, and a translation unit built with one makes rbnn_build_flags() non-zero — which
+    _hip.load() refuses.  Host-side compile of the common header only (seconds, no GPU)."""
+    import subprocess
+    import __graft_entry__ as ge
+    src = tmp_path / "probe.hip"
+    src.write_text('#include "%s/rbnn_common.hpp"\n'
+                   'extern __attribute__((weak)) int rbnn_ablation_build_marker;\n'
+                   'int main() { return (&rbnn_ablation_build_marker != nullptr) ? 7 : 0; }\n' % ge.CSRC)
+    base = [ge.HIPCC, "--offload-arch=gfx950", "-std=c++17", "--cuda-host-only", "-o", str(tmp_path / "probe"), str(src)]
+    r = subprocess.run(base + ["-DRBNN_DENSE_ABL_NOEPI"], capture_output=True, text=True)
+    assert r.returncode != 0 and "RBNN_ALLOW_ABLATION" in r.stderr
+    for flag in ("-DRBNN_ABL=4", "-DRBNN_X3_L1_ABL_SMALL", "-DRBNN_FAST_BUILD"):
+        assert subprocess.run(base + [flag], capture_output=True).returncode != 0
+    assert subprocess.run(base, capture_output=True).returncode == 0 and subprocess.run([str(tmp_path / "probe")]).returncode == 0
+    assert subprocess.run(base + ["-DRBNN_DENSE_ABL_NOEPI", "-DRBNN_ALLOW_ABLATION"], capture_output=True).returncode == 0
+    assert subprocess.run([str(tmp_path / "probe")]).returncode == 7          # the marker is planted: rbnn_build_flags() would say 1
+
+
+def test_load_refuses_a_library_built_with_ablation_switches(monkeypatch):
+    class Fake:
+        def __getattr__(self, name):
+            f = lambda *a: {"rbnn_abi_version": _hip.ABI_VERSION, "rbnn_build_flags": 1}.get(name, 0)
+            return f
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip.C, "CDLL", lambda path: Fake())
+    monkeypatch.delenv("RBNN_ALLOW_ABLATION", raising=False)
+    with pytest.raises(_hip.HipError, match="ablation"):
+        _hip.load()
+    monkeypatch.setenv("RBNN_ALLOW_ABLATION", "1")
+    assert _hip.load() is not None
+    monkeypatch.setattr(_hip, "_lib", None)                  # the next load() binds the real library again
 
 
 def _net(**kw):

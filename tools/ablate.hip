@@ -1,5 +1,5 @@
 // Diagnostic: time the two GEMM kernels of the C2 workload with parts of their K loops switched off.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_FAST_BUILD -DRBNN_ABL=<bits> -o /tmp/ablate_<bits> tools/ablate.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_ALLOW_ABLATION -DRBNN_FAST_BUILD -DRBNN_ABL=<bits> -o /tmp/ablate_<bits> tools/ablate.hip
 // Results of RBNN_ABL != 0 builds are wrong by construction; only the timings mean anything.
 #include "../robustbnns_amd/csrc/rbnn_kernels.hip"
 #include <cstdio>

@@ -1,5 +1,5 @@
 // Diagnostic: time the split-precision GEMM kernels of the C2 workload (variants via -D flags; see tools/run_variants_split.sh).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_FAST_BUILD <-D...> -o /tmp/abls tools/ablate_split.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_ALLOW_ABLATION -DRBNN_FAST_BUILD <-D...> -o /tmp/abls tools/ablate_split.hip
 #include "../robustbnns_amd/csrc/rbnn_kernels.hip"
 #include "../robustbnns_amd/csrc/rbnn_split.hip"
 #include <cstdio>

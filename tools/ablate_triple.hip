@@ -1,5 +1,5 @@
 // Diagnostic: time the triple-split GEMM kernels of the C2 workload (variants via -D flags; see tools/run_variants_triple.sh).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_FAST_BUILD <-D...> -o /tmp/ablt tools/ablate_triple.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_ALLOW_ABLATION -DRBNN_FAST_BUILD <-D...> -o /tmp/ablt tools/ablate_triple.hip
 #include "../robustbnns_amd/csrc/rbnn_kernels.hip"
 #ifdef RBNN_TRIPLE_ALT                                     // A/B against another version of the kernels: put it at tools/rbnn_triple_alt.hip
 #include "rbnn_triple_alt.hip"

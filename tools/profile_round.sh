@@ -30,23 +30,23 @@ if [ "$STAGE" = "bench" ]; then
 fi
 if [ "$STAGE" = "prof" ]; then
 cd /tmp
-prof() {   # prof <subdir> <workload> <extra bench args...>
-  local sub=$1 wl=$2; shift 2
+prof() {   # prof <subdir> <workload> <points> <samples per GPU> <extra bench args...>   (points / samples: what the command below runs at)
+  local sub=$1 wl=$2 pts=$3 smp=$4; shift 4
   mkdir -p $OUT/$sub
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$sub/trace -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/trace.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$sub/pmc_fetch -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_fetch.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/$sub/pmc_write -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_write.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/$sub/pmc_sq -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_sq.log 2>&1
   rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT/$sub/pmc_lds -o run -- python3 $R/bench.py --workload $wl --cpu-seconds 0 "$@" > $OUT/$sub/pmc_lds.log 2>&1
-  python3 $R/tools/summarize_profile.py $OUT/$sub $wl > $OUT/$sub/summary.txt 2>&1
+  python3 $R/tools/summarize_profile.py $OUT/$sub $wl $pts $smp > $OUT/$sub/summary.txt 2>&1
   cp $OUT/$sub/trace/run_kernel_stats.csv $OUT/$sub/kernel_stats.csv 2>/dev/null
   rm -rf $OUT/$sub/trace/run_kernel_trace.csv $OUT/$sub/pmc_*/run_kernel_trace.csv      # bulky; the summary keeps the per-kernel numbers
   head -30 $OUT/$sub/summary.txt
 }
-prof c2 c2 --steps 5 --warmup 2
+prof c2 c2 10000 100 --steps 5 --warmup 2
 if [ -z "${QUICK:-}" ]; then
-  prof c5 c5 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
-  prof conv conv --steps 3 --warmup 1
+  prof c5 c5 512 64 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
+  prof conv conv 2048 16 --steps 3 --warmup 1
 fi
 python3 - <<PY
 import json, glob, os

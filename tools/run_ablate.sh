@@ -2,7 +2,7 @@
 # usage: tools/run_ablate.sh "0 1 2 3 4 7 8 15 ..."   (run on the GPU box; builds one exe per bit set)
 mkdir -p gpurun_out/abl
 for b in $1; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_FAST_BUILD $EXTRA -DRBNN_ABL=$b -o /tmp/ablate_$b tools/ablate.hip 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_ALLOW_ABLATION -DRBNN_FAST_BUILD $EXTRA -DRBNN_ABL=$b -o /tmp/ablate_$b tools/ablate.hip 2>/dev/null &
 done
 wait
 for b in $1; do /tmp/ablate_$b; done 2>&1 | tee gpurun_out/abl/ablate.log

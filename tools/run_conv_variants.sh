@@ -2,6 +2,9 @@
 # usage: tools/run_conv_variants.sh "<flags1>" "<flags2>" ...   rebuilds librbnn_hip.so with extra -D flags for rbnn_conv.hip ON the GPU box and
 # times the conv / c5 bench workloads (triple mode only) for each flag set
 mkdir -p gpurun_out/abl
+# flag sets that contain an ablation switch (RBNN_*_ABL_*) must also carry -DRBNN_ALLOW_ABLATION (csrc/rbnn_common.hpp); the runs below are allowed to
+# load such a library (RBNN_ALLOW_ABLATION=1 here only), everything else refuses it (rbnn_build_flags(), robustbnns_amd/_hip.py)
+export RBNN_ALLOW_ABLATION=1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/robustbnns_amd/csrc
 for f in "$@"; do
@@ -12,4 +15,4 @@ for f in "$@"; do
    python bench.py --workload c5 --points 512 --iters 3 --steps 1 --warmup 1 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('c5  ', round(d['ms_per_step']/3,2), {k:round(v['avg_ms'],2) for k,v in d['roofline']['kernels'].items()})")
 done 2>&1 | tee $R/gpurun_out/abl/conv_variants.log
 # leave the tree as the sources say: the variant objects are newer than the sources, so build()'s staleness check would keep them
-cd $R && python -c "import __graft_entry__ as g; g.build(force=True)" > /dev/null 2>&1 && echo "[run_conv_variants] library rebuilt without variant flags"
+cd $R && unset RBNN_ALLOW_ABLATION && python -c "import __graft_entry__ as g; g.build(force=True)" > /dev/null 2>&1 && echo "[run_conv_variants] library rebuilt without variant flags"

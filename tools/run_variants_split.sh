@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/abl
 i=0
 for f in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_FAST_BUILD $f -o /tmp/svar_$i tools/ablate_split.hip 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRBNN_ALLOW_ABLATION -DRBNN_FAST_BUILD $f -o /tmp/svar_$i tools/ablate_split.hip 2>/dev/null &
   i=$((i+1))
 done
 wait

@@ -15,16 +15,25 @@ import sys
 
 out = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "c2"
+points = int(sys.argv[3]) if len(sys.argv) > 3 else None          # N and S per GPU of the profiled command (bench.py scales a conv record
+samples = int(sys.argv[4]) if len(sys.argv) > 4 else None         # taken at another size by points x samples and says so)
 
-# kernel-name fragment -> bench.py's roofline key (a key sums the kernels one C-ABI call launches)
+# kernel-name fragment -> bench.py's roofline key (a key sums the kernels one C-ABI call launches).  The fp32 kernels that EVERY precision
+# mode of the conv path launches (conv1, the head, their transposes) get their own "_common" keys: a profile run that times several modes
+# would otherwise book them under the fp32 mode's key only.
 MAIN = [("fc_forward_x3_kernel", "fc_forward_triple"), ("fc_grad_x3_kernel", "fc_input_grad_triple"), ("triple_dz_kernel", "fc_input_grad_triple"),
         ("fc_forward_split_kernel", "fc_forward_split"), ("fc_grad_split_kernel", "fc_input_grad_split"), ("split_dz_kernel", "fc_input_grad_split"),
         ("fc_forward_kernel", "fc_forward"), ("fc_grad_kernel", "fc_input_grad"),
         ("conv2_pool_x3_kernel", "conv_forward_triple"), ("conv_bwd_x3_kernel", "conv_input_grad_triple"), ("conv_bwd_dense_x3_kernel", "conv_input_grad_triple"),
         ("conv2_pool_split_kernel", "conv_forward_split"), ("conv1_pool_split_kernel", "conv_forward_split"),
         ("conv_bwd_split_kernel", "conv_input_grad_split"),
-        ("conv2_pool_kernel", "conv_forward"), ("conv1_pool_kernel", "conv_forward"), ("conv_fc_kernel", "conv_forward"),
-        ("conv_bwd_kernel", "conv_input_grad"), ("conv_fc_bwd_kernel", "conv_input_grad"), ("conv1_bwd_mfma_kernel", "conv_input_grad")]
+        ("conv2_pool_kernel", "conv_forward"), ("conv1_pool_kernel", "conv_forward_common"), ("conv_fc_kernel", "conv_forward_common"),
+        ("conv_bwd_kernel", "conv_input_grad"), ("conv_fc_bwd_kernel", "conv_input_grad_common"), ("conv1_bwd_mfma_kernel", "conv_input_grad_common"),
+        ("lowdim_kernel", "lowdim"), ("lowdim2_kernel", "lowdim")]
+# the streaming kernels of a step (same names in every mode; one launch each per pass, the draw once per step): their counters go into the
+# record's "small" table, which bench.py adds to a pass's counter total
+SMALL = ["svi_draw_flat_kernel", "svi_draw_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "step_tail_kernel",
+         "reduce_samples", "loss_dlogits", "sum_slabs_norms", "sum_slabs", "attack_step", "pgd_alpha"]
 SHORT = ["conv_bwd_dense_x3_kernel"] + [k for k, _ in MAIN] + ["svi_draw_flat_kernel", "svi_draw_kernel", "lowdim_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
                                 "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"]
 
@@ -73,7 +82,7 @@ def pmc(dirname, title):
     if acc:
         print(f"\n== PMC: {title} (mean per launch) ==")
     for k, d in acc.items():
-        if key_of(k) is None:
+        if key_of(k) is None and not any(n in k for n in SMALL):
             continue
         print(f"{k:32s} " + "  ".join(f"{c}={sum(v)/len(v):.4g}" for c, v in sorted(d.items())))
     return acc
@@ -88,12 +97,15 @@ for k, d in sq.items():                                     # matrix-pipe utilis
         busy = sum(d["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(d["SQ_VALU_MFMA_BUSY_CYCLES"])
         print(f"   {k}: SQ_VALU_MFMA_BUSY_CYCLES per SIMD = {busy / 1024:.4g} (1024 SIMDs)")
 tr = collections.defaultdict(lambda: {"fetch_size_kb_raw": 0.0, "write_size_kb": 0.0, "kernels": []})
+small = {}
 for k in set(f) & set(w):
     key = key_of(k)
-    if key is None:
-        continue
     fs = sum(f[k]["FETCH_SIZE"]) / len(f[k]["FETCH_SIZE"])
     wsz = sum(w[k]["WRITE_SIZE"]) / len(w[k]["WRITE_SIZE"])
+    if key is None:
+        if any(n in k for n in SMALL):
+            small[k] = {"fetch_size_kb_raw": fs, "write_size_kb": wsz, "hbm_bytes_per_launch": (2 * fs + wsz) * 1024}
+        continue
     tr[key]["fetch_size_kb_raw"] += fs
     tr[key]["write_size_kb"] += wsz
     tr[key]["kernels"].append(k)
@@ -102,7 +114,9 @@ for key, d in tr.items():
     d["note"] = "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)"
 if tr:
     print("\n== traffic json ==")
-    print(json.dumps(tr))
+    print(json.dumps({"kernels": tr, "small": small}))
     rel = "profiles/" + out.split("gpurun_out/")[-1] if "gpurun_out/" in out else out      # the copy that is committed, not the scratch path
-    json.dump({workload: tr, "source": f"{rel}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {workload} workload)"},
+    json.dump({workload: {"points": points, "samples": samples, "kernels": tr, "small": small},
+               "source": f"{rel}/summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, {workload} workload"
+                         + (f", N={points}, S={samples}" if points else "") + ")"},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
