@@ -79,7 +79,7 @@ class ConvStackedPosterior:
         self._split = None
         self._triple = None
         self._guide = None                      # ConvSviGuide: a redrawable SVI stack (for_guide / redraw)
-        self._dense = None                      # triple mode, 1x28x28: model.3.weight image of the dense conv2^T kernel
+        self._dense = None                      # triple mode: model.3.weight image of the dense conv2^T kernel (geometry-independent)
 
     # ------------------------------------------------------------------ redrawable SVI stack
     @classmethod
@@ -150,8 +150,10 @@ class ConvStackedPosterior:
             self._tmp = self._dense_tmp = self._dense_stage = self._rows_stage = None
 
     def dense_supported(self):
-        """The dense conv2^T kernel (rbnn_conv_input_grad_dense) is built for the 1x28x28 geometry."""
-        return self.input_shape == (1, 28, 28) and os.environ.get("RBNN_CONV_BWD_DENSE", "1") != "0"
+        """The dense conv2^T kernel (rbnn_conv_input_grad_dense: a GEMM per tap over the conv2 OUTPUT positions + col2im, no padding MFMAs)
+        covers both geometries — 1x28x28 in one pass over its 64 positions, 3x32x32 in two (64 + 36) — and all four activations;
+        RBNN_CONV_BWD_DENSE=0 keeps the gather form (rbnn_conv_input_grad_triple)."""
+        return os.environ.get("RBNN_CONV_BWD_DENSE", "1") != "0"
 
     def _build_dense(self, dense):
         """model.3.weight regrouped [S, K steps of 32 hc, 25 taps, 32 ci][32 hc] (hc zero-padded) as a triple-rows image."""
@@ -387,7 +389,7 @@ class ConvEngine(AttackEngine):
     def _grad_kernels(self, sidx, S, N, ws):
         if self.precision == "triple" and os.environ.get("RBNN_CONV_BWD_EXACT") != "1":
             _, k2_exp, bwd, fw_l1 = self.post.triple_images()
-            if self.post._dense is not None and self.post.dense_supported():      # 1x28x28: GEMM per tap over the conv2 outputs + col2im
+            if self.post._dense is not None and self.post.dense_supported():      # GEMM per tap over the conv2 outputs + col2im
                 return self.k.conv_input_grad_dense(self.post, self.post._dense, k2_exp, fw_l1, sidx, S, N, ws)
             self.post.refresh_lazy_images(triple_bwd=True)
             return self.k.conv_input_grad_triple(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)

@@ -1804,23 +1804,28 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
 #define RBNN_CONV_BWD_DENSE 1
 #endif
 template <class G> struct ConvBwdDenseLds {
-    static constexpr int NPOSP = G::NPT2 * 16;                            // positions, padded to whole MFMA tiles
+    // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
+    // hold (112 registers).  1x28x28: 64 positions, one pass.  3x32x32: 100 positions = pass 0 (positions 0..63) + pass 1 (64..99, three
+    // tiles); a pass streams the weights once more (L2) but routes only its own positions, and the two passes' col2im partial sums meet in
+    // registers (16 per gathering thread) — splitting the block over input-channel tiles or taps instead would route everything twice.
+    static constexpr int NPASS = (G::NPT2 + 3) / 4;
+    static constexpr int NPOSP = 64;                                      // positions of a pass, padded to whole MFMA tiles
     static constexpr int PLANE = NPOSP * 64, IMG = 3 * PLANE;             // one piece plane: NPOSP records of 32 hc halves
     static constexpr int NFL = 32 * G::NP2;                               // pooled cells of one K step
     static constexpr int STG = (NFL * 5 + 15) / 16 * 16;                  // staging: NFL dQ2 floats + NFL stash bytes
     static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
     static constexpr int AOFF = 2 * IMG + 2 * STG;                        // the eight waves' rings follow the image / staging buffers
     static constexpr int LOOP = AOFF + 8 * RING * SLOT;
-    static constexpr int EPI = 25 * NPOSP * 16 * 4;                       // T of one channel tile: [25 taps][pos][16 ci] floats
+    static constexpr int EPI = 25 * NPOSP * 16 * 4;                       // T of one channel tile and pass: [25 taps][pos][16 ci] floats
     static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
     static_assert(BYTES <= 160 * 1024, "LDS");
+    static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
 };
 
 template <int ACT, class G>
 __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2d, int k2_exp, float fw_l1) {
     using L = ConvBwdDenseLds<G>;
-    constexpr int NPT = G::NPT2, P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, NFL = L::NFL;
-    static_assert(NPOS_ == 64 && NPT == 4, "built for the 1x28x28 geometry (64 conv2 output positions = one per lane of the routing)");
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, NFL = L::NFL, NPASS = L::NPASS;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     char* const lds = (char*)lds_f;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -1847,22 +1852,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
     const float in_scale = ldexpf(1.f, e), out_scale = ldexpf(1.f, -(e + k2_exp));
 
-    // routing role of this thread: position gp = lane (gy, gx) of the 8 x 8 gradient map, channel quad qd = wave of the K step's 32
-    const int gy = lane / O2W_, gx = lane % O2W_, qd = wave;
-    // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells), and the stash
-    // code that routes window w here: argmax == w (and, ReLU, the pre-activation positive: bit 2); 15 never matches (window off the map)
-    int adq[4], ast[4], wcode[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
-        const int py = gy - (w >> 1), px = gx - (w & 1);
-        const bool ok = py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
-        const int cell = 4 * qd * NP2_ + (ok ? py * P2W_ + px : 0);
-        adq[w] = 4 * cell;
-        ast[w] = NFL * 4 + cell;
-        wcode[w] = ok ? (ACT == RBNN_ACT_RELU ? (w | 4) : w) : 15;
-    }
-    const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
-
     auto dma4 = [&](const void* g, void* l) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
     };
@@ -1877,9 +1866,55 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dQ2 + fb + b + lane),
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)((float*)S + b), 4, (i - i0) * 2048, 0);
         });
-        const int d = 64 * wave;                                            // stash: one dword (4 cells) per lane
-        if (4 * (d + lane) < nvalid) dma4(a.st2 + fb + 4 * (d + lane), S + NFL * 4 + 4 * d);
+        static_for<0, (NFL / 4 + 511) / 512>([&](auto I) {                   // stash: one dword (4 cells) per lane, 512 lanes per round
+            const int d = 512 * decltype(I)::value + 64 * wave;
+            if (4 * (d + lane) < nvalid) dma4(a.st2 + fb + 4 * (d + lane), S + NFL * 4 + 4 * d);
+        });
     };
+    // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
+    // private ring of RING slots, three 1-KiB pieces per tile (one per plane: lane p lands at row p >> 2, physical chunk p & 3 and
+    // fetches logical chunk (p & 3) ^ swz(row)), issued THREE taps ahead of their use: an L2 round trip (500+ cycles) is far longer than
+    // the 24 MFMAs of a tap, and registers for a deeper prefetch do not exist (112 accumulators + 48 B-fragment registers).  The
+    // wave's running tap index g = ks * ntap + i names the slot g & 3; nothing but this wave touches its ring (no barrier involved).
+    // (weight tiles are PLANE-major in memory — [tile][3 pieces][16 ci][64 B], conv.py::_build_dense — exactly as they sit in a ring slot: the
+    // immediate offset of global_load_lds applies to the global AND the LDS address, so a tile's three pieces share one address and one M0)
+    const int prow = lane >> 2;
+    const unsigned a_lane = (unsigned)(prow * 64 + (((lane & 3) ^ swz(prow)) * 16));    // per-lane part of a piece's source address
+    const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
+    char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
+    const int G_ = KS * ntap;                                              // tiles this wave consumes per pass
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // fragment of row li (position / input channel), K chunk lg
+    constexpr int NPP = P1W_ * P1W_;
+    static_assert(2 * NPP <= 512, "one thread per output position and pair of channel quads");
+    f32x4 part[2][2];                                                      // NPASS > 1: col2im partial sums of the earlier passes ([channel tile][quad of the pair])
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef RBNN_DENSE_ABL_NOMFMA
+#define DENSE_MFMA(A, B, C) (C)
+#else
+#define DENSE_MFMA(A, B, C) MFMA_H(A, B, C)
+#endif
+
+    static_for<0, NPASS>([&](auto PASS) {
+    constexpr int pass = decltype(PASS)::value;
+    constexpr int NPT = (G::NPT2 - 4 * pass) < 4 ? (G::NPT2 - 4 * pass) : 4;   // position tiles of this pass
+    if (pass) __syncthreads();                                             // the previous pass's T (LDS) has been gathered
+    // routing role of this thread: position gp = 64 * pass + lane (gy, gx) of the O2W x O2W gradient map, channel quad qd = wave of the K step's 32
+    const int gp = 64 * pass + lane, gy = gp / O2W_, gx = gp % O2W_, qd = wave;
+    // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells), and the stash
+    // code that routes window w here: argmax == w (and, ReLU, the pre-activation positive: bit 2); 15 never matches (window off the map,
+    // or a lane past the last position: its image row is zeros)
+    int adq[4], ast[4], wcode[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
+        const int py = gy - (w >> 1), px = gx - (w & 1);
+        const bool ok = gp < NPOS_ && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+        const int cell = 4 * qd * NP2_ + (ok ? py * P2W_ + px : 0);
+        adq[w] = 4 * cell;
+        ast[w] = NFL * 4 + cell;
+        wcode[w] = ok ? (ACT == RBNN_ACT_RELU ? (w | 4) : w) : 15;
+    }
+    const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
     // routing of ONE channel (j of this thread's quad) of K step ks from staging buffer sbuf: pool-2 argmax + activation derivative (gather
     // form), scaled, split into the three pieces.  Called between the MFMA groups of the previous K step so that its LDS reads and
     // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
@@ -1927,18 +1962,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     for (int t = 0; t < 7; ++t)
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
-    // private ring of RING slots, three 1-KiB pieces per tile (one per plane: lane p lands at row p >> 2, physical chunk p & 3 and
-    // fetches logical chunk (p & 3) ^ swz(row)), issued THREE taps ahead of their use: an L2 round trip (500+ cycles) is far longer than
-    // the 24 MFMAs of a tap, and registers for a deeper prefetch do not exist (112 accumulators + 48 B-fragment registers).  The
-    // wave's running tap index g = ks * ntap + i names the slot g & 3; nothing but this wave touches its ring (no barrier involved).
-    // (weight tiles are PLANE-major in memory — [tile][3 pieces][16 ci][64 B], conv.py::_build_dense — exactly as they sit in a ring slot: the
-    // immediate offset of global_load_lds applies to the global AND the LDS address, so a tile's three pieces share one address and one M0)
-    const int prow = lane >> 2;
-    const unsigned a_lane = (unsigned)(prow * 64 + (((lane & 3) ^ swz(prow)) * 16));    // per-lane part of a piece's source address
-    const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
-    char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
-    const int G_ = KS * ntap;                                              // tiles this wave consumes
     int iks = 0, itap = 0, ig = 0;                                         // (K step, tap, running index) of the next tile to issue
     auto a_issue = [&]() {
 #ifdef RBNN_DENSE_ABL_NOA
@@ -1958,7 +1981,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             if (++itap == ntap) { itap = 0; ++iks; }
         }
     };
-    const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // fragment of row li (position / input channel), K chunk lg
 
     stage_issue(0, 0);
     a_issue(); a_issue(); a_issue();
@@ -1971,11 +1993,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         route_store(0, p0, p1, p2);
     }
     if (KS > 1) stage_issue(1, 1);
-#ifdef RBNN_DENSE_ABL_NOMFMA
-#define DENSE_MFMA(A, B, C) (C)
-#else
-#define DENSE_MFMA(A, B, C) MFMA_H(A, B, C)
-#endif
     f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
     int g = 0;                                                             // running tile index of this wave
 #ifdef RBNN_DENSE_ABL_NOB
@@ -2058,7 +2075,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // (pos >> 1) & 3, which spreads eight consecutive positions over all 32 banks), and a gathering thread = one output position (Y, X) x two
     // channel quads adds up its <= 25 terms in (ky, kx) order with eight independent sums.  (First version: [tap][ci][pos] floats, 112
     // 4-way-conflicting ds_write_b32 per lane and one serial chain of ~60 dependent LDS reads per thread: 2.0 of the kernel's 11.0 ms,
-    // profiles/r03a/conv_dense_ablations.txt.) ----
+    // profiles/r03a/conv_dense_ablations.txt.)  With several passes a term belongs to the pass that holds its position; the sums of the
+    // earlier passes wait in `part` and the LAST pass adds them (fixed order: deterministic) and writes. ----
     float* const T = lds_f;
 #ifdef RBNN_DENSE_ABL_NOEPI
     {                                                                      // ablation (timing only): the accumulators stay live, nothing is gathered
@@ -2071,9 +2089,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         return;
     }
 #endif
-    constexpr int NPP = P1W_ * P1W_;
-    static_assert(2 * NPP <= 512, "one thread per output position and pair of channel quads");
-    for (int round = 0; round < 2; ++round) {
+    static_for<0, 2>([&](auto ROUND) {
+        constexpr int round = decltype(ROUND)::value;
         __syncthreads();                                                   // the loop buffers / the previous round's T are free
         if (ct == round) {
 #pragma unroll
@@ -2081,7 +2098,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 if (t < ntap) {
 #pragma unroll
                     for (int pt = 0; pt < NPT; ++pt) {
-                        const int pos = 16 * pt + li;                      // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][pos]
+                        const int pos = 16 * pt + li;                      // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][pos], pos local to the pass
                         *(f32x4*)(T + ((tap0 + t) * 64 + pos) * 16 + 4 * (lg ^ ((pos >> 1) & 3))) = acc[t][pt];
                     }
                 }
@@ -2090,43 +2107,54 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         if (tid < 2 * NPP) {
             const int qp = tid / NPP, pp = tid % NPP, Y = pp / P1W_, X = pp % P1W_;
             const int ky0 = max(0, Y - (O2W_ - 1)), ky1 = min(4, Y), kx0 = max(0, X - (O2W_ - 1)), kx1 = min(4, X);
-            // the five kx terms of a row are read together (ten independent ds_read_b128; terms outside [kx0, kx1] read a clamped position
-            // and add +0): a wave runs as long as its busiest lane, 25 terms for the interior positions, and one read pair per trip made that
-            // 25 dependent LDS round trips
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+            // the five kx terms of a row are read together (ten independent ds_read_b128; terms outside [kx0, kx1] — or, with several passes,
+            // at a position of another pass — read a clamped position and add +0): a wave runs as long as its busiest lane, 25 terms for the
+            // interior positions, and one read pair per trip made that 25 dependent LDS round trips
+            f32x4 s0 = part[round][0], s1 = part[round][1];
             for (int ky = ky0; ky <= ky1; ++ky) {
                 f32x4 u0[5], u1[5];
+                bool ok[5];
 #pragma unroll
                 for (int kx = 0; kx < 5; ++kx) {
-                    const int pos = (Y - ky) * O2W_ + min(max(X - kx, 0), O2W_ - 1), sw = (pos >> 1) & 3;
+                    int pos = (Y - ky) * O2W_ + min(max(X - kx, 0), O2W_ - 1) - 64 * pass;
+                    ok[kx] = kx >= kx0 && kx <= kx1;
+                    if (NPASS > 1) {
+                        ok[kx] = ok[kx] && pos >= 0 && pos < 64;
+                        pos = min(max(pos, 0), 63);
+                    }
+                    const int sw = (pos >> 1) & 3;
                     const float* const rowp = T + ((ky * 5 + kx) * 64 + pos) * 16;
                     u0[kx] = *(const f32x4*)(rowp + 4 * ((2 * qp) ^ sw));
                     u1[kx] = *(const f32x4*)(rowp + 4 * ((2 * qp + 1) ^ sw));
                 }
 #pragma unroll
                 for (int kx = 0; kx < 5; ++kx) {
-                    const float m = (kx >= kx0 && kx <= kx1) ? 1.f : 0.f;
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    s0 += m != 0.f ? u0[kx] : z;
-                    s1 += m != 0.f ? u1[kx] : z;
+                    s0 += ok[kx] ? u0[kx] : z;
+                    s1 += ok[kx] ? u1[kx] : z;
                 }
             }
-            float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * round + 8 * qp) * NPP + pp;
+            if (pass + 1 < NPASS) {
+                part[round][0] = s0;
+                part[round][1] = s1;
+            } else {
+                float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * round + 8 * qp) * NPP + pp;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float* const dst = dst0 + r * NPP;
-                const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
-                *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                for (int r = 0; r < 8; ++r) {
+                    float* const dst = dst0 + r * NPP;
+                    const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+                    *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                }
             }
         }
-    }
+    });
+    });
 }
 
 extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const void* K2_dense, int32_t k2_exp, float fw_l1,
                                           const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);
     if (rc) return rc;
-    if (net->in_channels != 1 || net->in_width != 28) return RBNN_ERR_UNSUPPORTED;
     if (!K2_dense || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
     if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
     if (!aligned16(K2_dense) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
@@ -2134,22 +2162,24 @@ extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const 
     a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = nullptr; a.Fw = net->Fw;
     a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
     hipStream_t st = (hipStream_t)stream;
-    using G = GeoMnist;
-    a.NP2 = G::NP2;
-    return for_activation(net->activation, [&](auto actc) {
-        constexpr int ACT = decltype(actc)::value;
-        int rc2;
-        {
-            const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
-            hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        a.NP2 = G::NP2;
+        return for_activation(net->activation, [&](auto actc) {
+            constexpr int ACT = decltype(actc)::value;
+            int rc2;
+            {
+                const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+                hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
+                if ((rc2 = launch_status())) return rc2;
+            }
+            constexpr int LDSB = ConvBwdDenseLds<G>::BYTES;
+            static unsigned long long attr = 0;
+            if (!ensure_dynamic_lds((const void*)conv_bwd_dense_x3_kernel<ACT, G>, LDSB, attr)) return (int)RBNN_ERR_LAUNCH;
+            hipLaunchKernelGGL((conv_bwd_dense_x3_kernel<ACT, G>), dim3(grid_for_items((long long)N * S)), dim3(512), LDSB, st, a, (const char*)K2_dense, k2_exp, fw_l1);
             if ((rc2 = launch_status())) return rc2;
-        }
-        constexpr int LDSB = ConvBwdDenseLds<G>::BYTES;
-        static unsigned long long attr = 0;
-        if (!ensure_dynamic_lds((const void*)conv_bwd_dense_x3_kernel<ACT, G>, LDSB, attr)) return (int)RBNN_ERR_LAUNCH;
-        hipLaunchKernelGGL((conv_bwd_dense_x3_kernel<ACT, G>), dim3(grid_for_items((long long)N * S)), dim3(512), LDSB, st, a, (const char*)K2_dense, k2_exp, fw_l1);
-        if ((rc2 = launch_status())) return rc2;
-        return launch_conv1_backward<ACT, G>(a, st);
+            return launch_conv1_backward<ACT, G>(a, st);
+        });
     });
 }
 

@@ -602,6 +602,40 @@ def test_conv_error_distribution_with_pinned_decisions(act, shape, Cn, Hc, S, N,
     assert float((pg - x[:3]).abs().max()) <= 0.2 + 1e-6 and float(pg.min()) >= 0 and float(pg.max()) <= 1
 
 
+@pytest.mark.parametrize("act,shape,Hc,S,N", [("leaky", (3, 32, 32), 512, 2, 37), ("relu", (3, 32, 32), 48, 3, 21), ("tanh", (3, 32, 32), 16, 2, 9),
+                                              ("sigm", (3, 32, 32), 272, 1, 5), ("leaky", (1, 28, 28), 80, 2, 19)])
+def test_conv_dense_backward_equals_gather_form(act, shape, Hc, S, N, monkeypatch):
+    """conv2^T in the dense form (GEMM per tap over the conv2 output positions + col2im; 3x32x32: two passes over 64 + 36 positions whose
+    col2im partial sums meet in registers) against the gather form on the same triple images: both sum the same exact f16 products in
+    fp32, in different orders — equal to fp32 rounding on EVERY point (the pooling / sign decisions come from the same stashes); channel
+    counts that are not multiples of 32 (zero-padded K step), one K step only (Hc = 16), and bit-determinism."""
+    from robustbnns_amd import _hip
+    from robustbnns_amd.conv import ConvEngine, ConvStackedPosterior
+    Cn, Din = 10, shape[0] * shape[1] * shape[2]
+    q2 = ((shape[1] - 4) // 2) - 5
+    post = O.synthetic_posterior("conv", Din, Hc, Cn, S, 0.04, in_ch=shape[0], head=q2 * q2 * Hc)
+    x, y = O.synthetic_inputs(N, shape, Cn, seed=3 * Hc + N)
+    lab = y.argmax(-1).int().to(DEV)
+    sp = ConvStackedPosterior(act, shape, Cn, Hc, post, DEV)
+    eng = ConvEngine(sp, precision="triple")
+    assert sp.triple_images() is not None and sp.dense_supported() and sp._dense is not None
+    out = {}
+    for form in ("dense", "gather", "dense2"):
+        monkeypatch.setenv("RBNN_CONV_BWD_DENSE", "0" if form == "gather" else "1")
+        out[form] = {m: eng.gradient(eng.pad_inputs(x), lab, None, S, hm).cpu().clone()
+                     for m, hm in (("mean_prob", _hip.LOSS_MEAN_PROB), ("per_sample", _hip.LOSS_PER_SAMPLE))}
+    for m in ("mean_prob", "per_sample"):
+        assert torch.equal(out["dense"][m], out["dense2"][m])                               # bit-deterministic
+        e = per_point_err(out["dense"][m], out["gather"][m])
+        print(f"[conv2^T dense vs gather {act} {shape} Hc={Hc} {m}] max {float(e.max()):.2e} median {float(e.median()):.2e}")
+        assert float(e.max()) < 2e-6
+    p64 = O.cast(post, torch.float64)
+    if act in ("tanh", "sigm"):                                                             # no kinks: the plain fp64 oracle on every point
+        ref = O.meanprob_gradients(x.double(), y.argmax(-1), p64, "conv", act, S).reshape(N, -1)
+        tie_free = per_point_err(out["gather"]["mean_prob"], ref) < TOL                     # (pooling ties aside: where the gather form agrees)
+        assert int(tie_free.sum()) >= N - 2 and float(per_point_err(out["dense"]["mean_prob"], ref)[tie_free].max()) < TOL
+
+
 @pytest.mark.parametrize("name", ["mnist_conv_h16_s2_n4_sigm", "mnist_conv_h16_s2_n4_tanh"])
 def test_conv_golden_smooth_activations(golden, name):
     """The reference allows its four activations on `conv` (model_nn.py:66-75,98-106): the reference-generated sigmoid / tanh
