@@ -482,7 +482,7 @@ int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor *tensors, int32_t n_tensors, i
                        uint32_t draw_id, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Low-dimensional fc nets (in_features <= 16, n_classes <= 10, arch fc; half-moons: 2 -> H -> 2) — the WHOLE hot path in one launch.
+ * Low-dimensional nets (in_features <= 16, n_classes <= 10; half-moons: 2 -> H -> 2) — arch fc: the WHOLE hot path in one launch.
  * One call = what a sequence of rbnn_fc_forward, rbnn_reduce_samples, rbnn_loss_dlogits, rbnn_fc_input_grad, rbnn_sum_slabs(_norms),
  * rbnn_pgd_alpha and `iters` x rbnn_attack_step computes, i.e. for every point the loop nest adversarialAttacks.py:118 -> :95 ->
  * model_bnn.py:251 (attack), lossGradients.py:20-40 (gradient) or model_bnn.py:243-258 (forward), in fp32 FMA arithmetic.
@@ -494,8 +494,16 @@ int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor *tensors, int32_t n_tensors, i
  *                            (adversarialAttacks.py:89), or alpha_scalar
  * P_scratch: [n_samples, n_points, 16] floats (required for MEAN_PROB gradients / attacks).  sample_idx as rbnn_fc_forward.
  * ------------------------------------------------------------------------------------------------------------ */
+/* fc2 (round 4; the reference's half-moons grid, grid_search_halfMoons.py:159-169: 2 -> H -> H -> 2, 250 HMC samples): hidden in
+ * {32, 64, 128, 256, 512}, in_stride == 16, Wm_pack4 required.  The H x H layer is a GEMM over the points of a sample (fp32 MFMA), so
+ * samples spread over the CUs and the mean over samples couples all blocks between forward and backward: one call issues, back to
+ * back on `stream`, per iteration: forward kernel, sum over samples, forward-again + backward kernel, slab sum + step (4 launches;
+ * 2 for the per-sample loss) — csrc/rbnn_lowdim.hip.  Same arguments and results as for fc, except that P_scratch must hold
+ * rbnn_lowdim_scratch_bytes() bytes (per-sample outputs, per-sample gradient slabs, the sum over samples), is always required, and for
+ * RBNN_LOWDIM_ATTACK `out` must not alias X (the iterate is kept in `out`). */
 typedef enum rbnn_lowdim_op { RBNN_LOWDIM_FORWARD = 0, RBNN_LOWDIM_GRADIENT = 1, RBNN_LOWDIM_ATTACK = 2 } rbnn_lowdim_op;
 int rbnn_lowdim_supported(const rbnn_posterior *net);      /* 1 when rbnn_lowdim_run covers this posterior */
+size_t rbnn_lowdim_scratch_bytes(const rbnn_posterior *net, int32_t n_points, int32_t n_samples);   /* bytes of P_scratch (0: bad arguments) */
 int rbnn_lowdim_run(const rbnn_posterior *net, int32_t op, int32_t loss_mode, int32_t out_kind, const float *X, const float *X0,
                     int32_t ldx, int32_t n_points, const int32_t *sample_idx, int32_t n_samples, const int32_t *labels, float inv_S,
                     float out_scale, float eps, const float *alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project,

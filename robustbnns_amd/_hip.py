@@ -151,6 +151,7 @@ SIGNATURES = {
     "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(TripleWorkspace),
                                          C.POINTER(_i32), _fp]),
     "rbnn_lowdim_supported": (_i32, [_PP]),
+    "rbnn_lowdim_scratch_bytes": (_sz, [_PP, _i32, _i32]),
     "rbnn_lowdim_run": (_i32, [_PP, _i32, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _fp, _f32, _f32, _f32, _fp, _f32, _i32, _i32, _i32,
                                _fp, _fp, _i32, _fp, _fp, _fp]),
     "rbnn_svi_draw_flat": (_i32, [C.POINTER(SviFlatTensor), _i32, _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
@@ -459,6 +460,9 @@ class HipKernels:
 
     def lowdim_supported(self, net):
         return bool(self.lib.rbnn_lowdim_supported(C.byref(net.descriptor())))
+
+    def lowdim_scratch_bytes(self, net, N, S):
+        return int(self.lib.rbnn_lowdim_scratch_bytes(C.byref(net.descriptor()), N, S))
 
     def lowdim_run(self, net, op, loss_mode, out_kind, X, X0, sidx, S, labels, inv_S, out_scale, eps, alpha, alpha_scalar, alpha_per_image,
                    project, iters, P, out, linf=None, l2=None):

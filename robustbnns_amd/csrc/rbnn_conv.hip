@@ -1803,6 +1803,9 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
 #ifndef RBNN_CONV_BWD_DENSE
 #define RBNN_CONV_BWD_DENSE 1
 #endif
+#ifndef RBNN_DENSE_STAGGER
+#define RBNN_DENSE_STAGGER 0
+#endif
 template <class G> struct ConvBwdDenseLds {
     // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
     // hold (112 registers).  1x28x28: 64 positions, one pass.  3x32x32: 100 positions = pass 0 (positions 0..63) + pass 1 (64..99, three
@@ -1998,6 +2001,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
 #ifdef RBNN_DENSE_ABL_NOB
     f16x8 b0[NPT], b1[NPT], b2[NPT];
 #endif
+    // R0 = the tap group at which a wave starts routing the NEXT K step's image (one channel per tap group, four groups).  The two waves of a
+    // SIMD (channel tiles 0 and 1 of the same tap quarter) run the same instruction stream between the same barriers; RBNN_DENSE_STAGGER
+    // shifts the second one's routing by that many tap groups so that one wave's vector work falls under the other's bare MFMA groups.
+    auto kloop = [&](auto R0C) {
+    constexpr int R0 = decltype(R0C)::value;
     for (int ks = 0; ks < KS; ++ks) {
         // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
         // vector-memory operations — the ring tiles issued since — may still be in flight
@@ -2065,11 +2073,17 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 ++g;
             }
 #ifndef RBNN_DENSE_ABL_NOROUTE
-            if (t < 4) route_one(ks + 1, (ks + 1) & 1, t, p0, p1, p2);     // the next K step's image, one channel per tap group
-            if (t == 3) route_store((ks + 1) & 1, p0, p1, p2);
+            if (t >= R0 && t < R0 + 4) route_one(ks + 1, (ks + 1) & 1, t - R0, p0, p1, p2);     // the next K step's image, one channel per tap group
+            if (t == R0 + 3) route_store((ks + 1) & 1, p0, p1, p2);
 #endif
         }
     }
+    };
+#if RBNN_DENSE_STAGGER
+    if (ct) kloop(std::integral_constant<int, RBNN_DENSE_STAGGER>{});
+    else
+#endif
+    kloop(std::integral_constant<int, 0>{});
     // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
     // registers are four consecutive channels (one ds_write_b128 per tile; the four channel quads of a position are XOR-swizzled by
     // (pos >> 1) & 3, which spreads eight consecutive positions over all 32 banks), and a gathering thread = one output position (Y, X) x two

@@ -372,13 +372,416 @@ template <int ACT> int launch_low_act(const LowArgs& a, hipStream_t st) {
     return small_c ? launch_low<ACT, 4, 2>(a, st) : launch_low<ACT, 4, 10>(a, st);
 }
 
+
+// =====================================================================================================
+// fc2 on low-dimensional inputs (the reference's half-moons grid: 2 -> H -> H -> 2, H in {32, 128, 256, 512}, 250 HMC samples,
+// grid_search_halfMoons.py:159-169).  The middle layer is H x H per sample — a real GEMM over the POINTS of a sample — so, unlike the fc
+// nets above, a (point, sample) pair cannot live in one thread, and samples must spread over the CUs: one block = one sample x a group of
+// <= 112 points.  The mean-probability loss couples all samples of a point (adversarialAttacks.py:74-76), i.e. all blocks, between
+// the forward and the backward: with no grid-wide barrier inside a kernel, a pass is FOUR launches issued back to back by one C call
+// (the generic path: 8 from Python) —
+//   low2_kernel<BWD = false>   layer 1 (D <= 16: VALU) -> LDS; layer 2 on v_mfma_f32_16x16x4_f32 (A = the sample's Wm rows from L2, B = the
+//                              hidden activations in LDS), activation on the accumulators; layer 3 as MFMAs that take those accumulators
+//                              as their B operand; softmax                                                       -> P[s, n, :]
+//   low2_reduce_kernel         sum over samples                                                                  -> Psum[n, :]  (or `out`)
+//   low2_kernel<BWD = true>    the forward again (cheaper than stashing two hidden layers in HBM), loss, dZ; dA2 = act' . (W2^T dZ) as
+//                              MFMAs -> LDS; dH1 = Wm^T dA2 on the MFMA from the pack_rows4 image of Wm (the same operand walk as
+//                              layer 2); dA1 = act' . dH1; g = W1^T dA1 as MFMAs fed from the accumulators       -> slab[s, n, :]
+//   low2_finish_kernel         sum of the S slabs in a fixed order, then the gradient + its norms, or the sign / project / clamp step
+// — three (two kernels) for the per-sample loss of lossGradients.py:29-40.  Every sum has a fixed order: results are deterministic.
+// =====================================================================================================
+struct Low2Args {
+    rbnn_posterior net;
+    const float* X;                // current iterate [N, ldx]
+    const int* sidx;
+    const int* labels;
+    float* P;                      // [S][N][16] per-sample probabilities (logits for the mean-logit loss / OUT_LOGITS)
+    const float* Psum;             // [N][16] sum over samples (BWD, mean-probability / mean-logit loss)
+    float* slabs;                  // [S][N][16] per-sample input gradients (BWD)
+    int ldx, N, S, NG, loss, probs, dq;
+    float inv_S;
+};
+
+template <int ACT> __device__ __forceinline__ float act_deriv_from_value(float hv) {
+    if (ACT == RBNN_ACT_RELU)  return hv > 0.f ? 1.f : 0.f;            // h > 0 <=> a > 0 (relu: h = max(a, 0); leaky: h = a or slope * a)
+    if (ACT == RBNN_ACT_LEAKY) return hv > 0.f ? 1.f : LEAKY_SLOPE;
+    return act_grad_from_value<ACT>(hv);
+}
+
+template <int NW, int KTW, int NPTB, bool BWD> struct Low2Lds {
+    static constexpr int H = 16 * NW * KTW, HS = H + 4, PT = 16 * NPTB;
+    static constexpr int FLOATS = PT * HS * (BWD ? 2 : 1) + PT * 16 + NW * PT * 16 + (BWD ? PT * 16 : 0);
+    static_assert(FLOATS * 4 <= 160 * 1024, "LDS");
+};
+
+template <int ACT, int NW, int KTW, int NPTB, bool BWD>
+__global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
+    using L = Low2Lds<NW, KTW, NPTB, BWD>;
+    constexpr int H = L::H, HS = L::HS, PT = L::PT, NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float sm2[];
+    float* const bufA = sm2;                                              // h1 [PT][HS]: hidden activations of layer 1, point-major
+    float* const bufB = bufA + PT * HS;                                   // BWD: dA2 [PT][HS]
+    float* const xs = bufA + PT * HS * (BWD ? 2 : 1);                     // inputs [PT][16]
+    float* const red = xs + PT * 16;                                      // cross-wave partials [NW][PT][16]
+    float* const dzb = red + NW * PT * 16;                                // BWD: dZ [PT][16]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s = blockIdx.x / a.NG, n0 = (blockIdx.x - s * a.NG) * PT;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const int C = a.net.n_classes, D = a.net.in_features, N = a.N;
+    const float* const W1 = a.net.W1 + (long long)sw * H * 16;            // [H][16] (in_stride = 16: zero columns beyond D)
+    const float* const b1 = a.net.b1 + (long long)sw * H;
+    const float* const Wm = a.net.Wm + (long long)sw * H * H;
+    const float* const bm = a.net.bm + (long long)sw * H;
+    const float* const W2 = a.net.W2 + (long long)sw * C * H;
+    const float* const b2 = a.net.b2 + (long long)sw * C;
+
+    for (int i = tid; i < PT * 16; i += NT) {
+        const int n = n0 + (i >> 4), d = i & 15;
+        xs[i] = (n < N && d < D) ? a.X[(long long)n * a.ldx + d] : 0.f;
+    }
+    __syncthreads();
+    // ---- layer 1: h1[pt][h] = act(b1[h] + W1[h, :] . x[pt, :]), four hidden units per item ----
+    for (int i = tid; i < PT * (H / 4); i += NT) {
+        const int pt = i / (H / 4), h = 4 * (i - pt * (H / 4));
+        f32x4 av = *(const f32x4*)(b1 + h);
+        for (int q = 0; q < a.dq; ++q) {
+            const f32x4 xv = *(const f32x4*)(xs + pt * 16 + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 w = *(const f32x4*)(W1 + (h + r) * 16 + 4 * q);
+                av[r] = fmaf(w[0], xv[0], av[r]); av[r] = fmaf(w[1], xv[1], av[r]); av[r] = fmaf(w[2], xv[2], av[r]); av[r] = fmaf(w[3], xv[3], av[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = act_fwd<ACT>(av[r]);
+        *(f32x4*)(bufA + pt * HS + h) = av;
+    }
+    __syncthreads();
+    // ---- H x H GEMM on the fp32 MFMA: acc[i][p] (rows 16 (wave KTW + i) .., points 16 p ..) = sum_k A[row][k] B[point][k].  A lane holds four
+    // consecutive k of its row (one 16-byte load = four MFMA K steps), a B lane the same four k of its point (one ds_read_b128);
+    // `ak` maps (row tile, 16-wide k step) to the lane's address: row-major Wm for the forward, the pack_rows4 image for Wm^T ----
+    auto gemm = [&](auto&& ak, const float* Bsm, f32x4 (&acc)[KTW][NPTB]) {
+#pragma unroll
+        for (int i = 0; i < KTW; ++i)
+#pragma unroll
+            for (int p = 0; p < NPTB; ++p) acc[i][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 an[KTW];
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) an[i] = *(const f32x4*)ak(i, 0);
+        for (int j = 0; j < H / 16; ++j) {
+            f32x4 ac[KTW], b[NPTB];
+#pragma unroll
+            for (int i = 0; i < KTW; ++i) ac[i] = an[i];
+            if (j + 1 < H / 16) {
+#pragma unroll
+                for (int i = 0; i < KTW; ++i) an[i] = *(const f32x4*)ak(i, j + 1);
+            }
+#pragma unroll
+            for (int p = 0; p < NPTB; ++p) b[p] = *(const f32x4*)(Bsm + (16 * p + li) * HS + 16 * j + 4 * lg);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < KTW; ++i)
+#pragma unroll
+                    for (int p = 0; p < NPTB; ++p) acc[i][p] = MFMA16(ac[i][r], b[p][r], acc[i][p]);
+        }
+    };
+    const int row0 = 16 * wave * KTW;                                     // this wave's first row (hidden unit) of either GEMM
+    f32x4 acc[KTW][NPTB];
+    gemm([&](int i, int j) { return Wm + (long long)(row0 + 16 * i + li) * H + 16 * j + 4 * lg; }, bufA, acc);
+    // acc[i][p][r] = a2[unit row0 + 16 i + 4 lg + r][point 16 p + li]: bias, activation (the value also carries act')
+    f32x4 zacc[NPTB];
+#pragma unroll
+    for (int p = 0; p < NPTB; ++p) zacc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+        const int hrow = row0 + 16 * i + 4 * lg;
+        const f32x4 bias = *(const f32x4*)(bm + hrow);
+        f32x4 w2f = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (li < C) w2f = *(const f32x4*)(W2 + li * H + hrow);
+#pragma unroll
+        for (int p = 0; p < NPTB; ++p) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][p][r] = act_fwd<ACT>(acc[i][p][r] + bias[r]);
+                zacc[p] = MFMA16(w2f[r], acc[i][p][r], zacc[p]);          // layer 3: the accumulator IS the B operand (K index = its row)
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NPTB; ++p) *(f32x4*)(red + (wave * PT + 16 * p + li) * 16 + 4 * lg) = zacc[p];      // Z^T[c = 4 lg + r][point] -> [point][c]
+    __syncthreads();
+    if (tid < PT) {
+        const int n = n0 + tid;
+        float z[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v = 0.f;
+            if (c < C) {
+                v = b2[c];
+                for (int w = 0; w < NW; ++w) v += red[(w * PT + tid) * 16 + c];
+            }
+            z[c] = v;
+        }
+        if (a.probs) {
+            float m = -INFINITY, den = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c < C) m = fmaxf(m, z[c]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { z[c] = (c < C) ? expf(z[c] - m) : 0.f; den += z[c]; }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) z[c] = z[c] / den;
+        }
+        if (!BWD) {
+            if (n < N) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(a.P + ((long long)s * N + n) * RBNN_CPAD + 4 * q) = (f32x4){z[4 * q], z[4 * q + 1], z[4 * q + 2], z[4 * q + 3]};
+            }
+        } else {
+            // dL/dlogits of this sample, exactly as rbnn_loss_dlogits: the loss gradient g on what the loss saw, through this sample's softmax
+            float g[16], e[16], dz[16];
+            const int y = (n < N) ? a.labels[n] : 0;
+            float m = -INFINITY, den = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                e[c] = (a.loss == RBNN_LOSS_PER_SAMPLE) ? z[c] : ((n < N && c < C) ? a.Psum[(long long)n * RBNN_CPAD + c] * a.inv_S : 0.f);
+                if (c < C) m = fmaxf(m, e[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { e[c] = (c < C) ? expf(e[c] - m) : 0.f; den += e[c]; }
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
+                dot += g[c] * z[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                dz[c] = (a.loss == RBNN_LOSS_MEAN_LOGIT) ? g[c] : (g[c] - dot) * z[c];
+                if (!(n < N && c < C)) dz[c] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dzb + tid * 16 + 4 * q) = (f32x4){dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]};
+        }
+    }
+    if constexpr (BWD) {
+        __syncthreads();
+        // ---- dA2[unit][point] = act'(h2) * sum_c W2[c][unit] dZ[point][c]: K = classes (<= 10: three K steps), -> LDS point-major ----
+        const int QC = (C + 3) / 4;
+        float bz[NPTB][3];
+#pragma unroll
+        for (int p = 0; p < NPTB; ++p)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) bz[p][q] = dzb[(16 * p + li) * 16 + 4 * q + lg];
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+            float aw[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) aw[q] = (4 * q + lg < C) ? W2[(4 * q + lg) * H + row0 + 16 * i + li] : 0.f;
+#pragma unroll
+            for (int p = 0; p < NPTB; ++p) {
+                f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) if (q < QC) t = MFMA16(aw[q], bz[p][q], t);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] *= act_deriv_from_value<ACT>(acc[i][p][r]);
+                *(f32x4*)(bufB + (16 * p + li) * HS + row0 + 16 * i + 4 * lg) = t;
+            }
+        }
+        __syncthreads();
+        // ---- dH1 = Wm^T dA2: the same walk with A from the pack_rows4 image [H/4][H][4] (four consecutive K per 16-byte load) ----
+        const float* const Wmp = a.net.Wm_pack4 + (long long)sw * H * H;
+        gemm([&](int i, int j) { return Wmp + ((long long)(4 * j + lg) * H + row0 + 16 * i + li) * 4; }, bufB, acc);
+        // ---- dA1 = act'(h1) * dH1;  g[d][point] = sum_h W1[h][d] dA1[h][point], again fed from the accumulators ----
+        f32x4 gacc[NPTB];
+#pragma unroll
+        for (int p = 0; p < NPTB; ++p) gacc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+            const int hrow = row0 + 16 * i + 4 * lg;
+            float w1f[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w1f[r] = W1[(hrow + r) * 16 + li];
+#pragma unroll
+            for (int p = 0; p < NPTB; ++p) {
+                const f32x4 hv = *(const f32x4*)(bufA + (16 * p + li) * HS + hrow);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gacc[p] = MFMA16(w1f[r], acc[i][p][r] * act_deriv_from_value<ACT>(hv[r]), gacc[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NPTB; ++p) *(f32x4*)(red + (wave * PT + 16 * p + li) * 16 + 4 * lg) = gacc[p];  // (red's Z partials were consumed before the last barrier)
+        __syncthreads();
+        for (int i = tid; i < PT * 4; i += NT) {
+            const int pt = i >> 2, q = i & 3, n = n0 + pt;
+            if (n < N) {
+                f32x4 v = *(const f32x4*)(red + pt * 16 + 4 * q);
+                for (int w = 1; w < NW; ++w) v += *(const f32x4*)(red + (w * PT + pt) * 16 + 4 * q);
+                *(f32x4*)(a.slabs + ((long long)s * N + n) * 16 + 4 * q) = v;
+            }
+        }
+    }
+}
+
+// Psum[n][c] = sum_s P[s][n][c] in the order s = 0, 1, ... (four interleaved chains, combined in a fixed order); `scale` applied at the end
+__global__ void __launch_bounds__(256) low2_reduce_kernel(const float* __restrict__ P, int S, int N, int C, float scale, float* __restrict__ out, int ldo) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * RBNN_CPAD) return;
+    const int n = i >> 4, c = i & 15;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const long long st = (long long)N * RBNN_CPAD;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+        s0 += P[s * st + i]; s1 += P[(s + 1) * st + i]; s2 += P[(s + 2) * st + i]; s3 += P[(s + 3) * st + i];
+    }
+    for (; s < S; ++s) s0 += P[s * st + i];
+    if (c < ldo) out[(long long)n * ldo + c] = (c < C) ? ((s0 + s1) + (s2 + s3)) * scale : 0.f;
+}
+
+struct Low2Finish {
+    const float* slabs; const float* Xcur; const float* X0; const float* alpha;
+    float *out, *linf, *l2;
+    int S, N, D, ldx, ldo, op, project, alpha_per_image;
+    float out_scale, eps, alpha_scalar;
+};
+
+// one thread per (point, column): sum of the S per-sample slabs (fixed order), then the gradient (+ norms by a 16-lane butterfly) or the step
+__global__ void __launch_bounds__(256) low2_finish_kernel(const Low2Finish a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = i >> 4, d = i & 15;
+    const bool live = n < a.N;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (live) {
+        const long long st = (long long)a.N * 16;
+        int s = 0;
+        for (; s + 3 < a.S; s += 4) {
+            s0 += a.slabs[s * st + i]; s1 += a.slabs[(s + 1) * st + i]; s2 += a.slabs[(s + 2) * st + i]; s3 += a.slabs[(s + 3) * st + i];
+        }
+        for (; s < a.S; ++s) s0 += a.slabs[s * st + i];
+    }
+    const float G = (s0 + s1) + (s2 + s3);
+    if (a.op == OP_GRADIENT) {
+        const float v = (live && d < a.D) ? G * a.out_scale : 0.f;
+        if (live && d < a.D) a.out[(long long)n * a.ldo + d] = v;
+        float m = fabsf(v), ss = v * v;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); ss += __shfl_xor(ss, o); }
+        if (live && d == 0) {
+            if (a.linf) a.linf[n] = m;
+            if (a.l2) a.l2[n] = sqrtf(ss);
+        }
+        return;
+    }
+    // the step, in rbnn_attack_step's operation order (adversarialAttacks.py:81-82, :103-105)
+    float x0 = (live && d < a.D) ? a.X0[(long long)n * a.ldx + d] : -INFINITY;
+    float step = a.alpha_scalar;
+    if (a.alpha) step = live ? a.alpha[n] : 0.f;
+    else if (a.alpha_per_image) {                                         // 2 / max of the CLEAN image (:89)
+        float m = x0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        step = 2.f / m;
+    }
+    if (live && d < a.D) {
+        const float x = a.Xcur[(long long)n * a.ldx + d];
+        const float sgn = (G > 0.f) ? 1.f : ((G < 0.f) ? -1.f : 0.f);
+        float pert = x + step * sgn;
+        if (a.project) pert = x0 + fminf(fmaxf(pert - x0, -a.eps), a.eps);
+        a.out[(long long)n * a.ldo + d] = fminf(fmaxf(pert, 0.f), 1.f);
+    }
+}
+
+template <int ACT, int NW, int KTW, int NPTB, bool BWD> int launch_low2_cfg(Low2Args a, hipStream_t st) {
+    using L = Low2Lds<NW, KTW, NPTB, BWD>;
+    a.NG = (a.N + L::PT - 1) / L::PT;
+    static unsigned long long attr = 0;
+    if (L::FLOATS * 4 > 64 * 1024 && !ensure_dynamic_lds((const void*)low2_kernel<ACT, NW, KTW, NPTB, BWD>, L::FLOATS * 4, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((low2_kernel<ACT, NW, KTW, NPTB, BWD>), dim3((unsigned)((long long)a.S * a.NG)), dim3(64 * NW), L::FLOATS * 4, st, a);
+    return launch_status();
+}
+
+// tile plan per hidden size: waves x unit tiles per wave x point tiles per block (accumulators <= 16 tiles, the two hidden images <= 133 KB)
+template <int ACT, bool BWD> int launch_low2_h(const Low2Args& a, hipStream_t st) {
+    switch (a.net.hidden) {
+        case 32:  return launch_low2_cfg<ACT, 2, 1, 7, BWD>(a, st);
+        case 64:  return launch_low2_cfg<ACT, 4, 1, 7, BWD>(a, st);
+        case 128: return launch_low2_cfg<ACT, 4, 2, 7, BWD>(a, st);
+        case 256: return launch_low2_cfg<ACT, 4, 4, 4, BWD>(a, st);
+        case 512: return launch_low2_cfg<ACT, 4, 8, 2, BWD>(a, st);
+    }
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+template <bool BWD> int launch_low2(const Low2Args& a, hipStream_t st) {
+    switch (a.net.activation) {
+        case RBNN_ACT_RELU:  return launch_low2_h<RBNN_ACT_RELU, BWD>(a, st);
+        case RBNN_ACT_LEAKY: return launch_low2_h<RBNN_ACT_LEAKY, BWD>(a, st);
+        case RBNN_ACT_SIGM:  return launch_low2_h<RBNN_ACT_SIGM, BWD>(a, st);
+        case RBNN_ACT_TANH:  return launch_low2_h<RBNN_ACT_TANH, BWD>(a, st);
+    }
+    return RBNN_ERR_UNSUPPORTED;
+}
+
+bool low2_hidden_ok(int H) { return H == 32 || H == 64 || H == 128 || H == 256 || H == 512; }
+
+// the fc2 sequence of one rbnn_lowdim_run call (see the header of this section); scratch = [P | slabs | Psum]
+int run_low2(const rbnn_posterior* net, int op, int loss, int out_kind, const float* X, const float* X0, int ldx, int N, const int* sidx, int S,
+             const int* labels, float inv_S, float out_scale, float eps, const float* alpha, float alpha_scalar, int alpha_per_image, int project,
+             int iters, float* scratch, float* out, int ldo, float* linf, float* l2, hipStream_t st) {
+    if (!net->Wm || !net->bm || !net->Wm_pack4 || !scratch) return RBNN_ERR_NULL;
+    if (!aligned16(net->Wm) || !aligned16(net->bm) || !aligned16(net->Wm_pack4) || !aligned16(scratch)) return RBNN_ERR_ALIGN;
+    const long long SN = (long long)S * N * RBNN_CPAD;
+    float* const P = scratch;
+    float* const slabs = scratch + SN;
+    float* const Psum = scratch + 2 * SN;
+    Low2Args a = {};
+    a.net = *net; a.sidx = sidx; a.labels = labels; a.P = P; a.Psum = Psum; a.slabs = slabs; a.ldx = ldx; a.N = N; a.S = S; a.loss = loss;
+    a.dq = net->in_features <= 4 ? 1 : (net->in_features + 3) / 4; a.inv_S = inv_S;
+    const unsigned rgrid = (unsigned)(((long long)N * RBNN_CPAD + 255) / 256);
+    int rc;
+    if (op == OP_FORWARD) {
+        a.X = X; a.probs = out_kind == RBNN_OUT_PROBS;
+        if ((rc = launch_low2<false>(a, st))) return rc;
+        hipLaunchKernelGGL(low2_reduce_kernel, dim3(rgrid), dim3(256), 0, st, P, S, N, net->n_classes, out_scale, out, ldo);
+        return launch_status();
+    }
+    a.probs = loss != RBNN_LOSS_MEAN_LOGIT;
+    const int T = op == OP_ATTACK ? iters : 1;
+    for (int it = 0; it < T; ++it) {
+        a.X = (it == 0) ? X : out;                                         // the iterate lives in `out` from the first step on
+        if (loss != RBNN_LOSS_PER_SAMPLE) {
+            if ((rc = launch_low2<false>(a, st))) return rc;
+            hipLaunchKernelGGL(low2_reduce_kernel, dim3(rgrid), dim3(256), 0, st, P, S, N, net->n_classes, 1.f, Psum, RBNN_CPAD);
+            if ((rc = launch_status())) return rc;
+        }
+        if ((rc = launch_low2<true>(a, st))) return rc;
+        Low2Finish f = {};
+        f.slabs = slabs; f.Xcur = a.X; f.X0 = X0 ? X0 : X; f.alpha = alpha; f.out = out; f.linf = linf; f.l2 = l2; f.S = S; f.N = N; f.D = net->in_features;
+        f.ldx = ldx; f.ldo = ldo; f.op = op; f.project = project; f.alpha_per_image = alpha_per_image; f.out_scale = out_scale; f.eps = eps;
+        f.alpha_scalar = alpha_scalar;
+        hipLaunchKernelGGL(low2_finish_kernel, dim3(rgrid), dim3(256), 0, st, f);
+        if ((rc = launch_status())) return rc;
+    }
+    return RBNN_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int rbnn_lowdim_supported(const rbnn_posterior* net) {
-    return net && net->arch == RBNN_ARCH_FC && net->in_features >= 1 && net->in_features <= 16 && net->n_classes >= 1 && net->n_classes <= 10 &&
-           net->hidden >= 32 && (net->hidden & 31) == 0 && net->in_stride >= 16 && (net->in_stride & 15) == 0;
+    if (!net || (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2)) return 0;
+    if (!(net->in_features >= 1 && net->in_features <= 16 && net->n_classes >= 1 && net->n_classes <= 10 && net->hidden >= 32 &&
+          (net->hidden & 31) == 0 && net->in_stride >= 16 && (net->in_stride & 15) == 0)) return 0;
+    if (net->arch == RBNN_ARCH_FC2) return net->in_stride == 16 && low2_hidden_ok(net->hidden);      // the fc2 tile plans (launch_low2_h)
+    return 1;
+}
+
+size_t rbnn_lowdim_scratch_bytes(const rbnn_posterior* net, int32_t n_points, int32_t n_samples) {
+    if (!net || n_points < 1 || n_samples < 1) return 0;
+    const size_t SN = (size_t)n_samples * n_points * RBNN_CPAD * sizeof(float);
+    return net->arch == RBNN_ARCH_FC2 ? 2 * SN + (size_t)n_points * RBNN_CPAD * sizeof(float) : SN;
 }
 
 int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, int32_t out_kind, const float* X, const float* X0, int32_t ldx,
@@ -395,8 +798,15 @@ int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, in
         if (loss_mode != RBNN_LOSS_MEAN_PROB && loss_mode != RBNN_LOSS_PER_SAMPLE && loss_mode != RBNN_LOSS_MEAN_LOGIT) return RBNN_ERR_UNSUPPORTED;
         if (loss_mode == RBNN_LOSS_MEAN_PROB && !P_scratch) return RBNN_ERR_NULL;
     }
+    if (net->arch == RBNN_ARCH_FC2 && !P_scratch) return RBNN_ERR_NULL;
     if (op == OP_ATTACK && (iters < 1 || (project && !X0))) return RBNN_ERR_SHAPE;
     if (!aligned16(net->W1) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
+    if (net->arch == RBNN_ARCH_FC2) {
+        if (op != OP_FORWARD && loss_mode != RBNN_LOSS_PER_SAMPLE && !P_scratch) return RBNN_ERR_NULL;
+        if (op == OP_ATTACK && out == X) return RBNN_ERR_SHAPE;             // the iterate is updated in `out` while X is still read
+        return run_low2(net, op, loss_mode, out_kind, X, X0, ldx, n_points, sample_idx, n_samples, labels, inv_S, out_scale, eps, alpha, alpha_scalar,
+                        alpha_per_image, project, iters, P_scratch, out, ldo, linf, l2, (hipStream_t)stream);
+    }
     LowArgs a = {};
     a.net = *net; a.X = X; a.X0 = X0 ? X0 : X; a.sidx = sample_idx; a.labels = labels; a.alpha = alpha; a.P = P_scratch; a.out = out;
     a.linf = linf; a.l2 = l2; a.ldx = ldx; a.N = n_points; a.S = n_samples; a.op = op; a.loss = loss_mode; a.out_kind = out_kind; a.ldo = ldo;

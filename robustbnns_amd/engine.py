@@ -90,10 +90,11 @@ class AttackEngine:
         # floor of the 7 kernels above: one kernel does the forward / the expected gradient / ALL iterations of an attack in fp32 FMA
         # arithmetic (rbnn_lowdim.hip).  Single process only (the sample-sharded step needs its all-reduces between the phases); calls it
         # does not cover (autograd hooks with an upstream gradient) run the fp32-MFMA kernels.
-        low = (isinstance(self.k, _hip.HipKernels) and self.world == 1 and getattr(self.post, "arch", None) == "fc"
+        low = (isinstance(self.k, _hip.HipKernels) and self.world == 1 and getattr(self.post, "arch", None) in ("fc", "fc2")
                and self.device.type == "cuda" and self.k.lowdim_supported(self.post))
         if want == "lowdim" and not low:
-            raise _hip.HipError("precision='lowdim' covers fc posteriors with in_features <= 16 and classes <= 10 on one GPU")
+            raise _hip.HipError("precision='lowdim' covers fc posteriors (fc2: hidden 32 ... 512, a power of two) with in_features <= 16 and "
+                                "classes <= 10 on one GPU")
         if want == "lowdim" or (want == "auto" and low):
             return "lowdim"
         # triple: full-width fp32 operands as three fp16 pieces, six exact product terms on the f16 matrix pipe, fp32 accumulation
@@ -315,7 +316,7 @@ class AttackEngine:
             out = torch.zeros(N, _hip.CPAD, dtype=torch.float32, device=self.device)
         if self.precision == "lowdim":
             self.k.lowdim_run(self.post, self.k.LOWDIM_FORWARD, 0, out_kind, Xp, None, sidx, S, None, 1.0, 1.0 / S, 0.0, None, 0.0, False, False,
-                              1, None, out)
+                              1, self._low_scratch(N, S) if self.post.arch == "fc2" else None, out)
             return out
         ws = self.workspace(N, S)
         self._forward_kernels(Xp, sidx, S, out_kind, ws)
@@ -375,11 +376,12 @@ class AttackEngine:
         """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad].  norms = (linf [N], l2 [N]) device
         buffers: filled with the per-point norms of that gradient in the same pass as the slab sum (rbnn_sum_slabs_norms)."""
         if self.precision == "lowdim" and G_up is None and mode in (LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_MEAN_LOGIT):
-            ws = self.workspace(Xp.shape[0], S)
             per = mode == LOSS_PER_SAMPLE
+            G = self._low_out(Xp.shape[0])
             self.k.lowdim_run(self.post, self.k.LOWDIM_GRADIENT, mode, 0, Xp, None, sidx, S, labels, 1.0 if per else 1.0 / S, 1.0 / S if per else 1.0,
-                              0.0, None, 0.0, False, False, 1, ws["P"], ws["G"], None if norms is None else norms[0], None if norms is None else norms[1])
-            return ws["G"]
+                              0.0, None, 0.0, False, False, 1, self._low_scratch(Xp.shape[0], S), G, None if norms is None else norms[0],
+                              None if norms is None else norms[1])
+            return G
         ws, n_slabs, S_tot = self.gradient_slabs(Xp, labels, sidx, S, mode, G_up)
         scale = 1.0 / S_tot if mode == LOSS_PER_SAMPLE else 1.0
         N, p = Xp.shape[0], self.post
@@ -541,15 +543,34 @@ class AttackEngine:
             self._scales = None
         return self.unpad(X, x)
 
+    def _low_out(self, N):
+        """[N, D_pad] gradient buffer of the lowdim path, cached per N (the generic path keeps its own in the workspace)."""
+        key = ("lowG", N)
+        t = self._ws_cache.pop(key, None)
+        if t is None:
+            t = torch.empty(N, self.post.Dp, dtype=torch.float32, device=self.device)
+        self._ws_cache[key] = t
+        return t
+
+    def _low_scratch(self, N, S):
+        """rbnn_lowdim_run's scratch (per-sample outputs; fc2: + per-sample gradient slabs + the sum over samples), cached per (N, S)."""
+        key = ("low", N, S)
+        t = self._ws_cache.pop(key, None)
+        if t is None:
+            t = torch.empty(self.k.lowdim_scratch_bytes(self.post, N, S) // 4, dtype=torch.float32, device=self.device)
+            while len(self._ws_cache) > 6:
+                self._ws_cache.pop(next(iter(self._ws_cache)))
+        self._ws_cache[key] = t
+        return t
+
     def _lowdim_attack(self, X, X0, labels, sidx, S, mode, alpha_t, alpha_scalar, alpha_per_image, eps, project, iters):
         """rbnn_lowdim_run(ATTACK): `iters` iterations from X (around X0) in one launch -> a new [N, D_pad] tensor.  FGSM: project False,
         the step is eps itself."""
-        ws = self.workspace(X.shape[0], S)
         out = torch.empty_like(X)               # the kernel writes every column d < D of every row; X is the unpadded [N, D] view
         if not project:
             alpha_scalar, alpha_per_image = eps, False
         self.k.lowdim_run(self.post, self.k.LOWDIM_ATTACK, mode, 0, X, X0, sidx, S, labels, 1.0 / S, 1.0, eps, alpha_t, alpha_scalar, alpha_per_image,
-                          project, iters, ws["P"], out)
+                          project, iters, self._low_scratch(X.shape[0], S), out)
         return out
 
     graph_safe = True                       # ConvEngine (per-call point blocking) turns this off

@@ -3,7 +3,7 @@
 
 Run in the build container only (the GPU box has no /root/reference):
 
-    python tests/golden/make_golden_trained.py [trained|mnist|mnist2|traj|files]
+    python tests/golden/make_golden_trained.py [trained|mnist|mnist2|traj|files|traj2]
 
 Everything here is produced by the reference's own functions, imported unmodified from /root/reference behind the inert
 keras / pyro stubs of make_golden.py (neither package is touched by these code paths):
@@ -348,6 +348,70 @@ def run_reference_files():
         print("  wrote", os.path.join("tests/golden/files", f), os.path.getsize(os.path.join(FILES, f)), "B")
 
 
+# ------------------------------------------------------------------------------------------------ (5) round 4: more PGD trajectories
+def run_traj_halfmoons_fc2(name):
+    """The reference's own PGD iterates on the trained half-moons fc2 posterior (the nets of trained_halfmoons_fc2_h32_m10: train_members is
+    deterministic, checked against that fixture's weights) — as a BNN (mean of probabilities), as an Ensemble_NN (mean of logits) and for
+    ONE deterministic member (n_samples=None), 8 points each."""
+    import utils
+    x_train, y_train, x_test, y_test, shape, C = utils.load_half_moons()
+    hidden, M, P = 32, 10, 8
+    nets = train_members("fc2", hidden, M, x_train, y_train, shape, C, "half_moons", n_sub=1500, epochs=8, lr=0.02, seed0=1000)
+    have = np.load(os.path.join(HERE, "trained_halfmoons_fc2_h32_m10.npz"), allow_pickle=True)
+    arrs = MG.state_arrays(nets)
+    assert all(np.array_equal(arrs[k], have[k]) for k in arrs), "training is not reproducible: the trajectory would belong to other weights"
+    x, y = torch.from_numpy(x_test[:P]), torch.from_numpy(y_test[:P])
+    out = {"x": x.numpy(), "y": y.numpy()}
+    out.update(arrs)
+    bnn = as_bnn(nets, "half_moons", "fc2", hidden, shape, C)
+    ens = as_ensemble(nets, "half_moons", "fc2", hidden, shape, C)
+    eps = 0.1
+    out["traj"], out["traj_grad"] = record_pgd_trajectory(bnn, x, y, eps, M)
+    out["ens_traj"], out["ens_traj_grad"] = record_pgd_trajectory(ens, x, y, eps, M)
+    out["nn0_traj"], out["nn0_traj_grad"] = record_pgd_trajectory(nets[0], x, y, eps, None)
+    meta = dict(dataset="half_moons", shape=list(shape), n_classes=C, hidden=hidden, act="leaky", arch="fc2", S=M, N=P,
+                traj_eps=eps, traj_ns=M, traj_points=P, weights_sha256=MG.sha(arrs))
+    out["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def run_traj_det_and_ensemble(name):
+    """PGD iterates of the reference for an Ensemble_NN (mean of logits, model_ensemble.py:57-67) and for a deterministic NN
+    (adversarialAttacks.py:287-350 path: n_samples=None) on the MNIST-shaped nets of make_golden.py's mnist_det_ens_fc_h32_m4_n6."""
+    import model_ensemble
+    import model_nn
+    have = np.load(os.path.join(HERE, "mnist_det_ens_fc_h32_m4_n6.npz"), allow_pickle=True)
+    import ast
+    m = ast.literal_eval(str(have["meta"]))
+    shape, C, H, M, P = tuple(m["shape"]), m["n_classes"], m["hidden"], m["M"], 4
+    nets = []
+    ens = model_ensemble.Ensemble_NN(dataset_name="mnist", hidden_size=H, activation=m["act"], architecture=m["arch"], epochs=1, lr=0.01,
+                                     input_shape=shape, output_size=C, ensemble_size=M)
+    ens.device = "cpu"
+    for i in range(M):
+        net = model_nn.NN(dataset_name="mnist", input_shape=shape, output_size=C, hidden_size=H, activation=m["act"], architecture=m["arch"],
+                          lr=0.01, epochs=1)
+        net.device = "cpu"
+        MG.fill_net(net, i, m["std"])
+        ens.ensemble_models[str(i)] = net
+        nets.append(net)
+    arrs = MG.state_arrays(nets)
+    assert all(np.array_equal(arrs[k], have[k]) for k in arrs)
+    x, y = torch.from_numpy(have["x"][:P]), torch.from_numpy(have["y"][:P])
+    out = {"x": x.numpy(), "y": y.numpy()}
+    out.update(arrs)
+    out["ens_traj"], out["ens_traj_grad"] = record_pgd_trajectory(ens, x, y, m["eps"], M)
+    out["nn0_traj"], out["nn0_traj_grad"] = record_pgd_trajectory(nets[0], x, y, m["eps"], None)
+    assert np.array_equal(out["ens_traj"][40], have["ens_pgd"][:P]) and np.array_equal(out["nn0_traj"][40], have["nn0_pgd"][:P])
+    meta = dict(m, N=P, S=M, traj_eps=m["eps"], traj_ns=M, traj_points=P, weights_sha256=MG.sha(arrs))
+    out["meta"] = np.array(repr(meta))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.astype("float32") if k.endswith("traj_grad") else v) for k, v in out.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     MG._install_stubs()
     sys.path.insert(0, MG.REF)
@@ -373,6 +437,9 @@ def main():
         run_traj_fc512("pgd_traj_mnist_fc_h512_s8_n8")
     if only in (None, "files"):
         run_reference_files()
+    if only in (None, "traj2"):
+        run_traj_halfmoons_fc2("pgd_traj_halfmoons_fc2_h32_m10")
+        run_traj_det_and_ensemble("pgd_traj_det_ens_fc_h32_m4_n6")
 
 
 if __name__ == "__main__":

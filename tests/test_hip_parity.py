@@ -141,10 +141,11 @@ def test_golden_deterministic_and_ensemble(golden):
     g1 = O.meanprob_gradients(x, lab, post, m["arch"], m["act"], 1, kind="ensemble")
     adv_equal(A.fgsm_attack(ens, x.to(DEV), lab.to(DEV), hyper, n_samples=M), g.t("ens_fgsm"), ge)
     adv_equal(A.fgsm_attack(nn0, x.to(DEV), lab.to(DEV), hyper, n_samples=None), g.t("nn0_fgsm"), g1)
-    pg = A.pgd_attack(ens, x.to(DEV), lab.to(DEV), hyper, n_samples=M).cpu()
-    assert float(((pg - g.t("ens_pgd")).abs() > 1e-6).double().mean()) < 0.02
-    pg = A.pgd_attack(nn0, x.to(DEV), lab.to(DEV), hyper, n_samples=None).cpu()
-    assert float(((pg - g.t("nn0_pgd")).abs() > 1e-6).double().mean()) < 0.02
+    # PGD through the call surface: the step itself is pinned one iteration at a time along the reference's own ensemble / deterministic-NN
+    # iterates (tests/test_hip_round3.py::test_pgd_single_steps_along_the_reference_trajectory, fixture pgd_traj_det_ens_fc_h32_m4_n6: the
+    # same nets); here the whole 40-step attacks of all points, held to the whole-attack gate (and printed)
+    pgd_whole_attack_statistic("mnist_det_ens ensemble", A.pgd_attack(ens, x.to(DEV), lab.to(DEV), hyper, n_samples=M), g.t("ens_pgd"))
+    pgd_whole_attack_statistic("mnist_det_ens deterministic NN", A.pgd_attack(nn0, x.to(DEV), lab.to(DEV), hyper, n_samples=None), g.t("nn0_pgd"))
     oa, aa, rob = A.attack_evaluation(ens, x, g.t("ens_fgsm"), y, DEV, n_samples=M)
     assert (oa, aa) == (float(g.arr["ens_eval_orig_acc"]), float(g.arr["ens_eval_adv_acc"]))
     assert float((rob.cpu() - g.t("ens_eval_softmax_rob")).abs().max()) < 1e-6

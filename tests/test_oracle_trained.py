@@ -111,18 +111,26 @@ def test_trained_mnist_shaped(golden, name):
     assert float((rob - g.t("bnn_pgd_rob")).abs().max()) < TOL
 
 
-@pytest.mark.parametrize("name", ["trained_halfmoons_fc_h32_m10", "pgd_traj_mnist_fc_h512_s8_n8"] + MNIST_SHAPED)
-def test_pgd_single_steps_along_the_reference_trajectory(golden, name):
+TRAJ = [(n, "bnn") for n in ["trained_halfmoons_fc_h32_m10", "pgd_traj_mnist_fc_h512_s8_n8"] + MNIST_SHAPED] + \
+       [("pgd_traj_halfmoons_fc2_h32_m10", "bnn"), ("pgd_traj_halfmoons_fc2_h32_m10", "ens"), ("pgd_traj_halfmoons_fc2_h32_m10", "nn0"),
+        ("pgd_traj_det_ens_fc_h32_m4_n6", "ens"), ("pgd_traj_det_ens_fc_h32_m4_n6", "nn0")]
+
+
+@pytest.mark.parametrize("name,kind", TRAJ)
+def test_pgd_single_steps_along_the_reference_trajectory(golden, name, kind):
     """adversarialAttacks.py:95-105 is a 40-step chaotic map: compare ONE step at a time, from the reference's own iterate k to its
-    iterate k+1 — zero non-marginal mismatches over all 40 steps."""
+    iterate k+1 — zero non-marginal mismatches over all 40 steps.  kind "bnn": mean of probabilities over the samples; "ens": the
+    reference's Ensemble_NN (mean of logits, model_ensemble.py:57-67); "nn0": one deterministic NN (n_samples=None) — round 4's fixtures."""
     g = golden(name); m = g.meta; post = g.posterior()
-    traj, tg = g.t("traj"), g.t("traj_grad")               # [41, P, *shape], [40, P, *shape]
+    pre = "" if kind == "bnn" else kind + "_"
+    traj, tg = g.t(pre + "traj"), g.t(pre + "traj_grad")   # [41, P, *shape], [40, P, *shape]
     P = traj.shape[1]
     x0, lab = traj[0], g.t("y")[:P].argmax(-1)
     assert torch.equal(x0, g.t("x")[:P])
     eps, alpha, _ = O.pgd_params(x0, {"epsilon": m["traj_eps"]})
+    S = 1 if kind == "nn0" else m["traj_ns"]
     marginal = 0
     for k in range(40):
-        nxt = O.pgd_step(traj[k], x0, lab, post, m["arch"], m["act"], m["traj_ns"], eps, alpha)
+        nxt = O.pgd_step(traj[k], x0, lab, post, m["arch"], m["act"], S, eps, alpha, kind="bnn" if kind == "bnn" else "ensemble")
         marginal += marginal_ok(nxt, traj[k + 1], tg[k], f"step {k}")
-    print(f"{name}: {marginal} marginal pixels differ over 40 steps x {P} points")
+    print(f"{name} [{kind}]: {marginal} marginal pixels differ over 40 steps x {P} points")
