@@ -426,7 +426,12 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
     float* const dzb = red + NW * PT * 16;                                // BWD: dZ [PT][16]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int s = blockIdx.x / a.NG, n0 = (blockIdx.x - s * a.NG) * PT;
+    // block -> (sample, point group): blocks b, b + 8, b + 16, ... share an XCD (round-robin dispatch, rbnn_common.hpp), so the NG point
+    // groups of a sample are spaced 8 apart: they run side by side on ONE XCD and share the sample's Wm (1 MB at hidden 512) in its L2
+    // (consecutive block numbers put them on four different XCDs, each fetching its own copy: 4.4 TB/s from beyond the L2)
+    const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
+    const int s = 8 * (bq / a.NG) + bx, n0 = (bq % a.NG) * PT;
+    if (s >= a.S) return;                                                 // (whole block: the grid covers ceil(S / 8) * 8 samples)
     const int sw = a.sidx ? a.sidx[s] : s;
     const int C = a.net.n_classes, D = a.net.in_features, N = a.N;
     const float* const W1 = a.net.W1 + (long long)sw * H * 16;            // [H][16] (in_stride = 16: zero columns beyond D)
@@ -436,60 +441,97 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
     const float* const W2 = a.net.W2 + (long long)sw * C * H;
     const float* const b2 = a.net.b2 + (long long)sw * C;
 
-    for (int i = tid; i < PT * 16; i += NT) {
-        const int n = n0 + (i >> 4), d = i & 15;
-        xs[i] = (n < N && d < D) ? a.X[(long long)n * a.ldx + d] : 0.f;
-    }
-    __syncthreads();
-    // ---- layer 1: h1[pt][h] = act(b1[h] + W1[h, :] . x[pt, :]), four hidden units per item ----
-    for (int i = tid; i < PT * (H / 4); i += NT) {
-        const int pt = i / (H / 4), h = 4 * (i - pt * (H / 4));
-        f32x4 av = *(const f32x4*)(b1 + h);
-        for (int q = 0; q < a.dq; ++q) {
-            const f32x4 xv = *(const f32x4*)(xs + pt * 16 + 4 * q);
+    // Software pipeline: THREE register sets of A, each reloaded for K step j + 3 right behind the MFMAs of step j that read it (no copies;
+    // an L2 / Infinity-Cache round trip is longer than the 4 KTW NPTB MFMAs of one step when one wave per SIMD is all the CU holds), B one
+    // step ahead (LDS).  gemm_load issues the first three steps' A loads — callers place it BEFORE the barriers / LDS phases in front of
+    // the product, so that those round trips overlap them.
+    constexpr int J = H / 16;
+    auto gemm_load = [&](auto&& ak, f32x4 (&A)[3][KTW]) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x4 w = *(const f32x4*)(W1 + (h + r) * 16 + 4 * q);
-                av[r] = fmaf(w[0], xv[0], av[r]); av[r] = fmaf(w[1], xv[1], av[r]); av[r] = fmaf(w[2], xv[2], av[r]); av[r] = fmaf(w[3], xv[3], av[r]);
-            }
-        }
+        for (int u = 0; u < 3; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = act_fwd<ACT>(av[r]);
-        *(f32x4*)(bufA + pt * HS + h) = av;
-    }
-    __syncthreads();
-    // ---- H x H GEMM on the fp32 MFMA: acc[i][p] (rows 16 (wave KTW + i) .., points 16 p ..) = sum_k A[row][k] B[point][k].  A lane holds four
-    // consecutive k of its row (one 16-byte load = four MFMA K steps), a B lane the same four k of its point (one ds_read_b128);
-    // `ak` maps (row tile, 16-wide k step) to the lane's address: row-major Wm for the forward, the pack_rows4 image for Wm^T ----
-    auto gemm = [&](auto&& ak, const float* Bsm, f32x4 (&acc)[KTW][NPTB]) {
+            for (int i = 0; i < KTW; ++i) A[u][i] = *(const f32x4*)ak(i, u < J ? u : 0);
+    };
+    auto gemm = [&](auto&& ak, const float* Bsm, f32x4 (&A)[3][KTW], f32x4 (&acc)[KTW][NPTB]) {
 #pragma unroll
         for (int i = 0; i < KTW; ++i)
 #pragma unroll
             for (int p = 0; p < NPTB; ++p) acc[i][p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 an[KTW];
+        f32x4 b[NPTB], bn[NPTB];
 #pragma unroll
-        for (int i = 0; i < KTW; ++i) an[i] = *(const f32x4*)ak(i, 0);
-        for (int j = 0; j < H / 16; ++j) {
-            f32x4 ac[KTW], b[NPTB];
+        for (int p = 0; p < NPTB; ++p) b[p] = *(const f32x4*)(Bsm + (16 * p + li) * HS + 4 * lg);
+        auto step = [&](f32x4 (&a)[KTW], int j) {
+            if (j + 1 < J) {
 #pragma unroll
-            for (int i = 0; i < KTW; ++i) ac[i] = an[i];
-            if (j + 1 < H / 16) {
-#pragma unroll
-                for (int i = 0; i < KTW; ++i) an[i] = *(const f32x4*)ak(i, j + 1);
+                for (int p = 0; p < NPTB; ++p) bn[p] = *(const f32x4*)(Bsm + (16 * p + li) * HS + 16 * (j + 1) + 4 * lg);
             }
-#pragma unroll
-            for (int p = 0; p < NPTB; ++p) b[p] = *(const f32x4*)(Bsm + (16 * p + li) * HS + 16 * j + 4 * lg);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int i = 0; i < KTW; ++i)
 #pragma unroll
-                    for (int p = 0; p < NPTB; ++p) acc[i][p] = MFMA16(ac[i][r], b[p][r], acc[i][p]);
+                    for (int p = 0; p < NPTB; ++p) acc[i][p] = MFMA16(a[i][r], b[p][r], acc[i][p]);
+            if (j + 3 < J) {
+#pragma unroll
+                for (int i = 0; i < KTW; ++i) a[i] = *(const f32x4*)ak(i, j + 3);
+            }
+#pragma unroll
+            for (int p = 0; p < NPTB; ++p) b[p] = bn[p];
+        };
+        for (int j = 0; j < J; j += 3) {
+            step(A[0], j);
+            if (j + 1 < J) step(A[1], j + 1);
+            if (j + 2 < J) step(A[2], j + 2);
         }
     };
     const int row0 = 16 * wave * KTW;                                     // this wave's first row (hidden unit) of either GEMM
+    auto ak_fwd = [&](int i, int j) { return Wm + (long long)(row0 + 16 * i + li) * H + 16 * j + 4 * lg; };     // Wm rows, row-major
+    const float* const Wmp = a.net.Wm_pack4 + (long long)sw * H * H;                                           // pack_rows4 image: Wm^T rows
+    auto ak_bwd = [&](int i, int j) { return Wmp + ((long long)(4 * j + lg) * H + row0 + 16 * i + li) * 4; };
+    f32x4 Areg[3][KTW];
+    for (int i = tid; i < PT * 16; i += NT) {
+        const int n = n0 + (i >> 4), d = i & 15;
+        xs[i] = (n < N && d < D) ? a.X[(long long)n * a.ldx + d] : 0.f;
+    }
+    gemm_load(ak_fwd, Areg);                                              // lands under the input tile's round trip and layer 1
+    __syncthreads();
+    // ---- layer 1: h1[pt][h] = act(b1[h] + W1[h, :] . x[pt, :]).  A thread owns four hidden units — their W1 rows and biases are loaded ONCE
+    // into registers — and walks over points (x from LDS, a broadcast): no global load inside the loop (first version: one (point, unit
+    // quad) item per trip with its W1 rows re-read from L2 every trip — 14 dependent round trips, 14 of the kernel's 22 us at hidden 128) ----
+    {
+        constexpr int HQ = H / 4, PSTEP = NT / HQ;
+        static_assert(NT % HQ == 0, "threads per unit quad");
+        const int h = 4 * (tid % HQ);
+        const f32x4 bq = *(const f32x4*)(b1 + h);
+        f32x4 w[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[r][q] = (q < a.dq) ? *(const f32x4*)(W1 + (h + r) * 16 + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int pt = tid / HQ; pt < PT; pt += PSTEP) {
+            f32x4 av = bq;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < a.dq) {
+                    const f32x4 xv = *(const f32x4*)(xs + pt * 16 + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        av[r] = fmaf(w[r][q][0], xv[0], av[r]); av[r] = fmaf(w[r][q][1], xv[1], av[r]);
+                        av[r] = fmaf(w[r][q][2], xv[2], av[r]); av[r] = fmaf(w[r][q][3], xv[3], av[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] = act_fwd<ACT>(av[r]);
+            *(f32x4*)(bufA + pt * HS + h) = av;
+        }
+    }
+    __syncthreads();
+    // ---- H x H GEMM on the fp32 MFMA: acc[i][p] (rows 16 (wave KTW + i) .., points 16 p ..) = sum_k A[row][k] B[point][k].  A lane holds four
+    // consecutive k of its row (one 16-byte load = four MFMA K steps), a B lane the same four k of its point (one ds_read_b128);
+    // `ak` maps (row tile, 16-wide k step) to the lane's address: row-major Wm for the forward, the pack_rows4 image for Wm^T ----
     f32x4 acc[KTW][NPTB];
-    gemm([&](int i, int j) { return Wm + (long long)(row0 + 16 * i + li) * H + 16 * j + 4 * lg; }, bufA, acc);
+    gemm(ak_fwd, bufA, Areg, acc);
     // acc[i][p][r] = a2[unit row0 + 16 i + 4 lg + r][point 16 p + li]: bias, activation (the value also carries act')
     f32x4 zacc[NPTB];
 #pragma unroll
@@ -566,6 +608,7 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
         }
     }
     if constexpr (BWD) {
+        gemm_load(ak_bwd, Areg);                                          // the second product's first A tiles: under the dZ / dA2 phases
         __syncthreads();
         // ---- dA2[unit][point] = act'(h2) * sum_c W2[c][unit] dZ[point][c]: K = classes (<= 10: three K steps), -> LDS point-major ----
         const int QC = (C + 3) / 4;
@@ -591,8 +634,7 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
         }
         __syncthreads();
         // ---- dH1 = Wm^T dA2: the same walk with A from the pack_rows4 image [H/4][H][4] (four consecutive K per 16-byte load) ----
-        const float* const Wmp = a.net.Wm_pack4 + (long long)sw * H * H;
-        gemm([&](int i, int j) { return Wmp + ((long long)(4 * j + lg) * H + row0 + 16 * i + li) * 4; }, bufB, acc);
+        gemm(ak_bwd, bufB, Areg, acc);
         // ---- dA1 = act'(h1) * dH1;  g[d][point] = sum_h W1[h][d] dA1[h][point], again fed from the accumulators ----
         f32x4 gacc[NPTB];
 #pragma unroll
@@ -624,19 +666,38 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
     }
 }
 
-// Psum[n][c] = sum_s P[s][n][c] in the order s = 0, 1, ... (four interleaved chains, combined in a fixed order); `scale` applied at the end
-__global__ void __launch_bounds__(256) low2_reduce_kernel(const float* __restrict__ P, int S, int N, int C, float scale, float* __restrict__ out, int ldo) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * RBNN_CPAD) return;
-    const int n = i >> 4, c = i & 15;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const long long st = (long long)N * RBNN_CPAD;
-    int s = 0;
-    for (; s + 3 < S; s += 4) {
-        s0 += P[s * st + i]; s1 += P[(s + 1) * st + i]; s2 += P[(s + 2) * st + i]; s3 += P[(s + 3) * st + i];
+// Sum over samples of a [S][N][16] buffer, one block per point: thread (column c, lane g of 16) adds the samples g, g + 16, ... (eight
+// independent loads in flight), then the 16 partials of a column are added in lane order by one thread — a fixed order: deterministic.
+// (First version: one thread per (point, column) walking all S samples — 63 dependent trips: 21 us of a 100-us pass at S = 250.)
+__device__ __forceinline__ float sum_over_samples(const float* __restrict__ buf, int S, int N, int n, float* sh) {
+    const int t = threadIdx.x, c = t & 15, g = t >> 4;
+    const long long st = (long long)N * 16;
+    const float* const p = buf + (long long)n * 16 + c;
+    float acc = 0.f;
+    int s = g;
+    for (; s + 7 * 16 < S; s += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(s + 16 * u) * st];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; s < S; ++s) s0 += P[s * st + i];
-    if (c < ldo) out[(long long)n * ldo + c] = (c < C) ? ((s0 + s1) + (s2 + s3)) * scale : 0.f;
+    for (; s < S; s += 16) acc += p[s * st];
+    sh[g * 16 + c] = acc;
+    __syncthreads();
+    float tot = 0.f;
+    if (t < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += sh[k * 16 + t];
+    }
+    return tot;                                                           // valid in threads 0..15 (column = thread)
+}
+
+__global__ void __launch_bounds__(256) low2_reduce_kernel(const float* __restrict__ P, int S, int N, int C, float scale, float* __restrict__ out, int ldo) {
+    __shared__ float sh[256];
+    const int n = blockIdx.x, c = threadIdx.x;
+    const float tot = sum_over_samples(P, S, N, n, sh);
+    if (c < 16 && c < ldo) out[(long long)n * ldo + c] = (c < C) ? tot * scale : 0.f;
 }
 
 struct Low2Finish {
@@ -646,44 +707,36 @@ struct Low2Finish {
     float out_scale, eps, alpha_scalar;
 };
 
-// one thread per (point, column): sum of the S per-sample slabs (fixed order), then the gradient (+ norms by a 16-lane butterfly) or the step
+// one block per point: sum of the S per-sample slabs (as above), then — threads 0..15, one per column — the gradient (+ norms by a 16-lane
+// butterfly) or the sign / project / clamp step
 __global__ void __launch_bounds__(256) low2_finish_kernel(const Low2Finish a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n = i >> 4, d = i & 15;
-    const bool live = n < a.N;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (live) {
-        const long long st = (long long)a.N * 16;
-        int s = 0;
-        for (; s + 3 < a.S; s += 4) {
-            s0 += a.slabs[s * st + i]; s1 += a.slabs[(s + 1) * st + i]; s2 += a.slabs[(s + 2) * st + i]; s3 += a.slabs[(s + 3) * st + i];
-        }
-        for (; s < a.S; ++s) s0 += a.slabs[s * st + i];
-    }
-    const float G = (s0 + s1) + (s2 + s3);
+    __shared__ float sh[256];
+    const int n = blockIdx.x, d = threadIdx.x;
+    const float G = sum_over_samples(a.slabs, a.S, a.N, n, sh);
+    if (d >= 16) return;
     if (a.op == OP_GRADIENT) {
-        const float v = (live && d < a.D) ? G * a.out_scale : 0.f;
-        if (live && d < a.D) a.out[(long long)n * a.ldo + d] = v;
+        const float v = (d < a.D) ? G * a.out_scale : 0.f;
+        if (d < a.D) a.out[(long long)n * a.ldo + d] = v;
         float m = fabsf(v), ss = v * v;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); ss += __shfl_xor(ss, o); }
-        if (live && d == 0) {
+        if (d == 0) {
             if (a.linf) a.linf[n] = m;
             if (a.l2) a.l2[n] = sqrtf(ss);
         }
         return;
     }
     // the step, in rbnn_attack_step's operation order (adversarialAttacks.py:81-82, :103-105)
-    float x0 = (live && d < a.D) ? a.X0[(long long)n * a.ldx + d] : -INFINITY;
+    const float x0 = (d < a.D) ? a.X0[(long long)n * a.ldx + d] : -INFINITY;
     float step = a.alpha_scalar;
-    if (a.alpha) step = live ? a.alpha[n] : 0.f;
+    if (a.alpha) step = a.alpha[n];
     else if (a.alpha_per_image) {                                         // 2 / max of the CLEAN image (:89)
         float m = x0;
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         step = 2.f / m;
     }
-    if (live && d < a.D) {
+    if (d < a.D) {
         const float x = a.Xcur[(long long)n * a.ldx + d];
         const float sgn = (G > 0.f) ? 1.f : ((G < 0.f) ? -1.f : 0.f);
         float pert = x + step * sgn;
@@ -697,7 +750,7 @@ template <int ACT, int NW, int KTW, int NPTB, bool BWD> int launch_low2_cfg(Low2
     a.NG = (a.N + L::PT - 1) / L::PT;
     static unsigned long long attr = 0;
     if (L::FLOATS * 4 > 64 * 1024 && !ensure_dynamic_lds((const void*)low2_kernel<ACT, NW, KTW, NPTB, BWD>, L::FLOATS * 4, attr)) return RBNN_ERR_LAUNCH;
-    hipLaunchKernelGGL((low2_kernel<ACT, NW, KTW, NPTB, BWD>), dim3((unsigned)((long long)a.S * a.NG)), dim3(64 * NW), L::FLOATS * 4, st, a);
+    hipLaunchKernelGGL((low2_kernel<ACT, NW, KTW, NPTB, BWD>), dim3((unsigned)(8LL * a.NG * ((a.S + 7) / 8))), dim3(64 * NW), L::FLOATS * 4, st, a);
     return launch_status();
 }
 
@@ -738,7 +791,7 @@ int run_low2(const rbnn_posterior* net, int op, int loss, int out_kind, const fl
     Low2Args a = {};
     a.net = *net; a.sidx = sidx; a.labels = labels; a.P = P; a.Psum = Psum; a.slabs = slabs; a.ldx = ldx; a.N = N; a.S = S; a.loss = loss;
     a.dq = net->in_features <= 4 ? 1 : (net->in_features + 3) / 4; a.inv_S = inv_S;
-    const unsigned rgrid = (unsigned)(((long long)N * RBNN_CPAD + 255) / 256);
+    const unsigned rgrid = (unsigned)N;                                   // low2_reduce_kernel / low2_finish_kernel: one block per point
     int rc;
     if (op == OP_FORWARD) {
         a.X = X; a.probs = out_kind == RBNN_OUT_PROBS;
