@@ -277,7 +277,8 @@ int rbnn_conv_input_grad_triple(const rbnn_conv_posterior *net, const void *K2_b
                                 const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
                                 const rbnn_conv_workspace *ws, void *stream);
 
-/* rbnn_conv_input_grad_triple's arithmetic in the DENSE form (1x28x28 only): conv2^T as one GEMM per tap over the 64 conv2 OUTPUT positions
+/* rbnn_conv_input_grad_triple's arithmetic in the DENSE form (both geometries): conv2^T as one GEMM per tap over the conv2 OUTPUT positions
+ * (64 at 1x28x28: one pass; 100 at 3x32x32: two passes over 64 + 36 positions whose col2im partial sums meet in registers)
  * (T[tap][ci][pos] = sum_hc W[hc][ci][tap] * dO2[hc][pos], every MFMA useful) + a col2im gather, instead of the gather form over the
  * zero-padded gradient image (36-39 % of whose MFMAs multiply padding).  K2_dense = rbnn_triple_rows image (ld 32) of model.3.weight
  * regrouped [S_total, ceil(Hc/32) K steps, 25 taps, 32 ci][32 hc] (hc zero-padded to a multiple of 32), holding W * 2^k2_exp.  Same G. */
@@ -436,6 +437,22 @@ int rbnn_fc_forward_triple(const rbnn_posterior *net, const rbnn_triple_images *
 int rbnn_fc_input_grad_triple(const rbnn_posterior *net, const rbnn_triple_images *tp, const int32_t *sample_idx,
                               int32_t n_samples, int32_t n_points, int32_t chunk, const rbnn_workspace *ws,
                               const rbnn_triple_workspace *tws, int32_t *n_slabs_out, void *stream);
+
+/* The tail of a step between the two GEMM calls, fused (round 4): what rbnn_reduce_samples (scale 1) + rbnn_loss_dlogits + the dZ re-scaling
+ * inside rbnn_fc_input_grad_triple compute, in ONE launch, bit for bit — P [n_samples][n_points][16] in, tws->dZ_gen / tws->g_scale out;
+ * the fp32 dZ buffer is not written at all.  mode: RBNN_LOSS_MEAN_PROB (adversarialAttacks.py:74-78), RBNN_LOSS_PER_SAMPLE
+ * (lossGradients.py:29-40) or RBNN_LOSS_MEAN_LOGIT (ensemble / NN); inv_S as rbnn_loss_dlogits.  Psum_out (nullable): sum_s P [n_points][ldo].
+ * rbnn_fc_input_grad_triple called afterwards with ws->dZ == NULL takes the image as given (it skips its own re-scaling launch).
+ * Single-GPU only: the sample-sharded step needs its all-reduce between the sum and the loss (AttackEngine._step_sharded). */
+int rbnn_step_tail_triple(int32_t mode, const float *P, const int32_t *labels, int32_t n_samples, float inv_S, int32_t n_points,
+                          int32_t n_classes, float *Psum_out, int32_t ldo, const rbnn_triple_workspace *tws, void *stream);
+
+/* rbnn_attack_step + rbnn_triple_rows_grouped of the NEW iterate in one pass (bit-identical X and image): inside a PGD loop
+ * (adversarialAttacks.py:95-105) the next iteration's forward then needs no image-builder launch.  dev_scale: record [0] of
+ * rbnn_input_scales (computed once per attack with floor_abs = 1); X_triple: ceil16(n_points) x ld_rows grouped image. */
+int rbnn_attack_step_triple(float *X, const float *X0, int32_t ldx, const float *G, int32_t n_slabs, size_t slab_stride, int32_t ldg,
+                            const float *alpha, float alpha_scalar, float eps, int32_t project, int32_t n_points, int32_t in_features,
+                            const rbnn_dev_scale *dev_scale, void *X_triple, int32_t ld_rows, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The SVI guide's draw written IN PLACE into a stacked posterior and all of its weight images, one launch, no eps tensor.

@@ -150,6 +150,8 @@ SIGNATURES = {
     "rbnn_fc_forward_triple": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(TripleWorkspace), _i32, _fp, _i32, _fp, _i32, _i32, _PW, _fp]),
     "rbnn_fc_input_grad_triple": (_i32, [_PP, C.POINTER(TripleImages), _fp, _i32, _i32, _i32, _PW, C.POINTER(TripleWorkspace),
                                          C.POINTER(_i32), _fp]),
+    "rbnn_step_tail_triple": (_i32, [_i32, _fp, _fp, _i32, _f32, _i32, _i32, _fp, _i32, C.POINTER(TripleWorkspace), _fp]),
+    "rbnn_attack_step_triple": (_i32, [_fp, _fp, _i32, _fp, _i32, _sz, _i32, _fp, _f32, _f32, _i32, _i32, _i32, _fp, _fp, _i32, _fp]),
     "rbnn_lowdim_supported": (_i32, [_PP]),
     "rbnn_lowdim_scratch_bytes": (_sz, [_PP, _i32, _i32]),
     "rbnn_lowdim_run": (_i32, [_PP, _i32, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _fp, _f32, _f32, _f32, _fp, _f32, _i32, _i32, _i32,
@@ -375,11 +377,27 @@ class HipKernels:
         check(self.lib.rbnn_fc_forward_triple(C.byref(net.descriptor()), C.byref(images), C.byref(t), x_exp, ptr(dev_scales), N,
                                               ptr(sidx), S, out_kind, C.byref(w), stream_of(tws["X_triple"])), "rbnn_fc_forward_triple")
 
-    def fc_input_grad_triple(self, net, images, sidx, S, N, chunk, ws, tws):
+    def step_tail_triple(self, mode, P, labels, S, inv_S, N, Cn, tws, Psum=None):
+        """reduce over samples + loss + dZ generator image in one launch (rbnn_step_tail_triple); the fp32 dZ is not written."""
+        require_gpu(P, "P")
+        t = self._tws(tws)
+        check(self.lib.rbnn_step_tail_triple(mode, ptr(P), ptr(labels), S, inv_S, N, Cn, ptr(Psum), 0 if Psum is None else Psum.stride(0), C.byref(t),
+                                             stream_of(P)), "rbnn_step_tail_triple")
+
+    def attack_step_triple(self, X, X0, G, K, slab_stride, ldg, alpha, alpha_scalar, eps, project, D, dev_scale, X_triple, ld_rows):
+        """attack_step + the grouped triple-rows image of the new iterate in one launch (rbnn_attack_step_triple)."""
+        require_gpu(X, "X")
+        check(self.lib.rbnn_attack_step_triple(ptr(X), ptr(X0), X.stride(0), ptr(G), K, slab_stride, ldg, ptr(alpha), alpha_scalar, eps, int(project),
+                                               X.shape[0], D, ptr(dev_scale), ptr(X_triple), ld_rows, stream_of(X)), "rbnn_attack_step_triple")
+
+    def fc_input_grad_triple(self, net, images, sidx, S, N, chunk, ws, tws, dz_ready=False):
+        """dz_ready: tws['dZ_gen'] / tws['g_scale'] were built by step_tail_triple — the fp32 dZ is not read."""
         w, t = self._ws(ws), self._tws(tws)
+        if dz_ready:
+            w.dZ = None
         n = C.c_int32(0)
         check(self.lib.rbnn_fc_input_grad_triple(C.byref(net.descriptor()), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
-                                                 C.byref(t), C.byref(n), stream_of(ws["dZ"])), "rbnn_fc_input_grad_triple")
+                                                 C.byref(t), C.byref(n), stream_of(ws["slabs"])), "rbnn_fc_input_grad_triple")
         return n.value
 
     # -- conv architecture ---------------------------------------------------------------------------

@@ -296,6 +296,7 @@ class ConvEngine(AttackEngine):
     samples, the loss kernels and the evaluation are inherited unchanged."""
 
     graph_safe = False                      # large jobs are cut into point blocks per call: no fixed launch sequence to capture
+    fused_tail = False                      # the conv kernels read the fp32 dZ (rbnn_step_tail_triple builds the fc generator image only)
     pipelined_comm = False                  # one cached workspace: the sample-sharded step keeps the plain sequence
 
     def workspace(self, N, S, chunk=0, tag=0):
@@ -386,7 +387,7 @@ class ConvEngine(AttackEngine):
         ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
         self.k.conv_forward_split(self.post, rows, k2_exp, 0, Xp, sidx, S, out_kind, ws, p1_dev_scale=ds[4:])
 
-    def _grad_kernels(self, sidx, S, N, ws):
+    def _grad_kernels(self, sidx, S, N, ws, dz_ready=False):
         if self.precision == "triple" and os.environ.get("RBNN_CONV_BWD_EXACT") != "1":
             _, k2_exp, bwd, fw_l1 = self.post.triple_images()
             if self.post._dense is not None and self.post.dense_supported():      # GEMM per tap over the conv2 outputs + col2im

@@ -614,6 +614,176 @@ __global__ void __launch_bounds__(256) triple_dz_kernel(const float* __restrict_
 }
 
 // ===================================================================================================
+// The tail of a step between the two GEMM kernels, fused (round 4): rbnn_reduce_samples + rbnn_loss_dlogits + triple_dz_kernel in ONE launch.
+// P [S][N][16] is read by one block per 16 points (its second and third pass hit the L2), the fp32 dZ [S][N][16] is never written:
+//   A  Psum[n][:] = sum_s P[s][n][:]             — sequentially in s by one thread per (point, class quad): the order of reduce_samples_kernel
+//   B  g = dL/d(what the loss saw)               — loss_dlogits_kernel's formulas, once per thread (not per sample) for the mean losses
+//   C  e(n) = 13 - ilogb(max_{s,c} |dZ[s][n][c]|) — dZ recomputed per sample from P (a dozen flops), as in triple_dz_kernel
+//   D  dZ again, x 2^e(n), three pieces, the generator image; gscale[n] = 2^-e(n)
+// Every operation and its order are those of the three kernels it replaces: the image is BIT-IDENTICAL (tests/test_hip_round4.py).
+// ===================================================================================================
+template <int MODE>
+__device__ __forceinline__ void tail_dz(const float* __restrict__ prow, const float (&gmean)[16], int y, int C, float inv_S, float (&out)[16]) {
+    float p[16], g[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *(const f32x4*)(prow + 4 * q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[4 * q + r] = v[r];
+    }
+    if (MODE == RBNN_LOSS_PER_SAMPLE) {
+        float t[16], m = -INFINITY, den = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? p[c] : -INFINITY; m = fmaxf(m, t[c]); }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? expf(t[c] - m) : 0.f; den += t[c]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (t[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) g[c] = gmean[c];
+    }
+    if (MODE == RBNN_LOSS_MEAN_LOGIT) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) out[c] = g[c];
+    } else {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) if (c < C) dot += g[c] * p[c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) out[c] = (c < C) ? (g[c] - dot) * p[c] : 0.f;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) step_tail_x3_kernel(const float* __restrict__ P, const int* __restrict__ labels, int S, float inv_S, int N,
+                                                           long long N_pad, int C, float* __restrict__ Psum_out, int ldo,
+                                                           uint4* __restrict__ dst, float* __restrict__ gscale) {
+    __shared__ float red[16][17];
+    __shared__ float psum[16][16];
+    const int p = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long long n = (long long)blockIdx.x * 16 + p;
+    if (MODE != RBNN_LOSS_PER_SAMPLE) {
+        if (q < 4) {
+            f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (n < N)
+                for (int s = 0; s < S; ++s) sum += *(const f32x4*)(P + ((long long)s * N + n) * RBNN_CPAD + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                psum[p][4 * q + r] = sum[r];
+                if (Psum_out && n < N && 4 * q + r < C) Psum_out[n * ldo + 4 * q + r] = sum[r];
+            }
+        }
+        __syncthreads();
+    }
+    const int y = (n < N) ? labels[n] : 0;
+    float gmean[16];
+    if (MODE != RBNN_LOSS_PER_SAMPLE) {
+        float t[16], m = -INFINITY, den = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? psum[p][c] * inv_S : -INFINITY; m = fmaxf(m, t[c]); }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? expf(t[c] - m) : 0.f; den += t[c]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) gmean[c] = (c < C) ? (t[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) gmean[c] = 0.f;
+    }
+    float m = 0.f;
+    if (n < N)
+        for (int s = q; s < S; s += 16) {
+            float dz[16];
+            tail_dz<MODE>(P + ((long long)s * N + n) * RBNN_CPAD, gmean, y, C, inv_S, dz);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) if (c < C) m = fmaxf(m, fabsf(dz[c]));
+        }
+    red[q][p] = m;
+    __syncthreads();
+    m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m = fmaxf(m, red[i][p]);
+    int e = 0;
+    if (m > 0.f && m < INFINITY) e = min(13 - ilogbf(m), 120);
+    if (q == 0) gscale[n] = ldexpf(1.f, -e);
+    const int sw = dz_swz3(n);
+    for (int s = q; s < S; s += 16) {
+        _Float16 d[3][10];
+        float dz[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dz[c] = 0.f;
+        if (n < N) tail_dz<MODE>(P + ((long long)s * N + n) * RBNN_CPAD, gmean, y, C, inv_S, dz);
+#pragma unroll
+        for (int c = 0; c < 10; ++c) {
+            const float x = (n < N && c < C) ? ldexpf(dz[c], e) : 0.f;
+            split3(x, d[0][c], d[1][c], d[2][c]);
+        }
+        uint4* const o = dst + ((long long)s * N_pad + n) * 4;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            union { f16x8 v; uint4 u; } w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w.v[j] = d[ch][j];
+            o[ch ^ sw] = w.u;
+        }
+        union { f16x8 v; uint4 u; } t;
+        t.v[0] = d[0][8]; t.v[1] = d[0][9]; t.v[2] = d[1][8]; t.v[3] = d[1][9];
+        t.v[4] = d[2][8]; t.v[5] = d[2][9]; t.v[6] = d[0][8]; t.v[7] = d[0][9];
+        o[3 ^ sw] = t.u;
+    }
+}
+
+// rbnn_attack_step + rbnn_triple_rows_grouped of the NEW iterate in one pass (a PGD loop then needs no image-builder launch per iteration):
+// one thread per (row, group of 8 columns) — the step in attack_step4_kernel's operation order (bit-identical X), then the three pieces of
+// the eight new values (bit-identical image).  Groups beyond D hold the image's zero padding.
+__global__ void __launch_bounds__(256) attack_step_x3_kernel(float* __restrict__ X, const float* __restrict__ X0, int ldx, const float* __restrict__ G,
+                                                             int K, long long slab_stride, int ldg, const float* __restrict__ alpha, float alpha_scalar,
+                                                             float eps, int project, long long N, int D, const rbnn_dev_scale* __restrict__ ds,
+                                                             uint4* __restrict__ dst, int groups) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * groups) return;
+    const long long n = i / groups;
+    const int gq = (int)(i % groups), d0 = 8 * gq;
+    const float scale = ds->scale;
+    float xn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xn[j] = 0.f;
+    if (d0 < D) {                                                          // D, ldx, ldg are multiples of 4: whole float4s
+        const float step = alpha ? alpha[n] : alpha_scalar;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = d0 + 4 * h;
+            if (d < D) {
+                f32x4 g = *(const f32x4*)(G + n * ldg + d);
+                for (int k = 1; k < K; ++k) g += *(const f32x4*)(G + k * slab_stride + n * ldg + d);
+                const f32x4 x = *(const f32x4*)(X + n * ldx + d);
+                f32x4 x0 = x, out;
+                if (project) x0 = *(const f32x4*)(X0 + n * ldx + d);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sgn = (g[r] > 0.f) ? 1.f : ((g[r] < 0.f) ? -1.f : 0.f);
+                    float pert = x[r] + step * sgn;
+                    if (project) pert = x0[r] + fminf(fmaxf(pert - x0[r], -eps), eps);
+                    out[r] = fminf(fmaxf(pert, 0.f), 1.f);
+                    xn[4 * h + r] = out[r];
+                }
+                *(f32x4*)(X + n * ldx + d) = out;
+            }
+        }
+    }
+    union { f16x8 v; uint4 u; } o[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (d0 + j < D) ? xn[j] * scale : 0.f;
+        _Float16 a, b, c;
+        split3(v, a, b, c);
+        o[0].v[j] = a; o[1].v[j] = b; o[2].v[j] = c;
+    }
+    uint4* const out = dst + (((n >> 4) * (groups >> 2) + (gq >> 2)) * 192 + (n & 15) * 4 + (gq & 3));
+    out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
+}
+
+// ===================================================================================================
 // T2: input gradient.  One block = one (256-point tile, TD*16-column group, chunk of samples) item, 4 waves of 64 points:
 //   acc[n][d] += sum_h dA[n][h] * W1[s][h][d],   dA[n][h] = act'(A_s[n][h]) * sum_c dZ[s][n][c] * W2[s][c][h]
 // A stage is 32 hidden units of one sample = ONE K step of the f16 MFMA:
@@ -1085,10 +1255,42 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
     return launch_forward_x3<true>(net->activation, b, st);
 }
 
+int rbnn_step_tail_triple(int32_t mode, const float* P, const int32_t* labels, int32_t S, float inv_S, int32_t N, int32_t C, float* Psum_out,
+                          int32_t ldo, const rbnn_triple_workspace* tws, void* stream) {
+    if (!P || !labels || !tws || !tws->dZ_gen || !tws->g_scale) return RBNN_ERR_NULL;
+    if (mode != RBNN_LOSS_MEAN_PROB && mode != RBNN_LOSS_PER_SAMPLE && mode != RBNN_LOSS_MEAN_LOGIT) return RBNN_ERR_UNSUPPORTED;
+    if (S < 1 || N < 1 || C < 1 || C > 10 || (Psum_out && ldo < C)) return RBNN_ERR_SHAPE;
+    if (!aligned16(P) || !aligned16(tws->dZ_gen)) return RBNN_ERR_ALIGN;
+    const long long n_pad = mask_ld(N);
+    const dim3 grid((unsigned)(n_pad / 16)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == RBNN_LOSS_MEAN_PROB)
+        hipLaunchKernelGGL(step_tail_x3_kernel<RBNN_LOSS_MEAN_PROB>, grid, block, 0, st, P, labels, S, inv_S, N, n_pad, C, Psum_out, ldo, (uint4*)tws->dZ_gen, tws->g_scale);
+    else if (mode == RBNN_LOSS_PER_SAMPLE)
+        hipLaunchKernelGGL(step_tail_x3_kernel<RBNN_LOSS_PER_SAMPLE>, grid, block, 0, st, P, labels, S, inv_S, N, n_pad, C, Psum_out, ldo, (uint4*)tws->dZ_gen, tws->g_scale);
+    else
+        hipLaunchKernelGGL(step_tail_x3_kernel<RBNN_LOSS_MEAN_LOGIT>, grid, block, 0, st, P, labels, S, inv_S, N, n_pad, C, Psum_out, ldo, (uint4*)tws->dZ_gen, tws->g_scale);
+    return launch_status();
+}
+
+int rbnn_attack_step_triple(float* X, const float* X0, int32_t ldx, const float* G, int32_t K, size_t slab_stride, int32_t ldg, const float* alpha,
+                            float alpha_scalar, float eps, int32_t project, int32_t N, int32_t D, const rbnn_dev_scale* dev_scale, void* X_triple,
+                            int32_t ld_rows, void* stream) {
+    if (!X || !G || (project && !X0) || !dev_scale || !X_triple) return RBNN_ERR_NULL;
+    if (N < 1 || D < 1 || ldx < D || ldg < D || K < 1 || ld_rows < D || (ld_rows & 31)) return RBNN_ERR_SHAPE;
+    if ((D & 3) || (ldx & 3) || (ldg & 3) || (slab_stride & 3)) return RBNN_ERR_SHAPE;
+    if (!aligned16(X) || !aligned16(G) || (project && !aligned16(X0)) || !aligned16(X_triple)) return RBNN_ERR_ALIGN;
+    const int groups = ld_rows / 8;
+    const long long total = (long long)N * groups;
+    hipLaunchKernelGGL(attack_step_x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       X, X0, ldx, G, K, (long long)slab_stride, ldg, alpha, alpha_scalar, eps, project, (long long)N, D, dev_scale, (uint4*)X_triple, groups);
+    return launch_status();
+}
+
 int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_images* tp, const int32_t* sidx, int32_t S,
                               int32_t N, int32_t chunk, const rbnn_workspace* ws, const rbnn_triple_workspace* tws,
                               int32_t* n_slabs_out, void* stream) {
-    if (!net || !tp || !ws || !tws || !ws->dZ || !ws->slabs) return RBNN_ERR_NULL;
+    if (!net || !tp || !ws || !tws || !ws->slabs) return RBNN_ERR_NULL;       // ws->dZ == NULL: tws->dZ_gen / g_scale are already built (rbnn_step_tail_triple)
     if (!tp->W1_cols || !tp->W2_gen || !tws->dZ_gen || !tws->g_scale) return RBNN_ERR_NULL;
     if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
     if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
@@ -1098,7 +1300,7 @@ int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_image
     const int H = net->hidden, Dp = net->in_stride, C = net->n_classes;
     if (H < 128 || (H % 128) || C < 1 || C > 10 || N < 1 || S < 1) return RBNN_ERR_SHAPE;
     if (tp->ld_cols != Dp || (Dp & 15)) return RBNN_ERR_SHAPE;
-    if (!aligned16(tp->W1_cols) || !aligned16(tp->W2_gen) || !aligned16(tws->dZ_gen) || !aligned16(ws->dZ)) return RBNN_ERR_ALIGN;
+    if (!aligned16(tp->W1_cols) || !aligned16(tp->W2_gen) || !aligned16(tws->dZ_gen) || (ws->dZ && !aligned16(ws->dZ))) return RBNN_ERR_ALIGN;
     if (fc2 && (!tp->Wm_cols || !ws->dhid1)) return RBNN_ERR_NULL;
     if (fc2 && (!aligned16(tp->Wm_cols) || !aligned16(ws->dhid1))) return RBNN_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
@@ -1112,9 +1314,11 @@ int rbnn_fc_input_grad_triple(const rbnn_posterior* net, const rbnn_triple_image
     const int nchunks = (S + chunk - 1) / chunk;
     if (n_slabs_out) *n_slabs_out = nchunks;
     const long long n_pad = mask_ld(N);
-    hipLaunchKernelGGL(triple_dz_kernel, dim3((unsigned)(n_pad / 16)), dim3(256), 0, st,
-                       ws->dZ, S, N, n_pad, C, (uint4*)tws->dZ_gen, tws->g_scale);
-    if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
+    if (ws->dZ) {
+        hipLaunchKernelGGL(triple_dz_kernel, dim3((unsigned)(n_pad / 16)), dim3(256), 0, st,
+                           ws->dZ, S, N, n_pad, C, (uint4*)tws->dZ_gen, tws->g_scale);
+        if (hipGetLastError() != hipSuccess) return RBNN_ERR_LAUNCH;
+    }
     GradX3Args g = {};
     g.dzg = (const char*)tws->dZ_gen; g.n_pad = n_pad; g.gscale = tws->g_scale;
     g.W2g = (const char*)tp->W2_gen;

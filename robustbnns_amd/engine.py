@@ -77,6 +77,7 @@ class AttackEngine:
         self._ws_cache = {}
         self.precision = self._resolve_precision(precision)
         self._scales = None                     # device-resident operand scales of an attack's iterates (split mode), set by the attack loops
+        self._carry_image = False               # inside pgd(): attack steps also write the next iterate's triple image
 
     def _resolve_precision(self, precision):
         """exact: both GEMMs in fp32 on the fp32 MFMA.  auto (the default): triple where it applies (below), else exact.
@@ -222,7 +223,8 @@ class AttackEngine:
         if self.precision == "triple":
             img = self.post.triple_images()
             ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
-            self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds, grouped=True)
+            if not ws.pop("x_image_ready", False):      # (inside a PGD loop the previous attack_step_triple has already written the iterate's image)
+                self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds, grouped=True)
             gf = ws.get("fc2_groups", (S, S))[0]
             if gf >= S:
                 return self.k.fc_forward_triple(self.post, img, ws["triple"], 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
@@ -238,9 +240,11 @@ class AttackEngine:
         self.k.split_rows(Xp, self.post.D, 0, ws["split"]["X_split"], img.ld_rows, dev_scale=ds)
         self.k.fc_forward_split(self.post, img, ws["split"]["X_split"], img.ld_rows, 0, Xp.shape[0], sidx, S, out_kind, ws, dev_scales=ds)
 
-    def _grad_kernels(self, sidx, S, N, ws):
+    def _grad_kernels(self, sidx, S, N, ws, dz_ready=False):
         if self.precision == "triple":
             gb = ws.get("fc2_groups", (S, S))[1]
+            if dz_ready:                        # the generator image of ALL samples was built by step_tail_triple: one call (its per-point scale spans them)
+                return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["triple"], dz_ready=True)
             if gb >= S:
                 return self.k.fc_input_grad_triple(self.post, self.post.triple_images(), sidx, S, N, ws["chunk"], ws, ws["triple"])
             n_slabs = 0                         # fc2: step 1 -> step 2 per group of samples (a multiple of the slab chunk) through ONE reused dhid1
@@ -361,16 +365,30 @@ class AttackEngine:
         ws = self.workspace(N, S, chunk)
         S_tot = self.total_samples(S)
         self._forward_kernels(Xp, sidx, S, OUT_LOGITS if mode == LOSS_MEAN_LOGIT else OUT_PROBS, ws)
+        # per-sample losses are averaged at the very end (lossGradients.py:40), the others inside the loss
+        inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
+        if self._fused_tail(mode, G_up) and ws.get("fc2_groups", (S, S))[1] >= S:
+            # one launch: sum over samples + loss + the dZ generator image (rbnn_step_tail_triple), bit-identical to the three it replaces;
+            # the fp32 dZ buffer is never written
+            self.k.step_tail_triple(mode, ws["P"], labels, S, inv_S, N, C, ws["triple"])
+            return ws, self._grad_kernels(sidx, S, N, ws, dz_ready=True), S_tot
         Psum = None
         if mode in (LOSS_MEAN_PROB, LOSS_MEAN_LOGIT):
             Psum = ws["Psum"]
             self.k.reduce_samples(ws["P"], S, N, C, 1.0, Psum)
             self._allreduce(Psum)                               # 64 B per point: the only exchange before the backward
-        # per-sample losses are averaged at the very end (lossGradients.py:40), the others inside the loss
-        inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
         self.k.loss_dlogits(mode, ws["P"], Psum, G_up, labels, S, inv_S, N, C, ws["dZ"])
         n_slabs = self._grad_kernels(sidx, S, N, ws)
         return ws, n_slabs, S_tot
+
+    fused_tail = True                       # ConvEngine: its kernels read the fp32 dZ
+
+    def _fused_tail(self, mode, G_up):
+        """The step's tail between the two GEMM kernels as ONE launch: triple mode, one GPU (the sharded step all-reduces between the sum
+        over samples and the loss), a label loss.  RBNN_FUSED_TAIL=0 keeps the three separate kernels (the A/B of tests and profiles)."""
+        return (self.fused_tail and self.precision == "triple" and self.world == 1 and G_up is None and isinstance(self.k, _hip.HipKernels)
+                and mode in (LOSS_MEAN_PROB, LOSS_PER_SAMPLE, LOSS_MEAN_LOGIT) and self.post.C <= 10
+                and os.environ.get("RBNN_FUSED_TAIL", "1") != "0")
 
     def gradient(self, Xp, labels, sidx, S, mode, G_up=None, norms=None):
         """Summed (and, sample-sharded, all-reduced) expected input gradient [N, D_pad].  norms = (linf [N], l2 [N]) device
@@ -415,7 +433,13 @@ class AttackEngine:
         if self.world > 1 and self.pipelined_comm:
             return self._step_sharded(X, X0, labels, sidx, S, mode, alpha, alpha_scalar, eps, project)
         ws, n_slabs, _ = self.gradient_slabs(X, labels, sidx, S, mode)
-        if self.world == 1:
+        if (self.world == 1 and self._carry_image and self._fused_tail(mode, None) and self._scales is not None and "triple" in ws
+                and p.D % 4 == 0):
+            # PGD: the step also writes the NEW iterate's triple image (rbnn_attack_step_triple) — the next forward launches no builder
+            self.k.attack_step_triple(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D,
+                                      self._scales, ws["triple"]["X_triple"], self.post.triple_images().ld_rows)
+            ws["x_image_ready"] = True
+        elif self.world == 1:
             self.k.attack_step(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D)
         else:
             G = ws["Gsum"] if "Gsum" in ws else ws["G"]
@@ -516,6 +540,7 @@ class AttackEngine:
             self.k.pgd_alpha(X0, self.post.D, alpha_t)
         self._scales = self._input_scales(X0, iterates=True)
         step = lambda: self._step(X, X0, labels, sidx, S, mode, alpha_t, 0.0 if alpha is None else float(alpha), float(epsilon), True)
+        self._carry_image = self.graph_safe     # (ConvEngine cuts a job into point blocks with one workspace: no image to carry)
         try:
             done = 0
             if before_step is not None:
@@ -541,6 +566,10 @@ class AttackEngine:
                 step()
         finally:
             self._scales = None
+            self._carry_image = False
+            for w in self._ws_cache.values():   # the last step's image belongs to no later forward
+                if isinstance(w, dict):
+                    w.pop("x_image_ready", None)
         return self.unpad(X, x)
 
     def _low_out(self, N):

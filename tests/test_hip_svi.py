@@ -222,16 +222,20 @@ def conv_guide_tensors(Cin, Hc, C, q2, seed):
     return loc, scl
 
 
-@pytest.mark.parametrize("act,Hc", [("leaky", 32), ("tanh", 16)])
-def test_conv_svi_redraws_in_place(act, Hc, tmp_path, monkeypatch):
+@pytest.mark.parametrize("act,Hc,shape", [("leaky", 32, (1, 28, 28)), ("tanh", 16, (1, 28, 28)), ("leaky", 48, (3, 32, 32))])
+def test_conv_svi_redraws_in_place(act, Hc, shape, tmp_path, monkeypatch):
+    """(3, 32, 32): BASELINE config 5 = "CIFAR-10 conv-BNN, SVI" — the geometry bench.py --workload c5 redraws in place every PGD iteration."""
     from robustbnns_amd import adversarialAttacks as AA
     from robustbnns_amd.conv import ConvSviGuide, ConvStackedPosterior
     from robustbnns_amd.model_bnn import BNN, set_rng_seed
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("RBNN_CIFAR_CONV", "1")
     C, S = 10, 3
-    loc, scl = conv_guide_tensors(1, Hc, C, 7, seed=Hc)
+    q2 = (shape[1] - 4) // 2 - 5
+    dataset = "mnist" if shape[0] == 1 else "cifar"
+    loc, scl = conv_guide_tensors(shape[0], Hc, C, q2, seed=Hc)
     # the flat draw against the oracle's generator, tensor by tensor (element e = component e % 4 of block e / 4)
-    post = ConvStackedPosterior.for_guide(ConvSviGuide(loc, scl, DEV), act, (1, 28, 28), C, Hc, S)
+    post = ConvStackedPosterior.for_guide(ConvSviGuide(loc, scl, DEV), act, shape, C, Hc, S)
     post.triple_images()
     post.redraw(0xFEEDFACE12345678, 5)
     got = post.state_dict
@@ -244,15 +248,15 @@ def test_conv_svi_redraws_in_place(act, Hc, tmp_path, monkeypatch):
             assert float(((got(s)[k].double().reshape(-1) - want).abs() / (sp * (1 + eps.abs()))).max()) < 2e-5, (k, s)
     # the derived images follow the drawn stack: the default engine (triple conv2) agrees with the fp32-MFMA engine on stored copies
     from robustbnns_amd.factory import make_engine, posterior_from_stacked
-    x, y = O.synthetic_inputs(8, (1, 28, 28), C, seed=4)
+    x, y = O.synthetic_inputs(8, shape, C, seed=4)
     stacked = {k: torch.stack([post.state_dict(i)[k] for i in range(S)]) for k in ConvSviGuide.TENSOR_IDS}
-    ex = make_engine(posterior_from_stacked("conv", act, (1, 28, 28), C, Hc, stacked, DEV), precision="exact")
+    ex = make_engine(posterior_from_stacked("conv", act, shape, C, Hc, stacked, DEV), precision="exact")
     tri = make_engine(post)
     assert tri.precision == "triple"
     assert rel_err(tri.forward(x, S).cpu(), ex.forward(x, S).cpu()) < 1e-5
     assert rel_err(tri.forward(x, S).cpu(), O.bnn_forward(x.double(), O.cast(stacked, torch.float64), "conv", act, S)) < 1e-5
     # through the call surface: one resident stack, redrawn per call / per PGD iteration, no sync inside the attack
-    bnn = BNN("mnist", Hc, act, "conv", "svi", 5, 0.01, None, None, (1, 28, 28), C)
+    bnn = BNN(dataset, Hc, act, "conv", "svi", 5, 0.01, None, None, shape, C)
     bnn.set_variational_params(loc, scl, DEV)
     set_rng_seed(0)
     p1 = bnn.forward(x, n_samples=S).cpu()
