@@ -222,7 +222,7 @@ def conv_guide_tensors(Cin, Hc, C, q2, seed):
     return loc, scl
 
 
-@pytest.mark.parametrize("act,Hc,shape", [("leaky", 32, (1, 28, 28)), ("tanh", 16, (1, 28, 28)), ("leaky", 48, (3, 32, 32))])
+@pytest.mark.parametrize("act,Hc,shape", [("leaky", 32, (1, 28, 28)), ("tanh", 16, (1, 28, 28)), ("leaky", 64, (3, 32, 32))])
 def test_conv_svi_redraws_in_place(act, Hc, shape, tmp_path, monkeypatch):
     """(3, 32, 32): BASELINE config 5 = "CIFAR-10 conv-BNN, SVI" — the geometry bench.py --workload c5 redraws in place every PGD iteration."""
     from robustbnns_amd import adversarialAttacks as AA
