@@ -74,6 +74,7 @@ class AttackEngine:
             if os.environ.get("RBNN_FORCE_COLLECTIVES") == "1":
                 self.world = max(self.world, 2)    # diagnostics: run the all-reduce path even in a 1-rank group
         self._S_total = total_samples
+        self._fake_comm = os.environ.get("RBNN_FAKE_COLLECTIVES") == "1" and os.environ.get("RBNN_FORCE_COLLECTIVES") == "1"
         self._ws_cache = {}
         self.precision = self._resolve_precision(precision)
         self._scales = None                     # device-resident operand scales of an attack's iterates (split mode), set by the attack loops
@@ -119,14 +120,20 @@ class AttackEngine:
     def device(self):
         return self.post.device
 
+    class _NoWork:
+        def wait(self):
+            return True
+
     def _allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 and not self._fake_comm:
             import torch.distributed as dist
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def _allreduce_async(self, t):
         """Start the all-reduce (RCCL runs it on its own stream) and return the work handle; .wait() orders the current
         stream after it.  Kernels launched in between overlap the exchange."""
+        if self._fake_comm:                      # diagnostics (RBNN_FAKE_COLLECTIVES=1 with RBNN_FORCE_COLLECTIVES=1): the sharded launch sequence
+            return self._NoWork()                # without any collective — separates what the sequence costs from what RCCL costs
         import torch.distributed as dist
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

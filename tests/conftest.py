@@ -119,7 +119,23 @@ def assert_close_to_reference(val, ref, truth64, tol=1e-5, noise=None, what=""):
         bound = torch.maximum(bound, 2 * noise.to(bound))
     bad = e_val > bound
     assert not bad.any(), f"{what}: {int(bad.sum())} points beyond the bound, worst {float((e_val / bound).max()):.2f}x at point {int((e_val / bound).argmax())}"
-    return int((bound > tol).sum())
+    relaxed = bound > tol
+    # how far past the 1e-5 bar the relaxed rows ACTUALLY are (the bound they are held to is derived, not the north star's): printed per case
+    RELAXED_LOG.append((what, int(relaxed.sum()), int(e_val.numel()), float((e_val[relaxed] / tol).max()) if relaxed.any() else 0.0,
+                        int((e_val > tol).sum()), float((e_val / tol).max())))
+    return int(relaxed.sum())
+
+
+RELAXED_LOG = []      # (what, rows held to the relaxed bound, rows, worst error / tol among them, rows whose error exceeds tol, worst error / tol overall)
+
+
+def relaxed_summary(reset=True):
+    """One line per assert_close_to_reference call since the last summary."""
+    lines = [f"    [relaxed bound] {w}: {r} of {n} rows held to the relaxed bound (their worst error {x:.2f} x 1e-5); rows actually beyond 1e-5: {b} "
+             f"(worst {o:.2f} x 1e-5)" for w, r, n, x, b, o in RELAXED_LOG]
+    if reset:
+        RELAXED_LOG.clear()
+    return "\n".join(lines)
 
 
 def assert_close_to_truth(val, truth64, tol=1e-5, noise=None, what="", rows=None, fp32_yardstick=None):

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close_to_reference, rel_err, saturation_noise
+from conftest import assert_close_to_reference, rel_err, relaxed_summary, saturation_noise
 from oracle import bnn_oracle as O
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
@@ -100,6 +100,7 @@ def test_trained_halfmoons_attack_and_evaluation(golden, name, kind, monkeypatch
                 assert (oa, aa) == want
                 assert float((rob.cpu() - g.t(kind + "_fgsm_rob")[e, k]).abs().max()) < TOL
     print(f"{name} {kind}: {relaxed} gradient rows at the fp32 saturation floor, {marg} marginal adversarial pixels")
+    print(relaxed_summary())
 
 
 @pytest.mark.parametrize("name", HALFMOONS)
@@ -177,6 +178,7 @@ def test_trained_mnist_shaped(golden, name, precision, monkeypatch):
     g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), arch, act, ns)
     relaxed = assert_close_to_reference(xg.grad.cpu(), g.t(f"bnn_fgsm_grad_ns{ns}"), g64, TOL, saturation_noise(x, post, arch, act, ns), "gradient")
     print(f"{name} [{precision}]: {relaxed} of {len(x)} gradient rows at the fp32 saturation floor")
+    print(relaxed_summary())
     P = m["pgd_points"]
     oa, aa, rob = AA.attack_evaluation(net=bnn, x_test=x[:P], x_attack=g.t("bnn_pgd_adv"), y_test=y[:P], device=DEV, n_samples=m["pgd_ns"])
     assert (oa, aa) == (float(g.arr["bnn_pgd_orig_acc"]), float(g.arr["bnn_pgd_adv_acc"]))
