@@ -492,9 +492,9 @@ def main():
               "split": {"fc_input_grad": "fc_grad_split_kernel (+ split_dz)", "fc_forward": "fc_forward_split_kernel",
                         "conv_forward": "conv2_pool_split_kernel (+ conv1_pool_split, conv_fc)", "conv_input_grad": "conv_bwd_split_kernel (+ conv_fc_bwd, conv1_bwd)"}}
     KNAMES["lowdim"] = {"lowdim": "lowdim_kernel (forward, loss, input gradient and step of ALL iterations in one launch; fp32 FMA)"}
-    KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (+ triple_dz)", "fc_forward": "fc_forward_x3_kernel",
+    KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (its dZ image comes from the fused tail kernel step_tail_x3_kernel)", "fc_forward": "fc_forward_x3_kernel",
                         "conv_forward": "conv2_pool_x3_kernel (+ conv1_pool, conv_fc)",
-                        "conv_input_grad": "conv_bwd_dense_x3_kernel at 1x28x28 / conv_bwd_x3_kernel at 3x32x32 (+ conv_fc_bwd, conv1_bwd)"}
+                        "conv_input_grad": "conv_bwd_dense_x3_kernel (both geometries; 3x32x32 in two passes over 64 + 36 output positions) (+ conv_fc_bwd, conv1_bwd)"}
     # which C-ABI calls run on the f16 pipe in each mode (the rest of that mode's calls are the fp32-MFMA kernels)
     F16_KERNELS = {"split": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"},
                    "triple": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}}
@@ -504,9 +504,9 @@ def main():
                                 "fc_input_grad": "fc_grad_split_kernel (x2: per-sample step through Wm, then W1; + split_dz)"})
         KNAMES["exact"].update({"fc_forward": "fc_forward_kernel (x2)", "fc_input_grad": "fc_grad_kernel (x2)"})
         KNAMES["triple"].update({"fc_forward": "fc_forward_x3_kernel (x2: layer 1 -> triple image, layer 2)",
-                                 "fc_input_grad": "fc_grad_x3_kernel (x2: per-sample step through Wm, then W1; + triple_dz)"})
+                                 "fc_input_grad": "fc_grad_x3_kernel (x2: per-sample step through Wm, then W1)"})
 
-    def roofline(mode, evs_by_name, ms_per_step):
+    def roofline(mode, evs_by_name, ms_per_step, svi_kind=False):
         kernels = {}
         passes_timed = args.steps * passes * w["iters"]
         for name, evs in evs_by_name.items():
@@ -551,7 +551,14 @@ def main():
                 traffic_src = rec.get("source")
             calls = [k for k in kernels if k in keys]
             if calls and all(tot(keys[k]) is not None for k in calls):
-                small = sum(v["hbm_bytes_per_launch"] for v in wl.get("small", {}).values()) * scale
+                # the streaming kernels THIS mode launches per pass (the record may hold other modes' kernels too): every mode steps and — SVI —
+                # draws; the f16 modes build the inputs' image (absmax + scale record + rows image); the sum over samples + loss is the fused
+                # tail kernel in the triple fc mode and two kernels elsewhere
+                want = ["attack_step", "pgd_alpha"] + (["svi_draw"] if svi_kind else [])
+                if mode in F16_KERNELS:
+                    want += ["absmax_kernel", "scale_finalize_kernel", mode + "_rows_kernel"]
+                want += ["step_tail_x3_kernel"] if (mode == "triple" and w["arch"] != "conv") else ["reduce_samples", "loss_dlogits"]
+                small = sum(v["hbm_bytes_per_launch"] for k_, v in wl.get("small", {}).items() if any(f in k_ for f in want)) * scale
                 counter = {"bytes_per_pass": sum(tot(keys[k]) for k in calls) + small, "small_kernels_bytes": small, "scaled": scaled,
                            "kernels": {k: tot(keys[k]) for k in calls}}
         fp32_eq = kernels[dom]["tflops"]
@@ -634,7 +641,7 @@ def main():
                                      "stored samples (HMC-style)"),
                        "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters),
                                                        ("samples_total", args.samples_total)) if v}},
-            "roofline": roofline(mode, evs, ms_per_step),
+            "roofline": roofline(mode, evs, ms_per_step, posterior_kind == "svi"),
         }
         if svi_rec is not None:
             out["svi"] = svi_rec
@@ -647,7 +654,7 @@ def main():
         for other in others:
             o_ms = 1e3 * other[1] / args.steps
             out[SUBKEY[other[0]]] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],
-                                     "roofline": roofline(other[0], other[2], o_ms)}
+                                     "roofline": roofline(other[0], other[2], o_ms, posterior_kind == "svi")}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -45,7 +45,7 @@ prof() {   # prof <subdir> <workload> <points> <samples per GPU> <extra bench ar
 }
 prof c2 c2 10000 100 --steps 5 --warmup 2
 if [ -z "${QUICK:-}" ]; then
-  prof c5 c5 512 64 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
+  prof c5 c5 512 62 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
   prof conv conv 2048 16 --steps 3 --warmup 1
 fi
 python3 - <<PY
