@@ -367,6 +367,8 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    t_start = time.perf_counter()
+
     def run(precision, kind=None):
         """warmup, then EXACTLY --steps timed steps between barrier + synchronize; returns (engine precision, seconds, kernel events).
         kind "svi": every step first redraws all S samples of the resident stack in place (PGD: before every iteration)."""
@@ -424,6 +426,8 @@ def main():
             if w["method"] == "pgd":
                 for e in eps_list:
                     eng.pgd(xs, labels, w["S"], e, alpha=None, iters=w["iters"], before_step=redraw if kind == "svi" else None)
+                    if rank == 0 and w["iters"] * w["N"] >= 200000:        # a step of minutes (c5 at its full definition): a heartbeat on stderr
+                        print(f"[bench] {args.workload}: eps={e:.5f} attack enqueued, t={time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
 
         for _ in range(args.warmup):
             step()
