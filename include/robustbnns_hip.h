@@ -286,6 +286,12 @@ int rbnn_conv_input_grad_dense(const rbnn_conv_posterior *net, const void *K2_de
                                const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
                                const rbnn_conv_workspace *ws, void *stream);
 
+/* Both triple images of model.3.weight from the fp32 stack K2w [n_samples][hidden][32 ci x 25 taps] (nn.Conv2d's order) in one launch, at the
+ * scale 2^k2_exp: K2_rows = what rbnn_conv_forward_triple reads (rbnn_triple_rows_grouped of the tap-major regrouping), K2_dense = what
+ * rbnn_conv_input_grad_dense reads; either may be NULL.  Bit-identical to building them through rbnn_triple_rows and permuted copies; a
+ * redrawable SVI stack calls it after every draw (robustbnns_amd/conv.py::ConvStackedPosterior.redraw). */
+int rbnn_conv_weight_images(const float *K2w, int32_t n_samples, int32_t hidden, int32_t k2_exp, void *K2_rows, void *K2_dense, void *stream);
+
 /* rbnn_conv_input_grad with conv2^T in split-half precision.  K2_bwd = rbnn_split_rows image of model.3.weight regrouped
  * [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8]: element (ci; chunk, t, lg, j) = W[hc = 16*chunk + 8*(lg&1) + j, ci,
  * tap = 2t + (lg>>1)] * 2^k2_exp (0 for the padded 26th tap); fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed

@@ -132,6 +132,7 @@ SIGNATURES = {
                                        C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_input_grad_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_input_grad_dense": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
+    "rbnn_conv_weight_images": (_i32, [_fp, _i32, _i32, _i32, _fp, _fp, _fp]),
     "rbnn_conv_forward_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                         C.POINTER(ConvWorkspace), _fp]),
     "rbnn_input_scales": (_i32, [_fp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _fp, _fp]),
@@ -444,6 +445,11 @@ class HipKernels:
         check(self.lib.rbnn_conv_input_grad_dense(C.byref(net.descriptor()), ptr(K2_dense), k2_exp, fw_l1, ptr(sidx), S, N, C.byref(w),
                                                   stream_of(ws["dZ"])), "rbnn_conv_input_grad_dense")
         return S
+
+    def conv_weight_images(self, K2w, S, H, k2_exp, rows=None, dense=None):
+        """model.3.weight's forward (grouped tap-major rows) and dense conv2^T triple images from the fp32 stack in one launch."""
+        require_gpu(K2w, "K2w")
+        check(self.lib.rbnn_conv_weight_images(ptr(K2w), S, H, k2_exp, ptr(rows), ptr(dense), stream_of(K2w)), "rbnn_conv_weight_images")
 
     def conv_input_grad_split(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):
         w = self._conv_ws(ws)

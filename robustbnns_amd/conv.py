@@ -110,10 +110,15 @@ class ConvStackedPosterior:
         self._k2ci_stale = True
         if self._triple is not None:
             dense = getattr(self, "_dense", None) is not None and self.dense_supported()
-            self._build_triple(self._triple[0], self._triple[2], with_bwd=not dense)
+            if self._fused_images():            # forward rows + dense conv2^T images by ONE kernel straight from the fp32 stack
+                _hip.HipKernels().conv_weight_images(self.K2w, self.S, self.H, self._triple[1], self._triple[0], getattr(self, "_dense", None))
+                if not dense:
+                    self._build_triple(self._triple[0], self._triple[2], with_fwd=False)
+            else:
+                self._build_triple(self._triple[0], self._triple[2], with_bwd=not dense)
+                if getattr(self, "_dense", None) is not None:
+                    self._build_dense(self._dense)
             self._bwd_stale = dense
-            if getattr(self, "_dense", None) is not None:
-                self._build_dense(self._dense)
         if self._split is not None:
             self._build_split(self._split[0], self._split[4])
         return self
@@ -141,6 +146,11 @@ class ConvStackedPosterior:
                          torch.zeros(S, H, 32, 26, dtype=torch.float32, device=self.device),
                          torch.empty(S * 32, (H // 16) * 13 * 32, dtype=torch.float32, device=self.device))
         return self._tmp
+
+    def _fused_images(self):
+        """rbnn_conv_weight_images builds the forward and the dense triple image in one launch (RBNN_CONV_FUSED_IMAGES=0: the stand-alone
+        builders — permuted copies + rbnn_triple_rows — kept as the reference the fused kernel is tested against)."""
+        return os.environ.get("RBNN_CONV_FUSED_IMAGES", "1") != "0" and self.H % 16 == 0
 
     def _free_staging(self):
         """A stored (HMC / ensemble) posterior builds its images ONCE: the builders' staging buffers — a second copy of the triple rows image,
@@ -224,11 +234,17 @@ class ConvStackedPosterior:
             S, H = self.S, self.H
             rows = torch.empty(S * H, 800 * 3, dtype=torch.int16, device=self.device)
             bwd = torch.empty(S * 32, (H // 16) * 13 * 32 * 3, dtype=torch.int16, device=self.device)
-            k2_exp = self._build_triple(rows, bwd)
-            self._triple = (rows, k2_exp, bwd, self._fw_l1())
             if self.dense_supported():
                 self._dense = torch.empty(S * ((H + 31) // 32) * 25 * 32, 32 * 3, dtype=torch.int16, device=self.device)
-                self._build_dense(self._dense)
+            if self._fused_images():
+                k2_exp = scale_exp(self._k2_max())
+                _hip.HipKernels().conv_weight_images(self.K2w, S, H, k2_exp, rows, self._dense)
+                self._build_triple(rows, bwd, with_fwd=False)
+            else:
+                k2_exp = self._build_triple(rows, bwd)
+                if self._dense is not None:
+                    self._build_dense(self._dense)
+            self._triple = (rows, k2_exp, bwd, self._fw_l1())
             self._free_staging()
         return self._triple
 

@@ -2180,6 +2180,83 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     });
 }
 
+// =====================================================================================================
+// Both triple images of model.3.weight — the forward's tap-major grouped rows image and the dense conv2^T image — from the fp32 stack in ONE
+// launch.  A redrawable SVI stack rebuilds them after every draw (BASELINE config 5: every PGD iteration); through their stand-alone builders
+// that was two permuted fp32 copies, two rbnn_triple_rows launches and two more permuted copies per draw (0.45 of the 0.6 ms a C5 draw took).
+// One block = one (sample, 32 output channels): its [32 hc][32 ci x 25 taps] cube is 100 KB of CONTIGUOUS fp32 — read once, coalesced, into
+// LDS — and both images leave as 1-KiB runs of 16-byte stores.  Same split3 of the same scaled values: the images are bit-identical to the
+// stand-alone builders' (tests/test_hip_round4.py).
+// =====================================================================================================
+namespace {
+constexpr int K2IMG_PITCH = 801;                                          // floats per hc row of the cube in LDS (odd: reads along hc spread over the banks)
+__global__ void __launch_bounds__(256) conv_k2_images_kernel(const float* __restrict__ K2w, int Hc, float scale, uint4* __restrict__ rows_img,
+                                                             uint4* __restrict__ dense_img) {
+    extern __shared__ __attribute__((aligned(16))) float cube[];          // [32 hc][K2IMG_PITCH], k = ci * 25 + tap (nn.Conv2d's order)
+    const int tid = threadIdx.x, KS = (Hc + 31) / 32;
+    const int s = blockIdx.x / KS, ks = blockIdx.x - s * KS;
+    const float* const src = K2w + ((long long)s * Hc + 32 * ks) * 800;
+    for (int i = tid; i < 32 * 200; i += 256) {                           // 16-byte loads: row i / 200, columns 4 (i % 200) ..
+        const int hcl = i / 200, c4 = 4 * (i - hcl * 200);
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (32 * ks + hcl < Hc) v = *(const f32x4*)(src + hcl * 800 + c4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cube[hcl * K2IMG_PITCH + c4 + r] = v[r] * scale;
+    }
+    __syncthreads();
+    union U { f16x8 v; uint4 u; };
+    if (rows_img) {
+        // forward image: rows = output channels, K = tap * 32 + ci, grouped [16-channel group][tap][3 pieces][16 channels][32 ci] halves;
+        // item = (tap, channel, unit of 8 ci): 64 consecutive items = one 1-KiB (group, tap, piece) run
+        for (int it = tid; it < 25 * 32 * 4; it += 256) {
+            const int u = it & 3, hcl = (it >> 2) & 31, tap = it >> 7;
+            const int hc = 32 * ks + hcl;
+            if (hc < Hc) {
+                U o[3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 p0, p1, p2;
+                    conv_split3(cube[hcl * K2IMG_PITCH + (8 * u + j) * 25 + tap], p0, p1, p2);
+                    o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
+                }
+                const long long G = ((long long)s * Hc + hc) >> 4;
+                uint4* const out = rows_img + ((G * 25 + tap) * 3) * 64 + (hc & 15) * 4 + u;
+                out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
+            }
+        }
+    }
+    if (dense_img) {
+        // dense image: [sample][K step = these 32 hc][tap][input-channel half][3 pieces][16 ci][32 hc] halves; item = (tap, ci, unit of 8 hc)
+        for (int it = tid; it < 25 * 32 * 4; it += 256) {
+            const int u = it & 3, ci = (it >> 2) & 31, tap = it >> 7;
+            U o[3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 p0, p1, p2;
+                conv_split3(cube[(8 * u + j) * K2IMG_PITCH + ci * 25 + tap], p0, p1, p2);
+                o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
+            }
+            const long long T = (((long long)s * KS + ks) * 25 + tap) * 2 + (ci >> 4);
+            uint4* const out = dense_img + (T * 3) * 64 + (ci & 15) * 4 + u;
+            out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int rbnn_conv_weight_images(const float* K2w, int32_t n_samples, int32_t hidden, int32_t k2_exp, void* K2_rows, void* K2_dense, void* stream) {
+    if (!K2w || (!K2_rows && !K2_dense)) return RBNN_ERR_NULL;
+    if (n_samples < 1 || hidden < 16 || (hidden & 15) || k2_exp < -100 || k2_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(K2w) || (K2_rows && !aligned16(K2_rows)) || (K2_dense && !aligned16(K2_dense))) return RBNN_ERR_ALIGN;
+    const int KS = (hidden + 31) / 32;
+    constexpr int LDSB = 32 * K2IMG_PITCH * 4;
+    static unsigned long long attr = 0;
+    if (!ensure_dynamic_lds((const void*)conv_k2_images_kernel, LDSB, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_k2_images_kernel, dim3((unsigned)((long long)n_samples * KS)), dim3(256), LDSB, (hipStream_t)stream,
+                       K2w, hidden, ldexpf(1.f, k2_exp), (uint4*)K2_rows, (uint4*)K2_dense);
+    return launch_status();
+}
+
 extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const void* K2_dense, int32_t k2_exp, float fw_l1,
                                           const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
     int rc = validate_conv(net);

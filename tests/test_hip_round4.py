@@ -95,3 +95,22 @@ def test_pgd_loop_launches_no_image_builder_after_the_first_iteration(monkeypatc
     assert torch.equal(p1, fresh.forward(x, S).cpu()) and torch.equal(adv, fresh.pgd(x, y, S, 0.1, iters=5).cpu())
     eng.fgsm(x, y, S, 0.1)                                       # FGSM: the plain step (its result's image is never read)
     assert calls["attack_step"] == 1 and calls["attack_step_triple"] == 5
+
+
+# ------------------------------------------------------------------ conv weight images in one launch
+@pytest.mark.parametrize("Hc,S", [(512, 3), (48, 2), (16, 2), (272, 1)])
+def test_conv_weight_images_kernel_equals_the_standalone_builders(Hc, S, monkeypatch):
+    """rbnn_conv_weight_images (forward grouped tap-major rows image + dense conv2^T image of model.3.weight from the fp32 stack, one launch:
+    what every SVI redraw of a conv posterior runs) against the stand-alone builders (permuted copies + rbnn_triple_rows): the same bits —
+    including channel counts that are not multiples of 32 (the dense image's zero-padded K step)."""
+    from robustbnns_amd.conv import ConvStackedPosterior
+    post = O.synthetic_posterior("conv", 784, Hc, 10, S, 0.05)
+    out = {}
+    for tag, env in (("standalone", "0"), ("fused", "1")):
+        monkeypatch.setenv("RBNN_CONV_FUSED_IMAGES", env)
+        sp = ConvStackedPosterior("leaky", (1, 28, 28), 10, Hc, post, DEV)
+        rows, k2_exp, bwd, _ = sp.triple_images()
+        out[tag] = (rows.cpu(), sp._dense.cpu(), bwd.cpu(), k2_exp)
+    assert out["fused"][3] == out["standalone"][3]
+    assert torch.equal(out["fused"][0], out["standalone"][0]) and torch.equal(out["fused"][1], out["standalone"][1])
+    assert torch.equal(out["fused"][2], out["standalone"][2])
