@@ -67,59 +67,94 @@ struct ConvArgs {
 // (3x32x32: 196 positions fill a 256-thread block well enough, and the two-halves form measured slower there: 2.45 -> 2.66 ms at c5)
 template <class G> constexpr int conv1_halves() { return G::CIN == 1 ? 2 : 1; }
 template <class G> constexpr int conv1_threads() { return (conv1_halves<G>() * G::P1W * G::P1W + 63) / 64 * 64; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RBNN_CONV1_W128
+#define RBNN_CONV1_W128 1
+#endif
+#ifndef RBNN_CONV1_WAVES
+#define RBNN_CONV1_WAVES 1
+#endif
 template <int ACT, class G>
-__global__ void __launch_bounds__(conv1_threads<G>()) conv1_pool_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(conv1_threads<G>(), RBNN_CONV1_WAVES) conv1_pool_kernel(const ConvArgs a) {
     constexpr int NPP = G::P1W * G::P1W, IW = G::IW, NTH = conv1_threads<G>();
-    // [c][ci][28: ky*5 + kx, 3 pad]: a tap row is 7 aligned float4; channels 16.. sit 4 floats further on, so that the one wave holding
-    // threads of both channel halves reads its two rows from different banks
-    __shared__ __attribute__((aligned(16))) float wsh[C1 * G::CIN * 28 + 4];
-    __shared__ float xsh[G::DIN];
+    // Weights in LDS as CHANNEL PAIRS: [c / 2][ci][tap][2] (52 floats per (pair, ci): thirteen aligned float4).  The FMA loop then runs on
+    // v_pk_fma_f32 — one instruction = the same tap of two output channels against one broadcast patch value — i.e. at the packed fp32 rate
+    // (round 4; the un-packed loop ran at 0.73 of the plain FMA rate: 2.09 ms per C5 pass).  Every output is still one fp32 FMA chain in
+    // the same (input channel, ky, kx) order: results are bit-identical.
+    constexpr int WROW = 52;
+    __shared__ __attribute__((aligned(16))) float wsh[(C1 / 2) * G::CIN * WROW];
+    __shared__ __attribute__((aligned(8))) float xsh[G::DIN];
+    static_assert(IW % 2 == 0, "patch pairs are 8-byte aligned");
     const long long sn = blockIdx.x;
     const int n = (int)(sn % a.N), s = (int)(sn / a.N), tid = threadIdx.x;
     const int sw = a.sidx ? a.sidx[s] : s;
-    for (int e = tid; e < C1 * G::K1; e += NTH) wsh[(e / 25) * 28 + e % 25 + (e >= C1 * G::K1 / 2 ? 4 : 0)] = a.K1w[(long long)sw * C1 * G::K1 + e];
+    for (int e = tid; e < C1 * G::K1; e += NTH) {                        // e = (c, ci, tap) as nn.Conv2d stores it
+        const int c = e / G::K1, k = e - c * G::K1;
+        wsh[((c >> 1) * G::CIN + k / 25) * WROW + 2 * (k % 25) + (c & 1)] = a.K1w[(long long)sw * C1 * G::K1 + e];
+    }
     for (int e = tid; e < G::DIN; e += NTH) xsh[e] = a.X[(long long)n * a.ldx + e];
     __syncthreads();
     constexpr int NH = conv1_halves<G>(), CPT = C1 / NH;                  // channels per thread
     if (tid >= NH * NPP) return;
     const int pos = tid % NPP, c0 = (tid / NPP) * CPT;
     const int py = pos / G::P1W, px = pos % G::P1W;
-    float patch[G::CIN][6][6];
+    // the 6 x 6 patch as 18 aligned PAIRS per input channel: v_pk_fma_f32 broadcasts either half of a pair to both lanes (op_sel), so a patch
+    // value costs half a register pair — spelled as a scalar broadcast the compiler kept every value twice (216 registers, two waves per SIMD)
+    f32x2 patch[G::CIN][6][3];
 #pragma unroll
     for (int ci = 0; ci < G::CIN; ++ci)
 #pragma unroll
         for (int y = 0; y < 6; ++y)
 #pragma unroll
-            for (int xx = 0; xx < 6; ++xx) patch[ci][y][xx] = xsh[ci * (IW * IW) + (2 * py + y) * IW + 2 * px + xx];
+            for (int j = 0; j < 3; ++j) patch[ci][y][j] = *(const f32x2*)(xsh + ci * (IW * IW) + (2 * py + y) * IW + 2 * px + 2 * j);
     float* const p1 = a.P1 + sn * G::P1SZ + pos;                         // dense [S][N][32][P1W][P1W]
     uint8_t* const st = a.st1 + sn * G::P1SZ + pos;
 #pragma unroll 1
-    for (int c = c0; c < c0 + CPT; ++c) {
-        float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int cp = c0 / 2; cp < (c0 + CPT) / 2; ++cp) {
+        f32x2 v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v4[q] = (f32x2){0.f, 0.f};
 #pragma unroll
         for (int ci = 0; ci < G::CIN; ++ci) {                             // channel-major accumulation, taps in (ky, kx) order
-            float wk[28];
-#pragma unroll
-            for (int v = 0; v < 7; ++v) *(f32x4*)(wk + 4 * v) = *(const f32x4*)(wsh + (c * G::CIN + ci) * 28 + (c >= C1 / 2 ? 4 : 0) + 4 * v);
+            asm volatile("" ::: "memory");                               // keep the three input channels' weight reads from being hoisted together (156 registers)
+            const float* const wrow = wsh + (cp * G::CIN + ci) * WROW;
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 5; ++kx)
+                for (int kx = 0; kx < 5; ++kx) {
+                    const int tap = ky * 5 + kx;
+#if RBNN_CONV1_W128
+                    const f32x4 w4 = *(const f32x4*)(wrow + 4 * (tap >> 1));
+                    const f32x2 wv = (tap & 1) ? (f32x2){w4[2], w4[3]} : (f32x2){w4[0], w4[1]};
+#else
+                    const f32x2 wv = *(const f32x2*)(wrow + 2 * tap);     // (a 16-byte read per tap pair keeps 52 more registers live: 252 VGPRs, two waves per SIMD)
+#endif
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) v4[dy * 2 + dx] = fmaf(wk[ky * 5 + kx], patch[ci][dy + ky][dx + kx], v4[dy * 2 + dx]);
+                        for (int dx = 0; dx < 2; ++dx) {
+                            // acc.{lo,hi} += w.{lo,hi} * pair.{half}: the broadcast is the instruction's op_sel (written as a vector splat,
+                            // the compiler hoisted 108 materialised (p, p) pairs out of the channel loop: 252 registers)
+                            const f32x2 pp = patch[ci][dy + ky][(dx + kx) >> 1];
+                            if ((dx + kx) & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(v4[dy * 2 + dx]) : "v"(wv), "v"(pp));
+                            else               asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(v4[dy * 2 + dx]) : "v"(wv), "v"(pp));
+                        }
+                }
         }
-        const float b = a.K1b[(long long)sw * C1 + c];
-        float best = 0.f, best_pre = 0.f;
-        int arg = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float pre = v4[q] + b, v = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
-            if (q == 0 || v > best) { best = v; best_pre = pre; arg = q; }   // first maximum wins (torch max_pool2d)
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * cp + h;
+            const float b = a.K1b[(long long)sw * C1 + c];
+            float best = 0.f, best_pre = 0.f;
+            int arg = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float pre = v4[q][h] + b, v = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+                if (q == 0 || v > best) { best = v; best_pre = pre; arg = q; }   // first maximum wins (torch max_pool2d)
+            }
+            p1[c * NPP] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
+            st[c * NPP] = (uint8_t)(arg | (best_pre > 0.f ? 4 : 0));
         }
-        p1[c * NPP] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
-        st[c * NPP] = (uint8_t)(arg | (best_pre > 0.f ? 4 : 0));
     }
 }
 
