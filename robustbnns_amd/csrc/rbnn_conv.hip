@@ -1629,14 +1629,17 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
 // With Cin > 1 the pass is repeated per input channel (the routed B operand is rebuilt from L2-resident data; the ring stays 62.5 KiB).
 template <class G> constexpr int conv1_bwd_ts() { return G::O1 % 8 == 0 ? G::O1 + 2 : G::O1; }
 template <int ACT, class G>
-__global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <= 160 * 1024 ? 3 : 2)) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
-    // ring row: [25 taps][TS Xa]; TS >= O1 with 4 * TS = 8 or 16 mod 32 (26 for O1 = 24, 28 for O1 = 28) keeps the accumulator stores at the
-    // 2-way minimum of a 64-lane ds_write_b32 (the four tap groups of a store land on different banks) and, at 1x28x28, the ring at 12.7 KiB
-    // per wave: three blocks per CU
-    constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW;
-    constexpr int RING = 5, TS = conv1_bwd_ts<G>(), TROW = 25 * TS;
+__global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
+    // T row buffer of ONE position row: [25 taps][TS Xa]; TS >= O1 with 4 * TS = 8 or 16 mod 32 (26 for O1 = 24, 28 for O1 = 28) keeps the
+    // accumulator stores at the 2-way minimum of a 64-lane ds_write_b32 (the four tap groups of a store land on different banks).
+    // Round 4: the last five rows of T used to sit in an LDS ring (14 KB per wave and input channel: two blocks per CU at 3x32x32, and the pass
+    // was repeated per input channel with the routed B operand rebuilt each time).  Now a lane keeps the five PARTIAL output rows that a T row
+    // contributes to in registers (ring[ci][ky]: column X = lane, output row Ya + ky), T lives in LDS for one row only (2.8 KB per wave),
+    // and the input-channel loop is INSIDE the row loop: stash bytes / pooled gradients are fetched and routed once per row, not Cin times.
+    constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW, CIN = G::CIN;
+    constexpr int TS = conv1_bwd_ts<G>(), TROW = 25 * TS;
     static_assert(O1 <= TS && (4 * TS) % 32 != 0 && O1 <= 32 && IW <= 64, "a conv1 output row fits two 16-wide MFMA tiles; an input row fits one wave");
-    __shared__ float lds[4 * RING * TROW];
+    __shared__ float lds[4 * TROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int NB = (a.N + 3) / 4;
     int id;
@@ -1645,7 +1648,7 @@ __global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <
     if (n >= a.N) return;                                                // whole wave idle; no block barrier anywhere
     const int sw = a.sidx ? a.sidx[s] : s;
     const long long sn = (long long)s * a.N + n;
-    float* const T = lds + wave * RING * TROW;
+    float* const T = lds + wave * TROW;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
 
     // this lane's 16 (channel, position) elements of a pooled row: pt = position tile (Xa = 16pt + li), channel c = 16kb + 4lg + r
@@ -1659,9 +1662,10 @@ __global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <
     const uint8_t* const st_sn = a.st1 + sn * G::P1SZ;
     const float* const d_sn = a.dP1 + sn * G::P1SZ;
 
-    for (int ci = 0; ci < G::CIN; ++ci) {
-        // A operand: A[i = tap][k = c], K step r of channel block kb is c = 16kb + 4lg + r (one f32x4 per (tap tile, channel block))
-        f32x4 aw[2][2];
+    // A operand per input channel: A[i = tap][k = c], K step r of channel block kb is c = 16kb + 4lg + r (one f32x4 per (tap tile, channel block))
+    f32x4 aw[CIN][2][2];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1669,60 +1673,57 @@ __global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int tap = 16 * mt + li, c = 16 * kb + 4 * lg + r;
-                    aw[mt][kb][r] = tap < 25 ? a.K1w[((long long)sw * C1 + c) * G::K1 + ci * 25 + tap] : 0.f;
+                    aw[ci][mt][kb][r] = tap < 25 ? a.K1w[((long long)sw * C1 + c) * G::K1 + ci * 25 + tap] : 0.f;
                 }
-        float* const Gout = a.G + sn * G::DIN + ci * (IW * IW);
-        auto emit_row = [&](int Y) {                                     // output row Y from the ring (rows Y-4 .. Y of T)
-            if (lane < IW) {
-                float g = 0.f;
+    float ring[CIN][5];                                                  // partial sums of output rows Ya .. Ya + 4, column X = lane
 #pragma unroll
-                for (int ky = 0; ky < 5; ++ky) {
-                    const int Yp = Y - ky;
-                    if (Yp < 0 || Yp > O1 - 1) continue;                 // wave-uniform
-                    const float* const row = T + (Yp % RING) * TROW + ky * 5 * TS;
+    for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
-                    for (int kx = 0; kx < 5; ++kx) {
-                        const int Xp = lane - kx;
-                        if (Xp >= 0 && Xp <= O1 - 1) g += row[kx * TS + Xp];
-                    }
+        for (int k = 0; k < 5; ++k) ring[ci][k] = 0.f;
+    float* const Gout = a.G + sn * G::DIN;
+    // the stash bytes and pooled gradients of pooled row py + 1 are fetched under the matrix work of row py (the wave has nothing
+    // else in flight: without this every row paid a full memory round trip, 1.24 ms at the conv-512 bench)
+    int stn[2][2][4];
+    float dn[2][2][4];
+    auto fetch = [&](int py) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    stn[pt][kb][r] = st_sn[eoff[pt][kb][r] + py * P1W_];
+                    dn[pt][kb][r] = d_sn[eoff[pt][kb][r] + py * P1W_];
                 }
-                Gout[Y * IW + lane] = g;
-            }
-        };
-        // the stash bytes and pooled gradients of pooled row py + 1 are fetched under the matrix work of row py (the wave has nothing
-        // else in flight: without this every row paid a full memory round trip, 1.24 ms at the conv-512 bench)
-        int stn[2][2][4];
-        float dn[2][2][4];
-        auto fetch = [&](int py) {
+    };
+    fetch(0);
+    for (int py = 0; py < P1W_; ++py) {
+        float gv[2][2][4];
+        int ar[2][2][4];
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+        for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        stn[pt][kb][r] = st_sn[eoff[pt][kb][r] + py * P1W_];
-                        dn[pt][kb][r] = d_sn[eoff[pt][kb][r] + py * P1W_];
-                    }
-        };
-        fetch(0);
-        for (int py = 0; py < P1W_; ++py) {
-            float gv[2][2][4];
-            int ar[2][2][4];
+                for (int r = 0; r < 4; ++r) {
+                    const int Xa = 16 * pt + li, st = stn[pt][kb][r];
+                    const float d = dn[pt][kb][r];
+                    gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
+                    ar[pt][kb][r] = (st & 3) ^ (Xa & 1);                 // == 2*half for the row half that owns the argmax, with the right column parity
+                }
+        if (py + 1 < P1W_) fetch(py + 1);
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt)
+        for (int half = 0; half < 2; ++half) {
+            const int Ya = 2 * py + half;
+            float b[2][2][4];                                            // the routed gradient row: B[k = channel][j = Xa], built ONCE for all input channels
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int Xa = 16 * pt + li, st = stn[pt][kb][r];
-                        const float d = dn[pt][kb][r];
-                        gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
-                        ar[pt][kb][r] = (st & 3) ^ (Xa & 1);             // == 2*half for the row half that owns the argmax, with the right column parity
-                    }
-            if (py + 1 < P1W_) fetch(py + 1);
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int Ya = 2 * py + half;
+                    for (int pt = 0; pt < 2; ++pt) b[pt][kb][r] = (ar[pt][kb][r] == 2 * half) ? gv[pt][kb][r] : 0.f;   // arg = 2*dy + dx
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
                 f32x4 acc[2][2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
@@ -1731,16 +1732,12 @@ __global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float b[2];
-#pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) b[pt] = (ar[pt][kb][r] == 2 * half) ? gv[pt][kb][r] : 0.f;   // arg = 2*dy + dx
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                            for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = MFMA16(aw[mt][kb][r], b[pt], acc[mt][pt]);
-                    }
-                float* const row = T + (Ya % RING) * TROW;
+                            for (int pt = 0; pt < 2; ++pt) acc[mt][pt] = MFMA16(aw[ci][mt][kb][r], b[pt][kb][r], acc[mt][pt]);
+                // (same wave: the LDS unit serves its requests in order — these stores follow the previous channel's reads, the reads below follow them)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1748,13 +1745,33 @@ __global__ void __launch_bounds__(256, (4 * 5 * 25 * conv1_bwd_ts<G>() * 4 * 3 <
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int tap = 16 * mt + 4 * lg + r;        // acc[mt][pt][r] = T[tap][Xa = 16pt + li]
-                            if (tap < 25 && 16 * pt + li < TS) row[tap * TS + 16 * pt + li] = acc[mt][pt][r];
+                            if (tap < 25 && 16 * pt + li < TS) T[tap * TS + 16 * pt + li] = acc[mt][pt][r];
                         }
-                emit_row(Ya);
+                if (lane < IW) {                                         // this T row's share of output rows Ya + ky: dX[Ya + ky][X] += T[(ky, kx)][X - kx]
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx) {
+                            const int Xp = lane - kx;
+                            if (Xp >= 0 && Xp <= O1 - 1) ring[ci][ky] += T[(ky * 5 + kx) * TS + Xp];
+                        }
+                }
+            }
+            // output row Ya has now received its last contribution (T rows Ya - 4 .. Ya): emit it, rotate the partial rows
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                if (lane < IW) Gout[ci * (IW * IW) + Ya * IW + lane] = ring[ci][0];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ring[ci][k] = ring[ci][k + 1];
+                ring[ci][4] = 0.f;
             }
         }
-        for (int Y = O1; Y < IW; ++Y) emit_row(Y);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                                          // the last four output rows: O1 .. IW - 1
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+            if (lane < IW) Gout[ci * (IW * IW) + (O1 + k) * IW + lane] = ring[ci][k];
 }
 
 // conv1^T: the matrix-pipe kernel; RBNN_CONV1_BWD_VALU keeps its VALU gather form selectable (same results up to summation order)
