@@ -392,6 +392,8 @@ def main():
         # its GEMM kernels (StackedPosterior.prefetch / flip: a second buffer set).  Measured (profiles/r03a/svi_prefetch_ab.txt): 7.85 vs 7.88 ms
         # per C2 step — the forward kernel slows down by what the hidden draw took — so the default draws between the steps
         pipe = (kind == "svi" and getattr(post_, "can_prefetch", lambda: False)() and os.environ.get("RBNN_SVI_PREFETCH", "0") == "1")
+        lazy_draw = (kind == "svi" and not pipe and eng.precision == "lowdim" and getattr(post_, "lazy_capable", lambda: False)()
+                     and os.environ.get("RBNN_LAZY_DRAW", "1") != "0")
         key = 0x5EED0000 + rank
 
         timed = [0]
@@ -406,7 +408,9 @@ def main():
                     post_.redraw(key, draws[0])
                 post_.prefetch(key, draws[0] + 1)
                 return
-            if kern.on:
+            if lazy_draw:                           # lowdim engines: the draw is generated INSIDE the next rbnn_lowdim_run launch (rbnn_lowdim_run_svi)
+                post_.redraw(key, draws[0], lazy=True)
+            elif kern.on:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 post_.redraw(key, draws[0])
@@ -469,6 +473,10 @@ def main():
                 k2 = int(sp_svi.K2w[0].numel())
                 wr = w["S"] * (4.0 * n_par + k2 * (4.0 + (12.24 if eng.precision == "triple" else 0.0)))
                 kname = "svi_draw_flat_kernel (1 launch: all six tensors, all samples) + 6 image-builder launches for model.3.weight"
+            if lazy_draw:
+                kname = ("none of its own: the weights of all samples are generated inside the lowdim launch from the guide (rbnn_lowdim_run_svi; "
+                         "same Philox counters as svi_draw_kernel, the stack is materialised only on demand)")
+                wr = 0.0
             svi = {"draws": timed[0], "draws_per_step": timed[0] / max(1, args.steps),
                    "overlap": ("the draw of step k + 1 runs on a side stream under the GEMM kernels of step k (second buffer set); draw_ms = the same launch timed "
                                "stand-alone outside the timed region" if pipe else "none: the draw runs between the steps on the same stream"),

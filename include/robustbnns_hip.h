@@ -532,6 +532,18 @@ int rbnn_lowdim_run(const rbnn_posterior *net, int32_t op, int32_t loss_mode, in
                     float out_scale, float eps, const float *alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project,
                     int32_t iters, float *P_scratch, float *out, int32_t ldo, float *linf, float *l2, void *stream);
 
+/* rbnn_svi_draw + rbnn_lowdim_run in ONE launch (arch fc, small posteriors: every block generates the weights of all samples of the call into its
+ * LDS cache from the guide — loc + sigma * eps(key or sample_keys[s], draw_id, tensor, sample, quad), rbnn_svi_draw's generator, the same
+ * weights — instead of copying them from the stack).  The stack is NOT written: a caller that needs it afterwards runs rbnn_svi_draw with the
+ * same (key, draw_id) (robustbnns_amd.posterior.StackedPosterior.materialize).  BASELINE config 1 (half-moons, SVI): a redraw + an FGSM pass
+ * was two launches at the launch floor.  rbnn_lowdim_fused_draw_supported: 1 when the call's samples fit the kernel's 60 KB weight cache. */
+int rbnn_lowdim_fused_draw_supported(const rbnn_posterior *net, int32_t n_points, int32_t n_samples);
+int rbnn_lowdim_run_svi(const rbnn_posterior *net, const rbnn_svi_guide *guide, const uint64_t *sample_keys, uint64_t key, uint32_t draw_id,
+                        int32_t op, int32_t loss_mode, int32_t out_kind, const float *X, const float *X0, int32_t ldx, int32_t n_points,
+                        const int32_t *sample_idx, int32_t n_samples, const int32_t *labels, float inv_S, float out_scale, float eps,
+                        const float *alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project, int32_t iters, float *P_scratch,
+                        float *out, int32_t ldo, float *linf, float *l2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

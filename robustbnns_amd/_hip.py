@@ -157,6 +157,9 @@ SIGNATURES = {
     "rbnn_lowdim_scratch_bytes": (_sz, [_PP, _i32, _i32]),
     "rbnn_lowdim_run": (_i32, [_PP, _i32, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _fp, _f32, _f32, _f32, _fp, _f32, _i32, _i32, _i32,
                                _fp, _fp, _i32, _fp, _fp, _fp]),
+    "rbnn_lowdim_fused_draw_supported": (_i32, [_PP, _i32, _i32]),
+    "rbnn_lowdim_run_svi": (_i32, [_PP, C.POINTER(SviGuide), _fp, C.c_uint64, C.c_uint32, _i32, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _fp, _f32,
+                                   _f32, _f32, _fp, _f32, _i32, _i32, _i32, _fp, _fp, _i32, _fp, _fp, _fp]),
     "rbnn_svi_draw_flat": (_i32, [C.POINTER(SviFlatTensor), _i32, _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
     "rbnn_svi_draw": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
     "rbnn_svi_draw_supported": (_i32, [_PP, _i32]),
@@ -483,14 +486,27 @@ class HipKernels:
     LOWDIM_FORWARD, LOWDIM_GRADIENT, LOWDIM_ATTACK = 0, 1, 2
 
     def lowdim_supported(self, net):
-        return bool(self.lib.rbnn_lowdim_supported(C.byref(net.descriptor())))
+        return bool(self.lib.rbnn_lowdim_supported(C.byref(net.descriptor(lazy_ok=True))))
 
     def lowdim_scratch_bytes(self, net, N, S):
-        return int(self.lib.rbnn_lowdim_scratch_bytes(C.byref(net.descriptor()), N, S))
+        return int(self.lib.rbnn_lowdim_scratch_bytes(C.byref(net.descriptor(lazy_ok=True)), N, S))
+
+    def lowdim_fused_draw_supported(self, net, N, S):
+        return bool(self.lib.rbnn_lowdim_fused_draw_supported(C.byref(net.descriptor(lazy_ok=True)), N, S))
 
     def lowdim_run(self, net, op, loss_mode, out_kind, X, X0, sidx, S, labels, inv_S, out_scale, eps, alpha, alpha_scalar, alpha_per_image,
                    project, iters, P, out, linf=None, l2=None):
         require_gpu(X, "X")
+        lazy = getattr(net, "_lazy", None)
+        if lazy is not None and S <= lazy[2] and self.lowdim_fused_draw_supported(net, X.shape[0], S):
+            # a pending (lazy) SVI draw: the weights are generated inside this launch — no rbnn_svi_draw launch, the stack stays as it was
+            key, draw_id, _, sample_keys = lazy
+            check(self.lib.rbnn_lowdim_run_svi(C.byref(net.descriptor(lazy_ok=True)), C.byref(net._guide.descriptor()), ptr(sample_keys),
+                                               C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF), op, loss_mode, out_kind, ptr(X),
+                                               ptr(X0), X.stride(0), X.shape[0], ptr(sidx), S, ptr(labels), inv_S, out_scale, eps, ptr(alpha), alpha_scalar,
+                                               int(alpha_per_image), int(project), iters, ptr(P), ptr(out), out.stride(0), ptr(linf), ptr(l2),
+                                               stream_of(X)), "rbnn_lowdim_run_svi")
+            return
         check(self.lib.rbnn_lowdim_run(C.byref(net.descriptor()), op, loss_mode, out_kind, ptr(X), ptr(X0), X.stride(0), X.shape[0], ptr(sidx), S,
                                        ptr(labels), inv_S, out_scale, eps, ptr(alpha), alpha_scalar, int(alpha_per_image), int(project), iters,
                                        ptr(P), ptr(out), out.stride(0), ptr(linf), ptr(l2), stream_of(X)), "rbnn_lowdim_run")

@@ -118,6 +118,59 @@ template <int ACT> __device__ __forceinline__ float act_grad_from_value(float h)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The SVI draw's generator (rbnn_svi.hip: svi_draw_kernel; rbnn_lowdim.hip: the draw fused into the one-launch path): eps is a pure function of
+// (key, draw id, tensor, sample, element quad) — Philox4x32-10 + Box-Muller on the hardware transcendentals.  Shared so that both kernels
+// produce the SAME weights for the same (key, draw).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four standard normals from one Philox block: Box-Muller on (x0, x1) and (x2, x3); u = (x + 0.5) 2^-32 in (0, 1)
+__device__ __forceinline__ void normal4(const uint32_t x[4], float n[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)x[2 * p] + 0.5f) * 2.3283064365386963e-10f;       // fp32: x + 0.5 rounds for x >= 2^24, still in (0, 1]
+        const float u2 = ((float)x[2 * p + 1] + 0.5f) * 2.3283064365386963e-10f;
+        // the hardware transcendentals: v_log_f32 (log2, 1 ulp) and v_sin_f32 / v_cos_f32, whose argument is in REVOLUTIONS — sin(2 pi u2)
+        // is one instruction.  (libm's logf + sincospif cost ~25 vector instructions per weight and made this kernel ALU-bound.)
+        const float r = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u1, 0.99999994f)));   // sqrt(-2 ln u1), ln = log2 * ln 2
+        n[2 * p] = r * __builtin_amdgcn_cosf(u2); n[2 * p + 1] = r * __builtin_amdgcn_sinf(u2);
+    }
+}
+
+enum { T_W1 = 0, T_B1 = 1, T_WM = 2, T_BM = 3, T_W2 = 4, T_B2 = 5 };
+
+struct Rng {
+    uint32_t k0, k1, c2, c3;
+    __device__ __forceinline__ void quad(int tensor, uint32_t q, float n[4]) const {
+        uint32_t x[4];
+        philox4x32_10(q, (uint32_t)tensor, c2, c3, k0, k1, x);
+        normal4(x, n);
+    }
+};
+
+// one weight of a [rows, cols] row-major guide tensor (quad index = r * ceil(cols/4) + c/4: eps does not depend on the padding)
+__device__ __forceinline__ void draw_quad(const Rng& rng, int tensor, const float* loc, const float* scl, int r, int c4, int cols, float w[4]) {
+    const int Q = (cols + 3) >> 2;
+    float n[4];
+    rng.quad(tensor, (uint32_t)(r * Q + c4), n);
+    const long long base = (long long)r * cols + 4 * c4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool in = 4 * c4 + j < cols;
+        w[j] = in ? fmaf(scl[base + j], n[j], loc[base + j]) : 0.f;              // Normal.rsample(): loc + eps * scale (model_bnn.py:127-130); scl = softplus(raw scale), applied ONCE per guide by the caller
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // host-side helpers
 // ---------------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -37,6 +37,13 @@ struct LowArgs {
     int ldx, N, S, op, loss, out_kind, ldo, iters, project, alpha_per_image, SL, PB;
     int cache_stride;              // > 0: floats per sample of the LDS weight cache (all S samples of the call fit)
     float inv_S, out_scale, eps, alpha_scalar;
+    // fused SVI draw (rbnn_lowdim_run_svi): the cache is GENERATED — loc + sigma * eps(key, draw, tensor, sample, quad), rbnn_svi_draw's generator —
+    // instead of copied from the stack: a redraw + a pass is one launch (the stack itself is not written: the host materialises it on demand)
+    rbnn_svi_guide g;
+    const unsigned long long* sample_keys;
+    unsigned long long key;
+    uint32_t draw_id;
+    int fused_draw;
 };
 
 template <int ACT> __device__ __forceinline__ float act_deriv(float a, float hv) {
@@ -177,6 +184,17 @@ __global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
                 if (e < total) {
                     const int sl = e / US, r = e - sl * US;
                     const int sw = a.sidx ? a.sidx[sl] : sl;
+                    if (a.fused_draw) {                                   // the same (tensor, quad) counters as svi_draw_kernel: identical weights
+                        const unsigned long long key = a.sample_keys ? a.sample_keys[sw] : a.key;
+                        const Rng rng = {(uint32_t)key, (uint32_t)(key >> 32), a.sample_keys ? 0u : (uint32_t)sw, a.draw_id};
+                        const int H0 = a.g.hidden, D = a.net.in_features;
+                        float w[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (r < u1) { if (r / DQ < H0 && 4 * (r % DQ) < D) draw_quad(rng, T_W1, a.g.W1_loc, a.g.W1_scale, r / DQ, r % DQ, D, w); }
+                        else if (r < u2) { if (4 * (r - u1) < H0) draw_quad(rng, T_B1, a.g.b1_loc, a.g.b1_scale, 0, r - u1, H0, w); }
+                        else if (r < u3) { const int i2 = r - u2, c = i2 / (H / 4), q = i2 - c * (H / 4); if (4 * q < H0) draw_quad(rng, T_W2, a.g.W2_loc, a.g.W2_scale, c, q, H0, w); }
+                        else draw_quad(rng, T_B2, a.g.b2_loc, a.g.b2_scale, 0, r - u3, Cn, w);
+                        v[u] = (f32x4){w[0], w[1], w[2], w[3]};
+                    } else
                     if (r < u1) v[u] = *(const f32x4*)(a.net.W1 + ((long long)sw * H + r / DQ) * a.net.in_stride + 4 * (r % DQ));
                     else if (r < u2) v[u] = *(const f32x4*)(a.net.b1 + (long long)sw * H + 4 * (r - u1));
                     else if (r < u3) v[u] = *(const f32x4*)(a.net.W2 + (long long)sw * Cn * H + 4 * (r - u2));
@@ -361,6 +379,7 @@ template <int ACT, int DQ, int CM> int launch_low(const LowArgs& a, hipStream_t 
     // the cache pays when a block is short of work to hide L2 latency with (few owned samples per thread) and fits the default 64 KB of
     // dynamic LDS; big posteriors keep reading through L1 / L2, where many resident waves hide the latency
     b.cache_stride = ((red_floats + ss * a.S) * sizeof(float) <= 60 * 1024) ? (int)ss : 0;
+    if (a.fused_draw && !b.cache_stride) return RBNN_ERR_UNSUPPORTED;      // (rbnn_lowdim_fused_draw_supported says so beforehand)
     const size_t lds = (red_floats + (b.cache_stride ? ss * a.S : 0)) * sizeof(float);
     hipLaunchKernelGGL((lowdim_kernel<ACT, DQ, CM>), dim3((unsigned)((a.N + a.PB - 1) / a.PB)), dim3(256), lds, st, b);
     return launch_status();
@@ -837,10 +856,28 @@ size_t rbnn_lowdim_scratch_bytes(const rbnn_posterior* net, int32_t n_points, in
     return net->arch == RBNN_ARCH_FC2 ? 2 * SN + (size_t)n_points * RBNN_CPAD * sizeof(float) : SN;
 }
 
-int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, int32_t out_kind, const float* X, const float* X0, int32_t ldx,
-                    int32_t n_points, const int32_t* sample_idx, int32_t n_samples, const int32_t* labels, float inv_S, float out_scale,
-                    float eps, const float* alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project, int32_t iters,
-                    float* P_scratch, float* out, int32_t ldo, float* linf, float* l2, void* stream) {
+// sample lanes per point: enough threads to fill the chip (256 CUs x 2 x 256) when N is small, one lane per point when N is large
+static void lowdim_plan(int n_points, int n_samples, int& SL, int& PB) {
+    const long long want = (131072 + (long long)n_points - 1) / n_points;
+    SL = (int)std::max(1LL, std::min<long long>(std::min<long long>(n_samples, 256), want));
+    PB = 256 / SL;
+}
+
+int rbnn_lowdim_fused_draw_supported(const rbnn_posterior* net, int32_t n_points, int32_t n_samples) {
+    if (!net || net->arch != RBNN_ARCH_FC || !rbnn_lowdim_supported(net) || n_points < 1 || n_samples < 1) return 0;
+    int SL, PB;
+    lowdim_plan(n_points, n_samples, SL, PB);
+    const int DQ = net->in_features <= 4 ? 1 : 4, CM = net->n_classes <= 2 ? 2 : 10, RW = std::max(4 * DQ, CM);
+    const size_t red_floats = ((size_t)SL * PB * RW + 3) & ~(size_t)3;
+    const size_t ss = (size_t)net->hidden * (4 * DQ + 1 + net->n_classes) + 4 * (size_t)((net->n_classes + 3) / 4);
+    return (red_floats + ss * n_samples) * sizeof(float) <= 60 * 1024;      // launch_low's weight cache holds every sample of the call
+}
+
+static int lowdim_run_impl(const rbnn_posterior* net, const rbnn_svi_guide* guide, const uint64_t* sample_keys, uint64_t key, uint32_t draw_id,
+                           int32_t op, int32_t loss_mode, int32_t out_kind, const float* X, const float* X0, int32_t ldx,
+                           int32_t n_points, const int32_t* sample_idx, int32_t n_samples, const int32_t* labels, float inv_S, float out_scale,
+                           float eps, const float* alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project, int32_t iters,
+                           float* P_scratch, float* out, int32_t ldo, float* linf, float* l2, void* stream) {
     if (!net || !X || !out || !net->W1 || !net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
     if (!rbnn_lowdim_supported(net)) return RBNN_ERR_UNSUPPORTED;
     if (net->activation < RBNN_ACT_RELU || net->activation > RBNN_ACT_TANH) return RBNN_ERR_UNSUPPORTED;
@@ -855,6 +892,7 @@ int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, in
     if (op == OP_ATTACK && (iters < 1 || (project && !X0))) return RBNN_ERR_SHAPE;
     if (!aligned16(net->W1) || !aligned16(net->b1) || !aligned16(net->W2)) return RBNN_ERR_ALIGN;
     if (net->arch == RBNN_ARCH_FC2) {
+        if (guide) return RBNN_ERR_UNSUPPORTED;
         if (op != OP_FORWARD && loss_mode != RBNN_LOSS_PER_SAMPLE && !P_scratch) return RBNN_ERR_NULL;
         if (op == OP_ATTACK && out == X) return RBNN_ERR_SHAPE;             // the iterate is updated in `out` while X is still read
         return run_low2(net, op, loss_mode, out_kind, X, X0, ldx, n_points, sample_idx, n_samples, labels, inv_S, out_scale, eps, alpha, alpha_scalar,
@@ -865,10 +903,13 @@ int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, in
     a.linf = linf; a.l2 = l2; a.ldx = ldx; a.N = n_points; a.S = n_samples; a.op = op; a.loss = loss_mode; a.out_kind = out_kind; a.ldo = ldo;
     a.iters = iters; a.project = project; a.alpha_per_image = alpha_per_image; a.inv_S = inv_S; a.out_scale = out_scale; a.eps = eps;
     a.alpha_scalar = alpha_scalar;
-    // sample lanes per point: enough threads to fill the chip (256 CUs x 2 x 256) when N is small, one lane per point when N is large
-    long long want = (131072 + (long long)n_points - 1) / n_points;
-    a.SL = (int)std::max(1LL, std::min<long long>(std::min<long long>(n_samples, 256), want));
-    a.PB = 256 / a.SL;
+    lowdim_plan(n_points, n_samples, a.SL, a.PB);
+    if (guide) {
+        if (!guide->W1_loc || !guide->W1_scale || !guide->b1_loc || !guide->b1_scale || !guide->W2_loc || !guide->W2_scale || !guide->b2_loc || !guide->b2_scale)
+            return RBNN_ERR_NULL;
+        if (guide->hidden < 1 || guide->hidden > net->hidden || !rbnn_lowdim_fused_draw_supported(net, n_points, n_samples)) return RBNN_ERR_UNSUPPORTED;
+        a.g = *guide; a.sample_keys = (const unsigned long long*)sample_keys; a.key = key; a.draw_id = draw_id; a.fused_draw = 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (net->activation) {
         case RBNN_ACT_RELU:  return launch_low_act<RBNN_ACT_RELU>(a, st);
@@ -877,6 +918,24 @@ int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, in
         case RBNN_ACT_TANH:  return launch_low_act<RBNN_ACT_TANH>(a, st);
     }
     return RBNN_ERR_UNSUPPORTED;
+}
+
+int rbnn_lowdim_run(const rbnn_posterior* net, int32_t op, int32_t loss_mode, int32_t out_kind, const float* X, const float* X0, int32_t ldx,
+                    int32_t n_points, const int32_t* sample_idx, int32_t n_samples, const int32_t* labels, float inv_S, float out_scale,
+                    float eps, const float* alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project, int32_t iters,
+                    float* P_scratch, float* out, int32_t ldo, float* linf, float* l2, void* stream) {
+    return lowdim_run_impl(net, nullptr, nullptr, 0, 0, op, loss_mode, out_kind, X, X0, ldx, n_points, sample_idx, n_samples, labels, inv_S, out_scale, eps,
+                           alpha, alpha_scalar, alpha_per_image, project, iters, P_scratch, out, ldo, linf, l2, stream);
+}
+
+int rbnn_lowdim_run_svi(const rbnn_posterior* net, const rbnn_svi_guide* guide, const uint64_t* sample_keys, uint64_t key, uint32_t draw_id,
+                        int32_t op, int32_t loss_mode, int32_t out_kind, const float* X, const float* X0, int32_t ldx,
+                        int32_t n_points, const int32_t* sample_idx, int32_t n_samples, const int32_t* labels, float inv_S, float out_scale,
+                        float eps, const float* alpha, float alpha_scalar, int32_t alpha_per_image, int32_t project, int32_t iters,
+                        float* P_scratch, float* out, int32_t ldo, float* linf, float* l2, void* stream) {
+    if (!guide) return RBNN_ERR_NULL;
+    return lowdim_run_impl(net, guide, sample_keys, key, draw_id, op, loss_mode, out_kind, X, X0, ldx, n_points, sample_idx, n_samples, labels, inv_S,
+                           out_scale, eps, alpha, alpha_scalar, alpha_per_image, project, iters, P_scratch, out, ldo, linf, l2, stream);
 }
 
 }  // extern "C"

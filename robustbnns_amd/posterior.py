@@ -271,13 +271,34 @@ class StackedPosterior:
         post._guide = guide
         return post
 
-    def redraw(self, key, draw_id=0, n_samples=None, sample_keys=None):
+    def lazy_capable(self):
+        """A draw can be left PENDING — recorded as (key, draw id) and generated inside the next rbnn_lowdim_run launch instead of by a launch of
+        its own — for fc nets of the lowdim kind with no weight images to keep in step (BASELINE config 1: a redraw + an FGSM pass at the
+        launch floor of two kernels becomes one)."""
+        return (self._guide is not None and self.arch == "fc" and self._triple is None and self._split is None and self._back is None
+                and self.device.type == "cuda" and self.D <= 16 and self.C <= 10)
+
+    def materialize(self):
+        """Run a pending (lazy) draw for real: rbnn_svi_draw with the recorded (key, draw id) — the same weights the fused launches generated.
+        Called by everything that reads the stack (the tensor attributes, descriptor(), state_dict(), shard())."""
+        lazy = self.__dict__.get("_lazy")
+        if lazy is not None:
+            self.__dict__["_lazy"] = None
+            self.redraw(lazy[0], lazy[1], lazy[2], lazy[3])
+        return self
+
+    def redraw(self, key, draw_id=0, n_samples=None, sample_keys=None, lazy=False):
         """W[s] = loc + softplus(scale) * eps(key, draw_id, s) for s < n_samples, written by ONE kernel (rbnn_svi_draw) into the fp32
         stack, the pack_rows4 images and — once they exist — the triple images.  sample_keys: int64 device tensor, one key per
-        sample (seeded draws, model_bnn.py:222-226).  No device->host sync, no allocation."""
+        sample (seeded draws, model_bnn.py:222-226).  No device->host sync, no allocation.  lazy=True (callers about to run the lowdim
+        kernels): only RECORD the draw where lazy_capable() — see materialize()."""
         if self._guide is None:
             raise _hip.HipError("redraw() needs a posterior built by StackedPosterior.for_guide")
         S = self.S if n_samples is None else int(n_samples)
+        self.__dict__["_lazy"] = None           # a newer draw supersedes a pending one
+        if lazy and self.lazy_capable():
+            self.__dict__["_lazy"] = (int(key), int(draw_id), S, sample_keys)
+            return self
         tri = self._triple[0] if self._triple is not None else None
         _hip.HipKernels().svi_draw(self, tri, self._guide, S, int(key), int(draw_id), sample_keys)
         if self._split is not None:             # the opt-in two-piece mode keeps its own images: rebuilt by its builders (same fixed scales)
@@ -371,16 +392,20 @@ class StackedPosterior:
                                     n0.input_shape, n0.output_size, n0.hidden_size, device)
 
     # ------------------------------------------------------------------ C-ABI view
-    def descriptor(self):
+    def descriptor(self, lazy_ok=False):
+        """lazy_ok: the caller does not read the weights behind the pointers (size queries) or generates them itself (the fused lowdim launch)."""
+        if not lazy_ok:
+            self.materialize()
         if self._desc is None:
             d = _hip.Posterior()
             d.arch, d.activation = _hip.ARCHS[self.arch], _hip.ACTIVATIONS[self.activation]
             d.in_features, d.in_stride, d.hidden, d.n_classes, d.n_stored = self.D, self.Dp, self.Hp, self.C, self.S
+            raw = lambda n: self.__dict__.get("_t_" + n)      # (not through the attributes: they would materialise a pending draw)
             for name in ("W1", "b1", "Wm", "bm", "W2", "b2"):
-                t = getattr(self, name)
+                t = raw(name)
                 setattr(d, name, None if t is None else C.c_void_p(t.data_ptr()))
-            d.W1_pack4 = None if self.W1p is None else C.c_void_p(self.W1p.data_ptr())
-            d.Wm_pack4 = None if self.Wmp is None else C.c_void_p(self.Wmp.data_ptr())
+            d.W1_pack4 = None if raw("W1p") is None else C.c_void_p(raw("W1p").data_ptr())
+            d.Wm_pack4 = None if raw("Wmp") is None else C.c_void_p(raw("Wmp").data_ptr())
             self._desc = d
         return self._desc
 
@@ -399,6 +424,7 @@ class StackedPosterior:
 
     def shard(self, rank, world):
         """Samples [rank*S/world, (rank+1)*S/world) as a new posterior (sample-sharded multi-GPU)."""
+        self.materialize()
         lo, hi = rank * self.S // world, (rank + 1) * self.S // world
         out = object.__new__(StackedPosterior)
         out.__dict__.update(self.__dict__)
@@ -410,3 +436,20 @@ class StackedPosterior:
         out._guide, out._back = None, None
         out._pack()
         return out
+
+
+def _stack_tensor(name):
+    """The stacked weight tensors as attributes that first materialise a pending lazy draw (StackedPosterior.materialize): whoever READS the stack
+    sees the weights of the last redraw(), whether it ran as its own launch or only inside the fused lowdim launches so far."""
+    def get(self):
+        if self.__dict__.get("_lazy") is not None:
+            self.materialize()
+        return self.__dict__.get("_t_" + name)
+
+    def put(self, value):
+        self.__dict__["_t_" + name] = value
+    return property(get, put)
+
+
+for _n in ("W1", "b1", "Wm", "bm", "W2", "b2", "W1p", "Wmp"):
+    setattr(StackedPosterior, _n, _stack_tensor(_n))

@@ -114,3 +114,49 @@ def test_conv_weight_images_kernel_equals_the_standalone_builders(Hc, S, monkeyp
     assert out["fused"][3] == out["standalone"][3]
     assert torch.equal(out["fused"][0], out["standalone"][0]) and torch.equal(out["fused"][1], out["standalone"][1])
     assert torch.equal(out["fused"][2], out["standalone"][2])
+
+
+# ------------------------------------------------------------------ the SVI draw fused into the lowdim launch (BASELINE config 1)
+@pytest.mark.parametrize("shape,H,C,S,N,act", [((1, 2, 1), 64, 2, 10, 100, "leaky"), ((1, 7, 1), 32, 10, 4, 37, "tanh"), ((1, 2, 1), 16, 2, 3, 500, "relu")])
+def test_lazy_svi_draw_inside_the_lowdim_launch_equals_draw_then_run(shape, H, C, S, N, act):
+    """redraw(lazy=True) only RECORDS (key, draw id); rbnn_lowdim_run_svi generates the same weights inside the pass (svi_draw_kernel's Philox
+    counters): forward, expected gradients, FGSM, a PGD iteration and seeded draws are BIT-IDENTICAL to redraw() + rbnn_lowdim_run, the stack is
+    untouched until somebody reads it — and reading it (attribute, state_dict, another engine) materialises exactly those weights."""
+    from robustbnns_amd import AttackEngine, StackedPosterior, _hip
+    from robustbnns_amd.posterior import SviGuide
+    D = shape[0] * shape[1] * shape[2]
+    g = torch.Generator().manual_seed(H + N)
+    names = {"model.1.weight": (H, D), "model.1.bias": (H,), "model.3.weight": (C, H), "model.3.bias": (C,)}
+    loc = {k: torch.randn(*v, generator=g) * 0.5 for k, v in names.items()}
+    scl = {k: -2.0 + 0.3 * torch.randn(*v, generator=g) for k, v in names.items()}
+    x, y = O.synthetic_inputs(N, shape, C, seed=N)
+    keys = torch.tensor([11, 5, 7, 3, 2, 9, 1, 8, 4, 6][:S], dtype=torch.int64, device=DEV)
+
+    def run(lazy):
+        post = StackedPosterior.for_guide(SviGuide(loc, scl, "fc", DEV), act, shape, C, S)
+        eng = AttackEngine(post)
+        assert eng.precision == "lowdim" and post.lazy_capable()
+        out = {}
+        post.redraw(0xABCDEF0123, 3, lazy=lazy)
+        assert (post.__dict__["_lazy"] is not None) == lazy
+        if lazy:
+            assert float(post.__dict__["_t_W1"].abs().max()) == 0.0          # nothing has been written to the stack yet
+        out["probs"] = eng.forward(x, S).cpu()
+        out["lg"] = eng.loss_gradients(x, y, S).cpu()
+        out["fgsm"] = eng.fgsm(x, y, S, 0.2).cpu()
+        out["pgd1"] = eng.pgd_continue(x, x, y, S, 0.1).cpu()
+        out["sub"] = eng.forward(x, 2, seeds=[S - 1, 0]).cpu()
+        if lazy:
+            assert float(post.__dict__["_t_W1"].abs().max()) == 0.0 and post.__dict__["_lazy"] is not None
+        post.redraw(0, 1, sample_keys=keys, lazy=lazy)                       # seeded draws: one key per sample
+        out["seeded"] = eng.forward(x, S).cpu()
+        out["W1"] = post.W1.clone().cpu()                                    # reading the stack materialises the pending draw
+        assert post.__dict__["_lazy"] is None
+        out["sd"] = post.state_dict(S - 1)["model.3.weight"]
+        out["exact"] = AttackEngine(post, precision="exact").forward(x, S).cpu()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["W1"].abs().max()) > 0 and rel_err(a["exact"], a["seeded"]) < TOL
