@@ -392,11 +392,15 @@ def main():
         # its GEMM kernels (StackedPosterior.prefetch / flip: a second buffer set).  Measured (profiles/r03a/svi_prefetch_ab.txt): 7.85 vs 7.88 ms
         # per C2 step — the forward kernel slows down by what the hidden draw took — so the default draws between the steps
         pipe = (kind == "svi" and getattr(post_, "can_prefetch", lambda: False)() and os.environ.get("RBNN_SVI_PREFETCH", "0") == "1")
-        lazy_draw = (kind == "svi" and not pipe and eng.precision == "lowdim" and getattr(post_, "lazy_capable", lambda: False)()
-                     and os.environ.get("RBNN_LAZY_DRAW", "1") != "0")
+        lazy_kind = (eng.precision if eng.precision in ("lowdim", "triple") and kind == "svi" and not pipe and w["arch"] != "conv"
+                     and os.environ.get("RBNN_LAZY_DRAW", "1") != "0" else None)
+        lazy_draw = lazy_kind == "lowdim" and getattr(post_, "lazy_capable", lambda: False)()
         key = 0x5EED0000 + rank
 
         timed = [0]
+        # triple engines: the draw writes the images the kernels read (rbnn_svi_draw_images); the fp32 W1 stack + its pack_rows4 copy (40 % of a
+        # full draw's bytes, read by no triple kernel) are materialised only if somebody reads them
+        lazy_kw = {"lazy": True} if lazy_kind == "triple" else {}
 
         def redraw():
             draws[0] += 1
@@ -413,11 +417,11 @@ def main():
             elif kern.on:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                post_.redraw(key, draws[0])
+                post_.redraw(key, draws[0], **lazy_kw)
                 e1.record()
                 draw_ev.append((e0, e1))
             else:
-                post_.redraw(key, draws[0])
+                post_.redraw(key, draws[0], **lazy_kw)
 
         def step():
             if kind == "svi":
@@ -469,6 +473,9 @@ def main():
             # cols images (6 + 6 B); reads are the guide's loc + scale (8 B per parameter, once per sample, L2-resident)
             wr = w["S"] * n_par * (8.0 + (12.0 if eng.precision == "triple" else 0.0))
             kname = "svi_draw_kernel (1 launch per draw)"
+            if lazy_kind == "triple":
+                wr = w["S"] * n_par * 12.0
+                kname = "svi_draw_kernel, images only (rbnn_svi_draw_images: triple rows + cols images, biases, W2; the fp32 W1 stack is materialised on demand)"
             if w["arch"] == "conv":         # fp32 stack by one launch; model.3.weight's regrouping (4 B) and triple images (6 + 6.24 B) by their builders
                 k2 = int(sp_svi.K2w[0].numel())
                 wr = w["S"] * (4.0 * n_par + k2 * (4.0 + (12.24 if eng.precision == "triple" else 0.0)))

@@ -487,6 +487,12 @@ typedef struct rbnn_svi_guide {    /* device pointers to the variational paramet
 #define RBNN_SVI_EPS_MAX 6.77f
 int rbnn_svi_draw(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
                   const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
+/* The same draw for a caller that is about to run the TRIPLE kernels only: W1 (Wm) are written as their triple images (12 B per weight), not
+ * as the fp32 stack + its pack_rows4 image (8 B per weight: 40 % of rbnn_svi_draw's writes, read by no triple kernel); b1 (bm) W2 b2 and the W2
+ * generator image as always.  Whoever needs the fp32 W1 / Wm later calls rbnn_svi_draw with the same (key, draw_id): the same weights
+ * (robustbnns_amd.posterior.StackedPosterior.materialize).  tp must not be NULL. */
+int rbnn_svi_draw_images(const rbnn_posterior *net, const rbnn_triple_images *tp, const rbnn_svi_guide *guide, int32_t n_samples,
+                         const uint64_t *sample_keys, uint64_t key, uint32_t draw_id, void *stream);
 /* 1 when rbnn_svi_draw covers this posterior (fc / fc2; W2 [n_classes, hidden] fits the 160 KB of LDS it is staged in; with triple
  * images: n_classes <= 10, hidden % 128 == 0) — the host falls back to rbnn_svi_materialize + a new stack otherwise. */
 int rbnn_svi_draw_supported(const rbnn_posterior *net, int32_t with_triple_images);

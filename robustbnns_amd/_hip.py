@@ -163,6 +163,7 @@ SIGNATURES = {
     "rbnn_svi_draw_flat": (_i32, [C.POINTER(SviFlatTensor), _i32, _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
     "rbnn_svi_draw": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
     "rbnn_svi_draw_supported": (_i32, [_PP, _i32]),
+    "rbnn_svi_draw_images": (_i32, [_PP, C.POINTER(TripleImages), C.POINTER(SviGuide), _i32, _fp, C.c_uint64, C.c_uint32, _fp]),
 }
 
 _lib = None
@@ -230,7 +231,7 @@ class HipKernels:
     # -- host-only --------------------------------------------------------------------------------
     def workspace_sizes(self, net, N, S, chunk=0):
         out = WorkspaceSizes()
-        check(self.lib.rbnn_workspace_query(C.byref(net.descriptor()), N, S, chunk, C.byref(out)), "rbnn_workspace_query")
+        check(self.lib.rbnn_workspace_query(C.byref(net.descriptor(lazy_ok=True)), N, S, chunk, C.byref(out)), "rbnn_workspace_query")
         d = {k: getattr(out, k) for k in WS_KEYS}
         d["n_slabs"], d["chunk"] = out.n_slabs, out.chunk
         return d
@@ -365,7 +366,7 @@ class HipKernels:
 
     def triple_workspace_sizes(self, net, images, N, S):
         out = TripleWorkspaceSizes()
-        check(self.lib.rbnn_triple_workspace_query(C.byref(net.descriptor()), C.byref(images), N, S, C.byref(out)),
+        check(self.lib.rbnn_triple_workspace_query(C.byref(net.descriptor(lazy_ok=True)), C.byref(images), N, S, C.byref(out)),
               "rbnn_triple_workspace_query")
         return {k: getattr(out, k) for k in TRIPLE_WS_KEYS}
 
@@ -378,7 +379,8 @@ class HipKernels:
 
     def fc_forward_triple(self, net, images, tws, x_exp, N, sidx, S, out_kind, ws, dev_scales=None):
         w, t = self._ws(ws), self._tws(tws)
-        check(self.lib.rbnn_fc_forward_triple(C.byref(net.descriptor()), C.byref(images), C.byref(t), x_exp, ptr(dev_scales), N,
+        # (lazy_ok: a pending images-only draw left the fp32 W1 / Wm stale, which the triple kernels never read)
+        check(self.lib.rbnn_fc_forward_triple(C.byref(net.descriptor(lazy_ok=True)), C.byref(images), C.byref(t), x_exp, ptr(dev_scales), N,
                                               ptr(sidx), S, out_kind, C.byref(w), stream_of(tws["X_triple"])), "rbnn_fc_forward_triple")
 
     def step_tail_triple(self, mode, P, labels, S, inv_S, N, Cn, tws, Psum=None):
@@ -400,7 +402,7 @@ class HipKernels:
         if dz_ready:
             w.dZ = None
         n = C.c_int32(0)
-        check(self.lib.rbnn_fc_input_grad_triple(C.byref(net.descriptor()), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
+        check(self.lib.rbnn_fc_input_grad_triple(C.byref(net.descriptor(lazy_ok=True)), C.byref(images), ptr(sidx), S, N, chunk, C.byref(w),
                                                  C.byref(t), C.byref(n), stream_of(ws["slabs"])), "rbnn_fc_input_grad_triple")
         return n.value
 
@@ -474,13 +476,17 @@ class HipKernels:
     def svi_draw_supported(self, net, with_triple_images):
         return bool(self.lib.rbnn_svi_draw_supported(C.byref(net.descriptor()), int(bool(with_triple_images))))
 
-    def svi_draw(self, net, images, guide, S, key, draw_id, sample_keys=None):
+    def svi_draw(self, net, images, guide, S, key, draw_id, sample_keys=None, images_only=False):
         """One launch: samples [0, S) of the stacked posterior `net` and all its weight images redrawn IN PLACE from the guide
-        (robustbnns_amd.posterior.SviGuide).  images: the posterior's TripleImages or None.  sample_keys: int64 device tensor [S]."""
-        require_gpu(net.W1, "W1")
-        check(self.lib.rbnn_svi_draw(C.byref(net.descriptor()), None if images is None else C.byref(images), C.byref(guide.descriptor()), S,
-                                     ptr(sample_keys), C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF),
-                                     stream_of(net.W1)), "rbnn_svi_draw")
+        (robustbnns_amd.posterior.SviGuide).  images: the posterior's TripleImages or None.  sample_keys: int64 device tensor [S].
+        images_only (rbnn_svi_draw_images): W1 / Wm into the triple images only — their fp32 stack and pack_rows4 copies are skipped."""
+        w1 = net.__dict__.get("_t_W1", None) if hasattr(net, "__dict__") else None
+        w1 = net.W1 if w1 is None else w1
+        require_gpu(w1, "W1")
+        fn = self.lib.rbnn_svi_draw_images if images_only else self.lib.rbnn_svi_draw
+        check(fn(C.byref(net.descriptor(lazy_ok=True)), None if images is None else C.byref(images), C.byref(guide.descriptor()), S,
+                 ptr(sample_keys), C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF),
+                 stream_of(w1)), "rbnn_svi_draw_images" if images_only else "rbnn_svi_draw")
 
     # -- low-dimensional fc nets: the whole hot path in one launch (rbnn_lowdim.hip) -------------------------
     LOWDIM_FORWARD, LOWDIM_GRADIENT, LOWDIM_ATTACK = 0, 1, 2
@@ -498,7 +504,7 @@ class HipKernels:
                    project, iters, P, out, linf=None, l2=None):
         require_gpu(X, "X")
         lazy = getattr(net, "_lazy", None)
-        if lazy is not None and S <= lazy[2] and self.lowdim_fused_draw_supported(net, X.shape[0], S):
+        if lazy is not None and getattr(net, "_triple", None) is None and S <= lazy[2] and self.lowdim_fused_draw_supported(net, X.shape[0], S):
             # a pending (lazy) SVI draw: the weights are generated inside this launch — no rbnn_svi_draw launch, the stack stays as it was
             key, draw_id, _, sample_keys = lazy
             check(self.lib.rbnn_lowdim_run_svi(C.byref(net.descriptor(lazy_ok=True)), C.byref(net._guide.descriptor()), ptr(sample_keys),

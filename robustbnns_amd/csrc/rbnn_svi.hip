@@ -37,6 +37,7 @@ struct DrawArgs {
     unsigned long long key;
     uint32_t draw_id;
     int S, has_tp, tiles_w1_d, tiles_wm_d, tiles_per_sample;
+    int images_only;               // rbnn_svi_draw_images: W1 / Wm go into the triple images only (their fp32 stack + pack_rows4 copies are skipped)
     float w1_scale, wm_scale, w2_scale;
 };
 
@@ -57,10 +58,12 @@ __device__ void draw_matrix_tile(const DrawArgs& a, const Rng& rng, int tensor, 
     }
     __syncthreads();
     // (1) fp32 stack [S][H][ldw] and (2) its pack_rows4 image [S][H/4][ldw][4]
+    if (W) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = t + 256 * i, hl = q >> 4, dq = q & 15, d = d0 + 4 * dq;
-        if (d < ldw) *(f32x4*)(W + ((long long)s * H + 32 * hb + hl) * ldw + d) = *(const f32x4*)&tile[hl][4 * dq];
+        for (int i = 0; i < 2; ++i) {
+            const int q = t + 256 * i, hl = q >> 4, dq = q & 15, d = d0 + 4 * dq;
+            if (d < ldw) *(f32x4*)(W + ((long long)s * H + 32 * hb + hl) * ldw + d) = *(const f32x4*)&tile[hl][4 * dq];
+        }
     }
     if (pack4) {
 #pragma unroll
@@ -179,13 +182,13 @@ __global__ void __launch_bounds__(256) svi_draw_kernel(const DrawArgs a) {
     float (*tile)[68] = (float (*)[68])dyn_lds;
     if (j < n_w1) {
         draw_matrix_tile(a, rng, T_W1, s, j / a.tiles_w1_d, j % a.tiles_w1_d, a.g.W1_loc, a.g.W1_scale, a.g.hidden, a.net.in_features,
-                         const_cast<float*>(a.net.W1), a.net.in_stride, const_cast<float*>(a.net.W1_pack4),
+                         a.images_only ? nullptr : const_cast<float*>(a.net.W1), a.net.in_stride, a.images_only ? nullptr : const_cast<float*>(a.net.W1_pack4),
                          a.has_tp ? (uint4*)const_cast<void*>(a.tp.W1_rows) : nullptr, a.tp.ld_rows,
                          a.has_tp ? (uint4*)const_cast<void*>(a.tp.W1_cols) : nullptr, a.tp.ld_cols, a.w1_scale, tile);
     } else if (j < n_w1 + n_wm) {
         const int jj = j - n_w1;
         draw_matrix_tile(a, rng, T_WM, s, jj / a.tiles_wm_d, jj % a.tiles_wm_d, a.g.Wm_loc, a.g.Wm_scale, a.g.hidden, a.g.hidden,
-                         const_cast<float*>(a.net.Wm), H, const_cast<float*>(a.net.Wm_pack4),
+                         a.images_only ? nullptr : const_cast<float*>(a.net.Wm), H, a.images_only ? nullptr : const_cast<float*>(a.net.Wm_pack4),
                          a.has_tp ? (uint4*)const_cast<void*>(a.tp.Wm_rows) : nullptr, H,
                          a.has_tp ? (uint4*)const_cast<void*>(a.tp.Wm_cols) : nullptr, H, a.wm_scale, tile);
     } else {
@@ -267,9 +270,10 @@ int rbnn_svi_draw_supported(const rbnn_posterior* net, int32_t with_triple_image
     return 1;
 }
 
-int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
-                  const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, void* stream) {
+static int svi_draw_impl(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
+                         const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, int images_only, void* stream) {
     if (!net || !g || !net->W1 || !net->b1 || !net->W2 || !net->b2) return RBNN_ERR_NULL;
+    if (images_only && !tp) return RBNN_ERR_NULL;
     if (!g->W1_loc || !g->W1_scale || !g->b1_loc || !g->b1_scale || !g->W2_loc || !g->W2_scale || !g->b2_loc || !g->b2_scale) return RBNN_ERR_NULL;
     if (net->arch != RBNN_ARCH_FC && net->arch != RBNN_ARCH_FC2) return RBNN_ERR_UNSUPPORTED;
     const bool fc2 = net->arch == RBNN_ARCH_FC2;
@@ -279,6 +283,7 @@ int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const
     if (net->in_features < 1 || net->in_stride < net->in_features || (net->in_stride & 15)) return RBNN_ERR_SHAPE;
     DrawArgs a = {};
     a.net = *net; a.g = *g; a.sample_keys = (const unsigned long long*)sample_keys; a.key = key; a.draw_id = draw_id; a.S = n_samples;
+    a.images_only = images_only;
     int extent = net->in_stride;
     if (tp) {
         if (!tp->W1_rows || !tp->W1_cols || !tp->W2_gen || (fc2 && (!tp->Wm_rows || !tp->Wm_cols))) return RBNN_ERR_NULL;
@@ -297,6 +302,16 @@ int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const
     if (lds > 64 * 1024 && !ensure_dynamic_lds((const void*)svi_draw_kernel, (int)SVI_DRAW_LDS_MAX, attr)) return RBNN_ERR_LAUNCH;
     hipLaunchKernelGGL(svi_draw_kernel, dim3((unsigned)((long long)n_samples * a.tiles_per_sample)), dim3(256), lds, (hipStream_t)stream, a);
     return launch_status();
+}
+
+int rbnn_svi_draw(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
+                  const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, void* stream) {
+    return svi_draw_impl(net, tp, g, n_samples, sample_keys, key, draw_id, 0, stream);
+}
+
+int rbnn_svi_draw_images(const rbnn_posterior* net, const rbnn_triple_images* tp, const rbnn_svi_guide* g, int32_t n_samples,
+                         const uint64_t* sample_keys, uint64_t key, uint32_t draw_id, void* stream) {
+    return svi_draw_impl(net, tp, g, n_samples, sample_keys, key, draw_id, 1, stream);
 }
 
 }  // extern "C"

@@ -284,7 +284,7 @@ class BNN(nn.Module):
         self._draws += 1
         # the key alone identifies the draw: reproducible under set_rng_seed.  lowdim engines (half-moons): the draw is left pending and generated
         # inside the next rbnn_lowdim_run launch (posterior.StackedPosterior.lazy_capable); anything else that reads the stack materialises it
-        if getattr(slot[1], "precision", None) == "lowdim" and hasattr(slot[0], "lazy_capable"):
+        if getattr(slot[1], "precision", None) in ("lowdim", "triple") and hasattr(slot[0], "lazy_capable"):
             slot[0].redraw(self._fresh_key(), 0, lazy=True)
         else:
             slot[0].redraw(self._fresh_key(), 0)

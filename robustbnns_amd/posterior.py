@@ -272,11 +272,14 @@ class StackedPosterior:
         return post
 
     def lazy_capable(self):
-        """A draw can be left PENDING — recorded as (key, draw id) and generated inside the next rbnn_lowdim_run launch instead of by a launch of
-        its own — for fc nets of the lowdim kind with no weight images to keep in step (BASELINE config 1: a redraw + an FGSM pass at the
-        launch floor of two kernels becomes one)."""
-        return (self._guide is not None and self.arch == "fc" and self._triple is None and self._split is None and self._back is None
-                and self.device.type == "cuda" and self.D <= 16 and self.C <= 10)
+        """A draw can be left (partly) PENDING.  Lowdim kind — fc nets with in_features <= 16 and no weight images: nothing is launched, the draw
+        is recorded as (key, draw id) and generated inside the next rbnn_lowdim_run launch (BASELINE config 1: a redraw + an FGSM pass at the launch
+        floor of two kernels becomes one).  Triple kind — the triple images exist: see below.  Either way materialize() completes it."""
+        if self._guide is None or self._split is not None or self._back is not None or self.device.type != "cuda":
+            return False
+        if self._triple is not None:            # the triple kind: the images ARE drawn now (rbnn_svi_draw_images), only the fp32 W1 / Wm stack and
+            return True                         # its pack_rows4 copy — 40 % of a full draw's writes, read by no triple kernel — are left pending
+        return self.arch == "fc" and self.D <= 16 and self.C <= 10
 
     def materialize(self):
         """Run a pending (lazy) draw for real: rbnn_svi_draw with the recorded (key, draw id) — the same weights the fused launches generated.
@@ -297,6 +300,8 @@ class StackedPosterior:
         S = self.S if n_samples is None else int(n_samples)
         self.__dict__["_lazy"] = None           # a newer draw supersedes a pending one
         if lazy and self.lazy_capable():
+            if self._triple is not None:
+                _hip.HipKernels().svi_draw(self, self._triple[0], self._guide, S, int(key), int(draw_id), sample_keys, images_only=True)
             self.__dict__["_lazy"] = (int(key), int(draw_id), S, sample_keys)
             return self
         tri = self._triple[0] if self._triple is not None else None

@@ -160,3 +160,46 @@ def test_lazy_svi_draw_inside_the_lowdim_launch_equals_draw_then_run(shape, H, C
     for k in a:
         assert torch.equal(a[k], b[k]), k
     assert float(a["W1"].abs().max()) > 0 and rel_err(a["exact"], a["seeded"]) < TOL
+
+
+@pytest.mark.parametrize("arch", ["fc", "fc2"])
+def test_images_only_svi_draw_for_triple_engines(arch):
+    """redraw(lazy=True) on a posterior with triple images = rbnn_svi_draw_images: the images, biases and W2 of a full draw — bit for bit —
+    while the fp32 W1 / Wm stack and its pack_rows4 copy (read by no triple kernel) stay untouched until somebody reads them; forward, gradients
+    and a PGD attack equal the full draw's; an fp32-MFMA engine on the same posterior (which DOES read the stack) sees the materialised weights."""
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    from robustbnns_amd.posterior import SviGuide
+    D, H, C, S, N = 784, 128, 10, 5, 200
+    g = torch.Generator().manual_seed(9)
+    names = {"model.1.weight": (H, D), "model.1.bias": (H,)}
+    names.update({"model.3.weight": (H, H), "model.3.bias": (H,), "model.5.weight": (C, H), "model.5.bias": (C,)} if arch == "fc2"
+                 else {"model.3.weight": (C, H), "model.3.bias": (C,)})
+    loc = {k: torch.randn(*v, generator=g) * 0.05 for k, v in names.items()}
+    scl = {k: torch.full(v, -3.0) for k, v in names.items()}
+    x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=1)
+
+    def run(lazy):
+        post = StackedPosterior.for_guide(SviGuide(loc, scl, arch, DEV), "leaky", (1, 28, 28), C, S)
+        eng = AttackEngine(post)
+        assert eng.precision == "triple"
+        post.triple_images()
+        assert post.lazy_capable()
+        post.redraw(0x1234, 2, lazy=lazy)
+        out = {"img": [t.clone().cpu() for t in post._triple[1]], "b1": post.__dict__["_t_b1"].clone().cpu(), "W2": post.__dict__["_t_W2"].clone().cpu()}
+        if lazy:
+            assert float(post.__dict__["_t_W1"].abs().max()) == 0.0 and post.__dict__["_lazy"] is not None
+        out["probs"] = eng.forward(x, S).cpu()
+        out["lg"] = eng.loss_gradients(x, y, S).cpu()
+        out["pgd"] = eng.pgd(x, y, S, 0.1, iters=3).cpu()
+        if lazy:
+            assert float(post.__dict__["_t_W1"].abs().max()) == 0.0          # three calls later the stack is still untouched
+        out["exact"] = AttackEngine(post, precision="exact").forward(x, S).cpu()     # reads the stack: materialises
+        assert post.__dict__["_lazy"] is None
+        out["W1"], out["W1p"] = post.W1.clone().cpu(), post.W1p.clone().cpu()
+        return out
+
+    a, b = run(False), run(True)
+    for k in ("b1", "W2", "probs", "lg", "pgd", "exact", "W1", "W1p"):
+        assert torch.equal(a[k], b[k]), k
+    assert all(torch.equal(p, q) for p, q in zip(a["img"], b["img"]))
+    assert float(a["W1"].abs().max()) > 0 and rel_err(a["exact"], a["probs"]) < TOL
