@@ -547,6 +547,10 @@ __device__ __forceinline__ void conv_split3(float v, _Float16& p0, _Float16& p1,
     p2 = (_Float16)r;
 }
 
+#ifndef RBNN_X3FWD_BPREFETCH
+#define RBNN_X3FWD_BPREFETCH 0                                           // 1: the B fragments of tap t + 1 read under tap t's MFMAs (round 4) — measured SLOWER: 1x28x28 8.42 -> 8.58 ms per forward call,
+                                                                          // 3x32x32 15.1 -> 16.5 (spills beside 56 accumulators): with two waves per SIMD the other wave fills a tap's post-barrier round trip
+#endif
 #ifndef RBNN_CONVX3_OLD_IMG
 #define RBNN_CONVX3_OLD_IMG 0                                            // 1: the round-2 image layout (pitch = P1W, chunk swizzle by (pos >> 2) & 1 only)
 #endif
@@ -668,20 +672,37 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
         };
         stage(0, 0);
         __syncthreads();                                                 // also orders the image fill (first chunk) / the previous chunk's pooling tiles
-        for (int tap = 0; tap < 25; ++tap) {
-            const int buf = tap & 1;
-            if (tap + 1 < 25) stage(tap + 1, buf ^ 1);
-            const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 3072 + foff;
+        // RBNN_X3FWD_BPREFETCH (off: measured slower, see its definition): B fragments (gathered from the point's image, which no barrier guards
+        // after the first) read ONE TAP AHEAD into a second register set, under the current tap's MFMAs (the two sets alternate: no copies)
+        // (3x32x32: seven position tiles x three planes x two sets do not fit beside the accumulators — only the plane of the FIRST product group,
+        // b2, is read ahead there; b0 / b1 follow behind the barrier and land under that group's MFMAs)
+        constexpr bool PF_ALL = RBNN_X3FWD_BPREFETCH && NPT <= 4;
+        auto load_b = [&](int tap, f16x8 (&b0)[NPT], f16x8 (&b1)[NPT], f16x8 (&b2)[NPT], bool lo, bool hi) {
             const int ky = tap / 5, toff = ky * IPITCH + (tap % 5);
-            f16x8 b0[NPT], b1[NPT], b2[NPT];
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
                 const int p = pbase[pt] + toff;
                 const char* const src = img + p * 64 + ((lg ^ x3_img_swz<G>(p, ybase[pt] + ky)) * 16);
-                b0[pt] = *(const f16x8*)src;
-                b1[pt] = *(const f16x8*)(src + L::IMGP);
-                b2[pt] = *(const f16x8*)(src + 2 * L::IMGP);
+                if (lo) { b0[pt] = *(const f16x8*)src; b1[pt] = *(const f16x8*)(src + L::IMGP); }
+                if (hi) b2[pt] = *(const f16x8*)(src + 2 * L::IMGP);
             }
+        };
+        f16x8 bA0[NPT], bA1[NPT], bA2[NPT], bB0[PF_ALL ? NPT : 1], bB1[PF_ALL ? NPT : 1], bB2[NPT];
+        auto tap_body = [&](int tap, f16x8 (&b0)[NPT], f16x8 (&b1)[NPT], f16x8 (&b2)[NPT], auto& n0, auto& n1, f16x8 (&n2)[NPT]) {
+            const int buf = tap & 1;
+            if (tap + 1 < 25) {
+                stage(tap + 1, buf ^ 1);
+#if RBNN_X3FWD_BPREFETCH
+                if constexpr (PF_ALL) load_b(tap + 1, n0, n1, n2, true, true);
+                else load_b(tap + 1, b0, b1, n2, false, true);            // (b0 / b1 unused by this call)
+#endif
+            }
+#if RBNN_X3FWD_BPREFETCH
+            if constexpr (!PF_ALL) load_b(tap, b0, b1, b2, true, false);
+#else
+            load_b(tap, b0, b1, b2, true, true);
+#endif
+            const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 3072 + foff;
 #pragma unroll
             for (int ht = 0; ht < HTW; ++ht) {
                 const f16x8 a0 = *(const f16x8*)(Wt + ht * 3072), a1 = *(const f16x8*)(Wt + ht * 3072 + 1024),
@@ -700,6 +721,18 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
                 for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b0[pt], acc[ht][pt]);
             }
             ring_wait_barrier<0>();                                      // tap+1's weights landed; everyone is done with this tile
+        };
+#if RBNN_X3FWD_BPREFETCH
+        load_b(0, bA0, bA1, bA2, PF_ALL, true);
+#endif
+        for (int tap = 0; tap < 25; tap += 2) {
+            if constexpr (PF_ALL) {
+                tap_body(tap, bA0, bA1, bA2, bB0, bB1, bB2);
+                if (tap + 1 < 25) tap_body(tap + 1, bB0, bB1, bB2, bA0, bA1, bA2);
+            } else {                                                     // one b0 / b1 set (read behind the barrier each tap), two b2 sets
+                tap_body(tap, bA0, bA1, bA2, bA0, bA1, bB2);
+                if (tap + 1 < 25) tap_body(tap + 1, bA0, bA1, bB2, bA0, bA1, bA2);
+            }
         }
         // epilogue (as conv2_pool_kernel): scale, bias, 2x2 / stride-1 max-pool of the pre-activations through a per-wave LDS tile
         // (aliases the weight buffers: every wave passed the barrier above), activation, stash.  The tile's channel pitch CPITCH = NPOS + 4
