@@ -573,7 +573,7 @@ def main():
                 # the streaming kernels THIS mode launches per pass (the record may hold other modes' kernels too): every mode steps and — SVI —
                 # draws; the f16 modes build the inputs' image (absmax + scale record + rows image); the sum over samples + loss is the fused
                 # tail kernel in the triple fc mode and two kernels elsewhere
-                want = ["attack_step", "pgd_alpha"] + (["svi_draw"] if svi_kind else [])
+                want = ["attack_step", "pgd_alpha"] + (["svi_draw", "conv_k2_images"] if svi_kind else [])
                 if mode in F16_KERNELS:
                     want += ["absmax_kernel", "scale_finalize_kernel", mode + "_rows_kernel"]
                 want += ["step_tail_x3_kernel"] if (mode == "triple" and w["arch"] != "conv") else ["reduce_samples", "loss_dlogits"]

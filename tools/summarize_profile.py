@@ -32,9 +32,9 @@ MAIN = [("fc_forward_x3_kernel", "fc_forward_triple"), ("fc_grad_x3_kernel", "fc
         ("lowdim_kernel", "lowdim"), ("lowdim2_kernel", "lowdim")]
 # the streaming kernels of a step (same names in every mode; one launch each per pass, the draw once per step): their counters go into the
 # record's "small" table, which bench.py adds to a pass's counter total
-SMALL = ["svi_draw_flat_kernel", "svi_draw_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "step_tail_x3_kernel",
+SMALL = ["svi_draw_flat_kernel", "svi_draw_kernel", "conv_k2_images_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "step_tail_x3_kernel",
          "reduce_samples", "loss_dlogits", "sum_slabs_norms", "sum_slabs", "attack_step", "pgd_alpha"]
-SHORT = ["conv_bwd_dense_x3_kernel"] + [k for k, _ in MAIN] + ["svi_draw_flat_kernel", "svi_draw_kernel", "lowdim_kernel", "step_tail_x3_kernel", "attack_step_x3_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
+SHORT = ["conv_bwd_dense_x3_kernel"] + [k for k, _ in MAIN] + ["svi_draw_flat_kernel", "svi_draw_kernel", "conv_k2_images_kernel", "lowdim_kernel", "step_tail_x3_kernel", "attack_step_x3_kernel", "triple_rows_kernel", "split_rows_kernel", "absmax_kernel", "scale_finalize_kernel", "reduce_samples", "loss_dlogits", "sum_slabs_norms",
                                 "sum_slabs", "attack_step", "pgd_alpha", "eval_metrics"]
 
 
