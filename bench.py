@@ -479,7 +479,8 @@ def main():
             if w["arch"] == "conv":         # fp32 stack by one launch; model.3.weight's regrouping (4 B) and triple images (6 + 6.24 B) by their builders
                 k2 = int(sp_svi.K2w[0].numel())
                 wr = w["S"] * (4.0 * n_par + k2 * (4.0 + (12.24 if eng.precision == "triple" else 0.0)))
-                kname = "svi_draw_flat_kernel (1 launch: all six tensors, all samples) + 6 image-builder launches for model.3.weight"
+                kname = ("svi_draw_flat_kernel (1 launch: all six tensors, all samples) + conv_k2_images_kernel (1 launch: both triple images of "
+                         "model.3.weight from the fp32 stack)")
             if lazy_draw:
                 kname = ("none of its own: the weights of all samples are generated inside the lowdim launch from the guide (rbnn_lowdim_run_svi; "
                          "same Philox counters as svi_draw_kernel, the stack is materialised only on demand)")

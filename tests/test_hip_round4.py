@@ -203,3 +203,56 @@ def test_images_only_svi_draw_for_triple_engines(arch):
         assert torch.equal(a[k], b[k]), k
     assert all(torch.equal(p, q) for p, q in zip(a["img"], b["img"]))
     assert float(a["W1"].abs().max()) > 0 and rel_err(a["exact"], a["probs"]) < TOL
+
+
+# ------------------------------------------------------------------ wide nets and replaced guide tensors
+def test_svi_draw_covers_wide_nets_and_falls_back_beyond():
+    """rbnn_svi_draw stages W2 [C, H] in dynamic LDS: hidden 2048 x 10 classes (80 KB) needed more than the 64 KB default and raised
+    RBNN_ERR_SHAPE — the limit is now the CU's 160 KB (hidden 4096), rbnn_svi_draw_supported says so, and BNN falls back to
+    rbnn_svi_materialize + a new stack beyond it instead of raising."""
+    import ctypes as C
+    from robustbnns_amd import _hip
+    from robustbnns_amd.model_bnn import BNN, set_rng_seed
+    lib = _hip.load()
+    d = _hip.Posterior()
+    d.arch, d.activation, d.in_features, d.in_stride, d.n_classes, d.n_stored = 0, 1, 784, 784, 10, 2
+    for H, want in ((2048, 1), (4096, 1), (8192, 0)):
+        d.hidden = H
+        assert lib.rbnn_svi_draw_supported(C.byref(d), 0) == want
+    d.hidden = 64
+    assert lib.rbnn_svi_draw_supported(C.byref(d), 0) == 1 and lib.rbnn_svi_draw_supported(C.byref(d), 1) == 0      # triple images: hidden % 128
+    x, _ = O.synthetic_inputs(8, (1, 28, 28), 10, seed=2)
+    for H, in_place in ((2048, True), (8192, False)):
+        g = torch.Generator().manual_seed(H)
+        shapes = {"model.1.weight": (H, 784), "model.1.bias": (H,), "model.3.weight": (10, H), "model.3.bias": (10,)}
+        loc = {k: torch.randn(*v, generator=g) * 0.02 for k, v in shapes.items()}
+        scl = {k: torch.full(v, -4.0) for k, v in shapes.items()}
+        bnn = BNN("mnist", H, "leaky", "fc", "svi", 5, 0.01, None, None, (1, 28, 28), 10)
+        bnn.set_variational_params(loc, scl, DEV)
+        assert bnn._in_place() == in_place
+        set_rng_seed(3)
+        p = bnn.forward(x, n_samples=2).cpu()
+        assert torch.isfinite(p).all() and float((p.sum(-1) - 1).abs().max()) < 1e-5
+        mean = O.bnn_forward(x.double(), {k: v.double().unsqueeze(0) for k, v in loc.items()}, "fc", "leaky", 1)
+        assert float((p - mean.float()).abs().max()) < 0.2                  # two draws around the guide's mean (sigma = 0.018)
+
+
+def test_replacing_a_guide_tensor_invalidates_the_cached_guide():
+    """`net.svi_loc[k] = new_tensor` (version 0 again, another address) without set_variational_params() must drop the guide's
+    bounds, its resident stacks and its seeded draws — they key on (data_ptr, _version) of every variational tensor."""
+    from robustbnns_amd.model_bnn import BNN
+    H = 128
+    g = torch.Generator().manual_seed(1)
+    shapes = {"model.1.weight": (H, 784), "model.1.bias": (H,), "model.3.weight": (10, H), "model.3.bias": (10,)}
+    loc = {k: torch.randn(*v, generator=g) * 0.05 for k, v in shapes.items()}
+    scl = {k: torch.full(v, -3.0) for k, v in shapes.items()}
+    bnn = BNN("mnist", H, "leaky", "fc", "svi", 5, 0.01, None, None, (1, 28, 28), 10)
+    bnn.set_variational_params(loc, scl, DEV)
+    x, _ = O.synthetic_inputs(16, (1, 28, 28), 10, seed=4)
+    p1 = bnn.forward(x, n_samples=3, seeds=[1, 2, 3]).cpu()
+    guide1 = bnn._guide
+    bnn.svi_loc["model.3.weight"] = (bnn.svi_loc["model.3.weight"] * 40.0).contiguous()       # a NEW tensor: 40x larger output weights
+    p2 = bnn.forward(x, n_samples=3, seeds=[1, 2, 3]).cpu()
+    assert bnn._guide is not guide1 and not torch.equal(p1, p2)
+    assert float(bnn._guide.bound["W2"]) > 20 * float(guide1.bound["W2"])                       # the image scale follows the new bound
+    assert torch.isfinite(p2).all()
