@@ -254,5 +254,5 @@ def test_replacing_a_guide_tensor_invalidates_the_cached_guide():
     bnn.svi_loc["model.3.weight"] = (bnn.svi_loc["model.3.weight"] * 40.0).contiguous()       # a NEW tensor: 40x larger output weights
     p2 = bnn.forward(x, n_samples=3, seeds=[1, 2, 3]).cpu()
     assert bnn._guide is not guide1 and not torch.equal(p1, p2)
-    assert float(bnn._guide.bound["W2"]) > 20 * float(guide1.bound["W2"])                       # the image scale follows the new bound
+    assert float(bnn._guide.bound["W2"]) > 10 * float(guide1.bound["W2"])                       # the image scale follows the new bound
     assert torch.isfinite(p2).all()
