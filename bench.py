@@ -655,6 +655,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
             "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job, "samples_per_rank": S_ranks,
+                       # the config's own n_samples and how many ranks it is split over (c5: 500 over 8 — this run holds shards 0 .. n_gpus-1 of that split)
+                       "n_samples_config": (w["S_split"][0] if "S_split" in w and not args.samples and not args.samples_total else S_job),
+                       "n_samples_config_ranks": (w["S_split"][1] if "S_split" in w and not args.samples and not args.samples_total else world),
                        "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none",
                        "posterior": ("svi: variational guide, all S samples redrawn in place (rbnn_svi_draw) every step — PGD: every iteration — inside "
                                      "the timed region" if posterior_kind == "svi" else
