@@ -1903,8 +1903,17 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
 #ifndef RBNN_CONV_BWD_DENSE
 #define RBNN_CONV_BWD_DENSE 1
 #endif
-#ifndef RBNN_DENSE_STAGGER
-#define RBNN_DENSE_STAGGER 0
+// RBNN_DENSE_STAMPS (diagnostic build, fenced like the ablation switches; the results stay right): s_memtime stamps of waves 0 and 3 of every
+// block, summed per segment into rbnn_dense_stamp_acc and read back by rbnn_debug_dense_stamps (tools/dense_stamps.py).  1: per-pass prologue /
+// K loop / col2im; 2: also the time inside the K loop's barrier (each stamp drains lgkmcnt: level 2 perturbs the loop it measures).
+#ifdef RBNN_DENSE_STAMPS
+__device__ unsigned long long rbnn_dense_stamp_acc[64];
+#define DSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0 && (wave == 0 || wave == 3)) atomicAdd(&rbnn_dense_stamp_acc[(wave ? 32 : 0) + (slot)], t_ - tprev); tprev = t_; } while (0)
+#define DSTAMP_ADD(slot, v) do { if (lane == 0 && (wave == 0 || wave == 3)) atomicAdd(&rbnn_dense_stamp_acc[(wave ? 32 : 0) + (slot)], (unsigned long long)(v)); } while (0)
+#else
+#define DSTAMP(slot) do { } while (0)
+#define DSTAMP_ADD(slot, v) do { } while (0)
 #endif
 template <class G> struct ConvBwdDenseLds {
     // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
@@ -1929,6 +1938,7 @@ template <int ACT, class G>
 __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2d, int k2_exp, float fw_l1) {
     using L = ConvBwdDenseLds<G>;
     constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, NFL = L::NFL, NPASS = L::NPASS;
+    constexpr int SMIN = NFL / 512 + (NFL / 4) / 512;                      // staging pieces every wave issues for a whole K step (stage_issue: its rounds of 512 lanes that lie inside the step entirely)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     char* const lds = (char*)lds_f;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -1945,6 +1955,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     const long long sn = (long long)s * a.N + n;
     const int F = a.Hc * NP2_, KS = (a.Hc + 31) / 32;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+#ifdef RBNN_DENSE_STAMPS
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+    unsigned long long barw = 0;
+#endif
 
     // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1 (as conv_bwd_x3_kernel)
     float dzmax = fabsf(a.dZ[sn * RBNN_CPAD + li]);
@@ -1985,7 +2000,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     const unsigned a_lane = (unsigned)(prow * 64 + (((lane & 3) ^ swz(prow)) * 16));    // per-lane part of a piece's source address
     const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
     char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
-    const int G_ = KS * ntap;                                              // tiles this wave consumes per pass
     const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // fragment of row li (position / input channel), K chunk lg
     constexpr int NPP = P1W_ * P1W_;
     static_assert(2 * NPP <= 512, "one thread per output position and pair of channel quads");
@@ -2065,28 +2079,28 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     for (int t = 0; t < 7; ++t)
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int iks = 0, itap = 0, ig = 0;                                         // (K step, tap, running index) of the next tile to issue
-    auto a_issue = [&]() {
-#ifdef RBNN_DENSE_ABL_NOA
-        if (ig >= 4) { ++ig; return; }                                     // ablation (timing only): no weight-tile traffic after the prologue
+    // Weight tile (K step iks_, tap tapi of this wave) -> ring slot.  ALWAYS issued — past the pass's last tile the callers name a tile of the
+    // last K step again (it lands in a consumed slot and is never read): with no "is there a tile left" test the K loop below has no branch
+    // between its MFMA groups and every counted wait is one immediate.
+    auto tile_issue = [&](int iks_, int tapi, int slot) {
+        // source = a block-uniform 64-bit base (the sample's image) + ONE 32-bit per-lane offset (tile offset + lane part; a sample's image is
+        // KS * 25 * 6 KiB): hipcc then uses the SGPR-base addressing form instead of a 64-bit vector add per piece
+        const unsigned off = (unsigned)((iks_ * 25 + tap0 + tapi) * (32 * 192)) + a_lane;
+        char* const dst = ring + slot * L::SLOT;
+        const auto gsrc = (const __attribute__((address_space(1))) void*)(Awave + off);
+        const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
+#ifdef RBNN_DENSE_ABL_PARTA
+        if (lane < RBNN_DENSE_ABL_PARTA)                                   // ablation (timing only): a fraction of every weight tile is fetched (same instruction and wait counts)
 #endif
-        if (ig < G_) {
-            // source = a block-uniform 64-bit base (the sample's image) + ONE 32-bit per-lane offset (tile offset + lane part; a sample's image is
-            // KS * 25 * 6 KiB): hipcc then uses the SGPR-base addressing form instead of a 64-bit vector add per piece
-            const unsigned off = (unsigned)((iks * 25 + tap0 + itap) * (32 * 192)) + a_lane;
-            char* const dst = ring + (ig & (L::RING - 1)) * L::SLOT;
-            const auto gsrc = (const __attribute__((address_space(1))) void*)(Awave + off);
-            const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
+        {
             __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
             __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
-            ++ig;
-            if (++itap == ntap) { itap = 0; ++iks; }
         }
     };
 
     stage_issue(0, 0);
-    a_issue(); a_issue(); a_issue();
+    tile_issue(0, 0, 0); tile_issue(0, 1, 1); tile_issue(0, 2, 2);         // (a wave has >= 6 taps)
     __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
     __syncthreads();
     {
@@ -2097,15 +2111,21 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     }
     if (KS > 1) stage_issue(1, 1);
     f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
-    int g = 0;                                                             // running tile index of this wave
 #ifdef RBNN_DENSE_ABL_NOB
     f16x8 b0[NPT], b1[NPT], b2[NPT];
 #endif
-    // R0 = the tap group at which a wave starts routing the NEXT K step's image (one channel per tap group, four groups).  The two waves of a
-    // SIMD (channel tiles 0 and 1 of the same tap quarter) run the same instruction stream between the same barriers; RBNN_DENSE_STAGGER
-    // shifts the second one's routing by that many tap groups so that one wave's vector work falls under the other's bare MFMA groups.
-    auto kloop = [&](auto R0C) {
-    constexpr int R0 = decltype(R0C)::value;
+    // The K loop, one instantiation per tap count NT of the wave (6 or 7: wave-uniform, chosen once) — so that which tile is issued at tap t
+    // (tile g + 3 = tap (t + 3) % NT of step ks + (t + 3) / NT), its ring slot and every wait count are compile-time facts and a K step is
+    // straight-line code.  (Round 3 kept running (K step, tap, index) counters with an "any tile left" test, a 7th-tap test and a choice of wait
+    // per tap: four scalar branches and ~20 scalar instructions between two taps' MFMA groups; adding three more branches per tap — one counted
+    // wait per weight plane — cost 6.6 % of the kernel, which is what pointed here.)
+    // The staging pieces of K step ks + 2 (dQ2 / stash rows: first touch, they come from HBM) are issued BEHIND tap 0's tile, and the first three
+    // taps' waits leave them outstanding: vmcnt counts in issue order, so a wait for a tile issued after them is a wait for them (round 3 issued
+    // them first and waited vmcnt(6) at tap 0: an HBM round trip per K step and wave).  They too are always issued (the last two steps re-stage
+    // the last step's rows into the free buffer) so that the count behind a tile is the same in every step; SMIN = pieces EVERY wave issues
+    // for a whole step (assuming fewer than were issued only waits longer) — 0 when the last step is half a step (Hc % 32 == 16).
+    auto kloop = [&](auto NTC, auto WHOLEC) {
+    constexpr int NT = decltype(NTC)::value, SB = decltype(WHOLEC)::value ? SMIN : 0;
     for (int ks = 0; ks < KS; ++ks) {
         // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
         // vector-memory operations — the ring tiles issued since — may still be in flight
@@ -2115,10 +2135,25 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         if (ks == 0)
 #endif
         {
+#if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
+            const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+#endif
             if (ks == 0) ring_wait_barrier<0>();                           // (nothing has been issued behind the prologue's staging piece yet)
             else ring_wait_barrier<9>();                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
+#if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
+            barw += __builtin_amdgcn_s_memtime() - tb_;
+#endif
         }
-        if (ks + 2 < KS) stage_issue(ks + 2, ks & 1);
+        const int ksn = min(ks + 1, KS - 1), gk = ks * NT;                 // gk = running index of the step's first tile (slot = index & 3)
+        auto issue = [&](auto TC) {                                        // tap t's tile: tile g + 3 -> the slot of tile g - 1 (consumed)
+            constexpr int t = decltype(TC)::value;
+#ifdef RBNN_DENSE_ABL_NOA
+            if (false)                                                     // ablation (timing only): no weight-tile traffic after the prologue
+#endif
+            tile_issue((t + 3) / NT ? ksn : ks, (t + 3) % NT, (gk + t + 3) & (L::RING - 1));
+        };
+        issue(std::integral_constant<int, 0>{});                           // tap 0's tile, then the staging pieces — both before the B fragments are
+        stage_issue(min(ks + 2, KS - 1), ks & 1);                          // live: the pieces' per-lane addresses need registers of their own
         const char* const I = lds + (ks & 1) * L::IMG + foff;
 #ifdef RBNN_DENSE_ABL_NOB
         if (ks == 0)                                                       // ablation (timing only): the B fragments of the first K step serve all
@@ -2132,58 +2167,58 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             b2[pt] = *(const f16x8*)(I + 2 * L::PLANE + pt * 1024);
         }
         Q p0, p1, p2;
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            if (t < 6 || ntap == 7) {                                      // taps 0..5 unconditionally; the 7th is wave-uniform
-                a_issue();                                                 // tile g + 3 -> slot (g + 3) & 3 = the slot of tile g - 1: consumed
-                // tile g + 1 has landed once all but the 6 youngest operations (tiles g + 2, g + 3; at a step's first tap the staging
-                // pieces instead of tile g + 2, which is then older and complete as well) are done
-                asm volatile("" ::: "memory");
+        static_for<0, NT>([&](auto TC) {
+            constexpr int t = decltype(TC)::value;
+            if constexpr (t > 0) issue(TC);
+            // tile g + 1 has landed once all but the 6 youngest operations (tiles g + 2, g + 3) are done — plus, in a step's first three
+            // taps, the staging pieces issued behind tile g + 3 of tap 0
+            asm volatile("" ::: "memory");
 #ifndef RBNN_DENSE_ABL_NOA
-                if (g + 3 < G_) __builtin_amdgcn_s_waitcnt(VMCNT(6));
-                else __builtin_amdgcn_s_waitcnt(VMCNT(0));                 // the last three tiles: nothing younger is issued behind them
+            __builtin_amdgcn_s_waitcnt(VMCNT(6 + (t < 3 ? SB : 0)));
 #endif
-                asm volatile("" ::: "memory");
-                const char* const nx = ring + ((g + 1) & (L::RING - 1)) * L::SLOT + foff;
-                // The six product groups, ordered by the piece of A they read — a2 | a1 a1 | a0 a0 a0 — so that each piece of the NEXT tile
-                // is loaded IN PLACE right behind the last MFMA that reads the current one (an MFMA reads its operands when it issues):
-                // no copies, and every reload has >= 12 MFMAs before its first use.  (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and
-                // a0*b1 the 2^-11 ones: apart from a0*b2, still small terms first.)
+            asm volatile("" ::: "memory");
+            const char* const nx = ring + ((gk + t + 1) & (L::RING - 1)) * L::SLOT + foff;
+            // The six product groups, ordered by the piece of A they read — a2 | a1 a1 | a0 a0 a0 — so that each piece of the NEXT tile
+            // is loaded IN PLACE right behind the last MFMA that reads the current one (an MFMA reads its operands when it issues):
+            // no copies, and every reload has >= 12 MFMAs before its first use.  (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and
+            // a0*b1 the 2^-11 ones: apart from a0*b2, still small terms first.)
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a2, b0[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a2, b0[pt], acc[t][pt]);
 #ifndef RBNN_DENSE_ABL_NOAREAD
-                a2 = *(const f16x8*)(nx + 2048);
+            a2 = *(const f16x8*)(nx + 2048);
 #endif
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b1[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b1[pt], acc[t][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b0[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b0[pt], acc[t][pt]);
 #ifndef RBNN_DENSE_ABL_NOAREAD
-                a1 = *(const f16x8*)(nx + 1024);
+            a1 = *(const f16x8*)(nx + 1024);
 #endif
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b2[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b2[pt], acc[t][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b1[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b1[pt], acc[t][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b0[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b0[pt], acc[t][pt]);
 #ifndef RBNN_DENSE_ABL_NOAREAD
-                a0 = *(const f16x8*)nx;
+            a0 = *(const f16x8*)nx;
 #endif
-                ++g;
-            }
 #ifndef RBNN_DENSE_ABL_NOROUTE
-            if (t >= R0 && t < R0 + 4) route_one(ks + 1, (ks + 1) & 1, t - R0, p0, p1, p2);     // the next K step's image, one channel per tap group
-            if (t == R0 + 3) route_store((ks + 1) & 1, p0, p1, p2);
+            if constexpr (t < 4) route_one(ks + 1, (ks + 1) & 1, t, p0, p1, p2);       // the next K step's image, one channel per tap group
+            if constexpr (t == 3) route_store((ks + 1) & 1, p0, p1, p2);
 #endif
-        }
+            __builtin_amdgcn_sched_barrier(0);                             // a tap is one scheduling region (the whole step as one region: routing reads hoisted across taps, 256 registers and scratch)
+        });
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): the tiles / staging pieces issued past the end have landed (the col2im tile aliases their slots)
     };
-#if RBNN_DENSE_STAGGER
-    if (ct) kloop(std::integral_constant<int, RBNN_DENSE_STAGGER>{});
-    else
-#endif
-    kloop(std::integral_constant<int, 0>{});
+    DSTAMP(8 * pass + 0);                                                  // prologue (pass 0: from the block's start; later passes: from the end of the previous col2im)
+    {
+        const bool whole = (a.Hc & 31) == 0;                               // block-uniform
+        if (ntap == 7) { if (whole) kloop(std::integral_constant<int, 7>{}, std::true_type{}); else kloop(std::integral_constant<int, 7>{}, std::false_type{}); }
+        else           { if (whole) kloop(std::integral_constant<int, 6>{}, std::true_type{}); else kloop(std::integral_constant<int, 6>{}, std::false_type{}); }
+    }
+    DSTAMP(8 * pass + 1);                                                  // K loop
     // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
     // registers are four consecutive channels (one ds_write_b128 per tile; the four channel quads of a position are XOR-swizzled by
     // (pos >> 1) & 3, which spreads eight consecutive positions over all 32 banks), and a gathering thread = one output position (Y, X) x two
@@ -2262,7 +2297,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             }
         }
     });
+    DSTAMP(8 * pass + 2);                                                  // col2im
     });
+#ifdef RBNN_DENSE_STAMPS
+    DSTAMP_ADD(24, __builtin_amdgcn_s_memtime() - tstart);
+    DSTAMP_ADD(25, 1);
+    DSTAMP_ADD(26, barw);
+#endif
 }
 
 // =====================================================================================================
@@ -2373,6 +2414,19 @@ extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const 
         });
     });
 }
+
+#ifdef RBNN_DENSE_STAMPS
+// diagnostic builds only: copy (and optionally clear) the stamp sums; out = 64 x u64
+extern "C" __attribute__((visibility("default"))) int rbnn_debug_dense_stamps(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return RBNN_ERR_LAUNCH;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rbnn_dense_stamp_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return RBNN_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[64] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rbnn_dense_stamp_acc), z, sizeof z) != hipSuccess) return RBNN_ERR_LAUNCH;
+    }
+    return RBNN_OK;
+}
+#endif
 
 extern "C" int rbnn_conv_input_grad_triple(const rbnn_conv_posterior* net, const void* K2_bwd, int32_t k2_exp, float fw_l1,
                                            const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
