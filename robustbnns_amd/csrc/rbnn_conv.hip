@@ -1915,6 +1915,9 @@ __device__ unsigned long long rbnn_dense_stamp_acc[64];
 #define DSTAMP(slot) do { } while (0)
 #define DSTAMP_ADD(slot, v) do { } while (0)
 #endif
+#ifndef RBNN_DENSE_COL2IM_RMW
+#define RBNN_DENSE_COL2IM_RMW 1
+#endif
 template <class G> struct ConvBwdDenseLds {
     // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
     // hold (112 registers).  1x28x28: 64 positions, one pass.  3x32x32: 100 positions = pass 0 (positions 0..63) + pass 1 (64..99, three
@@ -1928,7 +1931,12 @@ template <class G> struct ConvBwdDenseLds {
     static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
     static constexpr int AOFF = 2 * IMG + 2 * STG;                        // the eight waves' rings follow the image / staging buffers
     static constexpr int LOOP = AOFF + 8 * RING * SLOT;
+#if RBNN_DENSE_COL2IM_RMW
+    static constexpr int EIMG = G::P1W * G::P1W * 64;                     // col2im: one wave's partial gradient image [P1W x P1W output positions][16 ci] floats
+    static constexpr int EPI = 8 * EIMG;
+#else
     static constexpr int EPI = 25 * NPOSP * 16 * 4;                       // T of one channel tile and pass: [25 taps][pos][16 ci] floats
+#endif
     static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
     static_assert(BYTES <= 160 * 1024, "LDS");
     static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
@@ -2238,6 +2246,73 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         return;
     }
 #endif
+#if RBNN_DENSE_COL2IM_RMW
+    // (round 4, second half) col2im through WAVE-PRIVATE partial images instead of the T tile above: every wave adds the T tiles of its own
+    // taps into its own [P1W x P1W][16 ci] fp32 image in LDS (read - add - write of one ds_*_b128 per accumulator tile; within one tap the
+    // positions of a tile land on distinct outputs, taps follow each other in program order, nobody else touches the image: no atomics, a
+    // fixed order), then one output position x two channel quads per thread adds the four images of a channel tile in wave order.  Both channel
+    // tiles at once: two barriers per pass instead of four, 0.55 MB through LDS per pass instead of 0.86 (the T tile was written by half the
+    // waves and gathered with 2/3 of the reads masked off: 16.7k of a block's 135k cycles per pass, tools/dense_stamps.sh).  The channel quads of
+    // an output position are XOR-swizzled by (position >> 2) & 3: the 16 lanes of a ds_*_b128 service group cover positions p .. p + 3 and
+    // p + 12 .. p + 15 of a tile, whose 64-byte records would otherwise share banks four positions apart.
+    {
+        char* const img = lds + wave * L::EIMG;
+        __syncthreads();                                                   // the loop buffers are free (every wave is out of its K loop, its DMA drained)
+        for (int i = lane; i < L::EIMG / 16; i += 64) *(f32x4*)(img + 16 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int o0[NPT];
+        bool val[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int gpos = 64 * pass + 16 * pt + li;                     // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][gpos]
+            val[pt] = gpos < NPOS_;
+            o0[pt] = (gpos / O2W_) * P1W_ + gpos % O2W_;                   // output position of tap (0, 0)
+        }
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (t < ntap) {                                                // wave-uniform
+                const int tap = tap0 + t, shift = (tap / 5) * P1W_ + tap % 5;
+                f32x4 cur[NPT];
+                int ad[NPT];
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {                         // the tile's reads together, then its writes
+                    const int o = o0[pt] + shift;
+                    ad[pt] = o * 64 + ((lg ^ ((o >> 2) & 3)) << 4);
+                    if (val[pt]) cur[pt] = *(const f32x4*)(img + ad[pt]);
+                }
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt)
+                    if (val[pt]) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
+            }
+        __syncthreads();
+        if (tid < 2 * NPP) {
+            const int qp = tid / NPP, pp = tid % NPP, sw = (pp >> 2) & 3;
+            const char* const rec = lds + pp * 64;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {                               // channel tile c2 = waves 4 c2 .. 4 c2 + 3
+                f32x4 u0[4], u1[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u0[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp) ^ sw) << 4));
+                    u1[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp + 1) ^ sw) << 4));
+                }
+                const f32x4 s0 = part[c2][0] + (((u0[0] + u0[1]) + u0[2]) + u0[3]);   // earlier passes + this pass's four tap groups, in that order
+                const f32x4 s1 = part[c2][1] + (((u1[0] + u1[1]) + u1[2]) + u1[3]);
+                if (pass + 1 < NPASS) {
+                    part[c2][0] = s0;
+                    part[c2][1] = s1;
+                } else {
+                    float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * c2 + 8 * qp) * NPP + pp;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float* const dst = dst0 + r * NPP;
+                        const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+                        *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                    }
+                }
+            }
+        }
+    }
+#else
     static_for<0, 2>([&](auto ROUND) {
         constexpr int round = decltype(ROUND)::value;
         __syncthreads();                                                   // the loop buffers / the previous round's T are free
@@ -2297,6 +2372,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             }
         }
     });
+#endif
     DSTAMP(8 * pass + 2);                                                  // col2im
     });
 #ifdef RBNN_DENSE_STAMPS
