@@ -1929,8 +1929,9 @@ template <class G> struct ConvBwdDenseLds {
     static constexpr int NFL = 32 * G::NP2;                               // pooled cells of one K step
     static constexpr int STG = (NFL * 5 + 15) / 16 * 16;                  // staging: NFL dQ2 floats + NFL stash bytes
     static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
-    static constexpr int AOFF = 2 * IMG + 2 * STG;                        // the eight waves' rings follow the image / staging buffers
-    static constexpr int LOOP = AOFF + 8 * RING * SLOT;
+    static constexpr int AOFF = 2 * IMG;                                  // the eight waves' rings follow the images;
+    static constexpr int SOFF = AOFF + 8 * RING * SLOT;                   // the staging buffers come LAST, above the col2im images (EPI): a pass's first two K steps
+    static constexpr int LOOP = SOFF + 2 * STG;                           //   are staged before the previous pass's col2im and land under it
 #if RBNN_DENSE_COL2IM_RMW
     static constexpr int EIMG = G::P1W * G::P1W * 64;                     // col2im: one wave's partial gradient image [P1W x P1W output positions][16 ci] floats
     static constexpr int EPI = 8 * EIMG;
@@ -1938,6 +1939,7 @@ template <class G> struct ConvBwdDenseLds {
     static constexpr int EPI = 25 * NPOSP * 16 * 4;                       // T of one channel tile and pass: [25 taps][pos][16 ci] floats
 #endif
     static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
+    static_assert(EPI <= SOFF, "the staging buffers must survive the col2im");
     static_assert(BYTES <= 160 * 1024, "LDS");
     static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
 };
@@ -1969,20 +1971,26 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     unsigned long long barw = 0;
 #endif
 
-    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1 (as conv_bwd_x3_kernel)
-    float dzmax = fabsf(a.dZ[sn * RBNN_CPAD + li]);
+    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1 (as conv_bwd_x3_kernel).  The load is issued here; the scales are formed in the first
+    // pass's prologue, behind the staging / tile DMA issue (forming them here put the load's round trip in front of the DMA's)
+    const float dz_lane = a.dZ[sn * RBNN_CPAD + li];
+    float in_scale = 1.f, out_scale = 1.f;
+    auto set_scales = [&]() {
+        float dzmax = fabsf(dz_lane);
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
-    const float bound = 4.f * dzmax * fw_l1;
-    int e = 0;
-    if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
-    const float in_scale = ldexpf(1.f, e), out_scale = ldexpf(1.f, -(e + k2_exp));
+        for (int o = 8; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
+        const float bound = 4.f * dzmax * fw_l1;
+        int e = 0;
+        if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
+        in_scale = ldexpf(1.f, e);
+        out_scale = ldexpf(1.f, -(e + k2_exp));
+    };
 
     auto dma4 = [&](const void* g, void* l) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
     };
     auto stage_issue = [&](int ks, int buf) {                               // rows of channels 32ks .. of dQ2 and of the stash: contiguous in memory
-        char* const S = lds + 2 * L::IMG + buf * L::STG;
+        char* const S = lds + L::SOFF + buf * L::STG;
         const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
         const long long fb = sn * F + (long long)ks * NFL;
         static_for<0, (NFL + 511) / 512>([&](auto I) {                       // pieces 2 KiB apart on both sides: pairs share address and M0
@@ -2046,7 +2054,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     union Q { unsigned w[2]; uint2 u; };                                    // pieces of the thread's four channels: [j0 | j1 << 16], [j2 | j3 << 16]
     float vpend = 0.f;                                                     // the even channel of a pair waits for the odd one (split3_plain_pair)
     auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
-        const char* const sb = lds + 2 * L::IMG + sbuf * L::STG;
+        const char* const sb = lds + L::SOFF + sbuf * L::STG;
         const bool live = 32 * ks + 4 * qd + j < a.Hc;                     // wave-uniform; channels past Hc (and the step past the last): zeros
         int st[4];
         float dq[4];
@@ -2107,8 +2115,14 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         }
     };
 
-    stage_issue(0, 0);
+    // K steps 0 and 1 are staged together (one HBM round trip, not two) — by the first pass here, for a later pass by the pass before it, ahead
+    // of its col2im (the rows staged do not depend on the pass)
+    if (pass == 0) {
+        stage_issue(0, 0);
+        if (KS > 1) stage_issue(1, 1);
+    }
     tile_issue(0, 0, 0); tile_issue(0, 1, 1); tile_issue(0, 2, 2);         // (a wave has >= 6 taps)
+    if (pass == 0) set_scales();
     __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
     __syncthreads();
     {
@@ -2117,7 +2131,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         for (int j = 0; j < 4; ++j) route_one(0, 0, j, p0, p1, p2);
         route_store(0, p0, p1, p2);
     }
-    if (KS > 1) stage_issue(1, 1);
     f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
 #ifdef RBNN_DENSE_ABL_NOB
     f16x8 b0[NPT], b1[NPT], b2[NPT];
@@ -2226,6 +2239,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         if (ntap == 7) { if (whole) kloop(std::integral_constant<int, 7>{}, std::true_type{}); else kloop(std::integral_constant<int, 7>{}, std::false_type{}); }
         else           { if (whole) kloop(std::integral_constant<int, 6>{}, std::true_type{}); else kloop(std::integral_constant<int, 6>{}, std::false_type{}); }
     }
+    if (pass + 1 < NPASS) {                                                // the next pass's first two K steps: they land under this pass's col2im (whose barriers do not wait for them)
+        stage_issue(0, 0);
+        if (KS > 1) stage_issue(1, 1);
+    }
     DSTAMP(8 * pass + 1);                                                  // K loop
     // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
     // registers are four consecutive channels (one ds_write_b128 per tile; the four channel quads of a position are XOR-swizzled by
@@ -2257,7 +2274,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // p + 12 .. p + 15 of a tile, whose 64-byte records would otherwise share banks four positions apart.
     {
         char* const img = lds + wave * L::EIMG;
-        __syncthreads();                                                   // the loop buffers are free (every wave is out of its K loop, its DMA drained)
+        ring_wait_barrier<63>();                                           // the loop buffers are free: every wave is out of its K loop with its ring DMA drained (raw barriers here:
+                                                                           // __syncthreads() would wait for the next pass's staging pieces just issued)
         for (int i = lane; i < L::EIMG / 16; i += 64) *(f32x4*)(img + 16 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
         int o0[NPT];
         bool val[NPT];
@@ -2283,7 +2301,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                 for (int pt = 0; pt < NPT; ++pt)
                     if (val[pt]) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
             }
-        __syncthreads();
+        ring_wait_barrier<63>();
         if (tid < 2 * NPP) {
             const int qp = tid / NPP, pp = tid % NPP, sw = (pp >> 2) & 3;
             const char* const rec = lds + pp * 64;
