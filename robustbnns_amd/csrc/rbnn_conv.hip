@@ -2053,16 +2053,21 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
     union Q { unsigned w[2]; uint2 u; };                                    // pieces of the thread's four channels: [j0 | j1 << 16], [j2 | j3 << 16]
     float vpend = 0.f;                                                     // the even channel of a pair waits for the odd one (split3_plain_pair)
-    auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
+    // (two halves: the eight LDS reads of a channel are issued one tap group AHEAD of the selects that consume them — in one piece the selects
+    // waited for the reads right in front of the tap's MFMAs, an LDS round trip per routing tap with nothing issued behind it)
+    struct RouteIn { int st[4]; float dq[4]; };
+    auto route_load = [&](int sbuf, int j, RouteIn& in) {
         const char* const sb = lds + L::SOFF + sbuf * L::STG;
-        const bool live = 32 * ks + 4 * qd + j < a.Hc;                     // wave-uniform; channels past Hc (and the step past the last): zeros
-        int st[4];
-        float dq[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {                                      // eight independent LDS reads, then straight-line selects
-            st[w] = *(const unsigned char*)(sb + ast[w] + j * NP2_);
-            dq[w] = *(const float*)(sb + adq[w] + 4 * j * NP2_);
+        for (int w = 0; w < 4; ++w) {                                      // eight independent LDS reads
+            in.st[w] = *(const unsigned char*)(sb + ast[w] + j * NP2_);
+            in.dq[w] = *(const float*)(sb + adq[w] + 4 * j * NP2_);
         }
+    };
+    auto route_calc = [&](int ks, int j, const RouteIn& in, Q& p0, Q& p1, Q& p2) {
+        const bool live = 32 * ks + 4 * qd + j < a.Hc;                     // wave-uniform; channels past Hc (and the step past the last): zeros
+        const int (&st)[4] = in.st;
+        const float (&dq)[4] = in.dq;
         // window w routes here iff its stashed argmax is w; act' = 1 or the slope by bit 2 of the stash (folding act' into dQ2 in
         // conv_fc_bwd_kernel instead was measured: that kernel went from 1.1 to 2.35 ms on its byte loads of the stash).  ReLU: both
         // tests are one compare of the stash's low three bits (a cell whose pre-activation was <= 0 passes nothing on).
@@ -2082,6 +2087,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         const float vs = (live ? v : 0.f) * in_scale;
         if (!(j & 1)) vpend = vs;
         else split3_plain_pair(vpend, vs, 1.f, p0.w[j >> 1], p1.w[j >> 1], p2.w[j >> 1]);
+    };
+    auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
+        RouteIn in;
+        route_load(sbuf, j, in);
+        route_calc(ks, j, in, p0, p1, p2);
     };
     auto route_store = [&](int ibuf, const Q& p0, const Q& p1, const Q& p2) {
         char* const I = lds + ibuf * L::IMG;
@@ -2188,6 +2198,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             b2[pt] = *(const f16x8*)(I + 2 * L::PLANE + pt * 1024);
         }
         Q p0, p1, p2;
+        RouteIn rin;
         static_for<0, NT>([&](auto TC) {
             constexpr int t = decltype(TC)::value;
             if constexpr (t > 0) issue(TC);
@@ -2225,8 +2236,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             a0 = *(const f16x8*)nx;
 #endif
 #ifndef RBNN_DENSE_ABL_NOROUTE
-            if constexpr (t < 4) route_one(ks + 1, (ks + 1) & 1, t, p0, p1, p2);       // the next K step's image, one channel per tap group
-            if constexpr (t == 3) route_store((ks + 1) & 1, p0, p1, p2);
+            // the next K step's image: channel j of the thread's quad is read in tap group j and routed in tap group j + 1
+            if constexpr (t >= 1 && t < 5) route_calc(ks + 1, t - 1, rin, p0, p1, p2);
+            if constexpr (t < 4) route_load((ks + 1) & 1, t, rin);
+            if constexpr (t == 4) route_store((ks + 1) & 1, p0, p1, p2);
 #endif
             __builtin_amdgcn_sched_barrier(0);                             // a tap is one scheduling region (the whole step as one region: routing reads hoisted across taps, 256 registers and scratch)
         });
