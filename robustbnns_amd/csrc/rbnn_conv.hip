@@ -1918,6 +1918,9 @@ __device__ unsigned long long rbnn_dense_stamp_acc[64];
 #ifndef RBNN_DENSE_COL2IM_RMW
 #define RBNN_DENSE_COL2IM_RMW 1
 #endif
+#ifndef RBNN_DENSE_STAGGER
+#define RBNN_DENSE_STAGGER 0                                               // 1: the two waves of a SIMD route one tap group apart (the 6-tap loop has room for one)
+#endif
 template <class G> struct ConvBwdDenseLds {
     // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
     // hold (112 registers).  1x28x28: 64 positions, one pass.  3x32x32: 100 positions = pass 0 (positions 0..63) + pass 1 (64..99, three
@@ -2155,8 +2158,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // them first and waited vmcnt(6) at tap 0: an HBM round trip per K step and wave).  They too are always issued (the last two steps re-stage
     // the last step's rows into the free buffer) so that the count behind a tile is the same in every step; SMIN = pieces EVERY wave issues
     // for a whole step (assuming fewer than were issued only waits longer) — 0 when the last step is half a step (Hc % 32 == 16).
-    auto kloop = [&](auto NTC, auto WHOLEC) {
-    constexpr int NT = decltype(NTC)::value, SB = decltype(WHOLEC)::value ? SMIN : 0;
+    auto kloop = [&](auto NTC, auto WHOLEC, auto R0C) {
+    constexpr int NT = decltype(NTC)::value, SB = decltype(WHOLEC)::value ? SMIN : 0, R0 = decltype(R0C)::value;
     for (int ks = 0; ks < KS; ++ks) {
         // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
         // vector-memory operations — the ring tiles issued since — may still be in flight
@@ -2237,9 +2240,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
 #endif
 #ifndef RBNN_DENSE_ABL_NOROUTE
             // the next K step's image: channel j of the thread's quad is read in tap group j and routed in tap group j + 1
-            if constexpr (t >= 1 && t < 5) route_calc(ks + 1, t - 1, rin, p0, p1, p2);
-            if constexpr (t < 4) route_load((ks + 1) & 1, t, rin);
-            if constexpr (t == 4) route_store((ks + 1) & 1, p0, p1, p2);
+            // (R0: the channel-tile-1 wave of a SIMD routes RBNN_DENSE_STAGGER tap groups later than its channel-tile-0 partner)
+            if constexpr (t >= R0 + 1 && t < R0 + 5) route_calc(ks + 1, t - R0 - 1, rin, p0, p1, p2);
+            if constexpr (t >= R0 && t < R0 + 4) route_load((ks + 1) & 1, t - R0, rin);
+            if constexpr (t == R0 + 4) route_store((ks + 1) & 1, p0, p1, p2);
 #endif
             __builtin_amdgcn_sched_barrier(0);                             // a tap is one scheduling region (the whole step as one region: routing reads hoisted across taps, 256 registers and scratch)
         });
@@ -2249,8 +2253,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     DSTAMP(8 * pass + 0);                                                  // prologue (pass 0: from the block's start; later passes: from the end of the previous col2im)
     {
         const bool whole = (a.Hc & 31) == 0;                               // block-uniform
-        if (ntap == 7) { if (whole) kloop(std::integral_constant<int, 7>{}, std::true_type{}); else kloop(std::integral_constant<int, 7>{}, std::false_type{}); }
-        else           { if (whole) kloop(std::integral_constant<int, 6>{}, std::true_type{}); else kloop(std::integral_constant<int, 6>{}, std::false_type{}); }
+        using Z = std::integral_constant<int, 0>;
+        using R = std::integral_constant<int, RBNN_DENSE_STAGGER>;
+        if (!whole) { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::false_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::false_type{}, Z{}); }
+        else if (RBNN_DENSE_STAGGER && ct) { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, R{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, R{}); }
+        else { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, Z{}); }
     }
     if (pass + 1 < NPASS) {                                                // the next pass's first two K steps: they land under this pass's col2im (whose barriers do not wait for them)
         stage_issue(0, 0);
