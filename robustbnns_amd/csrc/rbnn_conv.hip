@@ -17,6 +17,14 @@
 // activation, and then the first one wins); their backward takes act' from the stored activation value, no sign bit.
 #include "rbnn_common.hpp"
 
+// build switches of the conv2^T dense kernel / conv1^T that more than one section reads (the rest sit next to their kernels)
+#ifndef RBNN_DENSE_COL2IM_RMW
+#define RBNN_DENSE_COL2IM_RMW 1
+#endif
+#ifndef RBNN_CONV1_BWD_X3
+#define RBNN_CONV1_BWD_X3 RBNN_DENSE_COL2IM_RMW                            // conv1^T behind the dense kernel on the f16 matrix pipe (triple-split), scaled by the dense kernel's max |dP1|
+#endif
+
 namespace {
 
 constexpr int C1 = 32;                                                 // conv1 output channels (model_nn.py:99)
@@ -1807,9 +1815,179 @@ __global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a
             if (lane < IW) Gout[ci * (IW * IW) + (O1 + k) * IW + lane] = ring[ci][k];
 }
 
+// conv1^T on the F16 matrix pipe (triple-split arithmetic; round 4, second half): conv1_bwd_mfma_kernel's structure — one wave = one (sample,
+// point), a row of T per conv1 output row, five partial output rows per lane in registers — with the 32-channel contraction as ONE K step of
+// v_mfma_f32_16x16x32_f16 (six exact product terms per fp32 product; the fp32 form needs eight K steps of 16x16x4 at twice the cycles each:
+// 1,024 matrix-pipe cycles per (row, input channel) against 384 here) and the rows of T packed over (input channel, tap): 75 rows = five
+// tiles at 3x32x32 (six before), one pass per position row for all input channels.  K index k = 8 lg + e of a lane <-> channel
+// c = 16 (e >> 2) + 4 lg + (e & 3): exactly the (channel block, quad) elements the routing already holds per lane.  Scales: the weights by
+// the wave's own max |w| (its A operand is the sample's whole conv1 weight tensor); the routed gradients by max |dP1| of the (sample,
+// point), which the dense conv2^T kernel leaves in G[sn][0] (this kernel reads it before it writes G) — so only rbnn_conv_input_grad_dense
+// launches this kernel; the other conv2^T forms keep the fp32 one.
+template <int ACT, class G>
+__global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) {
+    constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW, CIN = G::CIN;
+    constexpr int MROWS = CIN * 25, MT = (MROWS + 15) / 16;
+    constexpr int TS = conv1_bwd_ts<G>(), TROW = MT * 16 * TS;            // all MT * 16 rows exist: the accumulator stores need no row test
+    static_assert(O1 <= TS && (4 * TS) % 32 != 0 && O1 <= 32 && IW <= 64, "a conv1 output row fits two 16-wide MFMA tiles; an input row fits one wave");
+    __shared__ float lds[4 * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int NB = (a.N + 3) / 4;
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, n = (id % NB) * 4 + wave;
+    if (n >= a.N) return;                                                // whole wave idle; no block barrier anywhere
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const long long sn = (long long)s * a.N + n;
+    float* const T = lds + wave * TROW;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+    float* const Gout = a.G + sn * G::DIN;
+    const float gmax = Gout[0];                                          // max |dP1| of this (sample, point), from conv_bwd_dense_x3_kernel
+
+    int eoff[2][2][4];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eoff[pt][kb][r] = (16 * kb + 4 * lg + r) * (P1W_ * P1W_) + min((16 * pt + li) >> 1, P1W_ - 1);
+    const uint8_t* const st_sn = a.st1 + sn * G::P1SZ;
+    const float* const d_sn = a.dP1 + sn * G::P1SZ;
+
+    // A operand: row m = ci * 25 + tap of tile mt (a channel's weights are contiguous over m), K element e of this lane = channel 16 (e >> 2) + 4 lg + (e & 3)
+    union F8 { f16x8 v; unsigned w[4]; };
+    F8 aw0[MT], aw1[MT], aw2[MT];
+    float w_inv;
+    {
+        float wv[MT][8], wmax = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = 16 * mt + li, c = 16 * (e >> 2) + 4 * lg + (e & 3);
+                wv[mt][e] = m < MROWS ? a.K1w[((long long)sw * C1 + c) * G::K1 + m] : 0.f;
+                wmax = fmaxf(wmax, fabsf(wv[mt][e]));
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        int ew = 0;
+        if (wmax > 0.f && wmax < INFINITY) ew = max(-100, min(100, 13 - ilogbf(wmax)));
+        const float wsc = ldexpf(1.f, ew);
+        w_inv = ldexpf(1.f, -ew);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2)
+                split3_plain_pair(wv[mt][e] * wsc, wv[mt][e + 1] * wsc, 1.f, aw0[mt].w[e >> 1], aw1[mt].w[e >> 1], aw2[mt].w[e >> 1]);
+    }
+    int eg = 0;
+    if (gmax > 0.f && gmax < INFINITY) eg = max(-100, min(100, 13 - ilogbf(gmax)));
+    const float g_scale = ldexpf(1.f, eg), t_scale = ldexpf(1.f, -eg) * w_inv;
+
+    float ring[CIN][5];                                                  // partial sums of output rows Ya .. Ya + 4, column X = lane
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ring[ci][k] = 0.f;
+    int stn[2][2][4];
+    float dn[2][2][4];
+    auto fetch = [&](int py) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    stn[pt][kb][r] = st_sn[eoff[pt][kb][r] + py * P1W_];
+                    dn[pt][kb][r] = d_sn[eoff[pt][kb][r] + py * P1W_];
+                }
+    };
+    fetch(0);
+    for (int py = 0; py < P1W_; ++py) {
+        float gv[2][2][4];
+        int ar[2][2][4];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int Xa = 16 * pt + li, st = stn[pt][kb][r];
+                    const float d = dn[pt][kb][r] * g_scale;
+                    gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
+                    ar[pt][kb][r] = (st & 3) ^ (Xa & 1);                 // == 2*half for the row half that owns the argmax, with the right column parity
+                }
+        if (py + 1 < P1W_) fetch(py + 1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int Ya = 2 * py + half;
+            F8 b0[2], b1[2], b2[2];                                      // the routed gradient row, three piece planes: B[k][j = Xa], built ONCE for all input channels
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float ve = (ar[pt][e >> 2][e & 3] == 2 * half) ? gv[pt][e >> 2][e & 3] : 0.f;               // arg = 2*dy + dx
+                    const float vo = (ar[pt][(e + 1) >> 2][(e + 1) & 3] == 2 * half) ? gv[pt][(e + 1) >> 2][(e + 1) & 3] : 0.f;
+                    split3_plain_pair(ve, vo, 1.f, b0[pt].w[e >> 1], b1[pt].w[e >> 1], b2[pt].w[e >> 1]);
+                }
+            f32x4 acc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};                      // smallest terms first (as everywhere in the triple-split kernels)
+                    c = MFMA_H(aw2[mt].v, b0[pt].v, c);
+                    c = MFMA_H(aw1[mt].v, b1[pt].v, c);
+                    c = MFMA_H(aw0[mt].v, b2[pt].v, c);
+                    c = MFMA_H(aw1[mt].v, b0[pt].v, c);
+                    c = MFMA_H(aw0[mt].v, b1[pt].v, c);
+                    acc[mt][pt] = MFMA_H(aw0[mt].v, b0[pt].v, c);
+                }
+            // (same wave: the LDS unit serves its requests in order — these stores follow the previous row's reads, the reads below follow them)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * pt + li < TS) T[(16 * mt + 4 * lg + r) * TS + 16 * pt + li] = acc[mt][pt][r];   // T[m][Xa]
+            if (lane < IW) {                                             // this T row's share of output rows Ya + ky: dX[ci][Ya + ky][X] += T[ci * 25 + (ky, kx)][X - kx]
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 5; ++kx) {
+                            const int Xp = lane - kx;
+                            if (Xp >= 0 && Xp <= O1 - 1) ring[ci][ky] += T[(ci * 25 + ky * 5 + kx) * TS + Xp];
+                        }
+            }
+            // output row Ya has now received its last contribution (T rows Ya - 4 .. Ya): emit it, rotate the partial rows
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                if (lane < IW) Gout[ci * (IW * IW) + Ya * IW + lane] = ring[ci][0] * t_scale;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ring[ci][k] = ring[ci][k + 1];
+                ring[ci][4] = 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                                          // the last four output rows: O1 .. IW - 1
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+            if (lane < IW) Gout[ci * (IW * IW) + (O1 + k) * IW + lane] = ring[ci][k] * t_scale;
+}
+
 // conv1^T: the matrix-pipe kernel; RBNN_CONV1_BWD_VALU keeps its VALU gather form selectable (same results up to summation order)
 template <int ACT, class G>
-int launch_conv1_backward(const ConvBwdArgs& a, hipStream_t st) {
+int launch_conv1_backward(const ConvBwdArgs& a, hipStream_t st, bool dp1_max_in_g = false) {
+#if RBNN_CONV1_BWD_X3
+    if (dp1_max_in_g) {
+        hipLaunchKernelGGL((conv1_bwd_x3_kernel<ACT, G>), dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
+        return launch_status();
+    }
+#endif
 #ifndef RBNN_CONV1_BWD_VALU
     hipLaunchKernelGGL((conv1_bwd_mfma_kernel<ACT, G>), dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
 #else
@@ -1915,9 +2093,6 @@ __device__ unsigned long long rbnn_dense_stamp_acc[64];
 #define DSTAMP(slot) do { } while (0)
 #define DSTAMP_ADD(slot, v) do { } while (0)
 #endif
-#ifndef RBNN_DENSE_COL2IM_RMW
-#define RBNN_DENSE_COL2IM_RMW 1
-#endif
 #ifndef RBNN_DENSE_STAGGER
 #define RBNN_DENSE_STAGGER 0                                               // 1: the two waves of a SIMD route one tap group apart (the 6-tap loop has room for one)
 #endif
@@ -1943,6 +2118,7 @@ template <class G> struct ConvBwdDenseLds {
 #endif
     static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
     static_assert(EPI <= SOFF, "the staging buffers must survive the col2im");
+    static_assert(EPI + 64 <= SOFF, "room for the eight wave maxima behind the col2im images");
     static_assert(BYTES <= 160 * 1024, "LDS");
     static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
 };
@@ -2322,6 +2498,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                     if (val[pt]) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
             }
         ring_wait_barrier<63>();
+        float omax = 0.f;
         if (tid < 2 * NPP) {
             const int qp = tid / NPP, pp = tid % NPP, sw = (pp >> 2) & 3;
             const char* const rec = lds + pp * 64;
@@ -2344,11 +2521,28 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
                     for (int r = 0; r < 8; ++r) {
                         float* const dst = dst0 + r * NPP;
                         const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
-                        *dst = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                        const float o = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                        *dst = o;
+                        omax = fmaxf(omax, fabsf(o));
                     }
                 }
             }
         }
+#if RBNN_CONV1_BWD_X3
+        if (pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+            float* const wm = (float*)(lds + L::EPI);                      // (the rings' area: free)
+            if (lane == 0) wm[wave] = omax;
+            ring_wait_barrier<63>();
+            if (tid == 0) {
+                float m = wm[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) m = fmaxf(m, wm[w]);
+                a.G[sn * G::DIN] = m;
+            }
+        }
+#endif
     }
 #else
     static_for<0, 2>([&](auto ROUND) {
@@ -2524,7 +2718,7 @@ extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const 
             if (!ensure_dynamic_lds((const void*)conv_bwd_dense_x3_kernel<ACT, G>, LDSB, attr)) return (int)RBNN_ERR_LAUNCH;
             hipLaunchKernelGGL((conv_bwd_dense_x3_kernel<ACT, G>), dim3(grid_for_items((long long)N * S)), dim3(512), LDSB, st, a, (const char*)K2_dense, k2_exp, fw_l1);
             if ((rc2 = launch_status())) return rc2;
-            return launch_conv1_backward<ACT, G>(a, st);
+            return launch_conv1_backward<ACT, G>(a, st, true);
         });
     });
 }
