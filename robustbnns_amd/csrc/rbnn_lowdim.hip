@@ -409,6 +409,9 @@ template <int ACT> int launch_low_act(const LowArgs& a, hipStream_t st) {
 //   low2_finish_kernel         sum of the S slabs in a fixed order, then the gradient + its norms, or the sign / project / clamp step
 // — three (two kernels) for the per-sample loss of lossGradients.py:29-40.  Every sum has a fixed order: results are deterministic.
 // =====================================================================================================
+#ifndef RBNN_LOW2_STASH
+#define RBNN_LOW2_STASH 1                                                  // 0: the backward launch always recomputes the forward (the form until round 4's second half)
+#endif
 struct Low2Args {
     rbnn_posterior net;
     const float* X;                // current iterate [N, ldx]
@@ -417,6 +420,7 @@ struct Low2Args {
     float* P;                      // [S][N][16] per-sample probabilities (logits for the mean-logit loss / OUT_LOGITS)
     const float* Psum;             // [N][16] sum over samples (BWD, mean-probability / mean-logit loss)
     float* slabs;                  // [S][N][16] per-sample input gradients (BWD)
+    uint4* mask;                   // relu / leaky, a pass with a forward launch: [blocks][threads] sign bits of both hidden layers (low2_kernel<.., STASH>); else NULL
     int ldx, N, S, NG, loss, probs, dq;
     float inv_S;
 };
@@ -433,8 +437,14 @@ template <int NW, int KTW, int NPTB, bool BWD> struct Low2Lds {
     static_assert(FLOATS * 4 <= 160 * 1024, "LDS");
 };
 
-template <int ACT, int NW, int KTW, int NPTB, bool BWD>
+// STASH (relu / leaky; round 4, second half): act' of both hidden layers is one BIT per (unit, point).  The forward launch of a mean-probability /
+// mean-logit pass writes them (a.mask != NULL: 16 bytes per thread — bit (i NPTB + p) 4 + r of a lane = unit row0 + 16 i + 4 lg + r, point 16 p + li,
+// the accumulator layout both backward products read act' in), and low2_kernel<BWD, STASH> starts at dZ: no layer 1, no H x H forward product, no
+// softmax — the probabilities come from P.  (The per-sample loss has no forward launch, sigmoid / tanh need the activation values: they keep the
+// recomputing backward.)
+template <int ACT, int NW, int KTW, int NPTB, bool BWD, bool STASH = false>
 __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
+    static_assert(!STASH || (BWD && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY) && KTW * NPTB * 4 <= 64), "the stashed backward: relu / leaky, 64 bits per layer and lane");
     using L = Low2Lds<NW, KTW, NPTB, BWD>;
     constexpr int H = L::H, HS = L::HS, PT = L::PT, NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float sm2[];
@@ -508,6 +518,46 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
     const float* const Wmp = a.net.Wm_pack4 + (long long)sw * H * H;                                           // pack_rows4 image: Wm^T rows
     auto ak_bwd = [&](int i, int j) { return Wmp + ((long long)(4 * j + lg) * H + row0 + 16 * i + li) * 4; };
     f32x4 Areg[3][KTW];
+    f32x4 acc[KTW][NPTB];
+    const long long mslot = ((long long)blockIdx.x * NT + tid);           // this thread's 16 bytes of the sign-bit stash
+    unsigned m1lo = 0, m1hi = 0, m2lo = 0, m2hi = 0;                       // layer-1 / layer-2 sign bits of this lane's (i, p, r) elements
+    if constexpr (STASH) {
+        const uint4 mk = a.mask[mslot];
+        m1lo = mk.x; m1hi = mk.y; m2lo = mk.z; m2hi = mk.w;
+        gemm_load(ak_bwd, Areg);                                          // the Wm^T product's first A tiles: under the dZ phase
+        if (tid < PT) {
+            const int n = n0 + tid;
+            float z[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = (n < N) ? *(const f32x4*)(a.P + ((long long)s * N + n) * RBNN_CPAD + 4 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                z[4 * q] = v[0]; z[4 * q + 1] = v[1]; z[4 * q + 2] = v[2]; z[4 * q + 3] = v[3];
+            }
+            float g[16], e[16], dz[16];                                   // (as the recomputing backward below: rbnn_loss_dlogits on what the forward launch left in P)
+            const int y = (n < N) ? a.labels[n] : 0;
+            float m = -INFINITY, den = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                e[c] = (n < N && c < C) ? a.Psum[(long long)n * RBNN_CPAD + c] * a.inv_S : 0.f;
+                if (c < C) m = fmaxf(m, e[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { e[c] = (c < C) ? expf(e[c] - m) : 0.f; den += e[c]; }
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
+                dot += g[c] * z[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                dz[c] = (a.loss == RBNN_LOSS_MEAN_LOGIT) ? g[c] : (g[c] - dot) * z[c];
+                if (!(n < N && c < C)) dz[c] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *(f32x4*)(dzb + tid * 16 + 4 * q) = (f32x4){dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]};
+        }
+    } else {
     for (int i = tid; i < PT * 16; i += NT) {
         const int n = n0 + (i >> 4), d = i & 15;
         xs[i] = (n < N && d < D) ? a.X[(long long)n * a.ldx + d] : 0.f;
@@ -549,7 +599,6 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
     // ---- H x H GEMM on the fp32 MFMA: acc[i][p] (rows 16 (wave KTW + i) .., points 16 p ..) = sum_k A[row][k] B[point][k].  A lane holds four
     // consecutive k of its row (one 16-byte load = four MFMA K steps), a B lane the same four k of its point (one ds_read_b128);
     // `ak` maps (row tile, 16-wide k step) to the lane's address: row-major Wm for the forward, the pack_rows4 image for Wm^T ----
-    f32x4 acc[KTW][NPTB];
     gemm(ak_fwd, bufA, Areg, acc);
     // acc[i][p][r] = a2[unit row0 + 16 i + 4 lg + r][point 16 p + li]: bias, activation (the value also carries act')
     f32x4 zacc[NPTB];
@@ -567,6 +616,10 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             for (int r = 0; r < 4; ++r) {
                 acc[i][p][r] = act_fwd<ACT>(acc[i][p][r] + bias[r]);
                 zacc[p] = MFMA16(w2f[r], acc[i][p][r], zacc[p]);          // layer 3: the accumulator IS the B operand (K index = its row)
+                if constexpr (!BWD && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY) && KTW * NPTB * 4 <= 64) {
+                    const int bit = (i * NPTB + p) * 4 + r;               // (a constant after unrolling)
+                    if (acc[i][p][r] > 0.f) { if (bit < 32) m2lo |= 1u << (bit & 31); else m2hi |= 1u << (bit & 31); }
+                }
             }
         }
     }
@@ -626,8 +679,29 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             for (int q = 0; q < 4; ++q) *(f32x4*)(dzb + tid * 16 + 4 * q) = (f32x4){dz[4 * q], dz[4 * q + 1], dz[4 * q + 2], dz[4 * q + 3]};
         }
     }
+    if constexpr (!BWD && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY) && KTW * NPTB * 4 <= 64) {
+        if (a.mask) {                                                     // the sign bits of h1 in the same (i, p, r) order, and both layers' words out
+#pragma unroll
+            for (int i = 0; i < KTW; ++i)
+#pragma unroll
+                for (int p = 0; p < NPTB; ++p) {
+                    const f32x4 hv = *(const f32x4*)(bufA + (16 * p + li) * HS + row0 + 16 * i + 4 * lg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int bit = (i * NPTB + p) * 4 + r;
+                        if (hv[r] > 0.f) { if (bit < 32) m1lo |= 1u << (bit & 31); else m1hi |= 1u << (bit & 31); }
+                    }
+                }
+            a.mask[mslot] = make_uint4(m1lo, m1hi, m2lo, m2hi);
+        }
+    }
+    }                                                                     // (the forward: everything between the stash read and here)
+    auto stash_deriv = [&](unsigned lo, unsigned hi, int bit) -> float {  // act' from a sign bit (relu: 1 / 0, leaky: 1 / slope)
+        const bool pos = ((bit < 32 ? lo : hi) >> (bit & 31)) & 1u;
+        return pos ? 1.f : (ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE);
+    };
     if constexpr (BWD) {
-        gemm_load(ak_bwd, Areg);                                          // the second product's first A tiles: under the dZ / dA2 phases
+        if constexpr (!STASH) gemm_load(ak_bwd, Areg);                    // the second product's first A tiles: under the dZ / dA2 phases
         __syncthreads();
         // ---- dA2[unit][point] = act'(h2) * sum_c W2[c][unit] dZ[point][c]: K = classes (<= 10: three K steps), -> LDS point-major ----
         const int QC = (C + 3) / 4;
@@ -647,7 +721,7 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) if (q < QC) t = MFMA16(aw[q], bz[p][q], t);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[r] *= act_deriv_from_value<ACT>(acc[i][p][r]);
+                for (int r = 0; r < 4; ++r) t[r] *= STASH ? stash_deriv(m2lo, m2hi, (i * NPTB + p) * 4 + r) : act_deriv_from_value<ACT>(acc[i][p][r]);
                 *(f32x4*)(bufB + (16 * p + li) * HS + row0 + 16 * i + 4 * lg) = t;
             }
         }
@@ -666,9 +740,11 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             for (int r = 0; r < 4; ++r) w1f[r] = W1[(hrow + r) * 16 + li];
 #pragma unroll
             for (int p = 0; p < NPTB; ++p) {
-                const f32x4 hv = *(const f32x4*)(bufA + (16 * p + li) * HS + hrow);
+                f32x4 hv = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if constexpr (!STASH) hv = *(const f32x4*)(bufA + (16 * p + li) * HS + hrow);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gacc[p] = MFMA16(w1f[r], acc[i][p][r] * act_deriv_from_value<ACT>(hv[r]), gacc[p]);
+                for (int r = 0; r < 4; ++r)
+                    gacc[p] = MFMA16(w1f[r], acc[i][p][r] * (STASH ? stash_deriv(m1lo, m1hi, (i * NPTB + p) * 4 + r) : act_deriv_from_value<ACT>(hv[r])), gacc[p]);
             }
         }
 #pragma unroll
@@ -767,9 +843,20 @@ __global__ void __launch_bounds__(256) low2_finish_kernel(const Low2Finish a) {
 template <int ACT, int NW, int KTW, int NPTB, bool BWD> int launch_low2_cfg(Low2Args a, hipStream_t st) {
     using L = Low2Lds<NW, KTW, NPTB, BWD>;
     a.NG = (a.N + L::PT - 1) / L::PT;
+    const dim3 grid((unsigned)(8LL * a.NG * ((a.S + 7) / 8)));
+    constexpr bool CAN_STASH = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY) && KTW * NPTB * 4 <= 64;
+    if constexpr (!CAN_STASH) a.mask = nullptr;
+    if constexpr (BWD && CAN_STASH) {
+        if (a.mask) {                                                     // the forward launch of this pass left the sign bits: start at dZ
+            static unsigned long long attr_s = 0;
+            if (L::FLOATS * 4 > 64 * 1024 && !ensure_dynamic_lds((const void*)low2_kernel<ACT, NW, KTW, NPTB, true, true>, L::FLOATS * 4, attr_s)) return RBNN_ERR_LAUNCH;
+            hipLaunchKernelGGL((low2_kernel<ACT, NW, KTW, NPTB, true, true>), grid, dim3(64 * NW), L::FLOATS * 4, st, a);
+            return launch_status();
+        }
+    }
     static unsigned long long attr = 0;
     if (L::FLOATS * 4 > 64 * 1024 && !ensure_dynamic_lds((const void*)low2_kernel<ACT, NW, KTW, NPTB, BWD>, L::FLOATS * 4, attr)) return RBNN_ERR_LAUNCH;
-    hipLaunchKernelGGL((low2_kernel<ACT, NW, KTW, NPTB, BWD>), dim3((unsigned)(8LL * a.NG * ((a.S + 7) / 8))), dim3(64 * NW), L::FLOATS * 4, st, a);
+    hipLaunchKernelGGL((low2_kernel<ACT, NW, KTW, NPTB, BWD>), grid, dim3(64 * NW), L::FLOATS * 4, st, a);
     return launch_status();
 }
 
@@ -807,6 +894,7 @@ int run_low2(const rbnn_posterior* net, int op, int loss, int out_kind, const fl
     float* const P = scratch;
     float* const slabs = scratch + SN;
     float* const Psum = scratch + 2 * SN;
+    uint4* const mask = (uint4*)(scratch + 2 * SN + (long long)N * RBNN_CPAD);      // (16-byte aligned: every part is a multiple of 16 floats)
     Low2Args a = {};
     a.net = *net; a.sidx = sidx; a.labels = labels; a.P = P; a.Psum = Psum; a.slabs = slabs; a.ldx = ldx; a.N = N; a.S = S; a.loss = loss;
     a.dq = net->in_features <= 4 ? 1 : (net->in_features + 3) / 4; a.inv_S = inv_S;
@@ -819,6 +907,8 @@ int run_low2(const rbnn_posterior* net, int op, int loss, int out_kind, const fl
         return launch_status();
     }
     a.probs = loss != RBNN_LOSS_MEAN_LOGIT;
+    // relu / leaky with a forward launch in the pass: the forward leaves the sign bits of both hidden layers, the backward starts at dZ
+    a.mask = (RBNN_LOW2_STASH && loss != RBNN_LOSS_PER_SAMPLE && (net->activation == RBNN_ACT_RELU || net->activation == RBNN_ACT_LEAKY)) ? mask : nullptr;
     const int T = op == OP_ATTACK ? iters : 1;
     for (int it = 0; it < T; ++it) {
         a.X = (it == 0) ? X : out;                                         // the iterate lives in `out` from the first step on
@@ -853,7 +943,10 @@ int rbnn_lowdim_supported(const rbnn_posterior* net) {
 size_t rbnn_lowdim_scratch_bytes(const rbnn_posterior* net, int32_t n_points, int32_t n_samples) {
     if (!net || n_points < 1 || n_samples < 1) return 0;
     const size_t SN = (size_t)n_samples * n_points * RBNN_CPAD * sizeof(float);
-    return net->arch == RBNN_ARCH_FC2 ? 2 * SN + (size_t)n_points * RBNN_CPAD * sizeof(float) : SN;
+    if (net->arch != RBNN_ARCH_FC2) return SN;
+    // fc2: [P | slabs | Psum | sign-bit stash: 16 bytes per thread of every low2_kernel block; <= 256 threads per block of >= 32 points (launch_low2_h)]
+    const size_t groups = ((size_t)n_points + 31) / 32, blocks = 8 * groups * (((size_t)n_samples + 7) / 8);
+    return 2 * SN + (size_t)n_points * RBNN_CPAD * sizeof(float) + blocks * 256 * 16;
 }
 
 // sample lanes per point: enough threads to fill the chip (256 CUs x 2 x 256) when N is small, one lane per point when N is large
