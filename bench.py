@@ -514,7 +514,7 @@ def main():
     KNAMES["lowdim"] = {"lowdim": "lowdim_kernel (forward, loss, input gradient and step of ALL iterations in one launch; fp32 FMA)"}
     KNAMES["triple"] = {"fc_input_grad": "fc_grad_x3_kernel (its dZ image comes from the fused tail kernel step_tail_x3_kernel)", "fc_forward": "fc_forward_x3_kernel",
                         "conv_forward": "conv2_pool_x3_kernel (+ conv1_pool, conv_fc)",
-                        "conv_input_grad": "conv_bwd_dense_x3_kernel (both geometries; 3x32x32 in two passes over 64 + 36 output positions) (+ conv_fc_bwd, conv1_bwd)"}
+                        "conv_input_grad": "conv_bwd_dense_x3_kernel (both geometries; 3x32x32 in two passes over 64 + 36 output positions) (+ conv_fc_bwd, conv1_bwd_x3: conv1^T on the f16 pipe too)"}
     # which C-ABI calls run on the f16 pipe in each mode (the rest of that mode's calls are the fp32-MFMA kernels)
     F16_KERNELS = {"split": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"},
                    "triple": {"fc_forward", "fc_input_grad", "conv_forward", "conv_input_grad"}}

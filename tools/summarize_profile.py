@@ -25,6 +25,7 @@ MAIN = [("fc_forward_x3_kernel", "fc_forward_triple"), ("fc_grad_x3_kernel", "fc
         ("fc_forward_split_kernel", "fc_forward_split"), ("fc_grad_split_kernel", "fc_input_grad_split"), ("split_dz_kernel", "fc_input_grad_split"),
         ("fc_forward_kernel", "fc_forward"), ("fc_grad_kernel", "fc_input_grad"),
         ("conv2_pool_x3_kernel", "conv_forward_triple"), ("conv_bwd_x3_kernel", "conv_input_grad_triple"), ("conv_bwd_dense_x3_kernel", "conv_input_grad_triple"),
+        ("conv1_bwd_x3_kernel", "conv_input_grad_triple"),
         ("conv2_pool_split_kernel", "conv_forward_split"), ("conv1_pool_split_kernel", "conv_forward_split"),
         ("conv_bwd_split_kernel", "conv_input_grad_split"),
         ("conv2_pool_kernel", "conv_forward"), ("conv1_pool_kernel", "conv_forward_common"), ("conv_fc_kernel", "conv_forward_common"),
