@@ -526,9 +526,11 @@ int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor *tensors, int32_t n_tensors, i
 /* fc2 (round 4; the reference's half-moons grid, grid_search_halfMoons.py:159-169: 2 -> H -> H -> 2, 250 HMC samples): hidden in
  * {32, 64, 128, 256, 512}, in_stride == 16, Wm_pack4 required.  The H x H layer is a GEMM over the points of a sample (fp32 MFMA), so
  * samples spread over the CUs and the mean over samples couples all blocks between forward and backward: one call issues, back to
- * back on `stream`, per iteration: forward kernel, sum over samples, forward-again + backward kernel, slab sum + step (4 launches;
- * 2 for the per-sample loss) — csrc/rbnn_lowdim.hip.  Same arguments and results as for fc, except that P_scratch must hold
- * rbnn_lowdim_scratch_bytes() bytes (per-sample outputs, per-sample gradient slabs, the sum over samples), is always required, and for
+ * back on `stream`, per iteration: forward kernel, sum over samples, backward kernel, slab sum + step (4 launches; 2 for the
+ * per-sample loss) — csrc/rbnn_lowdim.hip.  relu / leaky: the forward kernel leaves one sign bit per hidden unit and (sample, point)
+ * and the backward kernel starts at dL/dlogits; sigmoid / tanh and the per-sample loss (which has no forward launch): the backward
+ * kernel recomputes the forward.  Same arguments and results as for fc, except that P_scratch must hold rbnn_lowdim_scratch_bytes()
+ * bytes (per-sample outputs, per-sample gradient slabs, the sum over samples, the sign bits), is always required, and for
  * RBNN_LOWDIM_ATTACK `out` must not alias X (the iterate is kept in `out`). */
 typedef enum rbnn_lowdim_op { RBNN_LOWDIM_FORWARD = 0, RBNN_LOWDIM_GRADIENT = 1, RBNN_LOWDIM_ATTACK = 2 } rbnn_lowdim_op;
 int rbnn_lowdim_supported(const rbnn_posterior *net);      /* 1 when rbnn_lowdim_run covers this posterior */
