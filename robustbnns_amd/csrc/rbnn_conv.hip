@@ -2105,7 +2105,8 @@ template <class G> struct ConvBwdDenseLds {
     static constexpr int NPOSP = 64;                                      // positions of a pass, padded to whole MFMA tiles
     static constexpr int PLANE = NPOSP * 64, IMG = 3 * PLANE;             // one piece plane: NPOSP records of 32 hc halves
     static constexpr int NFL = 32 * G::NP2;                               // pooled cells of one K step
-    static constexpr int STG = (NFL * 5 + 15) / 16 * 16;                  // staging: NFL dQ2 floats + NFL stash bytes
+    static constexpr int STG = (NFL * 5 + 4 * G::NP2 + 15) / 16 * 16;     // staging: NFL dQ2 floats + NFL stash bytes + 4 NP2 bytes that hold the code 8 (no window's: the
+                                                                          // windows of a position that lie off the pooled map read their stash byte here)
     static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
     static constexpr int AOFF = 2 * IMG;                                  // the eight waves' rings follow the images;
     static constexpr int SOFF = AOFF + 8 * RING * SLOT;                   // the staging buffers come LAST, above the col2im images (EPI): a pass's first two K steps
@@ -2161,6 +2162,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         const float bound = 4.f * dzmax * fw_l1;
         int e = 0;
         if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
+        e = __builtin_amdgcn_readfirstlane(e);                             // wave-uniform: the two scales live in scalar registers
         in_scale = ldexpf(1.f, e);
         out_scale = ldexpf(1.f, -(e + k2_exp));
     };
@@ -2172,16 +2174,20 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         char* const S = lds + L::SOFF + buf * L::STG;
         const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
         const long long fb = sn * F + (long long)ks * NFL;
+        // sources = a wave-uniform 64-bit base (the step's rows) + ONE 32-bit per-lane offset: the SGPR-base addressing form, no 64-bit vector add per piece
+        const char* const qrow = (const char*)(a.dQ2 + fb);
+        const char* const srow = (const char*)(a.st2 + fb);
+        const unsigned l4 = 4u * (unsigned)lane;
         static_for<0, (NFL + 511) / 512>([&](auto I) {                       // pieces 2 KiB apart on both sides: pairs share address and M0
             constexpr int i = decltype(I)::value, i0 = i & ~1;
             const int b = 512 * i0 + 64 * wave;                             // wave-uniform destination base
             if (b + 512 * (i - i0) + lane < nvalid)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.dQ2 + fb + b + lane),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qrow + (4u * (unsigned)b + l4)),
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)((float*)S + b), 4, (i - i0) * 2048, 0);
         });
         static_for<0, (NFL / 4 + 511) / 512>([&](auto I) {                   // stash: one dword (4 cells) per lane, 512 lanes per round
             const int d = 512 * decltype(I)::value + 64 * wave;
-            if (4 * (d + lane) < nvalid) dma4(a.st2 + fb + 4 * (d + lane), S + NFL * 4 + 4 * d);
+            if (4 * (d + lane) < nvalid) dma4(srow + (4u * (unsigned)d + l4), S + NFL * 4 + 4 * d);
         });
     };
     // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
@@ -2213,18 +2219,17 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     if (pass) __syncthreads();                                             // the previous pass's T (LDS) has been gathered
     // routing role of this thread: position gp = 64 * pass + lane (gy, gx) of the O2W x O2W gradient map, channel quad qd = wave of the K step's 32
     const int gp = 64 * pass + lane, gy = gp / O2W_, gx = gp % O2W_, qd = wave;
-    // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells), and the stash
-    // code that routes window w here: argmax == w (and, ReLU, the pre-activation positive: bit 2); 15 never matches (window off the map,
-    // or a lane past the last position: its image row is zeros)
-    int adq[4], ast[4], wcode[4];
+    // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells).  The stash code
+    // that routes window w here is w (argmax) with bit 2 = the pre-activation was positive; stash bytes are <= 7 by construction, so they
+    // are compared WHOLE (no masking), and a window off the map (or a lane past the last position: its image row is zeros) reads the byte 8
+    int adq[4], ast[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
         const int py = gy - (w >> 1), px = gx - (w & 1);
         const bool ok = gp < NPOS_ && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
         const int cell = 4 * qd * NP2_ + (ok ? py * P2W_ + px : 0);
         adq[w] = 4 * cell;
-        ast[w] = NFL * 4 + cell;
-        wcode[w] = ok ? (ACT == RBNN_ACT_RELU ? (w | 4) : w) : 15;
+        ast[w] = ok ? NFL * 4 + cell : NFL * 5;                            // off the map (or a lane past the last position): the never-matching byte (+ j NP2 <= 4 NP2 of them)
     }
     const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
     // routing of ONE channel (j of this thread's quad) of K step ks from staging buffer sbuf: pool-2 argmax + activation derivative (gather
@@ -2252,15 +2257,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         // tests are one compare of the stash's low three bits (a cell whose pre-activation was <= 0 passes nothing on).
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < 4; ++w) {                                      // (w: a constant after unrolling — compares against immediates)
             if (ACT == RBNN_ACT_RELU) {
-                v += (st[w] & 7) == wcode[w] ? dq[w] : 0.f;
-            } else if (ACT == RBNN_ACT_LEAKY) {                            // factor 1 / slope / 0 from the same three bits
-                const int m = st[w] & 7;
-                v = fmaf(dq[w], m == (wcode[w] | 4) ? 1.f : (m == wcode[w] ? slope : 0.f), v);
+                v += st[w] == (w | 4) ? dq[w] : 0.f;
+            } else if (ACT == RBNN_ACT_LEAKY) {                            // factor 1 / slope / 0
+                v = fmaf(dq[w], st[w] == (w | 4) ? 1.f : (st[w] == w ? slope : 0.f), v);
             } else {
-                const float g = (smooth_act<ACT>() || (st[w] & 4)) ? dq[w] : dq[w] * slope;   // smooth: act' already folded into dQ2
-                v += (st[w] & 3) == wcode[w] ? g : 0.f;
+                v += (st[w] & 11) == w ? dq[w] : 0.f;                      // sigmoid / tanh: act' is already folded into dQ2; bit 2 of the stash is ignored, bit 3 marks the dummy
             }
         }
         const float vs = (live ? v : 0.f) * in_scale;
@@ -2304,6 +2307,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         }
     };
 
+    if (pass == 0)                                                         // the never-matching stash bytes of both staging buffers (ordered before their first read by the prologue's barrier)
+        for (int i = tid; i < 2 * ((L::STG - NFL * 5) / 4); i += 512) {
+            constexpr int ND = (L::STG - NFL * 5) / 4;
+            *(unsigned*)(lds + L::SOFF + (i / ND) * L::STG + NFL * 5 + 4 * (i % ND)) = 0x08080808u;
+        }
     // K steps 0 and 1 are staged together (one HBM round trip, not two) — by the first pass here, for a later pass by the pass before it, ahead
     // of its col2im (the rows staged do not depend on the pass)
     if (pass == 0) {
