@@ -48,7 +48,7 @@ def test_ablation_switches_are_fenced(tmp_path):
     base = [ge.HIPCC, "--offload-arch=gfx950", "-std=c++17", "--cuda-host-only", "-o", str(tmp_path / "probe"), str(src)]
     r = subprocess.run(base + ["-DRBNN_DENSE_ABL_NOEPI"], capture_output=True, text=True)
     assert r.returncode != 0 and "RBNN_ALLOW_ABLATION" in r.stderr
-    for flag in ("-DRBNN_ABL=4", "-DRBNN_X3_L1_ABL_SMALL", "-DRBNN_FAST_BUILD"):
+    for flag in ("-DRBNN_ABL=4", "-DRBNN_X3_L1_ABL_SMALL", "-DRBNN_FAST_BUILD", "-DRBNN_DENSE_STAMPS=1", "-DRBNN_DENSE_ABL_PARTA=16"):   # (round 4: the stamp build, the partial weight tiles)
         assert subprocess.run(base + [flag], capture_output=True).returncode != 0
     assert subprocess.run(base, capture_output=True).returncode == 0 and subprocess.run([str(tmp_path / "probe")]).returncode == 0
     assert subprocess.run(base + ["-DRBNN_DENSE_ABL_NOEPI", "-DRBNN_ALLOW_ABLATION"], capture_output=True).returncode == 0
