@@ -1823,7 +1823,7 @@ __global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a
 // c = 16 (e >> 2) + 4 lg + (e & 3): exactly the (channel block, quad) elements the routing already holds per lane.  Scales: the weights by
 // the wave's own max |w| (its A operand is the sample's whole conv1 weight tensor); the routed gradients by max |dP1| of the (sample,
 // point), which the dense conv2^T kernel leaves in G[sn][0] (this kernel reads it before it writes G) — so only rbnn_conv_input_grad_dense
-// launches this kernel; the other conv2^T forms keep the fp32 one.
+// launches this kernel, and only for more than one input channel (launch_conv1_backward); the other conv2^T forms keep the fp32 one.
 template <int ACT, class G>
 __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) {
     constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW, CIN = G::CIN;
@@ -1983,7 +1983,7 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
 template <int ACT, class G>
 int launch_conv1_backward(const ConvBwdArgs& a, hipStream_t st, bool dp1_max_in_g = false) {
 #if RBNN_CONV1_BWD_X3
-    if (dp1_max_in_g) {
+    if (dp1_max_in_g && G::CIN > 1) {                                    // one input channel (1x28x28): two row tiles either way, and the fp32 kernel runs three waves per SIMD — measured 0.73 against 0.79 ms
         hipLaunchKernelGGL((conv1_bwd_x3_kernel<ACT, G>), dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
         return launch_status();
     }
@@ -2537,7 +2537,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             }
         }
 #if RBNN_CONV1_BWD_X3
-        if (pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
+        if (G::CIN > 1 && pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
             float* const wm = (float*)(lds + L::EPI);                      // (the rings' area: free)
