@@ -21,6 +21,9 @@
 #ifndef RBNN_DENSE_COL2IM_RMW
 #define RBNN_DENSE_COL2IM_RMW 1
 #endif
+#ifndef RBNN_CONV1_BWD_X3_MINCIN
+#define RBNN_CONV1_BWD_X3_MINCIN 2                                        // input channels from which conv1^T runs on the f16 pipe (1x28x28 keeps the fp32 kernel: see launch_conv1_backward)
+#endif
 #ifndef RBNN_CONV1_BWD_X3
 #define RBNN_CONV1_BWD_X3 RBNN_DENSE_COL2IM_RMW                            // conv1^T behind the dense kernel on the f16 matrix pipe (triple-split), scaled by the dense kernel's max |dP1|
 #endif
@@ -1670,7 +1673,7 @@ __global__ void __launch_bounds__(256) conv1_bwd_kernel(const ConvBwdArgs a) {
 // With Cin > 1 the pass is repeated per input channel (the routed B operand is rebuilt from L2-resident data; the ring stays 62.5 KiB).
 template <class G> constexpr int conv1_bwd_ts() { return G::O1 % 8 == 0 ? G::O1 + 2 : G::O1; }
 template <int ACT, class G>
-__global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
+__global__ void __launch_bounds__(256, (G::CIN == 1 ? 3 : 2)) conv1_bwd_mfma_kernel(const ConvBwdArgs a) {
     // T row buffer of ONE position row: [25 taps][TS Xa]; TS >= O1 with 4 * TS = 8 or 16 mod 32 (26 for O1 = 24, 28 for O1 = 28) keeps the
     // accumulator stores at the 2-way minimum of a 64-lane ds_write_b32 (the four tap groups of a store land on different banks).
     // Round 4: the last five rows of T used to sit in an LDS ring (14 KB per wave and input channel: two blocks per CU at 3x32x32, and the pass
@@ -1691,6 +1694,10 @@ __global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a
     const long long sn = (long long)s * a.N + n;
     float* const T = lds + wave * TROW;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+    int xcl[5];                                                           // the gather's column X - kx, clamped into the T row, and whether it lies inside
+    bool xok[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) { xok[kx] = lane - kx >= 0 && lane - kx <= G::O1 - 1; xcl[kx] = min(max(lane - kx, 0), G::O1 - 1); }
 
     // this lane's 16 (channel, position) elements of a pooled row: pt = position tile (Xa = 16pt + li), channel c = 16kb + 4lg + r
     int eoff[2][2][4];
@@ -1789,13 +1796,23 @@ __global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a
                             if (tap < 25 && 16 * pt + li < TS) T[tap * TS + 16 * pt + li] = acc[mt][pt][r];
                         }
                 if (lane < IW) {                                         // this T row's share of output rows Ya + ky: dX[Ya + ky][X] += T[(ky, kx)][X - kx]
+                    // all 25 reads first, UNCONDITIONAL at a clamped column, then the adds with the terms outside the row selected to +0: written as
+                    // `if (inside) ring += T[..]` every term became its own exec-masked block with its own wait — 25 dependent LDS round trips per
+                    // (row, input channel), ~90 % of this kernel's time (rocprofv3 + the instruction mix, round 4 third part)
+                    // (two tap rows = ten reads at a time, fenced: all 25 at once cost 24 registers and a wave per SIMD)
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky)
+                    for (int ky0 = 0; ky0 < 5; ky0 += 2) {
+                        float tv[2][5];
 #pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) {
-                            const int Xp = lane - kx;
-                            if (Xp >= 0 && Xp <= O1 - 1) ring[ci][ky] += T[(ky * 5 + kx) * TS + Xp];
-                        }
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int kx = 0; kx < 5; ++kx) if (ky0 + k2 < 5) tv[k2][kx] = T[((ky0 + k2) * 5 + kx) * TS + xcl[kx]];
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int kx = 0; kx < 5; ++kx) if (ky0 + k2 < 5) ring[ci][ky0 + k2] += xok[kx] ? tv[k2][kx] : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             // output row Ya has now received its last contribution (T rows Ya - 4 .. Ya): emit it, rotate the partial rows
@@ -1825,7 +1842,7 @@ __global__ void __launch_bounds__(256) conv1_bwd_mfma_kernel(const ConvBwdArgs a
 // point), which the dense conv2^T kernel leaves in G[sn][0] (this kernel reads it before it writes G) — so only rbnn_conv_input_grad_dense
 // launches this kernel, and only for more than one input channel (launch_conv1_backward); the other conv2^T forms keep the fp32 one.
 template <int ACT, class G>
-__global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) {
+__global__ void __launch_bounds__(256, 2) conv1_bwd_x3_kernel(const ConvBwdArgs a) {
     constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW, CIN = G::CIN;
     constexpr int MROWS = CIN * 25, MT = (MROWS + 15) / 16;
     constexpr int TS = conv1_bwd_ts<G>(), TROW = MT * 16 * TS;            // all MT * 16 rows exist: the accumulator stores need no row test
@@ -1841,6 +1858,10 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
     const long long sn = (long long)s * a.N + n;
     float* const T = lds + wave * TROW;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+    int xcl[5];                                                           // the gather's column X - kx, clamped into the T row, and whether it lies inside
+    bool xok[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) { xok[kx] = lane - kx >= 0 && lane - kx <= G::O1 - 1; xcl[kx] = min(max(lane - kx, 0), G::O1 - 1); }
     float* const Gout = a.G + sn * G::DIN;
     const float gmax = Gout[0];                                          // max |dP1| of this (sample, point), from conv_bwd_dense_x3_kernel
 
@@ -1905,7 +1926,7 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
     fetch(0);
     for (int py = 0; py < P1W_; ++py) {
         float gv[2][2][4];
-        int ar[2][2][4];
+        unsigned arp = 0;                                                // 2 bits per element (16 registers as ints: the difference between one and two waves per SIMD here)
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
@@ -1915,8 +1936,9 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
                     const int Xa = 16 * pt + li, st = stn[pt][kb][r];
                     const float d = dn[pt][kb][r] * g_scale;
                     gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
-                    ar[pt][kb][r] = (st & 3) ^ (Xa & 1);                 // == 2*half for the row half that owns the argmax, with the right column parity
+                    arp |= (unsigned)((st & 3) ^ (Xa & 1)) << (2 * ((pt * 2 + kb) * 4 + r));   // == 2*half for the row half that owns the argmax, with the right column parity
                 }
+        auto ar = [&](int pt, int kb, int r) { return (int)((arp >> (2 * ((pt * 2 + kb) * 4 + r))) & 3u); };
         if (py + 1 < P1W_) fetch(py + 1);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -1926,8 +1948,8 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
             for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
-                    const float ve = (ar[pt][e >> 2][e & 3] == 2 * half) ? gv[pt][e >> 2][e & 3] : 0.f;               // arg = 2*dy + dx
-                    const float vo = (ar[pt][(e + 1) >> 2][(e + 1) & 3] == 2 * half) ? gv[pt][(e + 1) >> 2][(e + 1) & 3] : 0.f;
+                    const float ve = (ar(pt, e >> 2, e & 3) == 2 * half) ? gv[pt][e >> 2][e & 3] : 0.f;               // arg = 2*dy + dx
+                    const float vo = (ar(pt, (e + 1) >> 2, (e + 1) & 3) == 2 * half) ? gv[pt][(e + 1) >> 2][(e + 1) & 3] : 0.f;
                     split3_plain_pair(ve, vo, 1.f, b0[pt].w[e >> 1], b1[pt].w[e >> 1], b2[pt].w[e >> 1]);
                 }
             f32x4 acc[MT][2];
@@ -1953,14 +1975,21 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
                         if (16 * pt + li < TS) T[(16 * mt + 4 * lg + r) * TS + 16 * pt + li] = acc[mt][pt][r];   // T[m][Xa]
             if (lane < IW) {                                             // this T row's share of output rows Ya + ky: dX[ci][Ya + ky][X] += T[ci * 25 + (ky, kx)][X - kx]
 #pragma unroll
-                for (int ci = 0; ci < CIN; ++ci)
+                for (int ci = 0; ci < CIN; ++ci) {                       // (unconditional reads at clamped columns, then selected adds: see conv1_bwd_mfma_kernel)
 #pragma unroll
-                    for (int ky = 0; ky < 5; ++ky)
+                    for (int ky0 = 0; ky0 < 5; ky0 += 2) {               // (two tap rows = ten reads at a time, fenced: registers)
+                        float tv[2][5];
 #pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) {
-                            const int Xp = lane - kx;
-                            if (Xp >= 0 && Xp <= O1 - 1) ring[ci][ky] += T[(ci * 25 + ky * 5 + kx) * TS + Xp];
-                        }
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int kx = 0; kx < 5; ++kx) if (ky0 + k2 < 5) tv[k2][kx] = T[(ci * 25 + (ky0 + k2) * 5 + kx) * TS + xcl[kx]];
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int kx = 0; kx < 5; ++kx) if (ky0 + k2 < 5) ring[ci][ky0 + k2] += xok[kx] ? tv[k2][kx] : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
             // output row Ya has now received its last contribution (T rows Ya - 4 .. Ya): emit it, rotate the partial rows
 #pragma unroll
@@ -1983,7 +2012,7 @@ __global__ void __launch_bounds__(256) conv1_bwd_x3_kernel(const ConvBwdArgs a) 
 template <int ACT, class G>
 int launch_conv1_backward(const ConvBwdArgs& a, hipStream_t st, bool dp1_max_in_g = false) {
 #if RBNN_CONV1_BWD_X3
-    if (dp1_max_in_g && G::CIN > 1) {                                    // one input channel (1x28x28): two row tiles either way, and the fp32 kernel runs three waves per SIMD — measured 0.73 against 0.79 ms
+    if (dp1_max_in_g && G::CIN >= RBNN_CONV1_BWD_X3_MINCIN) {                                    // one input channel (1x28x28): two row tiles either way, and the fp32 kernel runs three waves per SIMD — measured 0.73 against 0.79 ms
         hipLaunchKernelGGL((conv1_bwd_x3_kernel<ACT, G>), dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
         return launch_status();
     }
@@ -2537,7 +2566,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             }
         }
 #if RBNN_CONV1_BWD_X3
-        if (G::CIN > 1 && pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
+        if (G::CIN >= RBNN_CONV1_BWD_X3_MINCIN && pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
             float* const wm = (float*)(lds + L::EPI);                      // (the rings' area: free)
