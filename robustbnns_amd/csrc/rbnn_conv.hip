@@ -2199,7 +2199,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     auto dma4 = [&](const void* g, void* l) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
     };
-    auto stage_issue = [&](int ks, int buf) {                               // rows of channels 32ks .. of dQ2 and of the stash: contiguous in memory
+    // (wholec = std::true_type: the step is known to be a whole one — Hc % 32 == 0 —, so the pieces that lie inside a whole step entirely need no
+    // per-lane test: the K loop's calls; each tested piece is an exec-masked block of five instructions around its DMA)
+    auto stage_issue = [&](int ks, int buf, auto wholec) {                  // rows of channels 32ks .. of dQ2 and of the stash: contiguous in memory
+        constexpr bool WH = decltype(wholec)::value;
         char* const S = lds + L::SOFF + buf * L::STG;
         const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
         const long long fb = sn * F + (long long)ks * NFL;
@@ -2210,13 +2213,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         static_for<0, (NFL + 511) / 512>([&](auto I) {                       // pieces 2 KiB apart on both sides: pairs share address and M0
             constexpr int i = decltype(I)::value, i0 = i & ~1;
             const int b = 512 * i0 + 64 * wave;                             // wave-uniform destination base
-            if (b + 512 * (i - i0) + lane < nvalid)
+            if ((WH && 512 * i + 512 <= NFL) || b + 512 * (i - i0) + lane < nvalid)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qrow + (4u * (unsigned)b + l4)),
                                                  (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)((float*)S + b), 4, (i - i0) * 2048, 0);
         });
         static_for<0, (NFL / 4 + 511) / 512>([&](auto I) {                   // stash: one dword (4 cells) per lane, 512 lanes per round
             const int d = 512 * decltype(I)::value + 64 * wave;
-            if (4 * (d + lane) < nvalid) dma4(srow + (4u * (unsigned)d + l4), S + NFL * 4 + 4 * d);
+            if ((WH && 512 * decltype(I)::value + 512 <= NFL / 4) || 4 * (d + lane) < nvalid) dma4(srow + (4u * (unsigned)d + l4), S + NFL * 4 + 4 * d);
         });
     };
     // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
@@ -2344,8 +2347,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // K steps 0 and 1 are staged together (one HBM round trip, not two) — by the first pass here, for a later pass by the pass before it, ahead
     // of its col2im (the rows staged do not depend on the pass)
     if (pass == 0) {
-        stage_issue(0, 0);
-        if (KS > 1) stage_issue(1, 1);
+        stage_issue(0, 0, std::false_type{});
+        if (KS > 1) stage_issue(1, 1, std::false_type{});
     }
     tile_issue(0, 0, 0); tile_issue(0, 1, 1); tile_issue(0, 2, 2);         // (a wave has >= 6 taps)
     if (pass == 0) set_scales();
@@ -2400,7 +2403,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             tile_issue((t + 3) / NT ? ksn : ks, (t + 3) % NT, (gk + t + 3) & (L::RING - 1));
         };
         issue(std::integral_constant<int, 0>{});                           // tap 0's tile, then the staging pieces — both before the B fragments are
-        stage_issue(min(ks + 2, KS - 1), ks & 1);                          // live: the pieces' per-lane addresses need registers of their own
+        stage_issue(min(ks + 2, KS - 1), ks & 1, WHOLEC);                  // live: the pieces' per-lane addresses need registers of their own
         const char* const I = lds + (ks & 1) * L::IMG + foff;
 #ifdef RBNN_DENSE_ABL_NOB
         if (ks == 0)                                                       // ablation (timing only): the B fragments of the first K step serve all
@@ -2473,8 +2476,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         else { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, Z{}); }
     }
     if (pass + 1 < NPASS) {                                                // the next pass's first two K steps: they land under this pass's col2im (whose barriers do not wait for them)
-        stage_issue(0, 0);
-        if (KS > 1) stage_issue(1, 1);
+        stage_issue(0, 0, std::false_type{});
+        if (KS > 1) stage_issue(1, 1, std::false_type{});
     }
     DSTAMP(8 * pass + 1);                                                  // K loop
     // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
