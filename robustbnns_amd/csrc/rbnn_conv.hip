@@ -2148,7 +2148,7 @@ template <class G> struct ConvBwdDenseLds {
 #endif
     static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
     static_assert(EPI <= SOFF, "the staging buffers must survive the col2im");
-    static_assert(EPI + 64 <= SOFF, "room for the eight wave maxima behind the col2im images");
+    static_assert(EPI + 64 + 8 * 1024 <= SOFF, "room for the eight wave maxima and the waves' dummy records behind the col2im images");
     static_assert(BYTES <= 160 * 1024, "LDS");
     static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
 };
@@ -2515,6 +2515,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         for (int i = lane; i < L::EIMG / 16; i += 64) *(f32x4*)(img + 16 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
         int o0[NPT];
         bool val[NPT];
+        const int dummy = (L::EPI + 64 + lane * 16) - wave * L::EIMG + wave * 1024;   // (relative to img) behind the images and the wave maxima: 1 KiB per wave
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int gpos = 64 * pass + 16 * pt + li;                     // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][gpos]
@@ -2530,12 +2531,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
 #pragma unroll
                 for (int pt = 0; pt < NPT; ++pt) {                         // the tile's reads together, then its writes
                     const int o = o0[pt] + shift;
-                    ad[pt] = o * 64 + ((lg ^ ((o >> 2) & 3)) << 4);
-                    if (val[pt]) cur[pt] = *(const f32x4*)(img + ad[pt]);
+                    // lanes past the last position (the last pass's last tile) go through a private dummy record instead of an exec-masked
+                    // block per access (a masked LDS read is waited for inside its block: one round trip each, in series)
+                    ad[pt] = val[pt] ? o * 64 + ((lg ^ ((o >> 2) & 3)) << 4) : dummy;
+                    cur[pt] = *(const f32x4*)(img + ad[pt]);
                 }
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt)
-                    if (val[pt]) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
+                for (int pt = 0; pt < NPT; ++pt) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
             }
         ring_wait_barrier<63>();
         float omax = 0.f;
