@@ -189,6 +189,25 @@ def test_triple_abi_rejects_bad_arguments():
     assert lib.rbnn_conv_input_grad_triple(C.byref(cnet), None, 0, 1.0, None, 1, 4, None, None) != 0
 
 
+def test_lowdim_fc2_scratch_holds_the_sign_bit_stash():
+    """rbnn_lowdim_scratch_bytes (host arithmetic only): fc = the per-sample outputs; fc2 = outputs + gradient slabs + the sum over samples
+    + 16 bytes per thread of every low2_kernel block for the sign bits the forward launch leaves to the backward launch (round 4)."""
+    import ctypes as C
+    lib = _hip.load()
+    net = _hip.Posterior()
+    net.in_features, net.n_classes, net.hidden, net.in_stride = 2, 2, 128, 16
+    N, S = 100, 250
+    net.arch = 0                                                   # RBNN_ARCH_FC
+    assert lib.rbnn_lowdim_scratch_bytes(C.byref(net), N, S) == S * N * 16 * 4
+    net.arch = 1                                                   # RBNN_ARCH_FC2
+    base = 2 * S * N * 16 * 4 + N * 16 * 4
+    groups, blocks = (N + 31) // 32, 8 * ((N + 31) // 32) * ((S + 7) // 8)
+    assert lib.rbnn_lowdim_scratch_bytes(C.byref(net), N, S) == base + blocks * 256 * 16 and groups == 4
+    # hidden 128 runs 256-thread blocks of <= 112 points: one block per sample here, 8 * ceil(250 / 8) = 256 blocks of 4 KiB used
+    assert blocks * 256 * 16 >= 256 * 256 * 16
+    assert lib.rbnn_lowdim_scratch_bytes(None, N, S) == 0 and lib.rbnn_lowdim_scratch_bytes(C.byref(net), 0, S) == 0
+
+
 def test_compute_refuses_cpu_tensors():
     post = O.synthetic_posterior("fc", 2, 64, 2, 3, 0.5)
     sp = StackedPosterior("fc", "leaky", (1, 2, 1), 2, 64, post, "cpu")
