@@ -21,6 +21,12 @@
 #ifndef RBNN_DENSE_COL2IM_RMW
 #define RBNN_DENSE_COL2IM_RMW 1
 #endif
+#ifndef RBNN_FCBWD_NT
+#define RBNN_FCBWD_NT 1                                                    // conv_fc_bwd writes dQ2 (5 GB per C5 pass, re-read from HBM by the dense kernel in any case) with non-temporal stores:
+#endif                                                                     // they no longer push the sample's Fw out of the L2 — 1.54 -> 1.25 ms (same box, alternating: backward call 16.3 -> 16.0 ms)
+#ifndef RBNN_X3FWD_NT
+#define RBNN_X3FWD_NT 0                                                    // the same for conv2_pool_x3_kernel's Q2 / stash stores
+#endif
 #ifndef RBNN_CONV1_BWD_X3_MINCIN
 #define RBNN_CONV1_BWD_X3_MINCIN 2                                        // input channels from which conv1^T runs on the f16 pipe (1x28x28 keeps the fp32 kernel: see launch_conv1_backward)
 #endif
@@ -795,8 +801,13 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
                         stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
                     }
                     const long long o = sn * F + (long long)hcb * NP2_ + 4 * i4;       // a multiple of 4
+#if RBNN_X3FWD_NT
+                    __builtin_nontemporal_store(q, (f32x4*)(a.Q2 + o));
+                    __builtin_nontemporal_store(stw, (unsigned*)(a.st2 + o));
+#else
                     *(f32x4*)(a.Q2 + o) = q;
                     *(unsigned*)(a.st2 + o) = stw;
+#endif
                 }
             }
         }
@@ -1047,7 +1058,11 @@ __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_value<ACT>(h[r]);
             }
+#if RBNN_FCBWD_NT
+            __builtin_nontemporal_store(v, (f32x4*)dst);
+#else
             *(f32x4*)dst = v;
+#endif
         }
     }
 }
