@@ -1024,23 +1024,29 @@ __global__ void __launch_bounds__(256) conv_fc_bwd_kernel(const ConvBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[4][16 * 68];
     const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4, wv = threadIdx.x >> 6;
     const int F = a.Hc * a.NP2, FT = (F + 63) / 64, NT = (a.N + 15) / 16;
-    const long long item = (long long)blockIdx.x * 4 + wv;
-    if (item >= (long long)a.S * NT * FT) return;                        // (a whole wave: the tile is wave-private, no block barrier anywhere)
-    const int ft = (int)(item % FT), nt = (int)((item / FT) % NT), s = (int)(item / ((long long)FT * NT));
+    // (32-bit item arithmetic: the launch checks S * NT * FT < 2^31; 64-bit division by run-time values was ~400 of this kernel's 900 instructions)
+    const unsigned item = blockIdx.x * 4u + (unsigned)wv;
+    if (item >= (unsigned)a.S * (unsigned)NT * (unsigned)FT) return;     // (a whole wave: the tile is wave-private, no block barrier anywhere)
+    const unsigned it2 = item / (unsigned)FT;
+    const int ft = (int)(item - it2 * (unsigned)FT), s = (int)(it2 / (unsigned)NT), nt = (int)(it2 - (unsigned)s * (unsigned)NT);
     const int sw = a.sidx ? a.sidx[s] : s;
     const int n = min(nt * 16 + li, a.N - 1);
     const f32x4 av = *(const f32x4*)(a.dZ + ((long long)s * a.N + n) * RBNN_CPAD + 4 * lg);     // A[i = n][k = lg] for K step r: class 4lg + r
     float* const T = tile[wv];
+    // B[k = class][j = feature]: one wave-uniform 64-bit base (the sample's Fw) + 32-bit offsets, classes past C read class C - 1 and are selected to 0
+    // (spelled `c < C ? Fw[64-bit index] : 0`, each of the 16 loads was an exec-masked block behind a 64-bit multiply-add: 909 instructions per 4 KB of output)
+    const float* const Fws = a.Fw + (long long)sw * a.C * F;
+    unsigned coff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) coff[r] = (unsigned)min(4 * lg + r, a.C - 1) * (unsigned)F + (unsigned)(ft * 64 + li);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int f = ft * 64 + q * 16 + li;                                                  // F = NP2*Hc is a multiple of 16
-        if (ft * 64 + q * 16 >= F) break;
+        if (ft * 64 + q * 16 >= F) break;                                                     // F = NP2*Hc is a multiple of 16
         f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int c = 4 * lg + r;
-            const float b = c < a.C ? a.Fw[((long long)sw * a.C + c) * F + f] : 0.f;          // B[k = lg][j = f]
-            d = MFMA16(av[r], b, d);
+            const float bl = Fws[coff[r] + 16u * q];
+            d = MFMA16(av[r], 4 * lg + r < a.C ? bl : 0.f, d);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) T[(4 * lg + r) * 68 + q * 16 + li] = d[r];                 // d[r] = dQ2[n = 16nt + 4lg + r][f]
@@ -2048,6 +2054,7 @@ int launch_conv_backward(const ConvBwdArgs& a, hipStream_t st) {
     int rc;
     {
         const long long F = (long long)a.Hc * G::NP2, items = (long long)a.S * ((a.N + 15) / 16) * ((F + 63) / 64);
+        if (items >= (1LL << 31)) return (int)RBNN_ERR_SHAPE;                     // conv_fc_bwd_kernel decodes its item number in 32 bits
         hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
         if ((rc = launch_status())) return rc;
     }
@@ -2094,6 +2101,7 @@ extern "C" int rbnn_conv_input_grad_split(const rbnn_conv_posterior* net, const 
     hipStream_t st = (hipStream_t)stream;
     {
         const long long F = (long long)net->hidden * NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+        if (items >= (1LL << 31)) return (int)RBNN_ERR_SHAPE;                     // conv_fc_bwd_kernel decodes its item number in 32 bits
         hipLaunchKernelGGL((conv_fc_bwd_kernel<false, RBNN_ACT_LEAKY>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
         if ((rc = launch_status())) return rc;
     }
@@ -2767,6 +2775,7 @@ extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const 
             int rc2;
             {
                 const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+                if (items >= (1LL << 31)) return (int)RBNN_ERR_SHAPE;                     // conv_fc_bwd_kernel decodes its item number in 32 bits
                 hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
                 if ((rc2 = launch_status())) return rc2;
             }
@@ -2813,6 +2822,7 @@ extern "C" int rbnn_conv_input_grad_triple(const rbnn_conv_posterior* net, const
             int rc2;
             {
                 const long long F = (long long)a.Hc * G::NP2, items = (long long)S * ((N + 15) / 16) * ((F + 63) / 64);
+                if (items >= (1LL << 31)) return (int)RBNN_ERR_SHAPE;                     // conv_fc_bwd_kernel decodes its item number in 32 bits
                 hipLaunchKernelGGL((conv_fc_bwd_kernel<smooth_act<ACT>(), ACT>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, a);
                 if ((rc2 = launch_status())) return rc2;
             }
