@@ -13,7 +13,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 if [ "$STAGE" = "tests" ]; then
+  # (a heartbeat: the filtered log below appears only when pytest ends, and gpurun takes seven silent minutes for a hang)
+  (while sleep 60; do echo "[profile_round] tests running"; done) & HB=$!
   (timeout 1100 python -m pytest tests -m gpu -q -s 2>&1 | grep -vE "^(Saving|Loading|Producing|Evaluating|test accuracy|avg softmax|vanishing|increasing|null|image_idx| === |min = |$)" | tail -600) > $OUT/pytest_gpu.log
+  kill $HB 2>/dev/null
   tail -2 $OUT/pytest_gpu.log
   python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 fi
