@@ -21,9 +21,12 @@ every forward, model_bnn.py:230-232); the line's `svi` record carries the draw's
 stored samples is the `stored_posterior_mode` sub-record.  c3 says "HMC" (stored samples); c4 names neither (stored); c5 / conv say
 SVI too (one launch draws the six tensors, the conv2 weight images are rebuilt by their builders).
 
-N GPUs: one process per GPU; the posterior is SAMPLE-sharded (each rank holds its own S samples, so the job has S*N
-samples: weak scaling) and each step all-reduces sum_s p_s [N,16] and the summed gradients [N,784] over RCCL/xGMI
-(north star).  `--shard points` replicates the samples and splits points instead (no collective).
+N GPUs: one process per GPU.  With no --workload, `--gpus 1` runs C2 (BASELINE.json configs[1]) and `--gpus N` (N > 1) runs **C4**
+(configs[3]: n_samples = 2000 sharded 8-way = 250 samples per GPU, expected_loss_gradients + FGSM, the posterior SAMPLE-sharded, each
+step all-reducing sum_s p_s [N,16] and the summed gradients [N,784] over RCCL/xGMI — north star; weak scaling: per-GPU
+work fixed, at N = 8 exactly the config) as the headline, and attaches C2 POINT-sharded (`c2_point_sharded`: n_samples = 100 kept on every
+rank, the config's 10 000 points split over the ranks, no data-path collective, strong scaling) as a sub-record.  An explicit
+--workload / --shard runs that one record only.  `--shard points` replicates the samples and splits the workload's points over the ranks.
 
 Precision (`--precision`, default auto = the package's default).  Every mode computes on fp32 VALUES with fp32 accumulation; they
 differ in the matrix pipe used.  "exact": both GEMMs on v_mfma_f32_16x16x4_f32.  "triple" (what auto resolves to on the fc
@@ -55,6 +58,15 @@ F16_MFMA_SUSTAINED_FRAC = 0.72         # what a bare register-only loop of that 
                                        # tools/mfma_shape_bench.hip, profiles/r02t/experiments.txt (1764-1825 TFLOP/s)
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json `configs`, verbatim (tests/test_host_cpu.py asserts they equal the file's): `config.workload` of a line that measures one of them
+BASELINE_CONFIGS = {
+    "c1": "Half-Moons fc-BNN (2\u219264\u21922), SVI, n_samples=10, FGSM on 100 test points, --device=cpu reference",
+    "c2": "MNIST fc-BNN (784\u2192512\u219210), SVI, n_samples=100, FGSM eps=0.3 on 10k test points, 1\u00d7MI355X",
+    "c3": "Fashion-MNIST fc-BNN, HMC posterior, n_samples=500, PGD(iters=40, eps=0.3), 10k test points, 1\u00d7MI355X",
+    "c4": "MNIST fc-BNN, n_samples=2000 sharded 8-way, expected_loss_gradients + FGSM, RCCL all-reduce over xGMI, 8\u00d7MI355X",
+    "c5": "CIFAR-10 conv-BNN, SVI, n_samples=500, PGD(iters=100) grid over eps\u2208{2,4,8}/255, 8\u00d7MI355X with per-GPU HBM GB/s vs roofline",
+}
+
 WORKLOADS = {
     # name: input shape, hidden, classes, arch, act, S per GPU, N, method(s) of one step, iters, eps
     "c2": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
@@ -63,7 +75,7 @@ WORKLOADS = {
                desc="F-MNIST fc-BNN 784->512->10 (leaky), PGD T=40 eps=0.3, N=10000 points, S=500 samples/GPU"),
     # BASELINE.json configs[3]: S=2000 sharded 8-way = 250 samples per GPU; one step = loss_gradients (per-sample loss) + FGSM
     # (mean-probability loss) over all points, i.e. 2 x N x S attack-samples
-    "c4": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=250, N=10000, method="lossgrad+fgsm", iters=1, eps=0.3,
+    "c4": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=250, S_split=(2000, 8), N=10000, method="lossgrad+fgsm", iters=1, eps=0.3,
                passes=2, desc="MNIST fc-BNN 784->512->10 (leaky), expected_loss_gradients + FGSM eps=0.3, N=10000 points, "
                               "S=250 samples/GPU (S=2000 sharded 8-way at 8 GPUs)"),
     "conv": dict(shape=(1, 28, 28), H=512, C=10, arch="conv", act="leaky", S=16, N=2048, method="fgsm", iters=1, eps=0.3,
@@ -214,20 +226,49 @@ def spawn_ranks(args):
     return proc.returncode if (proc.returncode or last_json is not None) else 1
 
 
+class Runtime:
+    """What a bench process takes from the machine: the device of this rank, the collective backend, events and the kernel set.  The
+    host tests (tests/test_host_cpu.py: a 2-rank gloo run of `--gpus 2` with the CPU test double of the kernel interface) replace it;
+    bench.py itself only ever runs this one — HIP kernels through the C-ABI, RCCL, HIP events on the launch stream."""
+    backend = "nccl"                                                       # nccl == RCCL on ROCm
+
+    def open_device(self, local):
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def kernels_base(self):
+        from robustbnns_amd import _hip
+        return _hip.HipKernels
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+
+RUNTIME = Runtime()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)         # C2: 50 x 7.4 ms = 0.37 s timed (the f16-pipe kernels vary by a few % launch to launch)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--shard", default="samples", choices=["samples", "points"])
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: c2 on one GPU (BASELINE configs[1], what BENCH records); with --gpus N > 1: c4 (configs[3]: n_samples = 2000 "
+                         "sharded 8-way, 250 per GPU, sample-sharded over RCCL) as the headline + c2 point-sharded as the sub-record c2_point_sharded")
+    ap.add_argument("--shard", default=None, choices=["samples", "points"],
+                    help="samples (default): every rank holds its own samples and all points, two all-reduces per step, weak scaling; points: every "
+                         "rank holds the same samples and its share of the workload's points, no data-path collective, strong scaling")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--points", type=int, default=0, help="override N (debug)")
     ap.add_argument("--samples", type=int, default=0, help="override S per GPU (debug)")
+    ap.add_argument("--hidden", type=int, default=0, help="override the hidden size (debug)")
     ap.add_argument("--iters", type=int, default=0, help="override the PGD iteration count (debug)")
     ap.add_argument("--samples-total", type=int, default=0,
                     help="the JOB's posterior samples, split over the ranks as evenly as integers allow (rank r: floor(T (r+1) / G) - floor(T r / G)); "
-                         "c5 defaults to its config's 500 split 8-way (62 / 63 per GPU) whatever --gpus is, so that per-GPU work stays fixed")
+                         "c4 / c5 default to their config's 2000 / 500 split 8-way (250; 62 / 63 per GPU) whatever --gpus is, so that per-GPU work stays fixed")
     ap.add_argument("--precision", default="auto", choices=["auto", "exact", "triple", "split", "fast"],
                     help="arithmetic of the line's top level.  auto (the package default) = triple (full-width fp32 operands as three f16 pieces, "
                          "six exact product terms, f32 accumulate) where those kernels cover the workload, else exact (fp32 MFMA); the other "
@@ -245,48 +286,76 @@ def main():
         raise SystemExit(spawn_ranks(args))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    rt = RUNTIME
+    device = rt.open_device(local)
     group = None
     if world > 1 or os.environ.get("RBNN_FORCE_COLLECTIVES") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)           # nccl == RCCL on ROCm
+        if rt.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(rt.backend)
         group = dist.group.WORLD
 
+    # what the line measures.  One GPU: C2, the config BASELINE.json's metric is quoted on (and what the driver's BENCH record holds).  N > 1: the
+    # BASELINE configs that ARE multi-GPU jobs — C4 as the headline (sample-sharded, the north star's all-reduce of the summed gradients; at
+    # N = 8 exactly configs[3]) and C2 with its n_samples = 100 kept, point-sharded ("strictly faster when weights fit"), beside it
+    default_pair = args.workload is None and args.shard is None and world > 1
+    name = args.workload or ("c4" if world > 1 else "c2")
+    out = bench_one(args, name, args.shard or "samples", rt, rank, world, device, group)
+    if default_pair:
+        sub = bench_one(args, "c2", "points", rt, rank, world, device, group, sub_record=True)
+        if rank == 0:
+            out["c2_point_sharded"] = sub
+    if rank == 0:
+        import ctypes
+        # RCCL writes its version banner through C stdio (block-buffered when stdout is a file or pipe): flush it first so
+        # that the JSON line is the LAST line of the output
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+    if group is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=False):
+    """One workload, one sharding: warm up, time EXACTLY --steps steps between barrier + synchronize (max over ranks); rank 0 returns the record."""
     from robustbnns_amd import _hip
 
-    w = dict(WORKLOADS[args.workload])
+    w = dict(WORKLOADS[name])
     if args.points:
         w["N"] = args.points
     if args.samples:
         w["S"] = args.samples
     if args.iters:
         w["iters"] = args.iters
+    if args.hidden:
+        w["H"] = args.hidden
     shard_of = lambda T, ways, r: T * (r + 1) // ways - T * r // ways
-    sr = rank if args.shard == "samples" else 0                           # point-sharded: every rank holds the same (rank 0's) samples
+    sr = rank if shard == "samples" else 0                           # point-sharded: every rank holds the same (rank 0's) samples
     S_ranks = [w["S"]] * world
     if args.samples_total:
-        S_ranks = [shard_of(args.samples_total, world, r if args.shard == "samples" else 0) for r in range(world)]
+        S_ranks = [shard_of(args.samples_total, world, r if shard == "samples" else 0) for r in range(world)]
     elif "S_split" in w and not args.samples:
-        S_ranks = [shard_of(w["S_split"][0], w["S_split"][1], (r if args.shard == "samples" else 0) % w["S_split"][1]) for r in range(world)]
+        S_ranks = [shard_of(w["S_split"][0], w["S_split"][1], (r if shard == "samples" else 0) % w["S_split"][1]) for r in range(world)]
     w["S"] = S_ranks[rank]
     if min(S_ranks) < 1:
         raise SystemExit(f"--samples-total {args.samples_total}: fewer samples than ranks")
     eps_list = list(w["eps"]) if isinstance(w["eps"], (list, tuple)) else [w["eps"]]
     passes = w.get("passes", len(eps_list))                           # hot-path passes (each N x S x iters attack-samples) per step
-    x, y, post = make_problem(w, rank if args.shard == "samples" else 0, device)
+    x, y, post = make_problem(w, rank if shard == "samples" else 0, device)
     D = x[0].numel()
     from robustbnns_amd.factory import make_engine, posterior_from_stacked
     sp = posterior_from_stacked(w["arch"], w["act"], w["shape"], w["C"], w["H"], post, device)
     posterior_kind = args.posterior
     if posterior_kind == "config":
-        posterior_kind = "svi" if args.workload in SVI_NAMED else "stored"
+        posterior_kind = "svi" if name in SVI_NAMED else "stored"
     sp_svi = None
     # the redrawable SVI stack (a second full posterior + its images) is built only when a run will use it: the line's own kind, or the
     # "other kind of posterior" sub-record of a single-GPU fc / fc2 line
     if posterior_kind == "svi" or (world == 1 and w["arch"] != "conv" and not args.no_other_mode):
-        loc, scale = make_guide(w, rank if args.shard == "samples" else 0)
+        loc, scale = make_guide(w, rank if shard == "samples" else 0)
         if w["arch"] == "conv":
             from robustbnns_amd.conv import ConvStackedPosterior, ConvSviGuide
             sp_svi = ConvStackedPosterior.for_guide(ConvSviGuide(loc, scale, device), w["act"], w["shape"], w["C"], w["H"], w["S"])
@@ -294,7 +363,7 @@ def main():
             from robustbnns_amd.posterior import StackedPosterior, SviGuide
             sp_svi = StackedPosterior.for_guide(SviGuide(loc, scale, w["arch"], device), w["act"], w["shape"], w["C"], w["S"])
 
-    class TimedKernels(_hip.HipKernels):
+    class TimedKernels(rt.kernels_base()):
         """HIP events around the two GEMM kernels, on the stream they are launched on (torch's current stream)."""
         def __init__(self):
             super().__init__()
@@ -304,7 +373,7 @@ def main():
         def _timed(self, name, fn, *a, **kw):
             if not self.on:
                 return fn(*a, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = rt.event(), rt.event()
             e0.record()
             r = fn(*a, **kw)
             e1.record()
@@ -353,12 +422,17 @@ def main():
         def conv_input_grad_split(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad_split, *a, **kw)
 
-    if args.shard == "samples":
+    if shard == "samples":
         xs, ys, S_job, N_job = x, y, sum(S_ranks), w["N"]
     else:
-        g = torch.Generator().manual_seed(4321 + rank)                # weak scaling: every rank its own N points
-        xs = torch.rand((w["N"],) + w["shape"], generator=g, dtype=torch.float32) if rank else x
-        ys, S_job, N_job = y, w["S"], w["N"] * world
+        # point-sharded: every rank holds the SAME samples and its share of the workload's points (rank r: [N r / G, N (r+1) / G)) — the job is
+        # the config's own N x S whatever the GPU count (strong scaling), nothing is exchanged in the data path; from here on w["N"] is this
+        # rank's share (what its launches cover)
+        lo, hi = w["N"] * rank // world, w["N"] * (rank + 1) // world
+        xs, ys, S_job, N_job = x[lo:hi], y[lo:hi], w["S"], w["N"]
+        w["N"] = hi - lo
+        if w["N"] < 1:
+            raise SystemExit(f"--shard points: {N_job} points over {world} ranks leaves rank {rank} without work")
     xs = xs.to(device)
     labels = ys.to(device=device, dtype=torch.int32)
 
@@ -375,7 +449,7 @@ def main():
         kind = kind or posterior_kind
         kern = TimedKernels()
         post_ = sp_svi if kind == "svi" else sp
-        if args.shard == "samples":
+        if shard == "samples":
             eng = make_engine(post_, kernels=kern, group=group, total_samples=S_job, precision=precision)
             eng._S_total = S_job
         else:
@@ -415,7 +489,7 @@ def main():
             if lazy_draw:                           # lowdim engines: the draw is generated INSIDE the next rbnn_lowdim_run launch (rbnn_lowdim_run_svi)
                 post_.redraw(key, draws[0], lazy=True)
             elif kern.on:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = rt.event(), rt.event()
                 e0.record()
                 post_.redraw(key, draws[0], **lazy_kw)
                 e1.record()
@@ -435,29 +509,29 @@ def main():
                 for e in eps_list:
                     eng.pgd(xs, labels, w["S"], e, alpha=None, iters=w["iters"], before_step=redraw if kind == "svi" else None)
                     if rank == 0 and w["iters"] * w["N"] >= 200000:        # a step of minutes (c5 at its full definition): a heartbeat on stderr
-                        print(f"[bench] {args.workload}: eps={e:.5f} attack enqueued, t={time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
+                        print(f"[bench] {name}: eps={e:.5f} attack enqueued, t={time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
 
         for _ in range(args.warmup):
             step()
         if pipe:                                                          # the draw's own duration: stand-alone launches, outside the timed region
-            torch.cuda.synchronize()
+            rt.sync()
             for i in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = rt.event(), rt.event()
                 e0.record()
                 post_.redraw(key, 1000 + i)
                 e1.record()
                 draw_ev.append((e0, e1))
             post_._prefetched = False                                     # (those overwrote the front set: start the timed region with a fresh draw)
-        torch.cuda.synchronize()
+        rt.sync()
         barrier()
-        torch.cuda.synchronize()
+        rt.sync()
         kern.on = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        rt.sync()
         barrier()
-        torch.cuda.synchronize()
+        rt.sync()
         dt = time.perf_counter() - t0
         kern.on = False
         if world > 1:
@@ -552,7 +626,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             rec = json.load(open(pmc))
-            wl = rec.get(args.workload) or {}
+            wl = rec.get(name) or {}
             tab, scale, scaled = wl.get("kernels", {}), 1.0, None
             if wl.get("points") and (wl["points"], wl["samples"]) != (w["N"], w["S"]):
                 if w["arch"] == "conv":
@@ -629,10 +703,10 @@ def main():
     SUBKEY = {"exact": "exact_fp32_mode", "triple": "triple_f16x6_mode", "split": "split_f16x3_mode"}
     mode, dt, evs, svi_rec = run(args.precision)
     other_kind = None
-    if world == 1 and not args.no_other_mode and sp_svi is not None and args.workload != "c5":      # the same workload on the other kind of posterior (c5: a step is minutes)
+    if world == 1 and not args.no_other_mode and not sub_record and sp_svi is not None and name != "c5":      # the same workload on the other kind of posterior (c5: a step is minutes)
         other_kind = run(args.precision, "stored" if posterior_kind == "svi" else "svi")
     others = []
-    if world == 1 and not args.no_other_mode:
+    if world == 1 and not args.no_other_mode and not sub_record:
         for want in ("exact", "triple", "split"):                         # the other precision modes on the same workload
             if want == mode or (mode == "lowdim" and want != "exact"):
                 continue
@@ -652,18 +726,22 @@ def main():
         out = {
             "metric": "attack-samples/sec (test_pts x posterior_samples x PGD_iters)",
             "value": units / dt, "unit": "attack-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # weak: per-GPU work fixed as GPUs are added (sample-sharded: every rank its own S samples x all N points); strong: the job fixed
+            # (point-sharded: the config's N x S split over the ranks)
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (shard == "points" and world > 1) else "weak", "vs_baseline": None,
             "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
-            "config": {"workload": w["desc"], "name": args.workload, "points": N_job, "samples_total": S_job, "samples_per_rank": S_ranks,
+            # `workload`: BASELINE.json's own string for the config this line measures (c1 .. c5), `description`: what was run, in full
+            "config": {"workload": BASELINE_CONFIGS.get(name, w["desc"]), "description": w["desc"], "name": name, "points": N_job,
+                       "points_per_rank": ([N_job * (r + 1) // world - N_job * r // world for r in range(world)] if shard == "points" else [N_job] * world), "samples_total": S_job, "samples_per_rank": S_ranks,
                        # the config's own n_samples and how many ranks it is split over (c5: 500 over 8 — this run holds shards 0 .. n_gpus-1 of that split)
                        "n_samples_config": (w["S_split"][0] if "S_split" in w and not args.samples and not args.samples_total else S_job),
                        "n_samples_config_ranks": (w["S_split"][1] if "S_split" in w and not args.samples and not args.samples_total else world),
-                       "iters": w["iters"], "passes_per_step": passes, "shard": args.shard if world > 1 else "none",
+                       "iters": w["iters"], "passes_per_step": passes, "shard": shard if world > 1 else "none",
                        "posterior": ("svi: variational guide, all S samples redrawn in place (rbnn_svi_draw) every step — PGD: every iteration — inside "
                                      "the timed region" if posterior_kind == "svi" else
                                      "stored samples (HMC-style)"),
                        "overrides": {k: v for k, v in (("points", args.points), ("samples", args.samples), ("iters", args.iters),
-                                                       ("samples_total", args.samples_total)) if v}},
+                                                       ("samples_total", args.samples_total), ("hidden", args.hidden)) if v}},
             "roofline": roofline(mode, evs, ms_per_step, posterior_kind == "svi"),
         }
         if svi_rec is not None:
@@ -678,16 +756,11 @@ def main():
             o_ms = 1e3 * other[1] / args.steps
             out[SUBKEY[other[0]]] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],
                                      "roofline": roofline(other[0], other[2], o_ms, posterior_kind == "svi")}
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and not sub_record:
             out["cpu_baseline"] = cpu_baseline(w, x, y, post, args.cpu_seconds)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        # RCCL writes its version banner through C stdio (block-buffered when stdout is a file or pipe): flush it first so
-        # that the JSON line is the LAST line of the output
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
-    if group is not None:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -531,7 +531,8 @@ int rbnn_svi_draw_flat(const rbnn_svi_flat_tensor *tensors, int32_t n_tensors, i
  * and the backward kernel starts at dL/dlogits; sigmoid / tanh and the per-sample loss (which has no forward launch): the backward
  * kernel recomputes the forward.  Same arguments and results as for fc, except that P_scratch must hold rbnn_lowdim_scratch_bytes()
  * bytes (per-sample outputs, per-sample gradient slabs, the sum over samples, the sign bits), is always required, and for
- * RBNN_LOWDIM_ATTACK `out` must not alias X (the iterate is kept in `out`). */
+ * RBNN_LOWDIM_ATTACK `out` must not alias X (the iterate is kept in `out`: iteration 0 reads X with row stride ldx, every later one reads
+ * `out` with ITS row stride ldo — the two strides are independent, a compact out beside a padded X is legal; X0 always has X's stride). */
 typedef enum rbnn_lowdim_op { RBNN_LOWDIM_FORWARD = 0, RBNN_LOWDIM_GRADIENT = 1, RBNN_LOWDIM_ATTACK = 2 } rbnn_lowdim_op;
 int rbnn_lowdim_supported(const rbnn_posterior *net);      /* 1 when rbnn_lowdim_run covers this posterior */
 size_t rbnn_lowdim_scratch_bytes(const rbnn_posterior *net, int32_t n_points, int32_t n_samples);   /* bytes of P_scratch (0: bad arguments) */

@@ -504,8 +504,11 @@ class HipKernels:
                    project, iters, P, out, linf=None, l2=None):
         require_gpu(X, "X")
         lazy = getattr(net, "_lazy", None)
-        if lazy is not None and getattr(net, "_triple", None) is None and S <= lazy[2] and self.lowdim_fused_draw_supported(net, X.shape[0], S):
-            # a pending (lazy) SVI draw: the weights are generated inside this launch — no rbnn_svi_draw launch, the stack stays as it was
+        if (lazy is not None and getattr(net, "_triple", None) is None and sidx is None and S <= lazy[2]
+                and self.lowdim_fused_draw_supported(net, X.shape[0], S)):
+            # a pending (lazy) SVI draw: the weights are generated inside this launch — no rbnn_svi_draw launch, the stack stays as it was.
+            # Only for the identity sample map (the first S <= drawn samples): an index buffer could name samples the draw does not cover —
+            # and would read past sample_keys — so such a call materialises the draw first (net.descriptor() below does) and reads the stack
             key, draw_id, _, sample_keys = lazy
             check(self.lib.rbnn_lowdim_run_svi(C.byref(net.descriptor(lazy_ok=True)), C.byref(net._guide.descriptor()), ptr(sample_keys),
                                                C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF), op, loss_mode, out_kind, ptr(X),

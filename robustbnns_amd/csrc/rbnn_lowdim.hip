@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(256) low2_reduce_kernel(const float* __restric
 struct Low2Finish {
     const float* slabs; const float* Xcur; const float* X0; const float* alpha;
     float *out, *linf, *l2;
-    int S, N, D, ldx, ldo, op, project, alpha_per_image;
+    int S, N, D, ldx, ldcur, ldo, op, project, alpha_per_image;      // ldx: X0's row stride; ldcur: the current iterate's (X's at iteration 0, out's afterwards)
     float out_scale, eps, alpha_scalar;
 };
 
@@ -832,7 +832,7 @@ __global__ void __launch_bounds__(256) low2_finish_kernel(const Low2Finish a) {
         step = 2.f / m;
     }
     if (d < a.D) {
-        const float x = a.Xcur[(long long)n * a.ldx + d];
+        const float x = a.Xcur[(long long)n * a.ldcur + d];
         const float sgn = (G > 0.f) ? 1.f : ((G < 0.f) ? -1.f : 0.f);
         float pert = x + step * sgn;
         if (a.project) pert = x0 + fminf(fmaxf(pert - x0, -a.eps), a.eps);
@@ -911,7 +911,8 @@ int run_low2(const rbnn_posterior* net, int op, int loss, int out_kind, const fl
     a.mask = (RBNN_LOW2_STASH && loss != RBNN_LOSS_PER_SAMPLE && (net->activation == RBNN_ACT_RELU || net->activation == RBNN_ACT_LEAKY)) ? mask : nullptr;
     const int T = op == OP_ATTACK ? iters : 1;
     for (int it = 0; it < T; ++it) {
-        a.X = (it == 0) ? X : out;                                         // the iterate lives in `out` from the first step on
+        a.X = (it == 0) ? X : out;                                         // the iterate lives in `out` from the first step on,
+        a.ldx = (it == 0) ? ldx : ldo;                                     // with out's row stride (a compact out beside a padded X is legal)
         if (loss != RBNN_LOSS_PER_SAMPLE) {
             if ((rc = launch_low2<false>(a, st))) return rc;
             hipLaunchKernelGGL(low2_reduce_kernel, dim3(rgrid), dim3(256), 0, st, P, S, N, net->n_classes, 1.f, Psum, RBNN_CPAD);
@@ -920,7 +921,7 @@ int run_low2(const rbnn_posterior* net, int op, int loss, int out_kind, const fl
         if ((rc = launch_low2<true>(a, st))) return rc;
         Low2Finish f = {};
         f.slabs = slabs; f.Xcur = a.X; f.X0 = X0 ? X0 : X; f.alpha = alpha; f.out = out; f.linf = linf; f.l2 = l2; f.S = S; f.N = N; f.D = net->in_features;
-        f.ldx = ldx; f.ldo = ldo; f.op = op; f.project = project; f.alpha_per_image = alpha_per_image; f.out_scale = out_scale; f.eps = eps;
+        f.ldx = ldx; f.ldcur = a.ldx; f.ldo = ldo; f.op = op; f.project = project; f.alpha_per_image = alpha_per_image; f.out_scale = out_scale; f.eps = eps;
         f.alpha_scalar = alpha_scalar;
         hipLaunchKernelGGL(low2_finish_kernel, dim3(rgrid), dim3(256), 0, st, f);
         if ((rc = launch_status())) return rc;

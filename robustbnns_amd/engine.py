@@ -75,6 +75,13 @@ class AttackEngine:
                 self.world = max(self.world, 2)    # diagnostics: run the all-reduce path even in a 1-rank group
         self._S_total = total_samples
         self._fake_comm = os.environ.get("RBNN_FAKE_COLLECTIVES") == "1" and os.environ.get("RBNN_FORCE_COLLECTIVES") == "1"
+        if self._fake_comm:
+            # diagnostics only (tools/collectives_ab.sh): the sharded launch sequence with NO exchange.  In a group of more than one rank that
+            # would silently return every rank's partial sums as the result, so it is refused there
+            import torch.distributed as dist
+            if group is None or dist.get_world_size(group) != 1:
+                raise _hip.HipError("RBNN_FAKE_COLLECTIVES=1 skips every all-reduce: it is a timing diagnostic for a 1-rank group "
+                                    "(with RBNN_FORCE_COLLECTIVES=1), never valid with more than one rank")
         self._ws_cache = {}
         self.precision = self._resolve_precision(precision)
         self._scales = None                     # device-resident operand scales of an attack's iterates (split mode), set by the attack loops
@@ -230,7 +237,9 @@ class AttackEngine:
         if self.precision == "triple":
             img = self.post.triple_images()
             ds = self._scales if self._scales is not None else self._input_scales(Xp, iterates=False)
-            if not ws.pop("x_image_ready", False):      # (inside a PGD loop the previous attack_step_triple has already written the iterate's image)
+            # inside a PGD loop the previous attack_step_triple has already written the iterate's image — of THAT tensor: the record names the
+            # buffer the image was built for, and any forward on this workspace consumes it (a forward on other inputs overwrites the image)
+            if ws.pop("x_image_ready", None) != Xp.data_ptr():
                 self.k.triple_rows(Xp, self.post.D, 0, ws["triple"]["X_triple"], img.ld_rows, dev_scale=ds, grouped=True)
             gf = ws.get("fc2_groups", (S, S))[0]
             if gf >= S:
@@ -445,7 +454,7 @@ class AttackEngine:
             # PGD: the step also writes the NEW iterate's triple image (rbnn_attack_step_triple) — the next forward launches no builder
             self.k.attack_step_triple(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D,
                                       self._scales, ws["triple"]["X_triple"], self.post.triple_images().ld_rows)
-            ws["x_image_ready"] = True
+            ws["x_image_ready"] = X.data_ptr()
         elif self.world == 1:
             self.k.attack_step(X, X0, ws["slabs"], n_slabs, X.shape[0] * p.Dp, p.Dp, alpha, alpha_scalar, eps, project, p.D)
         else:

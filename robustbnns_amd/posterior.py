@@ -302,7 +302,8 @@ class StackedPosterior:
         if lazy and self.lazy_capable():
             if self._triple is not None:
                 _hip.HipKernels().svi_draw(self, self._triple[0], self._guide, S, int(key), int(draw_id), sample_keys, images_only=True)
-            self.__dict__["_lazy"] = (int(key), int(draw_id), S, sample_keys)
+            # (the pending record owns a COPY of the keys: an in-place edit of the caller's tensor before materialize() must not change the draw)
+            self.__dict__["_lazy"] = (int(key), int(draw_id), S, None if sample_keys is None else sample_keys.clone())
             return self
         tri = self._triple[0] if self._triple is not None else None
         _hip.HipKernels().svi_draw(self, tri, self._guide, S, int(key), int(draw_id), sample_keys)

@@ -1,7 +1,9 @@
 """GPU tests (-m gpu) of rbnn_lowdim_run — the one-launch hot path of low-dimensional fc nets (half-moons), what `precision="auto"`
 resolves to for in_features <= 16: against the fp64 oracle, against the 7-kernel fp32-MFMA path on the same posterior, and the
-T-iteration attack in one launch against T one-iteration launches.  (The reference's half-moons fixtures — golden and trained — run
-through this path in tests/test_hip_parity.py and tests/test_hip_round3.py, whose engines are built with the default precision.)"""
+T-iteration attack in one launch against T one-iteration launches.  (The reference's half-moons fixtures run through this path in
+tests/test_hip_parity.py — GOLDEN_MODES' "auto" entries: forward_probs, loss_gradients, meanprob_grad, FGSM / PGD images and the evaluation
+triple of halfmoons_fc_h64_s10_n100 and halfmoons_fc2_h32_s6_n40 on the lowdim kernels — and, the trained posteriors, in
+tests/test_hip_round3.py, whose engines are built with the default precision.)"""
 import pytest
 import torch
 

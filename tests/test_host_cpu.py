@@ -538,6 +538,26 @@ def test_pyro_param_store_layout_roundtrip(tmp_path):
         other.load(device="cpu", rel_path=rel)                  # written by the fc guide: no model.5.* entries
 
 
+def test_fake_collectives_are_refused_outside_a_one_rank_group(monkeypatch):
+    """RBNN_FAKE_COLLECTIVES=1 (+ RBNN_FORCE_COLLECTIVES=1) turns every all-reduce into a no-op — a timing diagnostic for a 1-rank group
+    (tools/collectives_ab.sh).  With more than one rank it would return partial sums as results: refused."""
+    import torch.distributed as dist
+    O_post = O.synthetic_posterior("fc", 16, 32, 3, 2, 0.3)
+    sp = StackedPosterior("fc", "leaky", (1, 4, 4), 3, 32, O_post, "cpu")
+    monkeypatch.setenv("RBNN_FAKE_COLLECTIVES", "1")
+    monkeypatch.setenv("RBNN_FORCE_COLLECTIVES", "1")
+    group = object()
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: 2)
+    with pytest.raises(_hip.HipError, match="never valid with more than one rank"):
+        AttackEngine(sp, kernels=FakeKernels(), group=group)
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: 1)
+    eng = AttackEngine(sp, kernels=FakeKernels(), group=group)
+    assert eng._fake_comm and eng.world == 2                 # the sharded launch sequence, no exchange
+    monkeypatch.delenv("RBNN_FAKE_COLLECTIVES")
+    monkeypatch.setattr(dist, "get_world_size", lambda g=None: 2)
+    assert not AttackEngine(sp, kernels=FakeKernels(), group=group)._fake_comm
+
+
 # ----------------------------------------------------------------------------- bench.py --gpus N outside torchrun
 def test_bench_spawns_ranks_as_a_child_process(monkeypatch, capsys):
     """`python bench.py --gpus N` without a torchrun environment (the driver's scaling command) starts the ranks as a child
@@ -573,6 +593,113 @@ def test_bench_spawns_ranks_as_a_child_process(monkeypatch, capsys):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
     with pytest.raises(SystemExit, match="only 1 GPU"):
         bench.main()
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench, root
+
+
+def test_bench_config_strings_are_baseline_jsons():
+    """`config.workload` of a line that measures a BASELINE config is that config's string, verbatim."""
+    import json
+    bench, root = _load_bench()
+    configs = json.load(open(os.path.join(root, "BASELINE.json")))["configs"]
+    assert [bench.BASELINE_CONFIGS[k] for k in ("c1", "c2", "c3", "c4", "c5")] == configs
+    assert bench.WORKLOADS["c4"]["S_split"] == (2000, 8) and bench.WORKLOADS["c4"]["S"] == 250 and bench.WORKLOADS["c5"]["S_split"] == (500, 8)
+
+
+class _HostEvent:
+    def record(self):
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+def _bench_rank(rank, world, port, argv, q):
+    """One rank of `bench.py --gpus N` under gloo on the CPU: bench.main() itself, with bench.RUNTIME replaced (CPU device, gloo, the test
+    double of the kernel interface, host-clock events) — the orchestration, the sharding arithmetic and the record are the bench's own."""
+    import contextlib
+    import io
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, here)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    torch.set_num_threads(1)
+    bench, _ = _load_bench()
+    from fake_kernels import FakeKernels
+
+    class CpuRuntime:
+        backend = "gloo"
+        open_device = staticmethod(lambda local: torch.device("cpu"))
+        kernels_base = staticmethod(lambda: FakeKernels)
+        event = staticmethod(_HostEvent)
+        sync = staticmethod(lambda: None)
+
+    bench.RUNTIME = CpuRuntime()
+    sys.argv = ["bench.py"] + argv
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    if rank == 0:
+        q.put(buf.getvalue().strip().splitlines()[-1])
+    else:
+        assert "{" not in buf.getvalue()            # one JSON line per job: rank 0's
+
+
+def _bench_world(world, argv):
+    import json
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = [ctx.Process(target=_bench_rank, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        line = q.get(timeout=600)
+    finally:
+        for p in procs:
+            p.join(timeout=180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return json.loads(line)
+
+
+def test_bench_default_multi_gpu_line_is_baseline_config_4_with_c2_point_sharded():
+    """`bench.py --gpus 2` (what the driver's scaling run issues, no --workload): the headline is BASELINE config 4 — n_samples = 2000 split
+    8-way, this run holding shards 0 and 1 (250 samples each), sample-sharded with the two all-reduces, `loss_gradients` + FGSM = 2 passes
+    per step, weak scaling — and C2 with its n_samples = 100 KEPT, point-sharded (strong scaling), is the sub-record.  Two gloo ranks on the
+    CPU with the test double (points and hidden size cut down by the debug overrides, which the line reports)."""
+    import json
+    bench, root = _load_bench()
+    configs = json.load(open(os.path.join(root, "BASELINE.json")))["configs"]
+    out = _bench_world(2, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "24", "--hidden", "32", "--posterior", "stored"])
+    c = out["config"]
+    assert c["workload"] == configs[3] and c["name"] == "c4" and out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert (c["n_samples_config"], c["n_samples_config_ranks"], c["samples_per_rank"], c["samples_total"]) == (2000, 8, [250, 250], 500)
+    assert c["shard"] == "samples" and c["passes_per_step"] == 2 and c["points"] == 24 and c["overrides"] == {"points": 24, "hidden": 32}
+    assert out["unit"] == "attack-samples/s" and abs(out["value"] - 24 * 500 * 2 * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-6 * out["value"]
+    assert set(out["roofline"]["kernels"]) == {"fc_forward", "fc_input_grad"} and "cpu_baseline" not in out
+    sub = out["c2_point_sharded"]
+    sc = sub["config"]
+    assert sc["workload"] == configs[1] and sc["name"] == "c2" and sub["scaling"] == "strong" and sc["shard"] == "points"
+    assert (sc["n_samples_config"], sc["samples_per_rank"], sc["samples_total"], sc["points"], sc["points_per_rank"]) == (100, [100, 100], 100, 24, [12, 12])
+    assert abs(sub["value"] - 24 * 100 / (sub["ms_per_step"] * 1e-3)) < 1e-6 * sub["value"]
+
+
+def test_bench_explicit_workload_on_two_ranks_is_one_record():
+    out = _bench_world(2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2", "--points", "16", "--hidden", "32", "--samples", "3",
+                           "--posterior", "stored"])
+    assert out["config"]["name"] == "c2" and "c2_point_sharded" not in out and out["config"]["samples_per_rank"] == [3, 3] and out["scaling"] == "weak"
 
 
 # ----------------------------------------------------------------------------- files WRITTEN BY THE REFERENCE (SURVEY 8f2)
