@@ -443,7 +443,7 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
 
     t_start = time.perf_counter()
 
-    def run(precision, kind=None):
+    def run(precision, kind=None, separate_calls=os.environ.get("RBNN_C4_SEPARATE") == "1"):
         """warmup, then EXACTLY --steps timed steps between barrier + synchronize; returns (engine precision, seconds, kernel events).
         kind "svi": every step first redraws all S samples of the resident stack in place (PGD: before every iteration)."""
         kind = kind or posterior_kind
@@ -500,6 +500,12 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
         def step():
             if kind == "svi":
                 redraw()
+            if w["method"] == "lossgrad+fgsm" and not separate_calls:
+                # C4: expected_loss_gradients + FGSM on the same inputs and samples — one forward, the tail + backward GEMM twice
+                # (AttackEngine.loss_gradients_and_fgsm; both results bit-identical to the two calls: tests/test_hip_round5.py)
+                for e in eps_list:
+                    eng.loss_gradients_and_fgsm(xs, labels, w["S"], e)
+                return
             if "lossgrad" in w["method"]:
                 eng.loss_gradients(xs, labels, w["S"])
             if "fgsm" in w["method"]:
@@ -705,6 +711,9 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
     other_kind = None
     if world == 1 and not args.no_other_mode and not sub_record and sp_svi is not None and name != "c5":      # the same workload on the other kind of posterior (c5: a step is minutes)
         other_kind = run(args.precision, "stored" if posterior_kind == "svi" else "svi")
+    separate = None
+    if w["method"] == "lossgrad+fgsm" and world == 1 and not args.no_other_mode and not sub_record and os.environ.get("RBNN_C4_SEPARATE") != "1":
+        separate = run(args.precision, separate_calls=True)           # the same step as loss_gradients() then fgsm(): four GEMMs (rounds 1-4)
     others = []
     if world == 1 and not args.no_other_mode and not sub_record:
         for want in ("exact", "triple", "split"):                         # the other precision modes on the same workload
@@ -752,6 +761,11 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
             if other_kind[3] is not None:
                 rec["svi"] = other_kind[3]
             out["stored_posterior_mode" if posterior_kind == "svi" else "svi_posterior_mode"] = rec
+        if w["method"] == "lossgrad+fgsm":
+            out["config"]["forward_shared"] = os.environ.get("RBNN_C4_SEPARATE") != "1"
+        if separate is not None:
+            out["separate_calls_mode"] = {"value": units / separate[1], "ms_per_step": 1e3 * separate[1] / args.steps,
+                                          "note": "loss_gradients() then fgsm(): the forward GEMM runs twice (what rounds 1-4 measured as c4)"}
         for other in others:
             o_ms = 1e3 * other[1] / args.steps
             out[SUBKEY[other[0]]] = {"value": units / other[1], "ms_per_step": o_ms, "dtype": DTYPES[other[0]],

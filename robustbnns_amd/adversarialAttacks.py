@@ -137,13 +137,70 @@ def attack(net, x_test, y_test, dataset_name, device, method, filename, savedir=
     else:
         raise UnboundLocalError("local variable 'perturbed_image' referenced before assignment")   # :131
 
+    _attack_side_effects(x_test, adversarial_attack, method, filename, savedir, n_samples)
+    return adversarial_attack
+
+
+def _attack_side_effects(x_test, adversarial_attack, method, filename, savedir, n_samples):
+    """adversarialAttacks.py:133-141: the two PNG grids and the pickle of an attack() call."""
     path = TESTS + filename + "/" if savedir is None else TESTS + savedir + "/"
     name = filename + "_" + str(method)
     plot_save_grid_images(images=x_test, filename=name + "_original.png", savedir=path)
     plot_save_grid_images(images=adversarial_attack, filename=name + "_attack.png", savedir=path)
     name = name + "_attackSamp=" + str(n_samples) + "_attack.pkl" if n_samples else name + "_attack.pkl"
     save_to_pickle(data=adversarial_attack, path=path, filename=name)
-    return adversarial_attack
+
+
+class FgsmGrid:
+    """FGSM attacks of ONE set of inputs over a grid of (epsilon, n_samples) — plot_eps_attacks.py:16-33 — as one resident job.  For a net
+    whose forward sees the same weights on every call (an HMC posterior's stored samples, an Ensemble_NN, a deterministic NN) the gradient
+    does not depend on epsilon (it enters after `sign`, adversarialAttacks.py:74-82) and attack_evaluation's forward of the clean inputs
+    (:177-181) is the same for every epsilon: per n_samples ONE gradient pass and ONE clean forward, per cell one sign / clamp launch and
+    one forward of the adversarial inputs.  `attack` / `evaluate` keep the side effects, prints and return values of the module-level
+    `attack` / `attack_evaluation`; every cell equals theirs (tests).  An SVI net draws fresh weights per forward (model_bnn.py:230-232):
+    nothing is shared, the two functions are called as they are."""
+
+    def __init__(self, net, x_test, y_test, dataset_name, device):
+        self.net, self.x_test, self.y_test, self.dataset_name, self.device = net, x_test, y_test, dataset_name, device
+        self.shared = not _redraw(net, None, False)
+        self._grad, self._clean = {}, {}
+        self.gradient_passes = self.clean_forwards = 0          # what the grid cost (printed by the drivers' tests)
+
+    def attack(self, epsilon, n_samples, filename, savedir=None):
+        """attack(net, ..., method="fgsm", hyperparams={"epsilon": epsilon}, n_samples=n_samples) — adversarialAttacks.py:111-143."""
+        hyper = {"epsilon": epsilon}
+        if not self.shared:
+            return attack(net=self.net, x_test=self.x_test, y_test=self.y_test, dataset_name=self.dataset_name, device=self.device,
+                          method="fgsm", filename=filename, savedir=savedir, hyperparams=hyper, n_samples=n_samples)
+        print(f"\nProducing fgsm attacks on {self.dataset_name}:")
+        images = self.x_test.to(self.device)
+        eng, S, seeds, mode = _hot_path(self.net, n_samples, False)
+        if n_samples not in self._grad:
+            self._grad[n_samples] = eng.attack_gradient(images, self.y_test.argmax(-1).to(self.device), S, seeds=seeds, mode=mode)
+            self.gradient_passes += 1
+        if images.is_leaf:
+            images.requires_grad = True                        # fgsm_attack's visible side effect (:73)
+        adversarial_attack = eng.fgsm_from_gradient(images, self._grad[n_samples], epsilon).to(images.device).requires_grad_(True)
+        _attack_side_effects(self.x_test, adversarial_attack, "fgsm", filename, savedir, n_samples)
+        return adversarial_attack
+
+    def evaluate(self, x_attack, n_samples):
+        """attack_evaluation(net, x_test, x_attack, y_test, device, n_samples) — adversarialAttacks.py:151-198."""
+        if not self.shared:
+            return attack_evaluation(net=self.net, x_test=self.x_test, x_attack=x_attack, y_test=self.y_test, device=self.device, n_samples=n_samples)
+        print(f"\nEvaluating against the attacks", end="")
+        if n_samples:
+            print(f" with {n_samples} defence samples")
+        random.seed(0)
+        set_rng_seed(0)
+        eng, S, _, mode = _hot_path(self.net, n_samples, False)
+        logits = mode == _hip.LOSS_MEAN_LOGIT
+        if n_samples not in self._clean:
+            self._clean[n_samples] = eng.clean_outputs(self.x_test.to(self.device), S, logits=logits)
+            self.clean_forwards += 1
+        original_accuracy, adversarial_accuracy, rob, _, _ = eng.evaluate(
+            self.x_test.to(self.device), x_attack.to(self.device), self.y_test, S, logits=logits, clean=self._clean[n_samples])
+        return _evaluation_report(original_accuracy, adversarial_accuracy, rob)
 
 
 def load_attack(method, filename, savedir=None, n_samples=None, rel_path=TESTS):
@@ -164,6 +221,10 @@ def attack_evaluation(net, x_test, x_attack, y_test, device, n_samples=None):
     eng, S, _, mode = _hot_path(net, n_samples, False)
     original_accuracy, adversarial_accuracy, rob, _, _ = eng.evaluate(
         x_test.to(device), x_attack.to(device), y_test, S, logits=(mode == _hip.LOSS_MEAN_LOGIT))
+    return _evaluation_report(original_accuracy, adversarial_accuracy, rob)
+
+
+def _evaluation_report(original_accuracy, adversarial_accuracy, rob):
     print(f"\ntest accuracy = {original_accuracy}\tadversarial accuracy = {adversarial_accuracy}", end="\t")
     if rob.min() < 0. or rob.max() > 1.:
         raise ValueError("Softmax difference should be in [0,1]")          # :48-49

@@ -314,6 +314,7 @@ class ConvEngine(AttackEngine):
     graph_safe = False                      # large jobs are cut into point blocks per call: no fixed launch sequence to capture
     fused_tail = False                      # the conv kernels read the fp32 dZ (rbnn_step_tail_triple builds the fc generator image only)
     pipelined_comm = False                  # one cached workspace: the sample-sharded step keeps the plain sequence
+    shared_forward = False                  # the backward overwrites the forward's Q2 with dQ2: loss_gradients_and_fgsm runs the two calls
 
     def workspace(self, N, S, chunk=0, tag=0):
         """One workspace per (N, S); `chunk` / `tag` are the fc engine's knobs (slab plan, pipelined point blocks) and do not
@@ -380,10 +381,21 @@ class ConvEngine(AttackEngine):
         return self._blocked(lambda xb, yb: AttackEngine.pgd(self, xb, yb, n_samples, epsilon, alpha, iters, seeds, mode, before_step),
                              x, y, n_samples=n_samples)
 
-    def evaluate(self, x, x_attack, y, n_samples, logits=False):
+    def attack_gradient(self, x, y, n_samples, seeds=None, mode=_hip.LOSS_MEAN_PROB):
         y = torch.as_tensor(y)
-        parts = self._blocked(lambda xb, ab, yb: AttackEngine.evaluate(self, xb, ab, yb, n_samples, logits), x, x_attack, y,
-                              n_samples=n_samples, cat=False)
+        return self._blocked(lambda xb, yb: AttackEngine.attack_gradient(self, xb, yb, n_samples, seeds, mode), x, y, n_samples=n_samples)
+
+    def clean_outputs(self, x, n_samples, logits=False):
+        return self._blocked(lambda xb: AttackEngine.clean_outputs(self, xb, n_samples, logits), x, n_samples=n_samples)
+
+    def evaluate(self, x, x_attack, y, n_samples, logits=False, clean=None):
+        y = torch.as_tensor(y)
+        if clean is not None:
+            parts = self._blocked(lambda xb, ab, yb, cb: AttackEngine.evaluate(self, xb, ab, yb, n_samples, logits, cb), x, x_attack, y, clean,
+                                  n_samples=n_samples, cat=False)
+        else:
+            parts = self._blocked(lambda xb, ab, yb: AttackEngine.evaluate(self, xb, ab, yb, n_samples, logits), x, x_attack, y,
+                                  n_samples=n_samples, cat=False)
         if isinstance(parts, tuple):
             return parts
         n = x.shape[0]

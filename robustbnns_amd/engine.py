@@ -377,25 +377,31 @@ class AttackEngine:
     # ------------------------------------------------------------------ expected input gradient
     def gradient_slabs(self, Xp, labels, sidx, S, mode, G_up=None, chunk=0):
         """Runs forward + loss + backward; leaves n_slabs partial gradients [N, D_pad] in ws['slabs']."""
-        N, C = Xp.shape[0], self.post.C
+        N = Xp.shape[0]
         ws = self.workspace(N, S, chunk)
         S_tot = self.total_samples(S)
         self._forward_kernels(Xp, sidx, S, OUT_LOGITS if mode == LOSS_MEAN_LOGIT else OUT_PROBS, ws)
+        return ws, self._loss_backward(ws, labels, sidx, S, N, mode, S_tot, G_up), S_tot
+
+    def _loss_backward(self, ws, labels, sidx, S, N, mode, S_tot, G_up=None):
+        """From a finished forward — P[s, n, :] and the activation-derivative stash in `ws` — the loss in use -> dL/dlogits -> the backward
+        GEMM; returns the slab count.  Reads the forward's state without changing it (fc / fc2): two losses can be differentiated from ONE
+        forward (loss_gradients_and_fgsm)."""
+        C = self.post.C
         # per-sample losses are averaged at the very end (lossGradients.py:40), the others inside the loss
         inv_S = 1.0 if mode == LOSS_PER_SAMPLE else 1.0 / S_tot
         if self._fused_tail(mode, G_up) and ws.get("fc2_groups", (S, S))[1] >= S:
             # one launch: sum over samples + loss + the dZ generator image (rbnn_step_tail_triple), bit-identical to the three it replaces;
             # the fp32 dZ buffer is never written
             self.k.step_tail_triple(mode, ws["P"], labels, S, inv_S, N, C, ws["triple"])
-            return ws, self._grad_kernels(sidx, S, N, ws, dz_ready=True), S_tot
+            return self._grad_kernels(sidx, S, N, ws, dz_ready=True)
         Psum = None
         if mode in (LOSS_MEAN_PROB, LOSS_MEAN_LOGIT):
             Psum = ws["Psum"]
             self.k.reduce_samples(ws["P"], S, N, C, 1.0, Psum)
             self._allreduce(Psum)                               # 64 B per point: the only exchange before the backward
         self.k.loss_dlogits(mode, ws["P"], Psum, G_up, labels, S, inv_S, N, C, ws["dZ"])
-        n_slabs = self._grad_kernels(sidx, S, N, ws)
-        return ws, n_slabs, S_tot
+        return self._grad_kernels(sidx, S, N, ws)
 
     fused_tail = True                       # ConvEngine: its kernels read the fp32 dZ
 
@@ -530,6 +536,61 @@ class AttackEngine:
             self._scales = None
         return self.unpad(X, x)
 
+    def attack_gradient(self, x, y, n_samples, seeds=None, mode=LOSS_MEAN_PROB):
+        """The summed (sample-sharded: all-reduced) input gradient whose SIGN fgsm takes, [N, D_pad] on the device.  epsilon enters an
+        FGSM attack only after the sign (adversarialAttacks.py:81-82): one gradient serves every epsilon of a grid (fgsm_from_gradient)."""
+        sidx, S = self.sample_index(n_samples, seeds)
+        xin = self._flat(x) if self.precision == "lowdim" else self.pad_inputs(x)
+        return self.gradient(xin, to_labels(y, self.device), sidx, S, mode).clone()
+
+    def fgsm_from_gradient(self, x, G, epsilon):
+        """clamp(x + epsilon * sign(G), 0, 1) for every row of x (adversarialAttacks.py:81-82; rbnn_attack_step's operation order) from a
+        gradient of attack_gradient(): no forward, no backward."""
+        p = self.post
+        X = self.pad_inputs(x, clone=True)
+        self.k.attack_step(X, None, G, 1, 0, p.Dp, None, float(epsilon), 0.0, False, p.D)
+        return self.unpad(X, x)
+
+    shared_forward = True                   # ConvEngine: its backward overwrites the forward's activations in place (Q2 -> dQ2)
+
+    def loss_gradients_and_fgsm(self, x, y, n_samples, epsilon=0.3, seeds=None, mode=LOSS_MEAN_PROB):
+        """loss_gradients(x, y) AND fgsm(x, y) on the same inputs and samples — BASELINE config 4's step ("expected_loss_gradients + FGSM") —
+        from ONE forward.  The two differ only in the loss (lossGradients.py:33-34: CE of every sample's own prediction, averaged at the
+        end :40; adversarialAttacks.py:74-76: CE of the mean prediction): P[s, n, :] and the activation-derivative stash are the same, so
+        the forward GEMM runs once and the tail + backward GEMM twice — three GEMMs instead of four.  Every kernel call, its arguments and
+        its order of operations are those of the two separate calls: both results are BIT-IDENTICAL to them (tests/test_hip_round5.py).
+        Returns (expected loss gradients, adversarial inputs), both of x's shape.  Sample-sharded: the three exchanges of the separate
+        calls (summed per-sample-loss gradients; sum_s p_s; summed mean-loss gradients)."""
+        if not self.shared_forward or self.precision == "lowdim" or mode != LOSS_MEAN_PROB:
+            # (an ensemble's / a deterministic net's attack differentiates the mean LOGITS: its forward leaves logits, the per-sample loss needs
+            # probabilities — nothing to share; the lowdim kernels recompute the forward inside their one launch)
+            return self.loss_gradients(x, y, n_samples, seeds), self.fgsm(x, y, n_samples, epsilon, seeds, mode)
+        sidx, S = self.sample_index(n_samples, seeds)
+        labels = to_labels(y, self.device)
+        p = self.post
+        X = self.pad_inputs(x, clone=True)
+        N = X.shape[0]
+        self._scales = self._input_scales(X, iterates=False)
+        try:
+            ws = self.workspace(N, S)
+            S_tot = self.total_samples(S)
+            self._forward_kernels(X, sidx, S, OUT_PROBS, ws)
+            G = ws["Gsum"] if "Gsum" in ws else ws["G"]
+            n_slabs = self._loss_backward(ws, labels, sidx, S, N, LOSS_PER_SAMPLE, S_tot)
+            self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0 / S_tot, G)
+            self._allreduce(G)
+            expected = self.unpad(G, x)
+            n_slabs = self._loss_backward(ws, labels, sidx, S, N, mode, S_tot)
+            if self.world == 1:
+                self.k.attack_step(X, None, ws["slabs"], n_slabs, N * p.Dp, p.Dp, None, float(epsilon), 0.0, False, p.D)
+            else:
+                self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0, G)
+                self._allreduce(G)
+                self.k.attack_step(X, None, G, 1, 0, p.Dp, None, float(epsilon), 0.0, False, p.D)
+        finally:
+            self._scales = None
+        return expected, self.unpad(X, x)
+
     def pgd(self, x, y, n_samples, epsilon, alpha=None, iters=40, seeds=None, mode=LOSS_MEAN_PROB, before_step=None):
         """adversarialAttacks.pgd_attack on every row of x (adversarialAttacks.py:86-108).
         alpha=None: 2/max(image) per image (:89); a float: the same step for all (2/225, :91).
@@ -654,13 +715,21 @@ class AttackEngine:
         return self.unpad(X, x)
 
     # ------------------------------------------------------------------ evaluation
-    def evaluate(self, x, x_attack, y, n_samples, logits=False):
-        """attack_evaluation's numbers (adversarialAttacks.py:173-196): (orig acc %, adv acc %, rob [N])."""
+    def clean_outputs(self, x, n_samples, logits=False):
+        """The mean output [N, 16] of the CLEAN inputs — attack_evaluation's first forward (adversarialAttacks.py:177-181) — to be handed to
+        evaluate(clean=...) by callers that score many attacks of the same inputs with the same samples (an epsilon grid)."""
+        sidx, S = self.sample_index(n_samples)
+        prep = self._flat if self.precision == "lowdim" else self.pad_inputs
+        return self.forward_padded(prep(x), sidx, S, OUT_LOGITS if logits else OUT_PROBS)
+
+    def evaluate(self, x, x_attack, y, n_samples, logits=False, clean=None):
+        """attack_evaluation's numbers (adversarialAttacks.py:173-196): (orig acc %, adv acc %, rob [N]).  clean: clean_outputs(x, ...) of
+        the same inputs / samples, computed once by the caller — the forward of the clean set is then skipped."""
         sidx, S = self.sample_index(n_samples)
         kind = OUT_LOGITS if logits else OUT_PROBS
         labels = to_labels(y, self.device)
         prep = self._flat if self.precision == "lowdim" else self.pad_inputs
-        o = self.forward_padded(prep(x), sidx, S, kind)
+        o = clean if clean is not None else self.forward_padded(prep(x), sidx, S, kind)
         a = self.forward_padded(prep(x_attack), sidx, S, kind)
         counts = torch.zeros(2, dtype=torch.int32, device=self.device)
         rob = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)

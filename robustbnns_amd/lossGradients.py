@@ -36,6 +36,28 @@ def loss_gradients(net, data_loader, device, filename, savedir, n_samples=None):
     return grads
 
 
+def loss_gradients_and_fgsm(net, x_test, y_test, device, n_samples, hyperparams=None):
+    """`loss_gradients` (lossGradients.py:52-68) and an FGSM `attack` (adversarialAttacks.py:69-83, :111-131) on the same inputs and the
+    same posterior samples — BASELINE config 4's job — from ONE forward pass (AttackEngine.loss_gradients_and_fgsm: three GEMMs instead of
+    four; both results bit-identical to the two calls).  For nets whose two calls see the same weights: an HMC posterior (stored samples;
+    seeds [0..n) are its first n samples either way).  An SVI net draws seeded weights for the gradients (:29-33) and fresh ones for the
+    attack (model_bnn.py:230-232) — different samples, nothing to share: the two calls are made as they are.
+    -> (expected loss gradients [N, ...] device tensor, adversarial inputs [N, ...] device tensor); no files are written."""
+    if not n_samples:
+        raise NameError("name 'net_copy' is not defined")
+    epsilon = hyperparams["epsilon"] if hyperparams is not None else 0.3
+    images, labels = x_test.to(device), y_test
+    if getattr(net, "inference", None) == "hmc":
+        eng, S, _, _ = net.hot_path(n_samples)
+        return eng.loss_gradients_and_fgsm(images, labels, S, epsilon)
+    from .adversarialAttacks import fgsm_attack
+    eng, S, seeds, _ = net.hot_path(n_samples, seeds=list(range(n_samples)))
+    grads = eng.loss_gradients(images, labels, S, seeds=seeds)
+    lab = torch.as_tensor(labels)
+    lab = lab.argmax(-1) if lab.dim() >= 2 else lab
+    return grads, fgsm_attack(net, images, lab.to(device), hyperparams, n_samples=n_samples).detach()
+
+
 def save_loss_gradients(loss_gradients, n_samples, filename, savedir, relpath=DATA):
     """lossGradients.py:70-72"""
     save_to_pickle(data=loss_gradients, path=relpath + savedir, filename=filename + "_samp=" + str(n_samples) + "_lossGrads.pkl")

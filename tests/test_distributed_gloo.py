@@ -47,6 +47,9 @@ def _worker(rank, world, port, arch, q, comm_blocks=2, dims=(784, 32, 10, 6, 12,
         out = {"probs": eng.forward(x, eng.post.S), "lg": eng.loss_gradients(x, y, eng.post.S),
                "fgsm": eng.fgsm(x, y, eng.post.S, 0.3), "pgd": eng.pgd(x[:3], y[:3], eng.post.S, 0.3, iters=5),
                "gm": eng.gradient(eng.pad_inputs(x), y.argmax(-1).int(), None, eng.post.S, _hip.LOSS_MEAN_PROB).clone()}
+        # BASELINE config 4's step on ONE forward: the same results as the two calls, on every rank
+        both = eng.loss_gradients_and_fgsm(x, y, eng.post.S, 0.3)
+        assert torch.equal(both[0], out["lg"]) and torch.equal(both[1], out["fgsm"])
         if rank == 0:
             single = AttackEngine(full, kernels=FakeKernels())
             ref = {"probs": single.forward(x, S), "lg": single.loss_gradients(x, y, S), "fgsm": single.fgsm(x, y, S, 0.3),

@@ -70,3 +70,113 @@ def test_forward_on_other_inputs_inside_a_pgd_loop_does_not_take_the_iterates_im
     with_cb = eng.pgd(x, y, S, 0.1, iters=5, before_step=lambda: seen.append(eng.forward(other.to(DEV), S).clone()))
     assert len(seen) == 4 and all(torch.equal(s, want_other) for s in seen)
     assert torch.equal(with_cb, plain)
+
+
+# ------------------------------------------------------------------ BASELINE config 4's step on one forward
+@pytest.mark.parametrize("arch,Hn,Cn,S,N,act,precision", [
+    ("fc", 512, 10, 23, 1000, "leaky", "triple"), ("fc", 128, 3, 5, 77, "relu", "triple"), ("fc2", 256, 10, 9, 300, "leaky", "triple"),
+    ("fc", 128, 7, 12, 257, "tanh", "triple"), ("fc2", 128, 10, 6, 130, "sigm", "triple"),
+    ("fc", 512, 10, 11, 600, "leaky", "exact"), ("fc2", 32, 10, 4, 50, "tanh", "exact"), ("fc", 16, 10, 3, 40, "leaky", "exact"),
+    ("fc", 256, 10, 10, 513, "leaky", "split"), ("fc2", 128, 10, 5, 100, "relu", "split")])
+def test_shared_forward_is_bit_identical_to_loss_gradients_then_fgsm(arch, Hn, Cn, S, N, act, precision):
+    """AttackEngine.loss_gradients_and_fgsm: rbnn_fc_forward* once, then (per-sample loss -> backward GEMM -> 1/S sum) and (mean-probability
+    loss -> backward GEMM -> sign step) from the same P and stash.  The backward kernels must leave the forward's state untouched — every
+    architecture, activation kind (1-bit stash / stored derivative), precision mode: expected gradients and FGSM images equal, bit for bit,
+    those of loss_gradients() followed by fgsm(); also with a sample-index call, and repeated (nothing stale in the workspace)."""
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    post = O.synthetic_posterior(arch, 784, Hn, Cn, S, 0.05)
+    x, y = O.synthetic_inputs(N, (1, 28, 28), Cn, seed=Hn + N)
+    sp = StackedPosterior(arch, act, (1, 28, 28), Cn, Hn, post, DEV)
+    eng = AttackEngine(sp, precision=precision)
+    assert eng.precision == precision
+    launches = []
+    for fn in ("fc_forward", "fc_forward_triple", "fc_forward_split"):
+        real = getattr(eng.k, fn)
+        setattr(eng.k, fn, (lambda real: lambda *a, **kw: (launches.append("fwd"), real(*a, **kw))[1])(real))
+    lg, adv = eng.loss_gradients(x, y, S).cpu(), eng.fgsm(x, y, S, 0.2).cpu()
+    n_sep = len(launches)
+    del launches[:]
+    lg2, adv2 = eng.loss_gradients_and_fgsm(x, y, S, 0.2)
+    assert 2 * len(launches) == n_sep
+    assert torch.equal(lg2.cpu(), lg) and torch.equal(adv2.cpu(), adv)
+    seeds = [S - 1, 0, S // 2]
+    a, b = eng.loss_gradients_and_fgsm(x, y, 3, 0.1, seeds=seeds)
+    assert torch.equal(a.cpu(), eng.loss_gradients(x, y, 3, seeds=seeds).cpu()) and torch.equal(b.cpu(), eng.fgsm(x, y, 3, 0.1, seeds=seeds).cpu())
+    lg3, adv3 = eng.loss_gradients_and_fgsm(x, y, S, 0.2)
+    assert torch.equal(lg3.cpu(), lg) and torch.equal(adv3.cpu(), adv)
+    # sanity against the fp64 oracle (the separate calls are pinned elsewhere; this guards the comparison itself against "both empty")
+    ref = O.loss_gradients(x[:8].double(), y[:8].double(), O.cast(post, torch.float64), arch, act, S)
+    assert rel_err(lg2[:8].cpu(), ref.float()) < 1e-4
+
+
+def test_caller_level_loss_gradients_and_fgsm_on_an_hmc_bnn(golden):
+    """lossGradients.loss_gradients_and_fgsm(net, ...) on the reference's fixture: the reference's own loss_gradients and fgsm arrays."""
+    from robustbnns_amd import lossGradients
+    from robustbnns_amd.model_bnn import BNN
+    g = golden("mnist_fc_h512_s8_n8_leaky"); m = g.meta
+    bnn = BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], 0, tuple(m["shape"]), m["n_classes"])
+    bnn.set_posterior_samples(g.posterior(), DEV)
+    x, y = g.t("x"), g.t("y")
+    grads, adv = lossGradients.loss_gradients_and_fgsm(bnn, x, y, DEV, m["S"], {"epsilon": m["eps"]})
+    assert rel_err(grads.cpu(), g.t("loss_gradients")) < TOL
+    ref_g = g.t("meanprob_grad").reshape(len(x), -1)
+    safe = ref_g.abs() > TAU * ref_g.abs().max(dim=1, keepdim=True)[0]
+    assert not (((adv.cpu().reshape(len(x), -1) - g.t("fgsm").reshape(len(x), -1)).abs() > 1e-6) & safe).any()
+
+
+# ------------------------------------------------------------------ an FGSM eps grid as one resident job (SURVEY 8f1)
+def _hmc_bnn(g):
+    from robustbnns_amd.model_bnn import BNN
+    m = g.meta
+    bnn = BNN(m["dataset"], m["hidden"], m["act"], m["arch"], "hmc", None, None, m["S"], 0, tuple(m["shape"]), m["n_classes"])
+    bnn.set_posterior_samples(g.posterior(), DEV)
+    return bnn
+
+
+@pytest.mark.parametrize("name,dataset", [("trained_halfmoons_fc_h32_m10", "half_moons"), ("trained_halfmoons_fc2_h32_m10", "half_moons"),
+                                          ("trained_mnistshaped_fc_h128_m5", "mnist"), ("trained_mnistshaped_fc2_h128_m3", "mnist"),
+                                          ("trained_mnistshaped_conv_h16_m3", "mnist")])
+def test_fgsm_eps_grid_is_one_gradient_and_one_clean_forward_per_n_samples(golden, name, dataset, tmp_path, monkeypatch):
+    """build_eps_attacks_df (plot_eps_attacks.py:16-33) for FGSM on stored samples through adversarialAttacks.FgsmGrid: the gradient and the
+    clean-set forward are computed once per n_samples and reused by every epsilon.  Every cell's adversarial set is the SAME TENSOR, bit for
+    bit, as attack() returns for it (lowdim, triple and conv engines: the cached gradient is the sum the one-launch attack takes the sign
+    of), the evaluation triple equals attack_evaluation()'s, and the rows equal the reference's DataFrame; the cost of both forms is printed."""
+    import time
+    from robustbnns_amd import adversarialAttacks as AA, plot_eps_attacks
+    g = golden(name); m = g.meta; x, y = g.t("x"), g.t("y")
+    bnn = _hmc_bnn(g)
+    monkeypatch.chdir(tmp_path)
+    eps_list, ns_list = m["eps_list"], m["ns_list"]
+    grid = AA.FgsmGrid(bnn, x, y, dataset, DEV)
+    assert grid.shared
+    for eps in eps_list:
+        for ns in ns_list:
+            a = grid.attack(eps, ns, filename=bnn.name)
+            b = AA.attack(net=bnn, x_test=x, y_test=y, dataset_name=dataset, device=DEV, method="fgsm", filename=bnn.name, n_samples=ns,
+                          hyperparams={"epsilon": eps})
+            assert torch.equal(a, b), f"eps={eps} ns={ns}: {int((a != b).sum())} pixels differ"
+            ra = grid.evaluate(a, ns)
+            rb = AA.attack_evaluation(net=bnn, x_test=x, x_attack=b, y_test=y, device=DEV, n_samples=ns)
+            assert ra[:2] == rb[:2] and torch.equal(ra[2], rb[2])
+    assert (grid.gradient_passes, grid.clean_forwards) == (len(ns_list), len(ns_list))
+    # the driver: the reference's rows (where the fixture holds its DataFrame), and what the grid cost
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    df = plot_eps_attacks.build_eps_attacks_df(bnn=bnn, dataset=dataset, device=DEV, method="fgsm", x_test=x, y_test=y, epsilon_list=eps_list,
+                                               n_samples_list=ns_list, savedir=bnn.name)
+    torch.cuda.synchronize(); t_grid = time.perf_counter() - t0
+    cost = df.attrs["grid_cost"]
+    assert cost["gradient_passes"] == cost["clean_forwards"] == len(ns_list) and cost["cells"] == len(eps_list) * len(ns_list)
+    if "fgsm_df_epsilon" in g.arr:
+        for col in ("epsilon", "test_acc", "adv_acc", "n_samples"):
+            assert np.array_equal(df[col].to_numpy().astype("float64"), g.arr["fgsm_df_" + col]), col
+        assert np.abs(df["softmax_rob"].to_numpy() - g.arr["fgsm_df_softmax_rob"]).max() < TOL
+    t0 = time.perf_counter()
+    for eps in eps_list:
+        for ns in ns_list:
+            adv = AA.attack(net=bnn, x_test=x, y_test=y, dataset_name=dataset, device=DEV, method="fgsm", filename=bnn.name, n_samples=ns,
+                            hyperparams={"epsilon": eps})
+            AA.attack_evaluation(net=bnn, x_test=x, x_attack=adv, y_test=y, device=DEV, n_samples=ns)
+    torch.cuda.synchronize(); t_cells = time.perf_counter() - t0
+    print(f"\n   {name}: {cost['cells']} cells — resident grid {cost['gradient_passes']} gradient passes + {cost['clean_forwards']} clean forwards, "
+          f"{1e3 * t_grid / cost['cells']:.2f} ms per cell (host clock, PNG + pickle side effects included); per-cell loop "
+          f"{cost['cells']} + {cost['cells']}, {1e3 * t_cells / cost['cells']:.2f} ms per cell")

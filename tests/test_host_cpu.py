@@ -418,6 +418,22 @@ def test_eps_grid_driver_matches_reference(golden, tmp_path, monkeypatch):
     assert os.path.exists(m["csv_files"][0])
     back = plot_eps_attacks.load_eps_attacks_df(m["dataset"], m["method"], bnn.name)
     assert len(back) == len(df) and list(back.columns) == m["columns"]
+    # an FGSM grid on stored samples is one resident job: ONE gradient pass and ONE clean forward per n_samples, whatever the number of epsilons
+    cost = df.attrs["grid_cost"]
+    assert cost == {"cells": len(m["epsilon_list"]) * len(m["n_samples_list"]), "gradient_passes": len(m["n_samples_list"]),
+                    "clean_forwards": len(m["n_samples_list"]), "shared": True}
+    # ... and every cell is what the module-level attack() + attack_evaluation() return (and write) for it
+    grid = adversarialAttacks.FgsmGrid(bnn, g.t("x"), g.t("y"), m["dataset"], "cpu")
+    for eps in m["epsilon_list"][:2]:
+        for ns in m["n_samples_list"]:
+            a = grid.attack(eps, ns, filename=bnn.name)
+            b = adversarialAttacks.attack(net=bnn, x_test=g.t("x"), y_test=g.t("y"), dataset_name=m["dataset"], device="cpu", method="fgsm",
+                                          filename=bnn.name, n_samples=ns, hyperparams={"epsilon": eps})
+            assert torch.equal(a, b) and a.requires_grad
+            assert torch.equal(adversarialAttacks.load_attack("fgsm", bnn.name, n_samples=ns), b)
+            ra, rb = grid.evaluate(a, ns), adversarialAttacks.attack_evaluation(net=bnn, x_test=g.t("x"), x_attack=b, y_test=g.t("y"), device="cpu", n_samples=ns)
+            assert ra[:2] == rb[:2] and torch.equal(ra[2], rb[2])
+    assert (grid.gradient_passes, grid.clean_forwards) == (len(m["n_samples_list"]),) * 2
 
 
 def test_forward_is_differentiable_like_the_reference_expects(golden):
@@ -536,6 +552,39 @@ def test_pyro_param_store_layout_roundtrip(tmp_path):
     shutil.copy(os.path.join(GOLDEN, "pyro_store_halfmoons_fc_h32.pt"), rel + other.name + "/" + other.name + "_weights.pt")
     with pytest.raises(KeyError, match="lacks"):
         other.load(device="cpu", rel_path=rel)                  # written by the fc guide: no model.5.* entries
+
+
+@pytest.mark.parametrize("arch,act", [("fc", "leaky"), ("fc2", "tanh")])
+def test_loss_gradients_and_fgsm_share_one_forward(arch, act):
+    """AttackEngine.loss_gradients_and_fgsm (BASELINE config 4's step): ONE forward launch, two backward launches, results equal to the
+    separate calls' — orchestration on the test double; the real kernels' bit-identity is tests/test_hip_round5.py."""
+    post = O.synthetic_posterior(arch, 784, 32, 10, 5, 0.06)
+    x, y = O.synthetic_inputs(9, (1, 28, 28), 10, seed=2)
+    sp = StackedPosterior(arch, act, (1, 28, 28), 10, 32, post, "cpu")
+    calls = []
+
+    class Counting(FakeKernels):
+        def fc_forward(self, *a, **kw):
+            calls.append("fwd")
+            return super().fc_forward(*a, **kw)
+
+        def fc_input_grad(self, *a, **kw):
+            calls.append("bwd")
+            return super().fc_input_grad(*a, **kw)
+
+    eng = AttackEngine(sp, kernels=Counting())
+    lg, adv = eng.loss_gradients(x, y, 5), eng.fgsm(x, y, 5, 0.25)
+    assert calls == ["fwd", "bwd", "fwd", "bwd"]
+    del calls[:]
+    lg2, adv2 = eng.loss_gradients_and_fgsm(x, y, 5, 0.25)
+    assert calls == ["fwd", "bwd", "bwd"]
+    assert torch.equal(lg2, lg) and torch.equal(adv2, adv)
+    seeds = [3, 0, 4]
+    lg3, adv3 = eng.loss_gradients_and_fgsm(x, y, 3, 0.25, seeds=seeds)
+    assert torch.equal(lg3, eng.loss_gradients(x, y, 3, seeds=seeds)) and torch.equal(adv3, eng.fgsm(x, y, 3, 0.25, seeds=seeds))
+    del calls[:]
+    eng.loss_gradients_and_fgsm(x, y, 5, 0.25, mode=_hip.LOSS_MEAN_LOGIT)        # mean-logit attack: nothing to share
+    assert calls == ["fwd", "bwd", "fwd", "bwd"]
 
 
 def test_fake_collectives_are_refused_outside_a_one_rank_group(monkeypatch):
