@@ -77,11 +77,19 @@ WORKLOADS = {
     # (mean-probability loss) over all points, i.e. 2 x N x S attack-samples
     "c4": dict(shape=(1, 28, 28), H=512, C=10, arch="fc", act="leaky", S=250, S_split=(2000, 8), N=10000, method="lossgrad+fgsm", iters=1, eps=0.3,
                passes=2, desc="MNIST fc-BNN 784->512->10 (leaky), expected_loss_gradients + FGSM eps=0.3, N=10000 points, "
-                              "S=250 samples/GPU (S=2000 sharded 8-way at 8 GPUs)"),
+                              "S=250 samples/GPU (S=2000 sharded 8-way at 8 GPUs); both gradients from ONE forward "
+                              "(AttackEngine.loss_gradients_and_fgsm: 3 GEMMs per step, results bit-identical to the two calls)"),
     "conv": dict(shape=(1, 28, 28), H=512, C=10, arch="conv", act="leaky", S=16, N=2048, method="fgsm", iters=1, eps=0.3,
                  desc="MNIST conv-BNN (conv5x5x32 - pool - conv5x5x512 - pool - fc, leaky), FGSM eps=0.3, N=2048 points, S=16 samples/GPU"),
     "fc2": dict(shape=(1, 28, 28), H=512, C=10, arch="fc2", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
                 desc="MNIST fc2-BNN 784->512->512->10 (leaky; the reference's saved model_1), FGSM eps=0.3, N=10000 points, S=100 samples/GPU"),
+    # hidden 1024: five of the reference's ten saved models (model_bnn.py:42-62) — model_2 / _4 / _8: conv-1024 (SVI), model_3 / _7: fc2-1024
+    # (HMC n_samples = 100 / SVI).  N cut so that a step stays a few tens of ms (conv: the per-(point, sample) activations double with Hc)
+    "conv1024": dict(shape=(1, 28, 28), H=1024, C=10, arch="conv", act="leaky", S=16, N=1024, method="fgsm", iters=1, eps=0.3,
+                     desc="(F-)MNIST conv-BNN at hidden 1024 (conv5x5x32 - pool - conv5x5x1024 - pool - fc, leaky; the reference's saved model_2 / _4 / _8), "
+                          "FGSM eps=0.3, N=1024 points, S=16 samples/GPU"),
+    "fc2_1024": dict(shape=(1, 28, 28), H=1024, C=10, arch="fc2", act="leaky", S=100, N=10000, method="fgsm", iters=1, eps=0.3,
+                     desc="(F-)MNIST fc2-BNN 784->1024->1024->10 (leaky; the reference's saved model_3 / _7), FGSM eps=0.3, N=10000 points, S=100 samples/GPU"),
     # BASELINE.json configs[4]: CIFAR-shaped conv-BNN, n_samples=500 over 8 GPUs (64 per GPU, 512 at 8), PGD T=100 for each eps of
     # the grid {2,4,8}/255, 10 000 points.  Shapes are BUILD-DEFINED (3x32x32 -> head 81*Hc; the reference's conv cannot express
     # them, SURVEY 8a note): parity unpinned.  One step = the whole eps grid = 3 x 100 iterations (minutes): profile with
@@ -149,7 +157,7 @@ def make_guide(w, rank):
     return loc, scale
 
 
-SVI_NAMED = {"c1", "c2", "c5", "conv"}      # BASELINE.json configs that say "SVI" (conv / c5: the in-place draw does not cover conv)
+SVI_NAMED = {"c1", "c2", "c5", "conv", "conv1024"}      # BASELINE.json configs that say "SVI" (conv / c5: the in-place draw does not cover conv)
 
 
 def cpu_baseline(w, x, y, post, budget_s):
@@ -643,14 +651,22 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
             sfx = "_" + mode if mode in F16_KERNELS else ""
             keys = {"fc_forward": ["fc_forward" + sfx], "fc_input_grad": ["fc_input_grad" + sfx], "lowdim": ["lowdim"],
                     "conv_forward": ["conv_forward" + sfx, "conv_forward_common"], "conv_input_grad": ["conv_input_grad" + sfx, "conv_input_grad_common"]}
-            def tot(names):
-                return sum(tab[n]["hbm_bytes_per_launch"] for n in names) * scale if names and all(n in tab for n in names) else None
+            # the record holds the mean over a kernel NAME's launches.  fc2: one C-ABI call launches the GEMM kernel twice (layer 1 and layer 2 /
+            # the step through Wm and the one through W1), so a call moves twice the per-launch mean; c4 on one forward: the forward call runs
+            # once per STEP of two passes (calls_per_pass 0.5)
+            per_call = 2.0 if w["arch"] == "fc2" else 1.0
+            cpp = {k_: min(1.0, len(e_) / max(1, passes_timed)) for k_, e_ in evs_by_name.items() if e_}
+
+            def tot(names, call=None):
+                if not (names and all(n in tab for n in names)):
+                    return None
+                return sum(tab[n]["hbm_bytes_per_launch"] for n in names) * scale * per_call * cpp.get(call, 1.0)
             traffic = tot(keys.get(dom))
             if traffic is not None:
                 traffic /= kernels[dom]["launches_per_pass"]
                 traffic_src = rec.get("source")
             calls = [k for k in kernels if k in keys]
-            if calls and all(tot(keys[k]) is not None for k in calls):
+            if calls and all(tot(keys[k], k) is not None for k in calls):
                 # the streaming kernels THIS mode launches per pass (the record may hold other modes' kernels too): every mode steps and — SVI —
                 # draws; the f16 modes build the inputs' image (absmax + scale record + rows image); the sum over samples + loss is the fused
                 # tail kernel in the triple fc mode and two kernels elsewhere
@@ -659,8 +675,8 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
                     want += ["absmax_kernel", "scale_finalize_kernel", mode + "_rows_kernel"]
                 want += ["step_tail_x3_kernel"] if (mode == "triple" and w["arch"] != "conv") else ["reduce_samples", "loss_dlogits"]
                 small = sum(v["hbm_bytes_per_launch"] for k_, v in wl.get("small", {}).items() if any(f in k_ for f in want)) * scale
-                counter = {"bytes_per_pass": sum(tot(keys[k]) for k in calls) + small, "small_kernels_bytes": small, "scaled": scaled,
-                           "kernels": {k: tot(keys[k]) for k in calls}}
+                counter = {"bytes_per_pass": sum(tot(keys[k], k) for k in calls) + small, "small_kernels_bytes": small, "scaled": scaled,
+                           "kernels": {k: tot(keys[k], k) for k in calls}}
         fp32_eq = kernels[dom]["tflops"]
         r = {"bound": "mfma", "kernel": KNAMES[mode][dom], "unit": "TFLOP/s", "traffic": traffic,
              "traffic_source": traffic_src, "traffic_scaled": scaled if traffic is not None else None,

@@ -504,11 +504,13 @@ class HipKernels:
                    project, iters, P, out, linf=None, l2=None):
         require_gpu(X, "X")
         lazy = getattr(net, "_lazy", None)
-        if (lazy is not None and getattr(net, "_triple", None) is None and sidx is None and S <= lazy[2]
+        covered = sidx is None or getattr(sidx, "_rbnn_max_index", 1 << 62) < (lazy[2] if lazy is not None else 0)
+        if (lazy is not None and getattr(net, "_triple", None) is None and covered and S <= lazy[2]
                 and self.lowdim_fused_draw_supported(net, X.shape[0], S)):
             # a pending (lazy) SVI draw: the weights are generated inside this launch — no rbnn_svi_draw launch, the stack stays as it was.
-            # Only for the identity sample map (the first S <= drawn samples): an index buffer could name samples the draw does not cover —
-            # and would read past sample_keys — so such a call materialises the draw first (net.descriptor() below does) and reads the stack
+            # Only when every sample the call names is one the draw covers: the identity map over the first S <= drawn samples, or an index
+            # buffer whose largest index is KNOWN on the host (AttackEngine.sample_index records it) and below the drawn count — the kernel
+            # reads sample_keys[sidx[s]].  Any other index buffer materialises the draw first (net.descriptor() below does) and reads the stack
             key, draw_id, _, sample_keys = lazy
             check(self.lib.rbnn_lowdim_run_svi(C.byref(net.descriptor(lazy_ok=True)), C.byref(net._guide.descriptor()), ptr(sample_keys),
                                                C.c_uint64(key & 0xFFFFFFFFFFFFFFFF), C.c_uint32(draw_id & 0xFFFFFFFF), op, loss_mode, out_kind, ptr(X),

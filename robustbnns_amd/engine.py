@@ -190,7 +190,9 @@ class AttackEngine:
             return None, len(idx)
         if idx == list(range(len(idx))):
             return None, len(idx)                               # prefix: identity map, no index buffer
-        return torch.tensor([i % self.post.S for i in idx], dtype=torch.int32, device=self.device), len(idx)
+        t = torch.tensor([i % self.post.S for i in idx], dtype=torch.int32, device=self.device)
+        t._rbnn_max_index = max(i % self.post.S for i in idx)          # known on the host: lets a pending lazy draw check its coverage without a sync
+        return t, len(idx)
 
     def workspace(self, N, S, chunk=0, tag=0):
         key = (N, S, chunk, tag)

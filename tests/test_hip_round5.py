@@ -180,3 +180,39 @@ def test_fgsm_eps_grid_is_one_gradient_and_one_clean_forward_per_n_samples(golde
     print(f"\n   {name}: {cost['cells']} cells — resident grid {cost['gradient_passes']} gradient passes + {cost['clean_forwards']} clean forwards, "
           f"{1e3 * t_grid / cost['cells']:.2f} ms per cell (host clock, PNG + pickle side effects included); per-cell loop "
           f"{cost['cells']} + {cost['cells']}, {1e3 * t_cells / cost['cells']:.2f} ms per cell")
+
+
+# ------------------------------------------------------------------ a pending lazy draw and an index buffer that leaves its coverage
+def test_lazy_draw_with_an_index_buffer_beyond_the_drawn_samples_materialises_first():
+    """A lazy draw of the first 4 of 10 samples (seeded: 4 keys), then a forward that names sample 7: the fused launch would generate a sample
+    the draw does not cover and read sample_keys[7] past the 4-element key tensor.  Such a call runs the draw for real and reads the
+    stack — the same numbers as the non-lazy sequence; an index buffer inside the coverage still takes the fused launch (the stack stays
+    untouched); the pending record owns a copy of the keys (an in-place edit of the caller's tensor does not change the draw)."""
+    from robustbnns_amd import AttackEngine, StackedPosterior
+    from robustbnns_amd.posterior import SviGuide
+    shape, H, C, S, N = (1, 2, 1), 32, 2, 10, 50
+    g = torch.Generator().manual_seed(5)
+    names = {"model.1.weight": (H, 2), "model.1.bias": (H,), "model.3.weight": (C, H), "model.3.bias": (C,)}
+    loc = {k: torch.randn(*v, generator=g) * 0.5 for k, v in names.items()}
+    scl = {k: -2.0 + 0.3 * torch.randn(*v, generator=g) for k, v in names.items()}
+    x, _ = O.synthetic_inputs(N, shape, C, seed=1)
+
+    def run(lazy):
+        keys = torch.tensor([11, 5, 7, 3], dtype=torch.int64, device=DEV)
+        post = StackedPosterior.for_guide(SviGuide(loc, scl, "fc", DEV), "leaky", shape, C, S)
+        eng = AttackEngine(post)
+        post.redraw(1, 0)                                                   # all ten samples hold a first draw
+        post.redraw(0, 2, n_samples=4, sample_keys=keys, lazy=lazy)         # the first four are redrawn (lazily)
+        keys.fill_(99)                                                      # the caller reuses its tensor
+        out = {"inside": eng.forward(x, 2, seeds=[3, 1]).cpu()}
+        if lazy:
+            assert post.__dict__["_lazy"] is not None                      # covered: generated inside the launch, still pending
+        out["beyond"] = eng.forward(x, 2, seeds=[7, 0]).cpu()
+        if lazy:
+            assert post.__dict__["_lazy"] is None                          # not covered: the draw was run, the stack read
+        out["W1"] = post.W1.clone().cpu()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

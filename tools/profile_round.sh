@@ -2,7 +2,8 @@
 # Run on the GPU box (via gpurun): usage: tools/profile_round.sh <tag> <stage>       -> gpurun_out/<tag>/...   (copy what should be judged into profiles/<tag>/)
 #   stage tests : the GPU test tier (-s: statistics printed), smoke()
 #   stage bench : every bench workload (JSON lines) + the 1-rank forced-collectives run
-#   stage prof  : rocprofv3 --kernel-trace --stats and the separate --pmc passes of c2 (+ c5, conv unless QUICK=1)
+#   stage prof  : rocprofv3 --kernel-trace --stats and the separate --pmc passes of the workloads in WLS (default "c2 c5 conv"; QUICK=1: c2 only;
+#                 also: c3 c4 fc2 fc2_1024 conv1024 — five bench runs per workload, so three or four workloads per 20-minute call)
 # (a gpurun call is limited to 20 minutes: one stage per call)
 set -u
 TAG=${1:-r03}
@@ -27,6 +28,8 @@ if [ "$STAGE" = "bench" ]; then
   python bench.py --workload c5 --points 1024 --iters 10 --steps 1 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_c5_n1024_t10.json
   python bench.py --workload conv --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_conv.json
   python bench.py --workload fc2 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_fc2.json
+  python bench.py --workload fc2_1024 --steps 3 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_fc2_1024.json
+  python bench.py --workload conv1024 --steps 3 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_conv1024.json
   python bench.py --workload c1 --steps 200 --warmup 20 --cpu-seconds 5 2>/dev/null | tail -1 > $OUT/bench_c1.json
   RBNN_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 > $OUT/bench_c2_torchrun_1rank_forced_collectives.json
   for f in $OUT/bench*.json; do python3 -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$(basename $f)', d['precision_mode'], '%.4g' % d['value'], '%.4g ms' % d['ms_per_step'])"; done
@@ -46,11 +49,21 @@ prof() {   # prof <subdir> <workload> <points> <samples per GPU> <extra bench ar
   rm -rf $OUT/$sub/trace/run_kernel_trace.csv $OUT/$sub/pmc_*/run_kernel_trace.csv      # bulky; the summary keeps the per-kernel numbers
   head -30 $OUT/$sub/summary.txt
 }
-prof c2 c2 10000 100 --steps 5 --warmup 2
-if [ -z "${QUICK:-}" ]; then
-  prof c5 c5 512 62 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode
-  prof conv conv 2048 16 --steps 3 --warmup 1
-fi
+WLS=${WLS:-"c2 c5 conv"}
+[ -n "${QUICK:-}" ] && WLS="c2"
+for wl in $WLS; do
+  case $wl in
+    c2)       prof c2 c2 10000 100 --steps 5 --warmup 2 ;;
+    c3)       prof c3 c3 10000 500 --iters 2 --steps 1 --warmup 1 --no-other-mode ;;
+    c4)       prof c4 c4 10000 250 --steps 2 --warmup 1 --no-other-mode ;;
+    fc2)      prof fc2 fc2 10000 100 --steps 3 --warmup 1 --no-other-mode ;;
+    fc2_1024) prof fc2_1024 fc2_1024 10000 100 --steps 3 --warmup 1 --no-other-mode ;;
+    c5)       prof c5 c5 512 62 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode ;;
+    conv)     prof conv conv 2048 16 --steps 3 --warmup 1 ;;
+    conv1024) prof conv1024 conv1024 1024 16 --steps 3 --warmup 1 --no-other-mode ;;
+    *) echo "unknown workload $wl" ;;
+  esac
+done
 python3 - <<PY
 import json, glob, os
 out = {}
