@@ -421,9 +421,6 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
         def conv_input_grad(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad, *a, **kw)
 
-        def conv_input_grad_triple(self, *a, **kw):
-            return self._timed("conv_input_grad", super().conv_input_grad_triple, *a, **kw)
-
         def conv_input_grad_dense(self, *a, **kw):
             return self._timed("conv_input_grad", super().conv_input_grad_dense, *a, **kw)
 

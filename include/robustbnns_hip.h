@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RBNN_ABI_VERSION 8
+#define RBNN_ABI_VERSION 9
 #define RBNN_CPAD 16               /* class axis of P / dZ buffers is padded to 16 floats */
 
 typedef enum rbnn_status {
@@ -270,18 +270,14 @@ int rbnn_conv_forward_triple(const rbnn_conv_posterior *net, const void *K2_trip
                              const int32_t *sample_idx, int32_t n_samples, int32_t out_kind,
                              const rbnn_conv_workspace *ws, void *stream);
 
-/* rbnn_conv_input_grad with conv2^T in the triple-split mode (both geometries, all four activations).  K2_bwd = rbnn_triple_rows image of
- * model.3.weight regrouped [S_total*32 ci, (Hc/16 chunks) * 13 tap pairs * 4 * 8] exactly as for rbnn_conv_input_grad_split (one
- * 192-byte stage per (chunk, tap pair)); fw_l1 = max_f sum_c |model.7.weight[c, f]|.  Same G as rbnn_conv_input_grad. */
-int rbnn_conv_input_grad_triple(const rbnn_conv_posterior *net, const void *K2_bwd, int32_t k2_exp, float fw_l1,
-                                const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
-                                const rbnn_conv_workspace *ws, void *stream);
-
-/* rbnn_conv_input_grad_triple's arithmetic in the DENSE form (both geometries): conv2^T as one GEMM per tap over the conv2 OUTPUT positions
- * (64 at 1x28x28: one pass; 100 at 3x32x32: two passes over 64 + 36 positions whose col2im partial sums meet in registers)
- * (T[tap][ci][pos] = sum_hc W[hc][ci][tap] * dO2[hc][pos], every MFMA useful) + a col2im gather, instead of the gather form over the
- * zero-padded gradient image (36-39 % of whose MFMAs multiply padding).  K2_dense = rbnn_triple_rows image (ld 32) of model.3.weight
- * regrouped [S_total, ceil(Hc/32) K steps, 25 taps, 32 ci][32 hc] (hc zero-padded to a multiple of 32), holding W * 2^k2_exp.  Same G. */
+/* rbnn_conv_input_grad with conv2^T in the triple-split mode (both geometries, all four activations), DENSE form: conv2^T as one GEMM per tap
+ * over the conv2 OUTPUT positions (64 at 1x28x28: one pass; 100 at 3x32x32: two passes over 64 + 36 positions whose col2im contributions
+ * meet in wave-private partial images) — T[tap][ci][pos] = sum_hc W[hc][ci][tap] * dO2[hc][pos], every MFMA useful — + a col2im, instead of
+ * a gather over a zero-padded gradient image (the fp32 and split kernels' form: 36-39 % of its MFMAs multiply padding; the triple kernel of
+ * that form, rbnn_conv_input_grad_triple, was removed in ABI 9).  K2_dense = triple-rows image (ld 32) of model.3.weight regrouped
+ * [S_total, ceil(Hc/32) K steps, 25 taps, 32 ci][32 hc] (hc zero-padded to a multiple of 32), holding W * 2^k2_exp, as rbnn_conv_weight_images
+ * writes it; fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed gradients (a per-(sample, point) power-of-two scale is derived from
+ * it and max|dZ|).  Same G as rbnn_conv_input_grad. */
 int rbnn_conv_input_grad_dense(const rbnn_conv_posterior *net, const void *K2_dense, int32_t k2_exp, float fw_l1,
                                const int32_t *sample_idx, int32_t n_samples, int32_t n_points,
                                const rbnn_conv_workspace *ws, void *stream);

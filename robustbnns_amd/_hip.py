@@ -130,7 +130,6 @@ SIGNATURES = {
     "rbnn_conv_input_grad_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_forward_split": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
                                        C.POINTER(ConvWorkspace), _fp]),
-    "rbnn_conv_input_grad_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_input_grad_dense": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _f32, _fp, _i32, _i32, C.POINTER(ConvWorkspace), _fp]),
     "rbnn_conv_weight_images": (_i32, [_fp, _i32, _i32, _i32, _fp, _fp, _fp]),
     "rbnn_conv_forward_triple": (_i32, [C.POINTER(ConvPosterior), _fp, _i32, _i32, _fp, _fp, _i32, _i32, _fp, _i32, _i32,
@@ -167,7 +166,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipError(RuntimeError):
@@ -438,12 +437,6 @@ class HipKernels:
         check(self.lib.rbnn_conv_forward_triple(C.byref(net.descriptor()), ptr(K2_triple), k2_exp, p1_exp, ptr(p1_dev_scale), ptr(X),
                                                 X.stride(0), X.shape[0], ptr(sidx), S, out_kind, C.byref(w), stream_of(X)),
               "rbnn_conv_forward_triple")
-
-    def conv_input_grad_triple(self, net, K2_bwd, k2_exp, fw_l1, sidx, S, N, ws):
-        w = self._conv_ws(ws)
-        check(self.lib.rbnn_conv_input_grad_triple(C.byref(net.descriptor()), ptr(K2_bwd), k2_exp, fw_l1, ptr(sidx), S, N, C.byref(w),
-                                                   stream_of(ws["dZ"])), "rbnn_conv_input_grad_triple")
-        return S
 
     def conv_input_grad_dense(self, net, K2_dense, k2_exp, fw_l1, sidx, S, N, ws):
         w = self._conv_ws(ws)

@@ -105,32 +105,24 @@ class ConvStackedPosterior:
                "model.7.weight": self.Fw, "model.7.bias": self.Fb}
         items = [(g.loc[k], g.sigma[k], dst[k], g.TENSOR_IDS[k]) for k in dst]
         _hip.HipKernels().svi_draw_flat(items, S, int(key), int(draw_id), sample_keys)
-        # images nobody may read before the next draw are only marked stale (each is a 100+ MB permuted copy at Hc = 512): the fp32 kernels'
-        # input-channel regrouping, and the gather-form backward image while the dense conv2^T is what runs (refresh_lazy_images)
+        # an image nobody may read before the next draw is only marked stale (a 100+ MB permuted copy at Hc = 512): the fp32 kernels'
+        # input-channel regrouping (refresh_lazy_images)
         self._k2ci_stale = True
         if self._triple is not None:
-            dense = getattr(self, "_dense", None) is not None and self.dense_supported()
             if self._fused_images():            # forward rows + dense conv2^T images by ONE kernel straight from the fp32 stack
-                _hip.HipKernels().conv_weight_images(self.K2w, self.S, self.H, self._triple[1], self._triple[0], getattr(self, "_dense", None))
-                if not dense:
-                    self._build_triple(self._triple[0], self._triple[2], with_fwd=False)
+                _hip.HipKernels().conv_weight_images(self.K2w, self.S, self.H, self._triple[1], self._triple[0], self._dense)
             else:
-                self._build_triple(self._triple[0], self._triple[2], with_bwd=not dense)
-                if getattr(self, "_dense", None) is not None:
-                    self._build_dense(self._dense)
-            self._bwd_stale = dense
+                self._build_triple(self._triple[0])
+                self._build_dense(self._dense)
         if self._split is not None:
             self._build_split(self._split[0], self._split[4])
         return self
 
-    def refresh_lazy_images(self, k2ci=False, triple_bwd=False):
+    def refresh_lazy_images(self, k2ci=False):
         """Rebuild an image that redraw() only marked stale, right before a kernel that reads it."""
         if k2ci and getattr(self, "_k2ci_stale", False):
             self._regroup_k2ci()
             self._k2ci_stale = False
-        if triple_bwd and getattr(self, "_bwd_stale", False) and self._triple is not None:
-            self._build_triple(self._triple[0], self._triple[2], with_fwd=False)
-            self._bwd_stale = False
 
     def _k2_max(self):
         return self._guide.k2_max if self._guide is not None else float(self.K2w.abs().max())
@@ -159,12 +151,6 @@ class ConvStackedPosterior:
         if self._guide is None:
             self._tmp = self._dense_tmp = self._dense_stage = self._rows_stage = None
 
-    def dense_supported(self):
-        """The dense conv2^T kernel (rbnn_conv_input_grad_dense: a GEMM per tap over the conv2 OUTPUT positions + col2im, no padding MFMAs)
-        covers both geometries — 1x28x28 in one pass over its 64 positions, 3x32x32 in two (64 + 36) — and all four activations;
-        RBNN_CONV_BWD_DENSE=0 keeps the gather form (rbnn_conv_input_grad_triple)."""
-        return os.environ.get("RBNN_CONV_BWD_DENSE", "1") != "0"
-
     def _build_dense(self, dense):
         """model.3.weight regrouped [S, K steps of 32 hc, 25 taps, 32 ci][32 hc] (hc zero-padded) as a triple-rows image."""
         S, H = self.S, self.H
@@ -183,24 +169,20 @@ class ConvStackedPosterior:
         T = dense.shape[0] // 16
         dense.view(T, 3, 16, 32).copy_(self._dense_stage.view(T, 16, 3, 32).permute(0, 2, 1, 3))
 
-    def _build_triple(self, rows, bwd, with_fwd=True, with_bwd=True):
+    def _build_triple(self, rows):
+        """The forward's image through the stand-alone builders (the fused kernel, rbnn_conv_weight_images, is tested against this)."""
         S, H = self.S, self.H
-        k2, w26, kb = self._scratch()
+        k2 = self._scratch()[0]
         k = _hip.HipKernels()
         k2_exp = scale_exp(self._k2_max())
-        if with_fwd:
-            k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))                 # k = tap*32 + ci
-            # triple rows ([channel][tap][3 pieces][64 B]) into a staging copy, then grouped [16 channels][tap][3 pieces][16 rows][64 B]: the order
-            # a 16-channel group of one tap has in the kernel's stage tile (its three LDS-DMA pieces then differ by 1 KiB on both sides)
-            if getattr(self, "_rows_stage", None) is None:
-                self._rows_stage = torch.empty_like(rows)
-            k.triple_rows(k2, 800, k2_exp, self._rows_stage, 800)
-            G = S * H // 16
-            rows.view(G, 25, 3, 16, 32).copy_(self._rows_stage.view(G, 16, 25, 3, 32).permute(0, 2, 3, 1, 4))
-        if with_bwd:
-            w26[..., :25].copy_(self.K2w.view(S, H, 32, 25))
-            kb.view(S, 32, H // 16, 13, 2, 2, 8).copy_(w26.view(S, H // 16, 2, 8, 32, 13, 2).permute(0, 4, 1, 5, 6, 2, 3))
-            k.triple_rows(kb, kb.shape[1], k2_exp, bwd, kb.shape[1])
+        k2.view(S, H, 25, 32).copy_(self.K2w.view(S, H, 32, 25).permute(0, 1, 3, 2))                 # k = tap*32 + ci
+        # triple rows ([channel][tap][3 pieces][64 B]) into a staging copy, then grouped [16 channels][tap][3 pieces][16 rows][64 B]: the order
+        # a 16-channel group of one tap has in the kernel's stage tile (its three LDS-DMA pieces then differ by 1 KiB on both sides)
+        if getattr(self, "_rows_stage", None) is None:
+            self._rows_stage = torch.empty_like(rows)
+        k.triple_rows(k2, 800, k2_exp, self._rows_stage, 800)
+        G = S * H // 16
+        rows.view(G, 25, 3, 16, 32).copy_(self._rows_stage.view(G, 16, 25, 3, 32).permute(0, 2, 3, 1, 4))
         return k2_exp
 
     def _build_split(self, rows, bwd):
@@ -227,24 +209,19 @@ class ConvStackedPosterior:
         return self._range_ok
 
     def triple_images(self):
-        """(K2 triple-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32] for the forward, its exponent, the backward's
-        image [S*32 ci, chunk(Hc/16) x 13 tap pairs x lg(4 = tap parity*2 + channel octet) x 8 channels], max_f sum_c |Fw[c,f]|) —
-        built once, resident."""
+        """(K2 triple-rows image of model.3.weight regrouped tap-major [S*Hc, 25*32] for the forward, its exponent, the dense conv2^T image
+        [S, K steps of 32 hc, 25 taps, 32 ci][32 hc], max_f sum_c |Fw[c,f]|) — built once, resident."""
         if self._triple is None:
             S, H = self.S, self.H
             rows = torch.empty(S * H, 800 * 3, dtype=torch.int16, device=self.device)
-            bwd = torch.empty(S * 32, (H // 16) * 13 * 32 * 3, dtype=torch.int16, device=self.device)
-            if self.dense_supported():
-                self._dense = torch.empty(S * ((H + 31) // 32) * 25 * 32, 32 * 3, dtype=torch.int16, device=self.device)
+            self._dense = torch.empty(S * ((H + 31) // 32) * 25 * 32, 32 * 3, dtype=torch.int16, device=self.device)
             if self._fused_images():
                 k2_exp = scale_exp(self._k2_max())
                 _hip.HipKernels().conv_weight_images(self.K2w, S, H, k2_exp, rows, self._dense)
-                self._build_triple(rows, bwd, with_fwd=False)
             else:
-                k2_exp = self._build_triple(rows, bwd)
-                if self._dense is not None:
-                    self._build_dense(self._dense)
-            self._triple = (rows, k2_exp, bwd, self._fw_l1())
+                k2_exp = self._build_triple(rows)
+                self._build_dense(self._dense)
+            self._triple = (rows, k2_exp, self._dense, self._fw_l1())
             self._free_staging()
         return self._triple
 
@@ -417,11 +394,8 @@ class ConvEngine(AttackEngine):
 
     def _grad_kernels(self, sidx, S, N, ws, dz_ready=False):
         if self.precision == "triple" and os.environ.get("RBNN_CONV_BWD_EXACT") != "1":
-            _, k2_exp, bwd, fw_l1 = self.post.triple_images()
-            if self.post._dense is not None and self.post.dense_supported():      # GEMM per tap over the conv2 outputs + col2im
-                return self.k.conv_input_grad_dense(self.post, self.post._dense, k2_exp, fw_l1, sidx, S, N, ws)
-            self.post.refresh_lazy_images(triple_bwd=True)
-            return self.k.conv_input_grad_triple(self.post, bwd, k2_exp, fw_l1, sidx, S, N, ws)
+            _, k2_exp, dense, fw_l1 = self.post.triple_images()                 # conv2^T: a GEMM per tap over the conv2 outputs + col2im
+            return self.k.conv_input_grad_dense(self.post, dense, k2_exp, fw_l1, sidx, S, N, ws)
         if self.precision != "split" or os.environ.get("RBNN_CONV_BWD_EXACT") == "1":
             self.post.refresh_lazy_images(k2ci=True)
             return self.k.conv_input_grad(self.post, sidx, S, N, ws)

@@ -1,0 +1,1127 @@
+// rbnn_conv_x3.hip — the conv architecture (model_nn.py:93-106) in the TRIPLE-SPLIT mode (what precision="auto" runs on it, both geometries):
+// conv2 forward and conv2^T / conv1^T backward with every fp32 operand carried at full width as three fp16 pieces, six exact product terms per
+// fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulation (rbnn_triple.hip's arithmetic).  conv1 + pool, the Linear head and its transpose
+// are the fp32 kernels of rbnn_conv.hip (2 % of the MACs; rbnn_conv_common.hpp declares their launchers).
+//   conv2_pool_x3_kernel        forward conv2 + pool + activation + stash
+//   conv_bwd_dense_x3_kernel    conv2^T as a GEMM per tap over the conv2 OUTPUT positions + col2im (no padding MFMAs)
+//   conv1_bwd_x3_kernel         pool-1 routing + conv1^T (more than one input channel)
+//   conv_k2_images_kernel       both weight images of model.3.weight from the fp32 stack in one launch
+#include "rbnn_conv_common.hpp"
+
+#ifndef RBNN_X3FWD_NT
+#define RBNN_X3FWD_NT 0                                                    // non-temporal Q2 / stash stores of conv2_pool_x3_kernel: measured equal / slower
+#endif
+#ifndef RBNN_CONV1_BWD_X3_MINCIN
+#define RBNN_CONV1_BWD_X3_MINCIN 2                                        // input channels from which conv1^T runs on the f16 pipe (1x28x28 keeps the fp32 kernel)
+#endif
+
+using namespace rbnn_conv_shared;
+
+namespace {
+
+// =====================================================================================================
+// Triple-split ("f16x6") conv2 forward: the technique of rbnn_triple.hip — every fp32 operand carried at FULL width as three
+// fp16 pieces, six exact product terms per fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulation — on the layer that holds
+// 98 % of the MACs, for BOTH geometries.  Structure = conv2_pool_split_kernel's (K tap-major: one K step = one tap over the 32
+// input channels; the B operand of a lane is one ds_read_b128 per piece from the point's channel-last image resident in LDS):
+//   * conv1 is the exact conv1_pool_kernel (fp32 P1 image, ~2 % of the MACs); each block splits its two points' images into
+//     the three piece planes while loading them: img[point][piece][pos = y*P1W + x][32 ci] halves, 16-byte channel octet o at
+//     o ^ (((pos >> 2) & 1) << 1), scaled by the device record of rbnn_input_scales (|P1| <= sum|K1w| * max|x| + max|K1b|);
+//   * A = model.3.weight regrouped [hc][tap][ci] as a triple-rows image (rbnn_triple_rows, 25 K stages of 192 B per channel),
+//     staged per tap through three plane tiles of 64-B rows (fc_forward_x3_kernel's ring and `swz` chunk swizzle);
+//   * block = 8 waves = 4 channel groups (HTW tiles of 16 channels each) x 2 points; WROWS = 64 * HTW channels per chunk.
+//     1x28x28: WROWS 256 (96 KB of weight tiles + 2 x 27 KB images); 3x32x32: WROWS 128 (48 KB + 2 x 37 KB).
+// =====================================================================================================
+struct ConvX3Args {
+    const char* K2t; int k2_exp; int p1_exp;                             // triple-rows image of [S_total*Hc][25*32]
+    const rbnn_dev_scale* p1_ds;                                         // != NULL: the P1 scale lives on the device (rbnn_input_scales record [1])
+};
+
+__device__ __forceinline__ void conv_split3(float v, _Float16& p0, _Float16& p1, _Float16& p2) {
+    p0 = (_Float16)v;
+    float r = v - (float)p0;
+    p1 = (_Float16)r;
+    r -= (float)p1;
+    p2 = (_Float16)r;
+}
+
+#define RBNN_X3FWD_BPREFETCH 0                                           // 1: the B fragments of tap t + 1 read under tap t's MFMAs (round 4) — measured SLOWER: 1x28x28 8.42 -> 8.58 ms per forward call,
+                                                                          // 3x32x32 15.1 -> 16.5 (spills beside 56 accumulators): with two waves per SIMD the other wave fills a tap's post-barrier round trip
+#ifndef RBNN_CONVX3_OLD_IMG
+#define RBNN_CONVX3_OLD_IMG 0                                            // 1: the round-2 image layout (pitch = P1W, chunk swizzle by (pos >> 2) & 1 only)
+#endif
+// Image layout of conv2_pool_x3_kernel: position (y, x) of the pooled conv1 image is a 64-B record (32 channels) at index y * IPITCH + x;
+// 16-B channel octet o is stored at o ^ x3_img_swz(index, y).  A ds_read_b128 is served in four 16-lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}, +32 (rbnn_common.hpp); lane (li, lg) gathers octet lg of the position of output li + a tap offset.  Enumerating
+// every (tap, position tile, group) (tools/conv_x3_swizzle_search.py): with IPITCH = P1W and the swizzle ((idx >> 2) & 1) << 1 alone
+// EVERY gather is a 2-way conflict at 1x28x28 (2.0 LDS passes per read; PMC round 2: 36 % of the LDS cycles) and 2.9 passes at
+// 3x32x32 (43 %, the 12 idle lanes of the last tile all re-reading position 0 included).  1x28x28: XOR-ing the row parity into octet
+// bit 0 makes all of them conflict-free (1.0).  3x32x32: rows of 10 outputs do not tile the 4-position period; a pitch of 18 (48 KB
+// per point instead of 37) with the idle lanes spread over positions 0..11 brings it to 1.14.
+template <class G> struct ConvX3Img {
+    static constexpr bool MNIST = G::P1W == 12;
+    static constexpr int IPITCH = RBNN_CONVX3_OLD_IMG ? G::P1W : (MNIST ? 12 : 18);
+    static constexpr int ROWX = (!RBNN_CONVX3_OLD_IMG && MNIST) ? 1 : 0;
+};
+template <class G> __device__ __forceinline__ int x3_img_swz(int idx, int y) {
+    return ((((idx >> 2) & 1) << 1) ^ (ConvX3Img<G>::ROWX * (y & 1)));
+}
+
+template <class G, int WROWS> struct ConvX3Lds {
+    static constexpr int PLANEW = WROWS * 64, TILEW = 3 * PLANEW;        // one tap's weight tile: 3 planes of WROWS 64-B rows
+    static constexpr int IPOS = G::P1W * ConvX3Img<G>::IPITCH, IMGP = IPOS * 64, IMGB = 3 * IMGP;   // one point's image: 3 planes of IPOS 64-B position records
+    static constexpr int SCR = 8 * 16 * (G::NPOS + 4) * 4;               // the eight waves' pooling tiles (epilogue; alias the weight buffers)
+    static constexpr int WBUF = (2 * TILEW > SCR ? 2 * TILEW : SCR);
+    static constexpr int BYTES = WBUF + 2 * IMGB;
+};
+
+template <int ACT, class G, int WROWS>
+__global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a, const ConvX3Args x) {
+    using L = ConvX3Lds<G, WROWS>;
+    constexpr int HTW = WROWS / 64, NPT = G::NPT2, NW = 8;
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NPOS_ = G::NPOS, NP2_ = G::NP2;
+    constexpr int WPP = WROWS / 16 / NW;                                  // DMA pieces (16 rows of one plane) per wave per plane
+    static_assert(WROWS % 128 == 0 && L::BYTES <= 160 * 1024, "whole pieces per wave; LDS");
+    static_assert((16 * NP2_) % 4 == 0, "four pooled cells per lane");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* const ldsb = (char*)lds;
+    char* const imgs = ldsb + L::WBUF;
+
+    const int NB = (a.N + 1) / 2;                                         // blocks per sample
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, nb0 = (id % NB) * 2;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, wp = wave >> 2;                              // channel group, point of the pair
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const int n = min(nb0 + wp, a.N - 1);                                 // a ragged last block computes its first point twice, stores once
+    const bool live = nb0 + wp < a.N;
+    const long long sn = (long long)s * a.N + n;
+    const char* const Ws = x.K2t + (long long)sw * a.Hc * (K2 * 6);
+    const int F = a.Hc * NP2_;
+    const float p1_scale = x.p1_ds ? x.p1_ds->scale : ldexpf(1.f, x.p1_exp);
+    const float out_scale = x.p1_ds ? ldexpf(1.f, -x.k2_exp) * x.p1_ds->inv_scale : ldexpf(1.f, -(x.k2_exp + x.p1_exp));
+
+    // both points' fp32 images [32 ci][IPOS] -> three piece planes, channel-last, in LDS: one (position, channel octet) per thread-item
+    constexpr int IPITCH = ConvX3Img<G>::IPITCH, NSRC = P1W_ * P1W_;
+#ifdef RBNN_X3FWD_ABL_NOFILL
+    for (int i = tid; i < 2 * NSRC * 4 && a.Hc == 12345; i += 512) {     // ablation (timing only): the images are never filled
+#else
+    for (int i = tid; i < 2 * NSRC * 4; i += 512) {
+#endif
+        const int pt2 = i / (NSRC * 4), rem = i % (NSRC * 4), pos = rem >> 2, o = rem & 3;
+        const float* const src = a.P1 + ((long long)s * a.N + min(nb0 + pt2, a.N - 1)) * G::P1SZ + (8 * o) * NSRC + pos;
+        union { f16x8 v; uint4 u; unsigned w[4]; } q0, q1, q2;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+            split3_plain_pair(src[j * NSRC] * p1_scale, src[(j + 1) * NSRC] * p1_scale, 1.f, q0.w[j >> 1], q1.w[j >> 1], q2.w[j >> 1]);
+        const int iy = pos / P1W_, idx = iy * IPITCH + pos % P1W_;
+        char* const dst = imgs + pt2 * L::IMGB + idx * 64 + ((o ^ x3_img_swz<G>(idx, iy)) * 16);
+        *(uint4*)dst = q0.u;
+        *(uint4*)(dst + L::IMGP) = q1.u;
+        *(uint4*)(dst + 2 * L::IMGP) = q2.u;
+    }
+    const int prow = lane >> 2;
+    const unsigned src_off = (unsigned)(prow * 64 + ((lane & 3) ^ swz(prow)) * 16);   // inside a 1-KiB piece: row prow, logical chunk (lane & 3) ^ swz(row)
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);
+    // image position of output position 16pt + li (tap 0,0); positions past NPOS read (0,0), never stored
+    int pbase[NPT], ybase[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        int pos = pt * 16 + li;
+        if (pos >= NPOS_) pos = RBNN_CONVX3_OLD_IMG ? 0 : pos - NPOS_;  // idle lanes of the last tile: distinct valid positions (never stored)
+        ybase[pt] = pos / O2W_;
+        pbase[pt] = ybase[pt] * IPITCH + pos % O2W_;
+    }
+    const char* const img = imgs + wp * L::IMGB;
+    // epilogue roles: lane handles the four consecutive pooled cells 4 * (lane + 64 it) .. of a 16-channel tile; their offsets in the wave's tile
+    constexpr int CPITCH = NPOS_ + 4, EIT = (16 * NP2_ / 4 + 63) / 64;
+    int pbase_e[EIT][4];
+#pragma unroll
+    for (int it = 0; it < EIT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = min(4 * (lane + 64 * it) + j, 16 * NP2_ - 1), hl = idx / NP2_, p = idx % NP2_;
+            pbase_e[it][j] = hl * CPITCH + (p / P2W_) * O2W_ + (p % P2W_);
+        }
+    for (int hc0 = 0; hc0 < a.Hc; hc0 += WROWS) {
+        f32x4 acc[HTW][NPT];
+#pragma unroll
+        for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto stage = [&](int tap, int buf) {
+            // the weight image is grouped [16 channels][tap][3 pieces][16 rows][64 B] (conv.py::_build_triple) and a 16-channel group sits in the
+            // stage tile the same way — [group][3 pieces][1 KiB]: the immediate offset of global_load_lds applies to the global AND the LDS
+            // address, so a group's three pieces share one address register and one M0 write
+            char* const T = ldsb + buf * L::TILEW;
+#pragma unroll
+            for (int i = 0; i < WPP; ++i) {
+                const unsigned grp = min((unsigned)(hc0 >> 4) + (unsigned)(wave + NW * i), (unsigned)(a.Hc >> 4) - 1u);   // groups past Hc repeat the last one; never stored
+                const auto gsrc = (const __attribute__((address_space(1))) void*)(Ws + ((grp * 25u + (unsigned)tap) * 3072u + src_off));
+                const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)(T + (wave + NW * i) * 3072);
+                __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
+                __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
+            }
+        };
+        stage(0, 0);
+        __syncthreads();                                                 // also orders the image fill (first chunk) / the previous chunk's pooling tiles
+        // RBNN_X3FWD_BPREFETCH (off: measured slower, see its definition): B fragments (gathered from the point's image, which no barrier guards
+        // after the first) read ONE TAP AHEAD into a second register set, under the current tap's MFMAs (the two sets alternate: no copies)
+        // (3x32x32: seven position tiles x three planes x two sets do not fit beside the accumulators — only the plane of the FIRST product group,
+        // b2, is read ahead there; b0 / b1 follow behind the barrier and land under that group's MFMAs)
+        constexpr bool PF_ALL = RBNN_X3FWD_BPREFETCH && NPT <= 4;
+        auto load_b = [&](int tap, f16x8 (&b0)[NPT], f16x8 (&b1)[NPT], f16x8 (&b2)[NPT], bool lo, bool hi) {
+            const int ky = tap / 5, toff = ky * IPITCH + (tap % 5);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int p = pbase[pt] + toff;
+                const char* const src = img + p * 64 + ((lg ^ x3_img_swz<G>(p, ybase[pt] + ky)) * 16);
+                if (lo) { b0[pt] = *(const f16x8*)src; b1[pt] = *(const f16x8*)(src + L::IMGP); }
+                if (hi) b2[pt] = *(const f16x8*)(src + 2 * L::IMGP);
+            }
+        };
+        f16x8 bA0[NPT], bA1[NPT], bA2[NPT], bB0[PF_ALL ? NPT : 1], bB1[PF_ALL ? NPT : 1], bB2[NPT];
+        auto tap_body = [&](int tap, f16x8 (&b0)[NPT], f16x8 (&b1)[NPT], f16x8 (&b2)[NPT], auto& n0, auto& n1, f16x8 (&n2)[NPT]) {
+            const int buf = tap & 1;
+            if (tap + 1 < 25) {
+                stage(tap + 1, buf ^ 1);
+            }
+            load_b(tap, b0, b1, b2, true, true);
+            const char* const Wt = ldsb + buf * L::TILEW + (wq * HTW) * 3072 + foff;
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht) {
+                const f16x8 a0 = *(const f16x8*)(Wt + ht * 3072), a1 = *(const f16x8*)(Wt + ht * 3072 + 1024),
+                            a2 = *(const f16x8*)(Wt + ht * 3072 + 2048);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b2[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a2, b0[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a1, b1[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a1, b0[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b1[pt], acc[ht][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b0[pt], acc[ht][pt]);
+            }
+            ring_wait_barrier<0>();                                      // tap+1's weights landed; everyone is done with this tile
+        };
+        for (int tap = 0; tap < 25; tap += 2) {
+            if constexpr (PF_ALL) {
+                tap_body(tap, bA0, bA1, bA2, bB0, bB1, bB2);
+                if (tap + 1 < 25) tap_body(tap + 1, bB0, bB1, bB2, bA0, bA1, bA2);
+            } else {                                                     // one b0 / b1 set (read behind the barrier each tap), two b2 sets
+                tap_body(tap, bA0, bA1, bA2, bA0, bA1, bB2);
+                if (tap + 1 < 25) tap_body(tap + 1, bA0, bA1, bB2, bA0, bA1, bA2);
+            }
+        }
+        // epilogue (as conv2_pool_kernel): scale, bias, 2x2 / stride-1 max-pool of the pre-activations through a per-wave LDS tile
+        // (aliases the weight buffers: every wave passed the barrier above), activation, stash.  The tile's channel pitch CPITCH = NPOS + 4
+        // spreads the four channel groups of a store over the banks, and the cell -> tile offsets of a lane (pbase_e) are computed once per
+        // kernel: the divisions by NP2 / P2W per cell made this epilogue 1.1 of the kernel's 7.9 ms (profiles/r03a/conv_dense_ablations.txt)
+        float* const my = (float*)ldsb + wave * 16 * CPITCH;
+#ifdef RBNN_X3FWD_ABL_NOEPI
+        {                                                                  // ablation (timing only)
+            float sink = 0.f;
+#pragma unroll
+            for (int ht = 0; ht < HTW; ++ht)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) sink += acc[ht][pt][0] + acc[ht][pt][1] + acc[ht][pt][2] + acc[ht][pt][3];
+            if (sink == 1.2345e-30f) a.Q2[sn * F] = sink;
+            __syncthreads();
+            continue;
+        }
+#endif
+#pragma unroll
+        for (int ht = 0; ht < HTW; ++ht) {
+            const int hcb = hc0 + (wq * HTW + ht) * 16;                    // wave-uniform
+            if (hcb >= a.Hc) break;
+            const f32x4 bias = *(const f32x4*)(a.K2b + (long long)sw * a.Hc + hcb + 4 * lg);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (pt * 16 + li < NPOS_) {
+                        const float pre = acc[ht][pt][r] * out_scale + bias[r];   // sigmoid / tanh are pooled on their VALUES, as torch does
+                        my[(4 * lg + r) * CPITCH + pt * 16 + li] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+                    }
+            // four consecutive pooled cells per lane: one 16-byte store of Q2 and one 4-byte store of the stash (the tile's 16 x NP2
+            // cells are contiguous in both)
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int i4 = lane + 64 * it;
+                if (i4 < 16 * NP2_ / 4 && live) {
+                    f32x4 q;
+                    unsigned stw = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int base = pbase_e[it][j];
+                        float best = my[base];
+                        int arg = 0;
+                        if (my[base + 1] > best) { best = my[base + 1]; arg = 1; }
+                        if (my[base + O2W_] > best) { best = my[base + O2W_]; arg = 2; }
+                        if (my[base + O2W_ + 1] > best) { best = my[base + O2W_ + 1]; arg = 3; }
+                        q[j] = smooth_act<ACT>() ? best : act_fwd<ACT>(best);
+                        stw |= (unsigned)(arg | (best > 0.f ? 4 : 0)) << (8 * j);
+                    }
+                    const long long o = sn * F + (long long)hcb * NP2_ + 4 * i4;       // a multiple of 4
+#if RBNN_X3FWD_NT
+                    __builtin_nontemporal_store(q, (f32x4*)(a.Q2 + o));
+                    __builtin_nontemporal_store(stw, (unsigned*)(a.st2 + o));
+#else
+                    *(f32x4*)(a.Q2 + o) = q;
+                    *(unsigned*)(a.st2 + o) = stw;
+#endif
+                }
+            }
+        }
+        __syncthreads();                                                 // the pooling tiles alias the weight buffers of the next chunk
+    }
+}
+
+template <int ACT, class G>
+int launch_conv_forward_x3(const ConvArgs& a, const ConvX3Args& x, hipStream_t st) {
+    constexpr int WROWS = (G::CIN == 1 ? 256 : 128);
+    int rc = launch_conv1_pool(ACT, G::CIN, a, st);                       // conv1 + pool: the fp32 kernel of rbnn_conv.hip (2 % of the MACs)
+    if (rc) return rc;
+    constexpr int LDSB = ConvX3Lds<G, WROWS>::BYTES;
+    static unsigned long long attr = 0;                                   // per instantiation, one bit per device
+    if (!ensure_dynamic_lds((const void*)conv2_pool_x3_kernel<ACT, G, WROWS>, LDSB, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv2_pool_x3_kernel<ACT, G, WROWS>), dim3(grid_for_items((long long)((a.N + 1) / 2) * a.S)), dim3(512), LDSB, st, a, x);
+    if ((rc = launch_status())) return rc;
+    return launch_conv_fc(a, st);
+}
+
+}  // namespace
+
+extern "C" int rbnn_conv_forward_triple(const rbnn_conv_posterior* net, const void* K2_triple, int32_t k2_exp, int32_t p1_exp,
+                             const rbnn_dev_scale* p1_dev_scale, const float* X, int32_t ldx, int32_t N, const int32_t* sidx,
+                             int32_t S, int32_t out_kind, const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (!K2_triple || !X || !ws || !ws->P || !ws->P1 || !ws->st1 || !ws->Q2 || !ws->st2) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || ldx < net->in_channels * net->in_width * net->in_width) return RBNN_ERR_SHAPE;
+    if (k2_exp < -100 || k2_exp > 100 || p1_exp < -100 || p1_exp > 100) return RBNN_ERR_SHAPE;
+    if (out_kind != RBNN_OUT_PROBS && out_kind != RBNN_OUT_LOGITS) return RBNN_ERR_UNSUPPORTED;
+    if (!aligned16(K2_triple) || !aligned16(ws->P) || !aligned16(ws->P1) || !aligned16(ws->Q2)) return RBNN_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs a = {};
+    a.X = X; a.ldx = ldx; a.N = N;
+    a.K1w = net->K1w; a.K1b = net->K1b; a.K2w = net->K2w; a.K2b = net->K2b; a.Fw = net->Fw; a.Fb = net->Fb;
+    a.Hc = net->hidden; a.C = net->n_classes; a.sidx = sidx; a.S = S;
+    a.P1 = ws->P1; a.st1 = ws->st1; a.Q2 = ws->Q2; a.st2 = ws->st2; a.P = ws->P; a.out_kind = out_kind;
+    ConvX3Args x = {};
+    x.K2t = (const char*)K2_triple; x.k2_exp = k2_exp; x.p1_exp = p1_exp; x.p1_ds = p1_dev_scale;
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        a.NP2 = G::NP2;
+        return for_activation(net->activation, [&](auto act) { return launch_conv_forward_x3<decltype(act)::value, G>(a, x, st); });
+    });
+}
+
+namespace {
+
+// conv1^T on the F16 matrix pipe (triple-split arithmetic; round 4, second half): conv1_bwd_mfma_kernel's structure — one wave = one (sample,
+// point), a row of T per conv1 output row, five partial output rows per lane in registers — with the 32-channel contraction as ONE K step of
+// v_mfma_f32_16x16x32_f16 (six exact product terms per fp32 product; the fp32 form needs eight K steps of 16x16x4 at twice the cycles each:
+// 1,024 matrix-pipe cycles per (row, input channel) against 384 here) and the rows of T packed over (input channel, tap): 75 rows = five
+// tiles at 3x32x32 (six before), one pass per position row for all input channels.  K index k = 8 lg + e of a lane <-> channel
+// c = 16 (e >> 2) + 4 lg + (e & 3): exactly the (channel block, quad) elements the routing already holds per lane.  Scales: the weights by
+// the wave's own max |w| (its A operand is the sample's whole conv1 weight tensor); the routed gradients by max |dP1| of the (sample,
+// point), which the dense conv2^T kernel leaves in G[sn][0] (this kernel reads it before it writes G) — so only rbnn_conv_input_grad_dense
+// launches this kernel, and only for more than one input channel (launch_conv1_backward); the other conv2^T forms keep the fp32 one.
+template <int ACT, class G>
+__global__ void __launch_bounds__(256, 2) conv1_bwd_x3_kernel(const ConvBwdArgs a) {
+    constexpr int O1 = G::O1, P1W_ = G::P1W, IW = G::IW, CIN = G::CIN;
+    constexpr int MROWS = CIN * 25, MT = (MROWS + 15) / 16;
+    constexpr int TS = conv1_bwd_ts<G>(), TROW = MT * 16 * TS;            // all MT * 16 rows exist: the accumulator stores need no row test
+    static_assert(O1 <= TS && (4 * TS) % 32 != 0 && O1 <= 32 && IW <= 64, "a conv1 output row fits two 16-wide MFMA tiles; an input row fits one wave");
+    __shared__ float lds[4 * TROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int NB = (a.N + 3) / 4;
+    int id;
+    if (!item_of_block(blockIdx.x, NB * a.S, id)) return;
+    const int s = id / NB, n = (id % NB) * 4 + wave;
+    if (n >= a.N) return;                                                // whole wave idle; no block barrier anywhere
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const long long sn = (long long)s * a.N + n;
+    float* const T = lds + wave * TROW;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+    int xcl[5];                                                           // the gather's column X - kx, clamped into the T row, and whether it lies inside
+    bool xok[5];
+#pragma unroll
+    for (int kx = 0; kx < 5; ++kx) { xok[kx] = lane - kx >= 0 && lane - kx <= G::O1 - 1; xcl[kx] = min(max(lane - kx, 0), G::O1 - 1); }
+    float* const Gout = a.G + sn * G::DIN;
+    const float gmax = Gout[0];                                          // max |dP1| of this (sample, point), from conv_bwd_dense_x3_kernel
+
+    int eoff[2][2][4];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eoff[pt][kb][r] = (16 * kb + 4 * lg + r) * (P1W_ * P1W_) + min((16 * pt + li) >> 1, P1W_ - 1);
+    const uint8_t* const st_sn = a.st1 + sn * G::P1SZ;
+    const float* const d_sn = a.dP1 + sn * G::P1SZ;
+
+    // A operand: row m = ci * 25 + tap of tile mt (a channel's weights are contiguous over m), K element e of this lane = channel 16 (e >> 2) + 4 lg + (e & 3)
+    union F8 { f16x8 v; unsigned w[4]; };
+    F8 aw0[MT], aw1[MT], aw2[MT];
+    float w_inv;
+    {
+        float wv[MT][8], wmax = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = 16 * mt + li, c = 16 * (e >> 2) + 4 * lg + (e & 3);
+                wv[mt][e] = m < MROWS ? a.K1w[((long long)sw * C1 + c) * G::K1 + m] : 0.f;
+                wmax = fmaxf(wmax, fabsf(wv[mt][e]));
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        int ew = 0;
+        if (wmax > 0.f && wmax < INFINITY) ew = max(-100, min(100, 13 - ilogbf(wmax)));
+        const float wsc = ldexpf(1.f, ew);
+        w_inv = ldexpf(1.f, -ew);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2)
+                split3_plain_pair(wv[mt][e] * wsc, wv[mt][e + 1] * wsc, 1.f, aw0[mt].w[e >> 1], aw1[mt].w[e >> 1], aw2[mt].w[e >> 1]);
+    }
+    int eg = 0;
+    if (gmax > 0.f && gmax < INFINITY) eg = max(-100, min(100, 13 - ilogbf(gmax)));
+    const float g_scale = ldexpf(1.f, eg), t_scale = ldexpf(1.f, -eg) * w_inv;
+
+    float ring[CIN][5];                                                  // partial sums of output rows Ya .. Ya + 4, column X = lane
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) ring[ci][k] = 0.f;
+    int stn[2][2][4];
+    float dn[2][2][4];
+    auto fetch = [&](int py) {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    stn[pt][kb][r] = st_sn[eoff[pt][kb][r] + py * P1W_];
+                    dn[pt][kb][r] = d_sn[eoff[pt][kb][r] + py * P1W_];
+                }
+    };
+    fetch(0);
+    for (int py = 0; py < P1W_; ++py) {
+        float gv[2][2][4];
+        unsigned arp = 0;                                                // 2 bits per element (16 registers as ints: the difference between one and two waves per SIMD here)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int Xa = 16 * pt + li, st = stn[pt][kb][r];
+                    const float d = dn[pt][kb][r] * g_scale;
+                    gv[pt][kb][r] = (Xa < O1) ? ((smooth_act<ACT>() || (st & 4)) ? d : d * slope) : 0.f;
+                    arp |= (unsigned)((st & 3) ^ (Xa & 1)) << (2 * ((pt * 2 + kb) * 4 + r));   // == 2*half for the row half that owns the argmax, with the right column parity
+                }
+        auto ar = [&](int pt, int kb, int r) { return (int)((arp >> (2 * ((pt * 2 + kb) * 4 + r))) & 3u); };
+        if (py + 1 < P1W_) fetch(py + 1);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int Ya = 2 * py + half;
+            F8 b0[2], b1[2], b2[2];                                      // the routed gradient row, three piece planes: B[k][j = Xa], built ONCE for all input channels
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float ve = (ar(pt, e >> 2, e & 3) == 2 * half) ? gv[pt][e >> 2][e & 3] : 0.f;               // arg = 2*dy + dx
+                    const float vo = (ar(pt, (e + 1) >> 2, (e + 1) & 3) == 2 * half) ? gv[pt][(e + 1) >> 2][(e + 1) & 3] : 0.f;
+                    split3_plain_pair(ve, vo, 1.f, b0[pt].w[e >> 1], b1[pt].w[e >> 1], b2[pt].w[e >> 1]);
+                }
+            f32x4 acc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};                      // smallest terms first (as everywhere in the triple-split kernels)
+                    c = MFMA_H(aw2[mt].v, b0[pt].v, c);
+                    c = MFMA_H(aw1[mt].v, b1[pt].v, c);
+                    c = MFMA_H(aw0[mt].v, b2[pt].v, c);
+                    c = MFMA_H(aw1[mt].v, b0[pt].v, c);
+                    c = MFMA_H(aw0[mt].v, b1[pt].v, c);
+                    acc[mt][pt] = MFMA_H(aw0[mt].v, b0[pt].v, c);
+                }
+            // (same wave: the LDS unit serves its requests in order — these stores follow the previous row's reads, the reads below follow them)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * pt + li < TS) T[(16 * mt + 4 * lg + r) * TS + 16 * pt + li] = acc[mt][pt][r];   // T[m][Xa]
+            if (lane < IW) {                                             // this T row's share of output rows Ya + ky: dX[ci][Ya + ky][X] += T[ci * 25 + (ky, kx)][X - kx]
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {                       // (unconditional reads at clamped columns, then selected adds: see conv1_bwd_mfma_kernel)
+#pragma unroll
+                    for (int ky0 = 0; ky0 < 5; ky0 += 2) {               // (two tap rows = ten reads at a time, fenced: registers)
+                        float tv[2][5];
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int kx = 0; kx < 5; ++kx) if (ky0 + k2 < 5) tv[k2][kx] = T[(ci * 25 + (ky0 + k2) * 5 + kx) * TS + xcl[kx]];
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                            for (int kx = 0; kx < 5; ++kx) if (ky0 + k2 < 5) ring[ci][ky0 + k2] += xok[kx] ? tv[k2][kx] : 0.f;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            // output row Ya has now received its last contribution (T rows Ya - 4 .. Ya): emit it, rotate the partial rows
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                if (lane < IW) Gout[ci * (IW * IW) + Ya * IW + lane] = ring[ci][0] * t_scale;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ring[ci][k] = ring[ci][k + 1];
+                ring[ci][4] = 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                                          // the last four output rows: O1 .. IW - 1
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+            if (lane < IW) Gout[ci * (IW * IW) + (O1 + k) * IW + lane] = ring[ci][k] * t_scale;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// conv2^T, DENSE form (triple-split arithmetic), 1x28x28: a GEMM per tap over the conv2 OUTPUT positions + col2im, instead of the
+// gather form of conv_bwd_x3_kernel, whose zero-padded gradient image makes 36-39 % of its MFMAs multiply padding:
+//
+//     T[tap][ci][pos2] = sum_hc W[hc][ci][tap] * dO2[hc][pos2]          pos2 over the 8 x 8 conv2 outputs: M = 32 ci, N = 64, K = Hc
+//     dP1[ci][y + ky][x + kx] += T[(ky, kx)][ci][(y, x)]                 col2im, once per (sample, point)
+//
+// Every MFMA is useful (25 taps x 2 ci tiles x 4 position tiles x 6 product terms per 32 channels: 1200, against ~1970 issued by the
+// gather form).  One block = one (sample, point), 8 waves = 2 input-channel tiles x 4 tap groups (7 + 6 + 6 + 6 taps; the 7-tap groups
+// of the two channel tiles sit on different SIMDs): a wave holds T for its taps in <= 28 accumulator tiles over the WHOLE Hc loop.  Per
+// K step of 32 channels the block (a) routes the pooled gradients of those channels through the pool-2 argmax / activation derivative
+// into a dense channel-last image [64 positions][32 hc] of three fp16 piece planes (12 KB; the staging of dQ2 / stash rows by 4-byte
+// LDS-DMA and the image are double-buffered: one barrier per K step), (b) reads its B fragments ONCE (12 ds_read_b128: a fragment
+// feeds 7 taps = 42 MFMAs, against 12 in the gather form, which was LDS-bandwidth bound) and its A fragments — model.3.weight regrouped
+// [K step][tap][ci][32 hc] as a triple-rows image — straight from memory (L2: 2.4 MB per block, as the gather form).
+// Epilogue: the T tiles of one channel tile go to LDS ([25 taps][16 ci][64 pos] floats, aliasing the loop buffers) and every thread gathers
+// its dP1 outputs as a fixed-order sum of <= 25 terms (deterministic, no atomics); twice (two channel tiles).
+// =====================================================================================================
+#ifndef RBNN_CONV_BWD_DENSE
+#define RBNN_CONV_BWD_DENSE 1
+#endif
+// RBNN_DENSE_STAMPS (diagnostic build, fenced like the ablation switches; the results stay right): s_memtime stamps of waves 0 and 3 of every
+// block, summed per segment into rbnn_dense_stamp_acc and read back by rbnn_debug_dense_stamps (tools/dense_stamps.py).  1: per-pass prologue /
+// K loop / col2im; 2: also the time inside the K loop's barrier (each stamp drains lgkmcnt: level 2 perturbs the loop it measures).
+#ifdef RBNN_DENSE_STAMPS
+__device__ unsigned long long rbnn_dense_stamp_acc[64];
+#define DSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0 && (wave == 0 || wave == 3)) atomicAdd(&rbnn_dense_stamp_acc[(wave ? 32 : 0) + (slot)], t_ - tprev); tprev = t_; } while (0)
+#define DSTAMP_ADD(slot, v) do { if (lane == 0 && (wave == 0 || wave == 3)) atomicAdd(&rbnn_dense_stamp_acc[(wave ? 32 : 0) + (slot)], (unsigned long long)(v)); } while (0)
+#else
+#define DSTAMP(slot) do { } while (0)
+#define DSTAMP_ADD(slot, v) do { } while (0)
+#endif
+#ifndef RBNN_DENSE_STAGGER
+#define RBNN_DENSE_STAGGER 0                                               // 1: the two waves of a SIMD route one tap group apart (the 6-tap loop has room for one)
+#endif
+template <class G> struct ConvBwdDenseLds {
+    // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
+    // hold (112 registers).  1x28x28: 64 positions, one pass.  3x32x32: 100 positions = pass 0 (positions 0..63) + pass 1 (64..99, three
+    // tiles); a pass streams the weights once more (L2) but routes only its own positions, and the two passes' col2im partial sums meet in
+    // registers (16 per gathering thread) — splitting the block over input-channel tiles or taps instead would route everything twice.
+    static constexpr int NPASS = (G::NPT2 + 3) / 4;
+    static constexpr int NPOSP = 64;                                      // positions of a pass, padded to whole MFMA tiles
+    static constexpr int PLANE = NPOSP * 64, IMG = 3 * PLANE;             // one piece plane: NPOSP records of 32 hc halves
+    static constexpr int NFL = 32 * G::NP2;                               // pooled cells of one K step
+    static constexpr int STG = (NFL * 5 + 4 * G::NP2 + 15) / 16 * 16;     // staging: NFL dQ2 floats + NFL stash bytes + 4 NP2 bytes that hold the code 8 (no window's: the
+                                                                          // windows of a position that lie off the pooled map read their stash byte here)
+    static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
+    static constexpr int AOFF = 2 * IMG;                                  // the eight waves' rings follow the images;
+    static constexpr int SOFF = AOFF + 8 * RING * SLOT;                   // the staging buffers come LAST, above the col2im images (EPI): a pass's first two K steps
+    static constexpr int LOOP = SOFF + 2 * STG;                           //   are staged before the previous pass's col2im and land under it
+    static constexpr int EIMG = G::P1W * G::P1W * 64;                     // col2im: one wave's partial gradient image [P1W x P1W output positions][16 ci] floats
+    static constexpr int EPI = 8 * EIMG;
+    static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
+    static_assert(EPI <= SOFF, "the staging buffers must survive the col2im");
+    static_assert(EPI + 64 + 8 * 1024 <= SOFF, "room for the eight wave maxima and the waves' dummy records behind the col2im images");
+    static_assert(BYTES <= 160 * 1024, "LDS");
+    static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
+};
+
+template <int ACT, class G>
+__global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2d, int k2_exp, float fw_l1) {
+    using L = ConvBwdDenseLds<G>;
+    constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, NFL = L::NFL, NPASS = L::NPASS;
+    constexpr int SMIN = NFL / 512 + (NFL / 4) / 512;                      // staging pieces every wave issues for a whole K step (stage_issue: its rounds of 512 lanes that lie inside the step entirely)
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char* const lds = (char*)lds_f;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ct = wave >> 2, q = wave & 3;
+    // taps of this wave: 7 for q == ct (waves 0 and 5: SIMDs 0 and 1), 6 for the others, in tap order
+    const int ntap = 6 + (q == ct ? 1 : 0);
+    const int tap0 = 6 * q + (q > ct ? 1 : 0);
+
+    int id;
+    if (!item_of_block(blockIdx.x, a.N * a.S, id)) return;
+    const int s = id / a.N, n = id % a.N;
+    const int sw = a.sidx ? a.sidx[s] : s;
+    const long long sn = (long long)s * a.N + n;
+    const int F = a.Hc * NP2_, KS = (a.Hc + 31) / 32;
+    const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+#ifdef RBNN_DENSE_STAMPS
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+    unsigned long long barw = 0;
+#endif
+
+    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1 (as conv_bwd_x3_kernel).  The load is issued here; the scales are formed in the first
+    // pass's prologue, behind the staging / tile DMA issue (forming them here put the load's round trip in front of the DMA's)
+    const float dz_lane = a.dZ[sn * RBNN_CPAD + li];
+    float in_scale = 1.f, out_scale = 1.f;
+    auto set_scales = [&]() {
+        float dzmax = fabsf(dz_lane);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dzmax = fmaxf(dzmax, __shfl_xor(dzmax, o));
+        const float bound = 4.f * dzmax * fw_l1;
+        int e = 0;
+        if (bound > 0.f && bound < INFINITY) e = max(-100, min(100, 13 - ilogbf(bound)));
+        e = __builtin_amdgcn_readfirstlane(e);                             // wave-uniform: the two scales live in scalar registers
+        in_scale = ldexpf(1.f, e);
+        out_scale = ldexpf(1.f, -(e + k2_exp));
+    };
+
+    auto dma4 = [&](const void* g, void* l) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
+    };
+    // (wholec = std::true_type: the step is known to be a whole one — Hc % 32 == 0 —, so the pieces that lie inside a whole step entirely need no
+    // per-lane test: the K loop's calls; each tested piece is an exec-masked block of five instructions around its DMA)
+    auto stage_issue = [&](int ks, int buf, auto wholec) {                  // rows of channels 32ks .. of dQ2 and of the stash: contiguous in memory
+        constexpr bool WH = decltype(wholec)::value;
+        char* const S = lds + L::SOFF + buf * L::STG;
+        const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
+        const long long fb = sn * F + (long long)ks * NFL;
+        // sources = a wave-uniform 64-bit base (the step's rows) + ONE 32-bit per-lane offset: the SGPR-base addressing form, no 64-bit vector add per piece
+        const char* const qrow = (const char*)(a.dQ2 + fb);
+        const char* const srow = (const char*)(a.st2 + fb);
+        const unsigned l4 = 4u * (unsigned)lane;
+        static_for<0, (NFL + 511) / 512>([&](auto I) {                       // pieces 2 KiB apart on both sides: pairs share address and M0
+            constexpr int i = decltype(I)::value, i0 = i & ~1;
+            const int b = 512 * i0 + 64 * wave;                             // wave-uniform destination base
+            if ((WH && 512 * i + 512 <= NFL) || b + 512 * (i - i0) + lane < nvalid)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qrow + (4u * (unsigned)b + l4)),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)((float*)S + b), 4, (i - i0) * 2048, 0);
+        });
+        static_for<0, (NFL / 4 + 511) / 512>([&](auto I) {                   // stash: one dword (4 cells) per lane, 512 lanes per round
+            const int d = 512 * decltype(I)::value + 64 * wave;
+            if ((WH && 512 * decltype(I)::value + 512 <= NFL / 4) || 4 * (d + lane) < nvalid) dma4(srow + (4u * (unsigned)d + l4), S + NFL * 4 + 4 * d);
+        });
+    };
+    // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
+    // private ring of RING slots, three 1-KiB pieces per tile (one per plane: lane p lands at row p >> 2, physical chunk p & 3 and
+    // fetches logical chunk (p & 3) ^ swz(row)), issued THREE taps ahead of their use: an L2 round trip (500+ cycles) is far longer than
+    // the 24 MFMAs of a tap, and registers for a deeper prefetch do not exist (112 accumulators + 48 B-fragment registers).  The
+    // wave's running tap index g = ks * ntap + i names the slot g & 3; nothing but this wave touches its ring (no barrier involved).
+    // (weight tiles are PLANE-major in memory — [tile][3 pieces][16 ci][64 B], conv.py::_build_dense — exactly as they sit in a ring slot: the
+    // immediate offset of global_load_lds applies to the global AND the LDS address, so a tile's three pieces share one address and one M0)
+    const int prow = lane >> 2;
+    const unsigned a_lane = (unsigned)(prow * 64 + (((lane & 3) ^ swz(prow)) * 16));    // per-lane part of a piece's source address
+    const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
+    char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // fragment of row li (position / input channel), K chunk lg
+    constexpr int NPP = P1W_ * P1W_;
+    static_assert(2 * NPP <= 512, "one thread per output position and pair of channel quads");
+    f32x4 part[2][2];                                                      // NPASS > 1: col2im partial sums of the earlier passes ([channel tile][quad of the pair])
+#pragma unroll
+    for (int i = 0; i < 4; ++i) part[i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef RBNN_DENSE_ABL_NOMFMA
+#define DENSE_MFMA(A, B, C) (C)
+#else
+#define DENSE_MFMA(A, B, C) MFMA_H(A, B, C)
+#endif
+
+    static_for<0, NPASS>([&](auto PASS) {
+    constexpr int pass = decltype(PASS)::value;
+    constexpr int NPT = (G::NPT2 - 4 * pass) < 4 ? (G::NPT2 - 4 * pass) : 4;   // position tiles of this pass
+    if (pass) __syncthreads();                                             // the previous pass's T (LDS) has been gathered
+    // routing role of this thread: position gp = 64 * pass + lane (gy, gx) of the O2W x O2W gradient map, channel quad qd = wave of the K step's 32
+    const int gp = 64 * pass + lane, gy = gp / O2W_, gx = gp % O2W_, qd = wave;
+    // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells).  The stash code
+    // that routes window w here is w (argmax) with bit 2 = the pre-activation was positive; stash bytes are <= 7 by construction, so they
+    // are compared WHOLE (no masking), and a window off the map (or a lane past the last position: its image row is zeros) reads the byte 8
+    int adq[4], ast[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
+        const int py = gy - (w >> 1), px = gx - (w & 1);
+        const bool ok = gp < NPOS_ && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
+        const int cell = 4 * qd * NP2_ + (ok ? py * P2W_ + px : 0);
+        adq[w] = 4 * cell;
+        ast[w] = ok ? NFL * 4 + cell : NFL * 5;                            // off the map (or a lane past the last position): the never-matching byte (+ j NP2 <= 4 NP2 of them)
+    }
+    const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
+    // routing of ONE channel (j of this thread's quad) of K step ks from staging buffer sbuf: pool-2 argmax + activation derivative (gather
+    // form), scaled, split into the three pieces.  Called between the MFMA groups of the previous K step so that its LDS reads and
+    // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
+    union Q { unsigned w[2]; uint2 u; };                                    // pieces of the thread's four channels: [j0 | j1 << 16], [j2 | j3 << 16]
+    float vpend = 0.f;                                                     // the even channel of a pair waits for the odd one (split3_plain_pair)
+    // (two halves: the eight LDS reads of a channel are issued one tap group AHEAD of the selects that consume them — in one piece the selects
+    // waited for the reads right in front of the tap's MFMAs, an LDS round trip per routing tap with nothing issued behind it)
+    struct RouteIn { int st[4]; float dq[4]; };
+    auto route_load = [&](int sbuf, int j, RouteIn& in) {
+        const char* const sb = lds + L::SOFF + sbuf * L::STG;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                                      // eight independent LDS reads
+            in.st[w] = *(const unsigned char*)(sb + ast[w] + j * NP2_);
+            in.dq[w] = *(const float*)(sb + adq[w] + 4 * j * NP2_);
+        }
+    };
+    auto route_calc = [&](int ks, int j, const RouteIn& in, Q& p0, Q& p1, Q& p2) {
+        const bool live = 32 * ks + 4 * qd + j < a.Hc;                     // wave-uniform; channels past Hc (and the step past the last): zeros
+        const int (&st)[4] = in.st;
+        const float (&dq)[4] = in.dq;
+        // window w routes here iff its stashed argmax is w; act' = 1 or the slope by bit 2 of the stash (folding act' into dQ2 in
+        // conv_fc_bwd_kernel instead was measured: that kernel went from 1.1 to 2.35 ms on its byte loads of the stash).  ReLU: both
+        // tests are one compare of the stash's low three bits (a cell whose pre-activation was <= 0 passes nothing on).
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                                      // (w: a constant after unrolling — compares against immediates)
+            if (ACT == RBNN_ACT_RELU) {
+                v += st[w] == (w | 4) ? dq[w] : 0.f;
+            } else if (ACT == RBNN_ACT_LEAKY) {                            // factor 1 / slope / 0
+                v = fmaf(dq[w], st[w] == (w | 4) ? 1.f : (st[w] == w ? slope : 0.f), v);
+            } else {
+                v += (st[w] & 11) == w ? dq[w] : 0.f;                      // sigmoid / tanh: act' is already folded into dQ2; bit 2 of the stash is ignored, bit 3 marks the dummy
+            }
+        }
+        const float vs = (live ? v : 0.f) * in_scale;
+        if (!(j & 1)) vpend = vs;
+        else split3_plain_pair(vpend, vs, 1.f, p0.w[j >> 1], p1.w[j >> 1], p2.w[j >> 1]);
+    };
+    auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
+        RouteIn in;
+        route_load(sbuf, j, in);
+        route_calc(ks, j, in, p0, p1, p2);
+    };
+    auto route_store = [&](int ibuf, const Q& p0, const Q& p1, const Q& p2) {
+        char* const I = lds + ibuf * L::IMG;
+        *(uint2*)(I + rec) = p0.u;
+        *(uint2*)(I + L::PLANE + rec) = p1.u;
+        *(uint2*)(I + 2 * L::PLANE + rec) = p2.u;
+    };
+
+    f32x4 acc[7][NPT];
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Weight tile (K step iks_, tap tapi of this wave) -> ring slot.  ALWAYS issued — past the pass's last tile the callers name a tile of the
+    // last K step again (it lands in a consumed slot and is never read): with no "is there a tile left" test the K loop below has no branch
+    // between its MFMA groups and every counted wait is one immediate.
+    auto tile_issue = [&](int iks_, int tapi, int slot) {
+        // source = a block-uniform 64-bit base (the sample's image) + ONE 32-bit per-lane offset (tile offset + lane part; a sample's image is
+        // KS * 25 * 6 KiB): hipcc then uses the SGPR-base addressing form instead of a 64-bit vector add per piece
+        const unsigned off = (unsigned)((iks_ * 25 + tap0 + tapi) * (32 * 192)) + a_lane;
+        char* const dst = ring + slot * L::SLOT;
+        const auto gsrc = (const __attribute__((address_space(1))) void*)(Awave + off);
+        const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
+#ifdef RBNN_DENSE_ABL_PARTA
+        if (lane < RBNN_DENSE_ABL_PARTA)                                   // ablation (timing only): a fraction of every weight tile is fetched (same instruction and wait counts)
+#endif
+        {
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
+            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
+        }
+    };
+
+    if (pass == 0)                                                         // the never-matching stash bytes of both staging buffers (ordered before their first read by the prologue's barrier)
+        for (int i = tid; i < 2 * ((L::STG - NFL * 5) / 4); i += 512) {
+            constexpr int ND = (L::STG - NFL * 5) / 4;
+            *(unsigned*)(lds + L::SOFF + (i / ND) * L::STG + NFL * 5 + 4 * (i % ND)) = 0x08080808u;
+        }
+    // K steps 0 and 1 are staged together (one HBM round trip, not two) — by the first pass here, for a later pass by the pass before it, ahead
+    // of its col2im (the rows staged do not depend on the pass)
+    if (pass == 0) {
+        stage_issue(0, 0, std::false_type{});
+        if (KS > 1) stage_issue(1, 1, std::false_type{});
+    }
+    tile_issue(0, 0, 0); tile_issue(0, 1, 1); tile_issue(0, 2, 2);         // (a wave has >= 6 taps)
+    if (pass == 0) set_scales();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
+    __syncthreads();
+    {
+        Q p0, p1, p2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) route_one(0, 0, j, p0, p1, p2);
+        route_store(0, p0, p1, p2);
+    }
+    f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
+#ifdef RBNN_DENSE_ABL_NOB
+    f16x8 b0[NPT], b1[NPT], b2[NPT];
+#endif
+    // The K loop, one instantiation per tap count NT of the wave (6 or 7: wave-uniform, chosen once) — so that which tile is issued at tap t
+    // (tile g + 3 = tap (t + 3) % NT of step ks + (t + 3) / NT), its ring slot and every wait count are compile-time facts and a K step is
+    // straight-line code.  (Round 3 kept running (K step, tap, index) counters with an "any tile left" test, a 7th-tap test and a choice of wait
+    // per tap: four scalar branches and ~20 scalar instructions between two taps' MFMA groups; adding three more branches per tap — one counted
+    // wait per weight plane — cost 6.6 % of the kernel, which is what pointed here.)
+    // The staging pieces of K step ks + 2 (dQ2 / stash rows: first touch, they come from HBM) are issued BEHIND tap 0's tile, and the first three
+    // taps' waits leave them outstanding: vmcnt counts in issue order, so a wait for a tile issued after them is a wait for them (round 3 issued
+    // them first and waited vmcnt(6) at tap 0: an HBM round trip per K step and wave).  They too are always issued (the last two steps re-stage
+    // the last step's rows into the free buffer) so that the count behind a tile is the same in every step; SMIN = pieces EVERY wave issues
+    // for a whole step (assuming fewer than were issued only waits longer) — 0 when the last step is half a step (Hc % 32 == 16).
+    auto kloop = [&](auto NTC, auto WHOLEC, auto R0C) {
+    constexpr int NT = decltype(NTC)::value, SB = decltype(WHOLEC)::value ? SMIN : 0, R0 = decltype(R0C)::value;
+    for (int ks = 0; ks < KS; ++ks) {
+        // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
+        // vector-memory operations — the ring tiles issued since — may still be in flight
+        // (a raw s_barrier behind the counted wait: __syncthreads() makes hipcc drain vmcnt to 0 first — the three weight tiles in flight
+        // for the coming taps included)
+#ifdef RBNN_DENSE_ABL_NOBAR
+        if (ks == 0)
+#endif
+        {
+#if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
+            const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+#endif
+            if (ks == 0) ring_wait_barrier<0>();                           // (nothing has been issued behind the prologue's staging piece yet)
+            else ring_wait_barrier<9>();                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
+#if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
+            barw += __builtin_amdgcn_s_memtime() - tb_;
+#endif
+        }
+        const int ksn = min(ks + 1, KS - 1), gk = ks * NT;                 // gk = running index of the step's first tile (slot = index & 3)
+        auto issue = [&](auto TC) {                                        // tap t's tile: tile g + 3 -> the slot of tile g - 1 (consumed)
+            constexpr int t = decltype(TC)::value;
+#ifdef RBNN_DENSE_ABL_NOA
+            if (false)                                                     // ablation (timing only): no weight-tile traffic after the prologue
+#endif
+            tile_issue((t + 3) / NT ? ksn : ks, (t + 3) % NT, (gk + t + 3) & (L::RING - 1));
+        };
+        issue(std::integral_constant<int, 0>{});                           // tap 0's tile, then the staging pieces — both before the B fragments are
+        stage_issue(min(ks + 2, KS - 1), ks & 1, WHOLEC);                  // live: the pieces' per-lane addresses need registers of their own
+        const char* const I = lds + (ks & 1) * L::IMG + foff;
+#ifdef RBNN_DENSE_ABL_NOB
+        if (ks == 0)                                                       // ablation (timing only): the B fragments of the first K step serve all
+#else
+        f16x8 b0[NPT], b1[NPT], b2[NPT];
+#endif
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            b0[pt] = *(const f16x8*)(I + pt * 1024);
+            b1[pt] = *(const f16x8*)(I + L::PLANE + pt * 1024);
+            b2[pt] = *(const f16x8*)(I + 2 * L::PLANE + pt * 1024);
+        }
+        Q p0, p1, p2;
+        RouteIn rin;
+        static_for<0, NT>([&](auto TC) {
+            constexpr int t = decltype(TC)::value;
+            if constexpr (t > 0) issue(TC);
+            // tile g + 1 has landed once all but the 6 youngest operations (tiles g + 2, g + 3) are done — plus, in a step's first three
+            // taps, the staging pieces issued behind tile g + 3 of tap 0
+            asm volatile("" ::: "memory");
+#ifndef RBNN_DENSE_ABL_NOA
+            __builtin_amdgcn_s_waitcnt(VMCNT(6 + (t < 3 ? SB : 0)));
+#endif
+            asm volatile("" ::: "memory");
+            const char* const nx = ring + ((gk + t + 1) & (L::RING - 1)) * L::SLOT + foff;
+            // The six product groups, ordered by the piece of A they read — a2 | a1 a1 | a0 a0 a0 — so that each piece of the NEXT tile
+            // is loaded IN PLACE right behind the last MFMA that reads the current one (an MFMA reads its operands when it issues):
+            // no copies, and every reload has >= 12 MFMAs before its first use.  (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and
+            // a0*b1 the 2^-11 ones: apart from a0*b2, still small terms first.)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a2, b0[pt], acc[t][pt]);
+#ifndef RBNN_DENSE_ABL_NOAREAD
+            a2 = *(const f16x8*)(nx + 2048);
+#endif
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b1[pt], acc[t][pt]);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b0[pt], acc[t][pt]);
+#ifndef RBNN_DENSE_ABL_NOAREAD
+            a1 = *(const f16x8*)(nx + 1024);
+#endif
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b2[pt], acc[t][pt]);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b1[pt], acc[t][pt]);
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b0[pt], acc[t][pt]);
+#ifndef RBNN_DENSE_ABL_NOAREAD
+            a0 = *(const f16x8*)nx;
+#endif
+#ifndef RBNN_DENSE_ABL_NOROUTE
+            // the next K step's image: channel j of the thread's quad is read in tap group j and routed in tap group j + 1
+            // (R0: the channel-tile-1 wave of a SIMD routes RBNN_DENSE_STAGGER tap groups later than its channel-tile-0 partner)
+            if constexpr (t >= R0 + 1 && t < R0 + 5) route_calc(ks + 1, t - R0 - 1, rin, p0, p1, p2);
+            if constexpr (t >= R0 && t < R0 + 4) route_load((ks + 1) & 1, t - R0, rin);
+            if constexpr (t == R0 + 4) route_store((ks + 1) & 1, p0, p1, p2);
+#endif
+            __builtin_amdgcn_sched_barrier(0);                             // a tap is one scheduling region (the whole step as one region: routing reads hoisted across taps, 256 registers and scratch)
+        });
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): the tiles / staging pieces issued past the end have landed (the col2im tile aliases their slots)
+    };
+    DSTAMP(8 * pass + 0);                                                  // prologue (pass 0: from the block's start; later passes: from the end of the previous col2im)
+    {
+        const bool whole = (a.Hc & 31) == 0;                               // block-uniform
+        using Z = std::integral_constant<int, 0>;
+        using R = std::integral_constant<int, RBNN_DENSE_STAGGER>;
+        if (!whole) { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::false_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::false_type{}, Z{}); }
+        else if (RBNN_DENSE_STAGGER && ct) { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, R{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, R{}); }
+        else { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, Z{}); }
+    }
+    if (pass + 1 < NPASS) {                                                // the next pass's first two K steps: they land under this pass's col2im (whose barriers do not wait for them)
+        stage_issue(0, 0, std::false_type{});
+        if (KS > 1) stage_issue(1, 1, std::false_type{});
+    }
+    DSTAMP(8 * pass + 1);                                                  // K loop
+    // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
+    // registers are four consecutive channels (one ds_write_b128 per tile; the four channel quads of a position are XOR-swizzled by
+    // (pos >> 1) & 3, which spreads eight consecutive positions over all 32 banks), and a gathering thread = one output position (Y, X) x two
+    // channel quads adds up its <= 25 terms in (ky, kx) order with eight independent sums.  (First version: [tap][ci][pos] floats, 112
+    // 4-way-conflicting ds_write_b32 per lane and one serial chain of ~60 dependent LDS reads per thread: 2.0 of the kernel's 11.0 ms,
+    // profiles/r03a/conv_dense_ablations.txt.)  With several passes a term belongs to the pass that holds its position; the sums of the
+    // earlier passes wait in `part` and the LAST pass adds them (fixed order: deterministic) and writes. ----
+    float* const T = lds_f;
+#ifdef RBNN_DENSE_ABL_NOEPI
+    {                                                                      // ablation (timing only): the accumulators stay live, nothing is gathered
+        float sink = 0.f;
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) sink += acc[t][pt][0] + acc[t][pt][1] + acc[t][pt][2] + acc[t][pt][3];
+        if (sink == 1.2345e-30f) a.dP1[sn * G::P1SZ] = sink;
+        return;
+    }
+#endif
+    // (round 4, second half) col2im through WAVE-PRIVATE partial images instead of the T tile above: every wave adds the T tiles of its own
+    // taps into its own [P1W x P1W][16 ci] fp32 image in LDS (read - add - write of one ds_*_b128 per accumulator tile; within one tap the
+    // positions of a tile land on distinct outputs, taps follow each other in program order, nobody else touches the image: no atomics, a
+    // fixed order), then one output position x two channel quads per thread adds the four images of a channel tile in wave order.  Both channel
+    // tiles at once: two barriers per pass instead of four, 0.55 MB through LDS per pass instead of 0.86 (the T tile was written by half the
+    // waves and gathered with 2/3 of the reads masked off: 16.7k of a block's 135k cycles per pass, tools/dense_stamps.sh).  The channel quads of
+    // an output position are XOR-swizzled by (position >> 2) & 3: the 16 lanes of a ds_*_b128 service group cover positions p .. p + 3 and
+    // p + 12 .. p + 15 of a tile, whose 64-byte records would otherwise share banks four positions apart.
+    {
+        char* const img = lds + wave * L::EIMG;
+        ring_wait_barrier<63>();                                           // the loop buffers are free: every wave is out of its K loop with its ring DMA drained (raw barriers here:
+                                                                           // __syncthreads() would wait for the next pass's staging pieces just issued)
+        for (int i = lane; i < L::EIMG / 16; i += 64) *(f32x4*)(img + 16 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int o0[NPT];
+        bool val[NPT];
+        const int dummy = (L::EPI + 64 + lane * 16) - wave * L::EIMG + wave * 1024;   // (relative to img) behind the images and the wave maxima: 1 KiB per wave
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int gpos = 64 * pass + 16 * pt + li;                     // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][gpos]
+            val[pt] = gpos < NPOS_;
+            o0[pt] = (gpos / O2W_) * P1W_ + gpos % O2W_;                   // output position of tap (0, 0)
+        }
+#pragma unroll
+        for (int t = 0; t < 7; ++t)
+            if (t < ntap) {                                                // wave-uniform
+                const int tap = tap0 + t, shift = (tap / 5) * P1W_ + tap % 5;
+                f32x4 cur[NPT];
+                int ad[NPT];
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {                         // the tile's reads together, then its writes
+                    const int o = o0[pt] + shift;
+                    // lanes past the last position (the last pass's last tile) go through a private dummy record instead of an exec-masked
+                    // block per access (a masked LDS read is waited for inside its block: one round trip each, in series)
+                    ad[pt] = val[pt] ? o * 64 + ((lg ^ ((o >> 2) & 3)) << 4) : dummy;
+                    cur[pt] = *(const f32x4*)(img + ad[pt]);
+                }
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
+            }
+        ring_wait_barrier<63>();
+        float omax = 0.f;
+        if (tid < 2 * NPP) {
+            const int qp = tid / NPP, pp = tid % NPP, sw = (pp >> 2) & 3;
+            const char* const rec = lds + pp * 64;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {                               // channel tile c2 = waves 4 c2 .. 4 c2 + 3
+                f32x4 u0[4], u1[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    u0[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp) ^ sw) << 4));
+                    u1[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp + 1) ^ sw) << 4));
+                }
+                const f32x4 s0 = part[c2][0] + (((u0[0] + u0[1]) + u0[2]) + u0[3]);   // earlier passes + this pass's four tap groups, in that order
+                const f32x4 s1 = part[c2][1] + (((u1[0] + u1[1]) + u1[2]) + u1[3]);
+                if (pass + 1 < NPASS) {
+                    part[c2][0] = s0;
+                    part[c2][1] = s1;
+                } else {
+                    float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * c2 + 8 * qp) * NPP + pp;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        float* const dst = dst0 + r * NPP;
+                        const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+                        const float o = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                        *dst = o;
+                        omax = fmaxf(omax, fabsf(o));
+                    }
+                }
+            }
+        }
+        if (G::CIN >= RBNN_CONV1_BWD_X3_MINCIN && pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+            float* const wm = (float*)(lds + L::EPI);                      // (the rings' area: free)
+            if (lane == 0) wm[wave] = omax;
+            ring_wait_barrier<63>();
+            if (tid == 0) {
+                float m = wm[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) m = fmaxf(m, wm[w]);
+                a.G[sn * G::DIN] = m;
+            }
+        }
+    }
+    DSTAMP(8 * pass + 2);                                                  // col2im
+    });
+#ifdef RBNN_DENSE_STAMPS
+    DSTAMP_ADD(24, __builtin_amdgcn_s_memtime() - tstart);
+    DSTAMP_ADD(25, 1);
+    DSTAMP_ADD(26, barw);
+#endif
+}
+
+// =====================================================================================================
+// Both triple images of model.3.weight — the forward's tap-major grouped rows image and the dense conv2^T image — from the fp32 stack in ONE
+// launch.  A redrawable SVI stack rebuilds them after every draw (BASELINE config 5: every PGD iteration); through their stand-alone builders
+// that was two permuted fp32 copies, two rbnn_triple_rows launches and two more permuted copies per draw (0.45 of the 0.6 ms a C5 draw took).
+// One block = one (sample, 32 output channels): its [32 hc][32 ci x 25 taps] cube is 100 KB of CONTIGUOUS fp32 — read once, coalesced, into
+// LDS — and both images leave as 1-KiB runs of 16-byte stores.  Same split3 of the same scaled values: the images are bit-identical to the
+// stand-alone builders' (tests/test_hip_round4.py).
+// =====================================================================================================
+namespace {
+constexpr int K2IMG_PITCH = 801;                                          // floats per hc row of the cube in LDS (odd: reads along hc spread over the banks)
+__global__ void __launch_bounds__(256) conv_k2_images_kernel(const float* __restrict__ K2w, int Hc, float scale, uint4* __restrict__ rows_img,
+                                                             uint4* __restrict__ dense_img) {
+    extern __shared__ __attribute__((aligned(16))) float cube[];          // [32 hc][K2IMG_PITCH], k = ci * 25 + tap (nn.Conv2d's order)
+    const int tid = threadIdx.x, KS = (Hc + 31) / 32;
+    const int s = blockIdx.x / KS, ks = blockIdx.x - s * KS;
+    const float* const src = K2w + ((long long)s * Hc + 32 * ks) * 800;
+    for (int i = tid; i < 32 * 200; i += 256) {                           // 16-byte loads: row i / 200, columns 4 (i % 200) ..
+        const int hcl = i / 200, c4 = 4 * (i - hcl * 200);
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (32 * ks + hcl < Hc) v = *(const f32x4*)(src + hcl * 800 + c4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cube[hcl * K2IMG_PITCH + c4 + r] = v[r] * scale;
+    }
+    __syncthreads();
+    union U { f16x8 v; uint4 u; };
+    if (rows_img) {
+        // forward image: rows = output channels, K = tap * 32 + ci, grouped [16-channel group][tap][3 pieces][16 channels][32 ci] halves;
+        // item = (tap, channel, unit of 8 ci): 64 consecutive items = one 1-KiB (group, tap, piece) run
+        for (int it = tid; it < 25 * 32 * 4; it += 256) {
+            const int u = it & 3, hcl = (it >> 2) & 31, tap = it >> 7;
+            const int hc = 32 * ks + hcl;
+            if (hc < Hc) {
+                U o[3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 p0, p1, p2;
+                    conv_split3(cube[hcl * K2IMG_PITCH + (8 * u + j) * 25 + tap], p0, p1, p2);
+                    o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
+                }
+                const long long G = ((long long)s * Hc + hc) >> 4;
+                uint4* const out = rows_img + ((G * 25 + tap) * 3) * 64 + (hc & 15) * 4 + u;
+                out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
+            }
+        }
+    }
+    if (dense_img) {
+        // dense image: [sample][K step = these 32 hc][tap][input-channel half][3 pieces][16 ci][32 hc] halves; item = (tap, ci, unit of 8 hc)
+        for (int it = tid; it < 25 * 32 * 4; it += 256) {
+            const int u = it & 3, ci = (it >> 2) & 31, tap = it >> 7;
+            U o[3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 p0, p1, p2;
+                conv_split3(cube[(8 * u + j) * K2IMG_PITCH + ci * 25 + tap], p0, p1, p2);
+                o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
+            }
+            const long long T = (((long long)s * KS + ks) * 25 + tap) * 2 + (ci >> 4);
+            uint4* const out = dense_img + (T * 3) * 64 + (ci & 15) * 4 + u;
+            out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int rbnn_conv_weight_images(const float* K2w, int32_t n_samples, int32_t hidden, int32_t k2_exp, void* K2_rows, void* K2_dense, void* stream) {
+    if (!K2w || (!K2_rows && !K2_dense)) return RBNN_ERR_NULL;
+    if (n_samples < 1 || hidden < 16 || (hidden & 15) || k2_exp < -100 || k2_exp > 100) return RBNN_ERR_SHAPE;
+    if (!aligned16(K2w) || (K2_rows && !aligned16(K2_rows)) || (K2_dense && !aligned16(K2_dense))) return RBNN_ERR_ALIGN;
+    const int KS = (hidden + 31) / 32;
+    constexpr int LDSB = 32 * K2IMG_PITCH * 4;
+    static unsigned long long attr = 0;
+    if (!ensure_dynamic_lds((const void*)conv_k2_images_kernel, LDSB, attr)) return RBNN_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_k2_images_kernel, dim3((unsigned)((long long)n_samples * KS)), dim3(256), LDSB, (hipStream_t)stream,
+                       K2w, hidden, ldexpf(1.f, k2_exp), (uint4*)K2_rows, (uint4*)K2_dense);
+    return launch_status();
+}
+
+extern "C" int rbnn_conv_input_grad_dense(const rbnn_conv_posterior* net, const void* K2_dense, int32_t k2_exp, float fw_l1,
+                                          const int32_t* sidx, int32_t S, int32_t N, const rbnn_conv_workspace* ws, void* stream) {
+    int rc = validate_conv(net);
+    if (rc) return rc;
+    if (!K2_dense || !ws || !ws->dZ || !ws->P1 || !ws->Q2 || !ws->st1 || !ws->st2 || !ws->G) return RBNN_ERR_NULL;
+    if (N < 1 || S < 1 || k2_exp < -100 || k2_exp > 100 || !(fw_l1 >= 0.f)) return RBNN_ERR_SHAPE;
+    if (!aligned16(K2_dense) || !aligned16(ws->G)) return RBNN_ERR_ALIGN;
+    ConvBwdArgs a = {};
+    a.dZ = ws->dZ; a.st1 = ws->st1; a.st2 = ws->st2; a.K1w = net->K1w; a.K2cb = nullptr; a.Fw = net->Fw;
+    a.Hc = net->hidden; a.C = net->n_classes; a.N = N; a.S = S; a.sidx = sidx; a.dQ2 = ws->Q2; a.dP1 = ws->P1; a.G = ws->G;
+    hipStream_t st = (hipStream_t)stream;
+    return for_geometry(net, [&](auto g) {
+        using G = decltype(g);
+        a.NP2 = G::NP2;
+        return for_activation(net->activation, [&](auto actc) {
+            constexpr int ACT = decltype(actc)::value;
+            int rc2 = launch_conv_fc_bwd(ACT, a, st);                      // dQ2 = dZ . Fw (the fp32 kernel of rbnn_conv.hip)
+            if (rc2) return rc2;
+            constexpr int LDSB = ConvBwdDenseLds<G>::BYTES;
+            static unsigned long long attr = 0;
+            if (!ensure_dynamic_lds((const void*)conv_bwd_dense_x3_kernel<ACT, G>, LDSB, attr)) return (int)RBNN_ERR_LAUNCH;
+            hipLaunchKernelGGL((conv_bwd_dense_x3_kernel<ACT, G>), dim3(grid_for_items((long long)N * S)), dim3(512), LDSB, st, a, (const char*)K2_dense, k2_exp, fw_l1);
+            if ((rc2 = launch_status())) return rc2;
+            // conv1^T: on the f16 pipe for more than one input channel (scaled by the max |dP1| the dense kernel left in G[sn][0]); one input
+            // channel (1x28x28): two row tiles either way, and the fp32 kernel runs three waves per SIMD — measured 0.73 against 0.79 ms
+            if (G::CIN >= RBNN_CONV1_BWD_X3_MINCIN) {
+                hipLaunchKernelGGL((conv1_bwd_x3_kernel<ACT, G>), dim3(grid_for_items((long long)((a.N + 3) / 4) * a.S)), dim3(256), 0, st, a);
+                return launch_status();
+            }
+            return launch_conv1_bwd_fp32(ACT, G::CIN, a, st);
+        });
+    });
+}
+
+#ifdef RBNN_DENSE_STAMPS
+// diagnostic builds only: copy (and optionally clear) the stamp sums; out = 64 x u64
+extern "C" __attribute__((visibility("default"))) int rbnn_debug_dense_stamps(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return RBNN_ERR_LAUNCH;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rbnn_dense_stamp_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return RBNN_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[64] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rbnn_dense_stamp_acc), z, sizeof z) != hipSuccess) return RBNN_ERR_LAUNCH;
+    }
+    return RBNN_OK;
+}
+#endif

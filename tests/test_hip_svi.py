@@ -330,8 +330,8 @@ def test_prefetched_draws_equal_sequential_draws(monkeypatch):
 
 
 def test_conv_redraw_rebuilds_unread_images_on_demand(monkeypatch):
-    """redraw() only marks stale what no kernel of the running configuration reads (the fp32 kernels' input-channel regrouping, the gather-form
-    backward image while the dense conv2^T runs): whoever needs them afterwards gets them rebuilt from the CURRENT draw."""
+    """redraw() only marks stale what no kernel of the running configuration reads (the fp32 kernels' input-channel regrouping): whoever needs
+    it afterwards gets it rebuilt from the CURRENT draw."""
     from robustbnns_amd.conv import ConvSviGuide, ConvStackedPosterior
     from robustbnns_amd.factory import make_engine, posterior_from_stacked
     C, S, Hc, act = 10, 3, 32, "leaky"
@@ -340,18 +340,20 @@ def test_conv_redraw_rebuilds_unread_images_on_demand(monkeypatch):
     post.triple_images()
     x, y = O.synthetic_inputs(8, (1, 28, 28), C, seed=5)
     tri = make_engine(post)
-    assert tri.precision == "triple" and post.dense_supported()
+    assert tri.precision == "triple"
     post.redraw(0x1234, 0)
-    tri.loss_gradients(x, y, S)                                   # dense conv2^T: the gather image stays stale
+    tri.loss_gradients(x, y, S)                                   # the triple kernels: the fp32 regrouping stays stale
     post.redraw(0x5678, 1)
     g_dense = tri.loss_gradients(x, y, S).cpu()
-    assert post._bwd_stale and post._k2ci_stale
+    assert post._k2ci_stale
     stacked = {k: torch.stack([post.state_dict(i)[k] for i in range(S)]) for k in ConvSviGuide.TENSOR_IDS}
     ref = make_engine(posterior_from_stacked("conv", act, (1, 28, 28), C, Hc, stacked, DEV), precision="exact").loss_gradients(x, y, S).cpu()
-    monkeypatch.setenv("RBNN_CONV_BWD_DENSE", "0")               # the gather form now: its image is rebuilt from draw 0x5678 first
+    monkeypatch.setenv("RBNN_CONV_BWD_EXACT", "1")               # the fp32 gather-form backward behind the triple forward: K2ci rebuilt from draw 0x5678 first
     g_gather = tri.loss_gradients(x, y, S).cpu()
-    assert not post._bwd_stale
-    monkeypatch.delenv("RBNN_CONV_BWD_DENSE")
+    assert not post._k2ci_stale
+    monkeypatch.delenv("RBNN_CONV_BWD_EXACT")
+    post.redraw(0x5678, 1)                                        # the same draw again: stale once more
+    assert post._k2ci_stale
     ex = make_engine(post, precision="exact")                     # the fp32 kernels on the same resident posterior: K2ci rebuilt first
     g_exact = ex.loss_gradients(x, y, S).cpu()
     assert not post._k2ci_stale

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = _hip.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rbnn_abi_version() == _hip.ABI_VERSION == 8
+    assert lib.rbnn_abi_version() == _hip.ABI_VERSION == 9
     assert lib.rbnn_build_flags() == 0                       # a product build: no timing-only ablation switch in any translation unit
     assert lib.rbnn_strerror(0) == b"ok" and b"NULL" in lib.rbnn_strerror(-1)
 
@@ -186,7 +186,7 @@ def test_triple_abi_rejects_bad_arguments():
     assert (sizes.X_triple, sizes.hid_triple, sizes.g_scale) == (112 * 800 * 6, 7 * 112 * 512 * 6, 256 * 4)   # grouped images: whole 16-row groups
     cnet = _hip.ConvPosterior()
     assert lib.rbnn_conv_forward_triple(C.byref(cnet), None, 0, 0, None, None, 784, 4, None, 1, 0, None, None) != 0
-    assert lib.rbnn_conv_input_grad_triple(C.byref(cnet), None, 0, 1.0, None, 1, 4, None, None) != 0
+    assert lib.rbnn_conv_input_grad_dense(C.byref(cnet), None, 0, 1.0, None, 1, 4, None, None) != 0
 
 
 def test_lowdim_fc2_scratch_holds_the_sign_bit_stash():

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/run_conv_variants.sh "<flags1>" "<flags2>" ...   rebuilds librbnn_hip.so with extra -D flags for rbnn_conv.hip ON the GPU box and
+# usage: tools/run_conv_variants.sh "<flags1>" "<flags2>" ...   rebuilds librbnn_hip.so with extra -D flags for rbnn_conv_x3.hip (the triple-mode conv kernels) ON the GPU box and
 # times the conv / c5 bench workloads (triple mode only) for each flag set
 mkdir -p gpurun_out/abl
 # flag sets that contain an ablation switch (RBNN_*_ABL_*) must also carry -DRBNN_ALLOW_ABLATION (csrc/rbnn_common.hpp); the runs below are allowed to
@@ -9,8 +9,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R/robustbnns_amd/csrc
 for f in "$@"; do
   echo "== $f"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $f -c rbnn_conv.hip -o rbnn_conv.o 2>/dev/null && \
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o librbnn_hip.so rbnn_kernels.o rbnn_conv.o rbnn_split.o rbnn_triple.o rbnn_svi.o rbnn_lowdim.o && \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $f -c rbnn_conv_x3.hip -o rbnn_conv_x3.o 2>/dev/null && \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o librbnn_hip.so rbnn_kernels.o rbnn_conv.o rbnn_conv_x3.o rbnn_split.o rbnn_triple.o rbnn_svi.o rbnn_lowdim.o && \
   (cd $R && python bench.py --workload conv --steps 5 --warmup 1 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('conv', round(d['ms_per_step'],2), {k:round(v['avg_ms'],2) for k,v in d['roofline']['kernels'].items()})"; \
    python bench.py --workload c5 --points 512 --iters 3 --steps 1 --warmup 1 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('c5  ', round(d['ms_per_step']/3,2), {k:round(v['avg_ms'],2) for k,v in d['roofline']['kernels'].items()})")
 done 2>&1 | tee $R/gpurun_out/abl/conv_variants.log

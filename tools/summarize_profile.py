@@ -24,7 +24,7 @@ samples = int(sys.argv[4]) if len(sys.argv) > 4 else None         # taken at ano
 MAIN = [("fc_forward_x3_kernel", "fc_forward_triple"), ("fc_grad_x3_kernel", "fc_input_grad_triple"), ("triple_dz_kernel", "fc_input_grad_triple"),
         ("fc_forward_split_kernel", "fc_forward_split"), ("fc_grad_split_kernel", "fc_input_grad_split"), ("split_dz_kernel", "fc_input_grad_split"),
         ("fc_forward_kernel", "fc_forward"), ("fc_grad_kernel", "fc_input_grad"),
-        ("conv2_pool_x3_kernel", "conv_forward_triple"), ("conv_bwd_x3_kernel", "conv_input_grad_triple"), ("conv_bwd_dense_x3_kernel", "conv_input_grad_triple"),
+        ("conv2_pool_x3_kernel", "conv_forward_triple"), ("conv_bwd_dense_x3_kernel", "conv_input_grad_triple"),
         ("conv1_bwd_x3_kernel", "conv_input_grad_triple"),
         ("conv2_pool_split_kernel", "conv_forward_split"), ("conv1_pool_split_kernel", "conv_forward_split"),
         ("conv_bwd_split_kernel", "conv_input_grad_split"),
