@@ -274,9 +274,9 @@ int rbnn_conv_forward_triple(const rbnn_conv_posterior *net, const void *K2_trip
  * over the conv2 OUTPUT positions (64 at 1x28x28: one pass; 100 at 3x32x32: two passes over 64 + 36 positions whose col2im contributions
  * meet in wave-private partial images) — T[tap][ci][pos] = sum_hc W[hc][ci][tap] * dO2[hc][pos], every MFMA useful — + a col2im, instead of
  * a gather over a zero-padded gradient image (the fp32 and split kernels' form: 36-39 % of its MFMAs multiply padding; the triple kernel of
- * that form, rbnn_conv_input_grad_triple, was removed in ABI 9).  K2_dense = triple-rows image (ld 32) of model.3.weight regrouped
- * [S_total, ceil(Hc/32) K steps, 25 taps, 32 ci][32 hc] (hc zero-padded to a multiple of 32), holding W * 2^k2_exp, as rbnn_conv_weight_images
- * writes it; fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed gradients (a per-(sample, point) power-of-two scale is derived from
+ * that form, rbnn_conv_input_grad_triple, was removed in ABI 9).  K2_dense = triple image of model.3.weight * 2^k2_exp regrouped
+ * [S_total, ceil(Hc/32) K steps, 25 taps, 2 tiles of 16 ci][3 pieces][4 chunks of 8 hc][16 ci][8 hc] halves (hc zero-padded to a multiple of
+ * 32; a piece = 1 KiB, fragment-major: the kernel loads it straight into the MFMA's A registers), as rbnn_conv_weight_images writes it; fw_l1 = max_f sum_c |model.7.weight[c, f]| bounds the routed gradients (a per-(sample, point) power-of-two scale is derived from
  * it and max|dZ|).  Same G as rbnn_conv_input_grad. */
 int rbnn_conv_input_grad_dense(const rbnn_conv_posterior *net, const void *K2_dense, int32_t k2_exp, float fw_l1,
                                const int32_t *sample_idx, int32_t n_samples, int32_t n_points,

@@ -161,13 +161,14 @@ class ConvStackedPosterior:
         pad, rows = self._dense_tmp
         pad[:, :H].copy_(self.K2w.view(S, H, 32, 25))
         rows.view(S, KS, 25, 32, 32).copy_(pad.view(S, KS, 32, 32, 25).permute(0, 1, 4, 3, 2))         # [s, ks, tap, ci, hc]
-        # triple rows ([row][3 pieces][64 B]) into a staging copy, then each 16-row tile piece-major ([3 pieces][16 rows][64 B]) — the order
-        # the kernel's ring slots hold it in, so that a tile's three LDS-DMA pieces differ by the same offset on both sides
+        # triple rows ([row][3 pieces][64 B]) into a staging copy, then each 16-row tile piece-major and, inside a piece, FRAGMENT-major:
+        # [3 pieces][4 chunks of 8 hc][16 rows][16 B] — lane (row li, chunk lg) of the dense kernel owns bytes 16 (16 lg + li) of every piece,
+        # so a piece is one global_load_dwordx4 of 1 KiB contiguous straight into the MFMA's A registers
         if getattr(self, "_dense_stage", None) is None:
             self._dense_stage = torch.empty_like(dense)
         _hip.HipKernels().triple_rows(rows, 32, scale_exp(self._k2_max()), self._dense_stage, 32)
         T = dense.shape[0] // 16
-        dense.view(T, 3, 16, 32).copy_(self._dense_stage.view(T, 16, 3, 32).permute(0, 2, 1, 3))
+        dense.view(T, 3, 4, 16, 8).copy_(self._dense_stage.view(T, 16, 3, 4, 8).permute(0, 2, 3, 1, 4))
 
     def _build_triple(self, rows):
         """The forward's image through the stand-alone builders (the fused kernel, rbnn_conv_weight_images, is tested against this)."""

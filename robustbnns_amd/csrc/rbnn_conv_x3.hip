@@ -504,61 +504,68 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_x3_kernel(const ConvBwdArgs 
 }  // namespace
 
 // =====================================================================================================
-// conv2^T, DENSE form (triple-split arithmetic), 1x28x28: a GEMM per tap over the conv2 OUTPUT positions + col2im, instead of the
-// gather form of conv_bwd_x3_kernel, whose zero-padded gradient image makes 36-39 % of its MFMAs multiply padding:
+// conv2^T, DENSE form (triple-split arithmetic), both geometries: a GEMM per tap over the conv2 OUTPUT positions + col2im
+// (a gather over a zero-padded gradient image — the fp32 / split kernels' form — spends 36-39 % of its MFMAs on padding):
 //
-//     T[tap][ci][pos2] = sum_hc W[hc][ci][tap] * dO2[hc][pos2]          pos2 over the 8 x 8 conv2 outputs: M = 32 ci, N = 64, K = Hc
+//     T[tap][ci][pos2] = sum_hc W[hc][ci][tap] * dO2[hc][pos2]          pos2 over the O2W x O2W conv2 outputs: M = 32 ci, N = 64 per pass, K = Hc
 //     dP1[ci][y + ky][x + kx] += T[(ky, kx)][ci][(y, x)]                 col2im, once per (sample, point)
 //
-// Every MFMA is useful (25 taps x 2 ci tiles x 4 position tiles x 6 product terms per 32 channels: 1200, against ~1970 issued by the
-// gather form).  One block = one (sample, point), 8 waves = 2 input-channel tiles x 4 tap groups (7 + 6 + 6 + 6 taps; the 7-tap groups
-// of the two channel tiles sit on different SIMDs): a wave holds T for its taps in <= 28 accumulator tiles over the WHOLE Hc loop.  Per
-// K step of 32 channels the block (a) routes the pooled gradients of those channels through the pool-2 argmax / activation derivative
-// into a dense channel-last image [64 positions][32 hc] of three fp16 piece planes (12 KB; the staging of dQ2 / stash rows by 4-byte
-// LDS-DMA and the image are double-buffered: one barrier per K step), (b) reads its B fragments ONCE (12 ds_read_b128: a fragment
-// feeds 7 taps = 42 MFMAs, against 12 in the gather form, which was LDS-bandwidth bound) and its A fragments — model.3.weight regrouped
-// [K step][tap][ci][32 hc] as a triple-rows image — straight from memory (L2: 2.4 MB per block, as the gather form).
-// Epilogue: the T tiles of one channel tile go to LDS ([25 taps][16 ci][64 pos] floats, aliasing the loop buffers) and every thread gathers
-// its dP1 outputs as a fixed-order sum of <= 25 terms (deterministic, no atomics); twice (two channel tiles).
+// One block = one (sample, point), 8 waves = 2 input-channel tiles x 4 tap groups (7 + 6 + 6 + 6 taps; the 7-tap groups of the two channel
+// tiles sit on different SIMDs): a wave holds T of its taps in <= 28 accumulator tiles over the WHOLE Hc loop.  The conv2 output positions are
+// covered in PASSES of <= 4 position tiles (1x28x28: one pass of 64; 3x32x32: 64 + 36).  Per K step of 32 channels the block
+//   (a) routes the pooled gradients of those channels through the pool-2 argmax / activation derivative into a dense channel-last image
+//       [64 positions][32 hc] of three fp16 piece planes (12 KB; the rows of dQ2 / of the stash arrive by 4-byte LDS-DMA into a staging buffer;
+//       staging and image are double-buffered: ONE barrier per K step),
+//   (b) reads its B fragments ONCE (12 ds_read_b128 feed 7 taps = 168 MFMAs),
+//   (c) takes its A fragments — model.3.weight regrouped [K step][tap][ci][32 hc] as a triple image — STRAIGHT FROM MEMORY INTO REGISTERS
+//       (round 5).  Rounds 3-4 brought every weight tile in by LDS-DMA into a private ring of four 3-KiB slots per wave and read it back with
+//       ds_read_b128: 21 DMA pieces per wave and K step at 60-180 cycles of issue each (in-kernel stamps: 20k of a block's 208k K-loop cycles),
+//       336 KB of LDS traffic per K step beside the 96 KB of B-fragment reads, and 96 KB of LDS that forced the col2im images to alias the loop
+//       buffers (two block-wide barriers, a zero fill and a partial gather per pass, 16 registers of partial sums across the passes).  The image
+//       is now laid out fragment-major — a tile's piece is [4 K chunks][16 ci][16 B], lane l of a wave owns bytes 16 l .. 16 l + 15 — so a
+//       piece is ONE global_load_dwordx4 of 1 KiB contiguous, the compiler counts the waits, and two register sets alternate: tap t + 1's
+//       three pieces are requested at the top of tap t (an L2 round trip is ~200-500 cycles, a tap is 24 MFMAs = 384 cycles of this wave and
+//       as many of its SIMD partner).
+//   vmcnt counts in issue order, so a weight load issued behind a staging piece (first touch: HBM) cannot be consumed before that piece has
+//   landed — an HBM round trip under load is several thousand cycles, a tap 770.  Only TWO waves issue staging pieces (16-byte LDS-DMA, 1 KiB
+//   per piece, half of a K step's rows each, at the top of a K step behind tap 1's loads): waves 2 and 7, 6-tap waves on the two SIMDs whose
+//   other wave is a 6-tap wave too.  While such a wave waits for its pieces its SIMD partner has the matrix pipe to itself, and the two of them
+//   have a tap of slack per K step against the SIMDs that hold a 7-tap wave — where nobody ever waits for HBM.  (All six 6-tap waves staging:
+//   214k cycles per block in the K loops, a 7-tap wave 75k of them at the K-step barrier, profiles/r05e.)
+// col2im: every wave adds the T tiles of its own taps into its OWN [P1W x P1W][16 ci] fp32 image in LDS (read - add - write of one ds_*_b128
+// per accumulator tile, fixed order, nobody else touches it: no atomics, no barrier) right after a pass's K loop; the images persist over the
+// passes (zeroed once).  After the last pass one barrier, then one output position x two channel quads per thread adds the four images of a
+// channel tile in wave order, scales, folds act' in for sigmoid / tanh and writes dP1 — and leaves max |dP1| in G[sn][0] for conv1_bwd_x3_kernel.
 // =====================================================================================================
-#ifndef RBNN_CONV_BWD_DENSE
-#define RBNN_CONV_BWD_DENSE 1
-#endif
 // RBNN_DENSE_STAMPS (diagnostic build, fenced like the ablation switches; the results stay right): s_memtime stamps of waves 0 and 3 of every
-// block, summed per segment into rbnn_dense_stamp_acc and read back by rbnn_debug_dense_stamps (tools/dense_stamps.py).  1: per-pass prologue /
-// K loop / col2im; 2: also the time inside the K loop's barrier (each stamp drains lgkmcnt: level 2 perturbs the loop it measures).
+// block, summed per segment into rbnn_dense_stamp_acc and read back by rbnn_debug_dense_stamps (tools/dense_stamps.py): per pass the prologue,
+// the K loop and the col2im; slot 24 the whole block, 25 the block count, 26 the time inside the K loop's barriers (level 2 only).
 #ifdef RBNN_DENSE_STAMPS
+#ifndef RBNN_DENSE_STAMP_WA
+#define RBNN_DENSE_STAMP_WA 0                                              // the two stamped waves (default: the 7-tap wave 0 and the plain 6-tap wave 3; 2 and 7 are the staging waves)
+#define RBNN_DENSE_STAMP_WB 3
+#endif
 __device__ unsigned long long rbnn_dense_stamp_acc[64];
 #define DSTAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-        if (lane == 0 && (wave == 0 || wave == 3)) atomicAdd(&rbnn_dense_stamp_acc[(wave ? 32 : 0) + (slot)], t_ - tprev); tprev = t_; } while (0)
-#define DSTAMP_ADD(slot, v) do { if (lane == 0 && (wave == 0 || wave == 3)) atomicAdd(&rbnn_dense_stamp_acc[(wave ? 32 : 0) + (slot)], (unsigned long long)(v)); } while (0)
+        if (lane == 0 && (wave == RBNN_DENSE_STAMP_WA || wave == RBNN_DENSE_STAMP_WB)) atomicAdd(&rbnn_dense_stamp_acc[(wave == RBNN_DENSE_STAMP_WB ? 32 : 0) + (slot)], t_ - tprev); tprev = t_; } while (0)
+#define DSTAMP_ADD(slot, v) do { if (lane == 0 && (wave == RBNN_DENSE_STAMP_WA || wave == RBNN_DENSE_STAMP_WB)) atomicAdd(&rbnn_dense_stamp_acc[(wave == RBNN_DENSE_STAMP_WB ? 32 : 0) + (slot)], (unsigned long long)(v)); } while (0)
 #else
 #define DSTAMP(slot) do { } while (0)
 #define DSTAMP_ADD(slot, v) do { } while (0)
 #endif
-#ifndef RBNN_DENSE_STAGGER
-#define RBNN_DENSE_STAGGER 0                                               // 1: the two waves of a SIMD route one tap group apart (the 6-tap loop has room for one)
-#endif
+namespace {
 template <class G> struct ConvBwdDenseLds {
-    // The conv2 output positions are covered in PASSES of <= 4 position tiles (64 positions): 7 taps x 4 tiles is what a wave's accumulators
-    // hold (112 registers).  1x28x28: 64 positions, one pass.  3x32x32: 100 positions = pass 0 (positions 0..63) + pass 1 (64..99, three
-    // tiles); a pass streams the weights once more (L2) but routes only its own positions, and the two passes' col2im partial sums meet in
-    // registers (16 per gathering thread) — splitting the block over input-channel tiles or taps instead would route everything twice.
-    static constexpr int NPASS = (G::NPT2 + 3) / 4;
-    static constexpr int NPOSP = 64;                                      // positions of a pass, padded to whole MFMA tiles
-    static constexpr int PLANE = NPOSP * 64, IMG = 3 * PLANE;             // one piece plane: NPOSP records of 32 hc halves
+    static constexpr int NPASS = (G::NPT2 + 3) / 4;                       // passes of <= 4 position tiles: 7 taps x 4 tiles is what a wave's accumulators hold (112 registers)
+    static constexpr int PLANE = 64 * 64, IMG = 3 * PLANE;                // one piece plane of the routed image: 64 position records of 32 hc halves
     static constexpr int NFL = 32 * G::NP2;                               // pooled cells of one K step
     static constexpr int STG = (NFL * 5 + 4 * G::NP2 + 15) / 16 * 16;     // staging: NFL dQ2 floats + NFL stash bytes + 4 NP2 bytes that hold the code 8 (no window's: the
                                                                           // windows of a position that lie off the pooled map read their stash byte here)
-    static constexpr int RING = 4, SLOT = 3 * 1024;                       // per wave: RING weight tiles (one tap x 16 ci x 32 hc: three 1-KiB plane tiles)
-    static constexpr int AOFF = 2 * IMG;                                  // the eight waves' rings follow the images;
-    static constexpr int SOFF = AOFF + 8 * RING * SLOT;                   // the staging buffers come LAST, above the col2im images (EPI): a pass's first two K steps
-    static constexpr int LOOP = SOFF + 2 * STG;                           //   are staged before the previous pass's col2im and land under it
-    static constexpr int EIMG = G::P1W * G::P1W * 64;                     // col2im: one wave's partial gradient image [P1W x P1W output positions][16 ci] floats
-    static constexpr int EPI = 8 * EIMG;
-    static constexpr int BYTES = LOOP > EPI ? LOOP : EPI;
-    static_assert(EPI <= SOFF, "the staging buffers must survive the col2im");
-    static_assert(EPI + 64 + 8 * 1024 <= SOFF, "room for the eight wave maxima and the waves' dummy records behind the col2im images");
+    static constexpr int SOFF = 2 * IMG;                                  // two images, two staging buffers,
+    static constexpr int EOFF = SOFF + 2 * STG;                           // the eight waves' col2im images [P1W x P1W output positions][16 ci] floats,
+    static constexpr int EIMG = G::P1W * G::P1W * 64;
+    static constexpr int MOFF = EOFF + 8 * EIMG;                          // the eight wave maxima (64 B),
+    static constexpr int DOFF = MOFF + 64;                                // the waves' dummy records (1 KiB each: lanes past the last position read / write these)
+    static constexpr int BYTES = DOFF + 8 * 1024;
     static_assert(BYTES <= 160 * 1024, "LDS");
     static_assert(NPASS * 64 >= G::NPOS && (NPASS - 1) * 64 < G::NPOS, "passes of 64 positions");
 };
@@ -567,7 +574,6 @@ template <int ACT, class G>
 __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwdArgs a, const char* __restrict__ K2d, int k2_exp, float fw_l1) {
     using L = ConvBwdDenseLds<G>;
     constexpr int P1W_ = G::P1W, O2W_ = G::O2W, P2W_ = G::P2W, NP2_ = G::NP2, NPOS_ = G::NPOS, NFL = L::NFL, NPASS = L::NPASS;
-    constexpr int SMIN = NFL / 512 + (NFL / 4) / 512;                      // staging pieces every wave issues for a whole K step (stage_issue: its rounds of 512 lanes that lie inside the step entirely)
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     char* const lds = (char*)lds_f;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
@@ -576,6 +582,9 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // taps of this wave: 7 for q == ct (waves 0 and 5: SIMDs 0 and 1), 6 for the others, in tap order
     const int ntap = 6 + (q == ct ? 1 : 0);
     const int tap0 = 6 * q + (q > ct ? 1 : 0);
+    // staging role (see the header): waves 2 and 7 — 6-tap waves on the two SIMDs that hold two 6-tap waves — bring in the first / second half of a
+    // K step's rows; 0: this wave issues no staging piece
+    const int stg_role = wave == 2 ? 1 : (wave == 7 ? 2 : 0);
 
     int id;
     if (!item_of_block(blockIdx.x, a.N * a.S, id)) return;
@@ -590,8 +599,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     unsigned long long barw = 0;
 #endif
 
-    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1 (as conv_bwd_x3_kernel).  The load is issued here; the scales are formed in the first
-    // pass's prologue, behind the staging / tile DMA issue (forming them here put the load's round trip in front of the DMA's)
+    // per-(sample, point) scale: |dO2| <= 4 * max_c |dZ_c| * fw_l1.  The load is issued here; the scales are formed in the prologue, behind the
+    // staging DMA / weight load issue (forming them here put the load's round trip in front of theirs)
     const float dz_lane = a.dZ[sn * RBNN_CPAD + li];
     float in_scale = 1.f, out_scale = 1.f;
     auto set_scales = [&]() {
@@ -606,59 +615,73 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         out_scale = ldexpf(1.f, -(e + k2_exp));
     };
 
-    auto dma4 = [&](const void* g, void* l) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 4, 0, 0);
-    };
-    // (wholec = std::true_type: the step is known to be a whole one — Hc % 32 == 0 —, so the pieces that lie inside a whole step entirely need no
-    // per-lane test: the K loop's calls; each tested piece is an exec-masked block of five instructions around its DMA)
-    auto stage_issue = [&](int ks, int buf, auto wholec) {                  // rows of channels 32ks .. of dQ2 and of the stash: contiguous in memory
+    // Staging of K step ks into buffer buf: the step's rows of dQ2 (NFL floats) and of the stash (NFL bytes) are contiguous in memory, 16-byte aligned
+    // (Hc % 16 == 0) and copied verbatim by 16-byte LDS-DMA, 1 KiB per piece (rounds 3-4: 4-byte pieces of 256 B, four times as many).  The pieces are
+    // numbered dQ2 first, then stash; staging wave `half` (1 / 2) issues the first / second half of them.  Source = a wave-uniform 64-bit base + ONE
+    // 32-bit per-lane offset; consecutive pieces share the address and M0 (the immediate offset of global_load_lds applies to both sides).  wholec:
+    // the step is known to be a whole one (Hc % 32 == 0) — a piece that lies inside a whole step's rows needs no per-lane test.
+    constexpr int NPQ = (NFL * 4 + 1023) / 1024, NPS = (NFL + 1023) / 1024, NPH = (NPQ + NPS + 1) / 2;   // pieces: dQ2 rows, stash rows, first half
+    auto stage_issue = [&](int ks, int buf, auto wholec, auto halfc) {
         constexpr bool WH = decltype(wholec)::value;
+        constexpr int HALF = decltype(halfc)::value;
         char* const S = lds + L::SOFF + buf * L::STG;
-        const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // a multiple of 4 (Hc % 16 == 0)
+        const int nvalid = min(32, a.Hc - 32 * ks) * NP2_;                  // cells of the step (a multiple of 16)
         const long long fb = sn * F + (long long)ks * NFL;
-        // sources = a wave-uniform 64-bit base (the step's rows) + ONE 32-bit per-lane offset: the SGPR-base addressing form, no 64-bit vector add per piece
         const char* const qrow = (const char*)(a.dQ2 + fb);
         const char* const srow = (const char*)(a.st2 + fb);
-        const unsigned l4 = 4u * (unsigned)lane;
-        static_for<0, (NFL + 511) / 512>([&](auto I) {                       // pieces 2 KiB apart on both sides: pairs share address and M0
-            constexpr int i = decltype(I)::value, i0 = i & ~1;
-            const int b = 512 * i0 + 64 * wave;                             // wave-uniform destination base
-            if ((WH && 512 * i + 512 <= NFL) || b + 512 * (i - i0) + lane < nvalid)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qrow + (4u * (unsigned)b + l4)),
-                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)((float*)S + b), 4, (i - i0) * 2048, 0);
-        });
-        static_for<0, (NFL / 4 + 511) / 512>([&](auto I) {                   // stash: one dword (4 cells) per lane, 512 lanes per round
-            const int d = 512 * decltype(I)::value + 64 * wave;
-            if ((WH && 512 * decltype(I)::value + 512 <= NFL / 4) || 4 * (d + lane) < nvalid) dma4(srow + (4u * (unsigned)d + l4), S + NFL * 4 + 4 * d);
+        const unsigned l16 = 16u * (unsigned)lane;
+        static_for<(HALF == 1 ? 0 : NPH), (HALF == 1 ? NPH : NPQ + NPS)>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            constexpr bool ISQ = i < NPQ;
+            constexpr int j = ISQ ? i : i - NPQ;                           // piece j of its region
+            constexpr int bytes = ISQ ? NFL * 4 : NFL;
+            const char* const src = ISQ ? qrow : srow;
+            char* const dst = S + (ISQ ? 0 : NFL * 4);
+            // (the instruction's immediate offset is a signed 13-bit field: groups of four pieces share an address and an M0, offsets 0 .. 3072)
+            constexpr int j0 = j & ~3;
+            if ((WH && 1024 * (j + 1) <= bytes) || 1024u * j + l16 < (unsigned)(ISQ ? 4 * nvalid : nvalid))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (1024u * j0 + l16)),
+                                                 (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)(dst + 1024 * j0), 16, 1024 * (j - j0), 0);
         });
     };
-    // A operand: the wave's weight tiles (tap, 16 ci of its channel tile, 32 hc of the K step: 16 rows x 192 B) come in by LDS-DMA into a
-    // private ring of RING slots, three 1-KiB pieces per tile (one per plane: lane p lands at row p >> 2, physical chunk p & 3 and
-    // fetches logical chunk (p & 3) ^ swz(row)), issued THREE taps ahead of their use: an L2 round trip (500+ cycles) is far longer than
-    // the 24 MFMAs of a tap, and registers for a deeper prefetch do not exist (112 accumulators + 48 B-fragment registers).  The
-    // wave's running tap index g = ks * ntap + i names the slot g & 3; nothing but this wave touches its ring (no barrier involved).
-    // (weight tiles are PLANE-major in memory — [tile][3 pieces][16 ci][64 B], conv.py::_build_dense — exactly as they sit in a ring slot: the
-    // immediate offset of global_load_lds applies to the global AND the LDS address, so a tile's three pieces share one address and one M0)
-    const int prow = lane >> 2;
-    const unsigned a_lane = (unsigned)(prow * 64 + (((lane & 3) ^ swz(prow)) * 16));    // per-lane part of a piece's source address
-    const char* const Awave = K2d + (((long long)sw * KS * 25) * 32 + 16 * ct) * 192;   // wave-uniform part (SGPR pair): the DMA needs no vector address arithmetic
-    char* const ring = lds + L::AOFF + wave * (L::RING * L::SLOT);
-    const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // fragment of row li (position / input channel), K chunk lg
+    auto stage_by_role = [&](int ks, int buf) {                            // outside the K loop: wave-uniform branches
+        if (stg_role == 1) stage_issue(ks, buf, std::false_type{}, std::integral_constant<int, 1>{});
+        else if (stg_role == 2) stage_issue(ks, buf, std::false_type{}, std::integral_constant<int, 2>{});
+    };
+    // A operand: tile (K step, tap) of this wave's channel tile = three 1-KiB pieces [piece][4 K chunks][16 ci][16 B] (conv.py::_build_dense,
+    // conv_k2_images_kernel): lane (li, lg) owns row li, chunk lg = bytes 16 * lane of every piece.  A sample's image is KS * 25 * 6 KiB < 4 GB:
+    // source = a block-uniform 64-bit base (SGPR pair) + ONE 32-bit per-lane offset, the pieces by the instruction's immediate offset.
+    const char* const Awave = K2d + ((long long)sw * KS * 25 * 2 + ct) * 3072 + 16 * lane;
+    struct ATile { f16x8 p0, p1, p2; };
+    auto tile_load = [&](int iks_, int tapi, ATile& A) {
+        const char* const src = Awave + (unsigned)((iks_ * 25 + tap0 + tapi) * 6144);
+        A.p0 = *(const f16x8*)src;
+        A.p1 = *(const f16x8*)(src + 1024);
+        A.p2 = *(const f16x8*)(src + 2048);
+    };
+    const int foff = li * 64 + ((lg ^ swz(li)) * 16);                       // B fragment of position li (of a tile), K chunk lg
     constexpr int NPP = P1W_ * P1W_;
     static_assert(2 * NPP <= 512, "one thread per output position and pair of channel quads");
-    f32x4 part[2][2];                                                      // NPASS > 1: col2im partial sums of the earlier passes ([channel tile][quad of the pair])
-#pragma unroll
-    for (int i = 0; i < 4; ++i) part[i >> 1][i & 1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    char* const eimg = lds + L::EOFF + wave * L::EIMG;                      // this wave's col2im image
 #ifdef RBNN_DENSE_ABL_NOMFMA
 #define DENSE_MFMA(A, B, C) (C)
 #else
 #define DENSE_MFMA(A, B, C) MFMA_H(A, B, C)
 #endif
 
+    // ---- once per block: the never-matching stash bytes of both staging buffers, the wave's col2im image zeroed, K steps 0 and 1 staged together
+    // (one HBM round trip, not two), the first weight tile requested ----
+    for (int i = tid; i < 2 * ((L::STG - NFL * 5) / 4); i += 512) {
+        constexpr int ND = (L::STG - NFL * 5) / 4;
+        *(unsigned*)(lds + L::SOFF + (i / ND) * L::STG + NFL * 5 + 4 * (i % ND)) = 0x08080808u;
+    }
+    stage_by_role(0, 0);
+    if (KS > 1) stage_by_role(1, 1);
+    for (int i = lane; i < L::EIMG / 16; i += 64) *(f32x4*)(eimg + 16 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     static_for<0, NPASS>([&](auto PASS) {
     constexpr int pass = decltype(PASS)::value;
     constexpr int NPT = (G::NPT2 - 4 * pass) < 4 ? (G::NPT2 - 4 * pass) : 4;   // position tiles of this pass
-    if (pass) __syncthreads();                                             // the previous pass's T (LDS) has been gathered
     // routing role of this thread: position gp = 64 * pass + lane (gy, gx) of the O2W x O2W gradient map, channel quad qd = wave of the K step's 32
     const int gp = 64 * pass + lane, gy = gp / O2W_, gx = gp % O2W_, qd = wave;
     // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells).  The stash code
@@ -679,7 +702,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // vector work issue under the matrix pipe (one basic block with the MFMAs: no branch in between).
     union Q { unsigned w[2]; uint2 u; };                                    // pieces of the thread's four channels: [j0 | j1 << 16], [j2 | j3 << 16]
     float vpend = 0.f;                                                     // the even channel of a pair waits for the odd one (split3_plain_pair)
-    // (two halves: the eight LDS reads of a channel are issued one tap group AHEAD of the selects that consume them — in one piece the selects
+    // (two halves: the eight LDS reads of a channel are issued one tap AHEAD of the selects that consume them — in one piece the selects
     // waited for the reads right in front of the tap's MFMAs, an LDS round trip per routing tap with nothing issued behind it)
     struct RouteIn { int st[4]; float dq[4]; };
     auto route_load = [&](int sbuf, int j, RouteIn& in) {
@@ -712,11 +735,6 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         if (!(j & 1)) vpend = vs;
         else split3_plain_pair(vpend, vs, 1.f, p0.w[j >> 1], p1.w[j >> 1], p2.w[j >> 1]);
     };
-    auto route_one = [&](int ks, int sbuf, int j, Q& p0, Q& p1, Q& p2) {
-        RouteIn in;
-        route_load(sbuf, j, in);
-        route_calc(ks, j, in, p0, p1, p2);
-    };
     auto route_store = [&](int ibuf, const Q& p0, const Q& p1, const Q& p2) {
         char* const I = lds + ibuf * L::IMG;
         *(uint2*)(I + rec) = p0.u;
@@ -725,206 +743,135 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     };
 
     f32x4 acc[7][NPT];
-#pragma unroll
-    for (int t = 0; t < 7; ++t)
-#pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // Weight tile (K step iks_, tap tapi of this wave) -> ring slot.  ALWAYS issued — past the pass's last tile the callers name a tile of the
-    // last K step again (it lands in a consumed slot and is never read): with no "is there a tile left" test the K loop below has no branch
-    // between its MFMA groups and every counted wait is one immediate.
-    auto tile_issue = [&](int iks_, int tapi, int slot) {
-        // source = a block-uniform 64-bit base (the sample's image) + ONE 32-bit per-lane offset (tile offset + lane part; a sample's image is
-        // KS * 25 * 6 KiB): hipcc then uses the SGPR-base addressing form instead of a 64-bit vector add per piece
-        const unsigned off = (unsigned)((iks_ * 25 + tap0 + tapi) * (32 * 192)) + a_lane;
-        char* const dst = ring + slot * L::SLOT;
-        const auto gsrc = (const __attribute__((address_space(1))) void*)(Awave + off);
-        const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
-#ifdef RBNN_DENSE_ABL_PARTA
-        if (lane < RBNN_DENSE_ABL_PARTA)                                   // ablation (timing only): a fraction of every weight tile is fetched (same instruction and wait counts)
-#endif
-        {
-            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
-            __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
-        }
-    };
 
-    if (pass == 0)                                                         // the never-matching stash bytes of both staging buffers (ordered before their first read by the prologue's barrier)
-        for (int i = tid; i < 2 * ((L::STG - NFL * 5) / 4); i += 512) {
-            constexpr int ND = (L::STG - NFL * 5) / 4;
-            *(unsigned*)(lds + L::SOFF + (i / ND) * L::STG + NFL * 5 + 4 * (i % ND)) = 0x08080808u;
-        }
-    // K steps 0 and 1 are staged together (one HBM round trip, not two) — by the first pass here, for a later pass by the pass before it, ahead
-    // of its col2im (the rows staged do not depend on the pass)
-    if (pass == 0) {
-        stage_issue(0, 0, std::false_type{});
-        if (KS > 1) stage_issue(1, 1, std::false_type{});
-    }
-    tile_issue(0, 0, 0); tile_issue(0, 1, 1); tile_issue(0, 2, 2);         // (a wave has >= 6 taps)
+    // ---- prologue of the pass: staging of K steps 0 / 1 has been issued (by the block's prologue, or ahead of the previous pass's col2im); the first
+    // weight tile; the image of K step 0 for this pass's positions ----
+    // Register sets of the A operand: tap g (running index over the pass) of a wave WITHOUT a staging role reads set g & 1 and requests tap g + 1;
+    // a staging wave (6 taps, 16 accumulator registers to spare) runs THREE sets — tap t reads set t % 3 and requests tap t + 2 — so that the first
+    // wait that covers its staging pieces (issued at tap 0 behind tap 2's request) is that of tap 3
+    ATile A0, A1, A2;
+    tile_load(0, 0, A0);
+    if (stg_role) tile_load(0, 1, A1);
     if (pass == 0) set_scales();
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
-    __syncthreads();
+    ring_wait_barrier<0>();                                                // every wave's staging pieces have landed (and, pass > 0: every wave is out of the previous K loop)
     {
         Q p0, p1, p2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) route_one(0, 0, j, p0, p1, p2);
+        for (int j = 0; j < 4; ++j) {
+            RouteIn in;
+            route_load(0, j, in);
+            route_calc(0, j, in, p0, p1, p2);
+        }
         route_store(0, p0, p1, p2);
     }
-    f16x8 a0 = *(const f16x8*)(ring + foff), a1 = *(const f16x8*)(ring + 1024 + foff), a2 = *(const f16x8*)(ring + 2048 + foff);
-#ifdef RBNN_DENSE_ABL_NOB
-    f16x8 b0[NPT], b1[NPT], b2[NPT];
-#endif
-    // The K loop, one instantiation per tap count NT of the wave (6 or 7: wave-uniform, chosen once) — so that which tile is issued at tap t
-    // (tile g + 3 = tap (t + 3) % NT of step ks + (t + 3) / NT), its ring slot and every wait count are compile-time facts and a K step is
-    // straight-line code.  (Round 3 kept running (K step, tap, index) counters with an "any tile left" test, a 7th-tap test and a choice of wait
-    // per tap: four scalar branches and ~20 scalar instructions between two taps' MFMA groups; adding three more branches per tap — one counted
-    // wait per weight plane — cost 6.6 % of the kernel, which is what pointed here.)
-    // The staging pieces of K step ks + 2 (dQ2 / stash rows: first touch, they come from HBM) are issued BEHIND tap 0's tile, and the first three
-    // taps' waits leave them outstanding: vmcnt counts in issue order, so a wait for a tile issued after them is a wait for them (round 3 issued
-    // them first and waited vmcnt(6) at tap 0: an HBM round trip per K step and wave).  They too are always issued (the last two steps re-stage
-    // the last step's rows into the free buffer) so that the count behind a tile is the same in every step; SMIN = pieces EVERY wave issues
-    // for a whole step (assuming fewer than were issued only waits longer) — 0 when the last step is half a step (Hc % 32 == 16).
-    auto kloop = [&](auto NTC, auto WHOLEC, auto R0C) {
-    constexpr int NT = decltype(NTC)::value, SB = decltype(WHOLEC)::value ? SMIN : 0, R0 = decltype(R0C)::value;
-    for (int ks = 0; ks < KS; ++ks) {
-        // this wave's staging DMA of K step ks + 1 (issued a whole step ago, or in the prologue) has landed: at most the 9 youngest
-        // vector-memory operations — the ring tiles issued since — may still be in flight
-        // (a raw s_barrier behind the counted wait: __syncthreads() makes hipcc drain vmcnt to 0 first — the three weight tiles in flight
-        // for the coming taps included)
-#ifdef RBNN_DENSE_ABL_NOBAR
-        if (ks == 0)
-#endif
-        {
+    // One K step, PAR = parity of the running index of its first tap (the register set tap 0 reads): a wave with an even tap count (6) always
+    // runs PAR = 0; a 7-tap wave alternates, so its loop below is unrolled over two K steps.  A step is straight-line code: a tap is one
+    // scheduling region (the whole step as one region: the scheduler hoists the routing reads across taps into 256 registers and scratch), tile
+    // and staging requests are ALWAYS issued (past the end: the last step's tile / rows again, never read).
+    auto kstep = [&](int ks, auto NTC, auto PARC, auto WHOLEC, auto STGC) {
+        constexpr int NT = decltype(NTC)::value, PAR = decltype(PARC)::value, STGR = decltype(STGC)::value;
+        // image ks complete; every wave's staging pieces of step ks + 1 landed (issued a whole step ago: older than the three weight loads in
+        // flight for tap 0, which stay outstanding); image / staging ks - 1 free.  (A raw s_barrier behind the counted wait: __syncthreads()
+        // makes hipcc drain vmcnt to 0 first.)
 #if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
-            const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+        const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
-            if (ks == 0) ring_wait_barrier<0>();                           // (nothing has been issued behind the prologue's staging piece yet)
-            else ring_wait_barrier<9>();                                   // image ks complete; staging ks + 1 complete; image / staging ks - 1 free
+        ring_wait_barrier<(STGR ? 6 : 3)>();
 #if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
-            barw += __builtin_amdgcn_s_memtime() - tb_;
+        barw += __builtin_amdgcn_s_memtime() - tb_;
 #endif
-        }
-        const int ksn = min(ks + 1, KS - 1), gk = ks * NT;                 // gk = running index of the step's first tile (slot = index & 3)
-        auto issue = [&](auto TC) {                                        // tap t's tile: tile g + 3 -> the slot of tile g - 1 (consumed)
-            constexpr int t = decltype(TC)::value;
-#ifdef RBNN_DENSE_ABL_NOA
-            if (false)                                                     // ablation (timing only): no weight-tile traffic after the prologue
-#endif
-            tile_issue((t + 3) / NT ? ksn : ks, (t + 3) % NT, (gk + t + 3) & (L::RING - 1));
-        };
-        issue(std::integral_constant<int, 0>{});                           // tap 0's tile, then the staging pieces — both before the B fragments are
-        stage_issue(min(ks + 2, KS - 1), ks & 1, WHOLEC);                  // live: the pieces' per-lane addresses need registers of their own
+        const int ksn = min(ks + 1, KS - 1);
         const char* const I = lds + (ks & 1) * L::IMG + foff;
-#ifdef RBNN_DENSE_ABL_NOB
-        if (ks == 0)                                                       // ablation (timing only): the B fragments of the first K step serve all
-#else
         f16x8 b0[NPT], b1[NPT], b2[NPT];
-#endif
+        // (plane by plane, in the order the first tap's product groups want them: the first group starts after four reads, not ten)
 #pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) {
-            b0[pt] = *(const f16x8*)(I + pt * 1024);
-            b1[pt] = *(const f16x8*)(I + L::PLANE + pt * 1024);
-            b2[pt] = *(const f16x8*)(I + 2 * L::PLANE + pt * 1024);
-        }
+        for (int pt = 0; pt < NPT; ++pt) b0[pt] = *(const f16x8*)(I + pt * 1024);
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) b1[pt] = *(const f16x8*)(I + L::PLANE + pt * 1024);
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) b2[pt] = *(const f16x8*)(I + 2 * L::PLANE + pt * 1024);
         Q p0, p1, p2;
         RouteIn rin;
         static_for<0, NT>([&](auto TC) {
             constexpr int t = decltype(TC)::value;
-            if constexpr (t > 0) issue(TC);
-            // tile g + 1 has landed once all but the 6 youngest operations (tiles g + 2, g + 3) are done — plus, in a step's first three
-            // taps, the staging pieces issued behind tile g + 3 of tap 0
-            asm volatile("" ::: "memory");
-#ifndef RBNN_DENSE_ABL_NOA
-            __builtin_amdgcn_s_waitcnt(VMCNT(6 + (t < 3 ? SB : 0)));
-#endif
-            asm volatile("" ::: "memory");
-            const char* const nx = ring + ((gk + t + 1) & (L::RING - 1)) * L::SLOT + foff;
-            // The six product groups, ordered by the piece of A they read — a2 | a1 a1 | a0 a0 a0 — so that each piece of the NEXT tile
-            // is loaded IN PLACE right behind the last MFMA that reads the current one (an MFMA reads its operands when it issues):
-            // no copies, and every reload has >= 12 MFMAs before its first use.  (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and
-            // a0*b1 the 2^-11 ones: apart from a0*b2, still small terms first.)
+            constexpr int LA = STGR ? 2 : 1;                                // taps of lookahead
+            static_assert(!STGR || (NT % 3 == 0 && PAR == 0), "three sets: the set of a tap is t % 3 in every K step");
+            constexpr int ic = STGR ? t % 3 : (PAR + t) & 1, in = STGR ? (t + 2) % 3 : (PAR + t + 1) & 1;
+            ATile& cur = ic == 0 ? A0 : (ic == 1 ? A1 : A2);
+            ATile& nxt = in == 0 ? A0 : (in == 1 ? A1 : A2);
+            // a later tap's tile into a free register set (the compiler places the counted wait in front of the first MFMA that reads `cur`)
+            tile_load((t + LA) / NT ? ksn : ks, (t + LA) % NT, nxt);
+            // (the staging role is a compile-time fact here, so that the counted waits of the other waves know of no staging piece)
+            if constexpr (t == 0 && STGR != 0) stage_issue(min(ks + 2, KS - 1), ks & 1, WHOLEC, STGC);   // behind tap 2's request: first covered by the wait of tap 3
+            __builtin_amdgcn_sched_barrier(0);                             // the requests stay at the top of the tap (the scheduler sank them below the MFMAs: no time left to land)
+            // the six product groups, small terms first (a2*b0 and a1*b1 are the 2^-22 terms, a1*b0 and a0*b1 the 2^-11 ones)
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a2, b0[pt], acc[t][pt]);
-#ifndef RBNN_DENSE_ABL_NOAREAD
-            a2 = *(const f16x8*)(nx + 2048);
-#endif
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(cur.p2, b0[pt], acc[t][pt]);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b1[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(cur.p1, b1[pt], acc[t][pt]);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a1, b0[pt], acc[t][pt]);
-#ifndef RBNN_DENSE_ABL_NOAREAD
-            a1 = *(const f16x8*)(nx + 1024);
-#endif
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(cur.p1, b0[pt], acc[t][pt]);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b2[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(cur.p0, b2[pt], acc[t][pt]);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b1[pt], acc[t][pt]);
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(cur.p0, b1[pt], acc[t][pt]);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(a0, b0[pt], acc[t][pt]);
-#ifndef RBNN_DENSE_ABL_NOAREAD
-            a0 = *(const f16x8*)nx;
-#endif
+            for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = DENSE_MFMA(cur.p0, b0[pt], acc[t][pt]);
 #ifndef RBNN_DENSE_ABL_NOROUTE
-            // the next K step's image: channel j of the thread's quad is read in tap group j and routed in tap group j + 1
-            // (R0: the channel-tile-1 wave of a SIMD routes RBNN_DENSE_STAGGER tap groups later than its channel-tile-0 partner)
-            if constexpr (t >= R0 + 1 && t < R0 + 5) route_calc(ks + 1, t - R0 - 1, rin, p0, p1, p2);
-            if constexpr (t >= R0 && t < R0 + 4) route_load((ks + 1) & 1, t - R0, rin);
-            if constexpr (t == R0 + 4) route_store((ks + 1) & 1, p0, p1, p2);
+            // the next K step's image: channel j of the thread's quad is read in tap j and routed in tap j + 1
+            if constexpr (t >= 1 && t < 5) route_calc(ks + 1, t - 1, rin, p0, p1, p2);
+            if constexpr (t < 4) route_load((ks + 1) & 1, t, rin);
+            if constexpr (t == 4) route_store((ks + 1) & 1, p0, p1, p2);
 #endif
-            __builtin_amdgcn_sched_barrier(0);                             // a tap is one scheduling region (the whole step as one region: routing reads hoisted across taps, 256 registers and scratch)
+            __builtin_amdgcn_sched_barrier(0);
         });
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): the tiles / staging pieces issued past the end have landed (the col2im tile aliases their slots)
     };
     DSTAMP(8 * pass + 0);                                                  // prologue (pass 0: from the block's start; later passes: from the end of the previous col2im)
+    // The K loop and the col2im of the pass, instantiated per (tap count, staging role) of the wave and chosen once: a 6-tap wave's seventh
+    // accumulator row does not exist in its instantiation (16 registers: the staging waves' third A set)
+    auto run_pass = [&](auto NTC, auto STGC) {
+    constexpr int NT = decltype(NTC)::value;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[t][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-        const bool whole = (a.Hc & 31) == 0;                               // block-uniform
         using Z = std::integral_constant<int, 0>;
-        using R = std::integral_constant<int, RBNN_DENSE_STAGGER>;
-        if (!whole) { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::false_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::false_type{}, Z{}); }
-        else if (RBNN_DENSE_STAGGER && ct) { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, R{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, R{}); }
-        else { if (ntap == 7) kloop(std::integral_constant<int, 7>{}, std::true_type{}, Z{}); else kloop(std::integral_constant<int, 6>{}, std::true_type{}, Z{}); }
+        using O = std::integral_constant<int, 1>;
+        auto kloop = [&](auto WHOLEC) {
+            if constexpr (NT == 7) {
+                for (int ks = 0; ks < KS; ks += 2) {
+                    kstep(ks, NTC, Z{}, WHOLEC, STGC);
+                    if (ks + 1 < KS) kstep(ks + 1, NTC, O{}, WHOLEC, STGC);
+                }
+            } else {
+                for (int ks = 0; ks < KS; ++ks) kstep(ks, NTC, Z{}, WHOLEC, STGC);
+            }
+        };
+        if ((a.Hc & 31) == 0) kloop(std::true_type{}); else kloop(std::false_type{});      // block-uniform
     }
-    if (pass + 1 < NPASS) {                                                // the next pass's first two K steps: they land under this pass's col2im (whose barriers do not wait for them)
-        stage_issue(0, 0, std::false_type{});
-        if (KS > 1) stage_issue(1, 1, std::false_type{});
+    if (pass + 1 < NPASS) {                                                // the next pass's first two K steps: they land under this pass's col2im
+        stage_by_role(0, 0);
+        if (KS > 1) stage_by_role(1, 1);
     }
     DSTAMP(8 * pass + 1);                                                  // K loop
-    // ---- col2im: two rounds (input-channel tiles).  T of a round sits in LDS as [25 taps][64 pos][16 ci] floats: an accumulator tile's four
-    // registers are four consecutive channels (one ds_write_b128 per tile; the four channel quads of a position are XOR-swizzled by
-    // (pos >> 1) & 3, which spreads eight consecutive positions over all 32 banks), and a gathering thread = one output position (Y, X) x two
-    // channel quads adds up its <= 25 terms in (ky, kx) order with eight independent sums.  (First version: [tap][ci][pos] floats, 112
-    // 4-way-conflicting ds_write_b32 per lane and one serial chain of ~60 dependent LDS reads per thread: 2.0 of the kernel's 11.0 ms,
-    // profiles/r03a/conv_dense_ablations.txt.)  With several passes a term belongs to the pass that holds its position; the sums of the
-    // earlier passes wait in `part` and the LAST pass adds them (fixed order: deterministic) and writes. ----
-    float* const T = lds_f;
 #ifdef RBNN_DENSE_ABL_NOEPI
     {                                                                      // ablation (timing only): the accumulators stay live, nothing is gathered
         float sink = 0.f;
 #pragma unroll
-        for (int t = 0; t < 7; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) sink += acc[t][pt][0] + acc[t][pt][1] + acc[t][pt][2] + acc[t][pt][3];
         if (sink == 1.2345e-30f) a.dP1[sn * G::P1SZ] = sink;
-        return;
     }
-#endif
-    // (round 4, second half) col2im through WAVE-PRIVATE partial images instead of the T tile above: every wave adds the T tiles of its own
-    // taps into its own [P1W x P1W][16 ci] fp32 image in LDS (read - add - write of one ds_*_b128 per accumulator tile; within one tap the
-    // positions of a tile land on distinct outputs, taps follow each other in program order, nobody else touches the image: no atomics, a
-    // fixed order), then one output position x two channel quads per thread adds the four images of a channel tile in wave order.  Both channel
-    // tiles at once: two barriers per pass instead of four, 0.55 MB through LDS per pass instead of 0.86 (the T tile was written by half the
-    // waves and gathered with 2/3 of the reads masked off: 16.7k of a block's 135k cycles per pass, tools/dense_stamps.sh).  The channel quads of
-    // an output position are XOR-swizzled by (position >> 2) & 3: the 16 lanes of a ds_*_b128 service group cover positions p .. p + 3 and
-    // p + 12 .. p + 15 of a tile, whose 64-byte records would otherwise share banks four positions apart.
+#else
+    // ---- col2im of this pass into the wave's own image (no barrier: nobody else touches it).  The channel quads of an output position are
+    // XOR-swizzled by (position >> 2) & 3: the 16 lanes of a ds_*_b128 service group cover positions p .. p + 3 and p + 12 .. p + 15 of a
+    // tile, whose 64-byte records would otherwise share banks four positions apart. ----
     {
-        char* const img = lds + wave * L::EIMG;
-        ring_wait_barrier<63>();                                           // the loop buffers are free: every wave is out of its K loop with its ring DMA drained (raw barriers here:
-                                                                           // __syncthreads() would wait for the next pass's staging pieces just issued)
-        for (int i = lane; i < L::EIMG / 16; i += 64) *(f32x4*)(img + 16 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
         int o0[NPT];
         bool val[NPT];
-        const int dummy = (L::EPI + 64 + lane * 16) - wave * L::EIMG + wave * 1024;   // (relative to img) behind the images and the wave maxima: 1 KiB per wave
+        const int dummy = (L::DOFF + wave * 1024 + lane * 16) - (L::EOFF + wave * L::EIMG);   // (relative to eimg)
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int gpos = 64 * pass + 16 * pt + li;                     // acc[t][pt][r] = T[tap0 + t][ci = 4lg + r][gpos]
@@ -932,75 +879,81 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             o0[pt] = (gpos / O2W_) * P1W_ + gpos % O2W_;                   // output position of tap (0, 0)
         }
 #pragma unroll
-        for (int t = 0; t < 7; ++t)
-            if (t < ntap) {                                                // wave-uniform
-                const int tap = tap0 + t, shift = (tap / 5) * P1W_ + tap % 5;
-                f32x4 cur[NPT];
-                int ad[NPT];
+        for (int t = 0; t < NT; ++t) {
+            const int tap = tap0 + t, shift = (tap / 5) * P1W_ + tap % 5;
+            f32x4 cur[NPT];
+            int ad[NPT];
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) {                         // the tile's reads together, then its writes
-                    const int o = o0[pt] + shift;
-                    // lanes past the last position (the last pass's last tile) go through a private dummy record instead of an exec-masked
-                    // block per access (a masked LDS read is waited for inside its block: one round trip each, in series)
-                    ad[pt] = val[pt] ? o * 64 + ((lg ^ ((o >> 2) & 3)) << 4) : dummy;
-                    cur[pt] = *(const f32x4*)(img + ad[pt]);
-                }
-#pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) *(f32x4*)(img + ad[pt]) = cur[pt] + acc[t][pt];
+            for (int pt = 0; pt < NPT; ++pt) {                             // the tile's reads together, then its writes
+                const int o = o0[pt] + shift;
+                // lanes past the last position (the last pass's last tile) go through a private dummy record instead of an exec-masked
+                // block per access (a masked LDS read is waited for inside its block: one round trip each, in series)
+                ad[pt] = val[pt] ? o * 64 + ((lg ^ ((o >> 2) & 3)) << 4) : dummy;
+                cur[pt] = *(const f32x4*)(eimg + ad[pt]);
             }
-        ring_wait_barrier<63>();
-        float omax = 0.f;
-        if (tid < 2 * NPP) {
-            const int qp = tid / NPP, pp = tid % NPP, sw = (pp >> 2) & 3;
-            const char* const rec = lds + pp * 64;
 #pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {                               // channel tile c2 = waves 4 c2 .. 4 c2 + 3
-                f32x4 u0[4], u1[4];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    u0[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp) ^ sw) << 4));
-                    u1[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp + 1) ^ sw) << 4));
-                }
-                const f32x4 s0 = part[c2][0] + (((u0[0] + u0[1]) + u0[2]) + u0[3]);   // earlier passes + this pass's four tap groups, in that order
-                const f32x4 s1 = part[c2][1] + (((u1[0] + u1[1]) + u1[2]) + u1[3]);
-                if (pass + 1 < NPASS) {
-                    part[c2][0] = s0;
-                    part[c2][1] = s1;
-                } else {
-                    float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * c2 + 8 * qp) * NPP + pp;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float* const dst = dst0 + r * NPP;
-                        const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
-                        const float o = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
-                        *dst = o;
-                        omax = fmaxf(omax, fabsf(o));
-                    }
-                }
-            }
+            for (int pt = 0; pt < NPT; ++pt) *(f32x4*)(eimg + ad[pt]) = cur[pt] + acc[t][pt];
         }
-        if (G::CIN >= RBNN_CONV1_BWD_X3_MINCIN && pass + 1 == NPASS) {                                           // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-            float* const wm = (float*)(lds + L::EPI);                      // (the rings' area: free)
-            if (lane == 0) wm[wave] = omax;
-            ring_wait_barrier<63>();
-            if (tid == 0) {
-                float m = wm[0];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) m = fmaxf(m, wm[w]);
-                a.G[sn * G::DIN] = m;
-            }
-        }
+    }
+#endif
+    };
+    {
+        using N6 = std::integral_constant<int, 6>;
+        if (ntap == 7) run_pass(std::integral_constant<int, 7>{}, std::integral_constant<int, 0>{});
+        else if (stg_role == 1) run_pass(N6{}, std::integral_constant<int, 1>{});
+        else if (stg_role == 2) run_pass(N6{}, std::integral_constant<int, 2>{});
+        else run_pass(N6{}, std::integral_constant<int, 0>{});
     }
     DSTAMP(8 * pass + 2);                                                  // col2im
     });
+
+    // ---- the output: one thread = one output position x two channel quads; the four images of a channel tile in wave order ----
+    ring_wait_barrier<0>();                                                // every wave's col2im is in LDS
+    float omax = 0.f;
+    if (tid < 2 * NPP) {
+        const int qp = tid / NPP, pp = tid % NPP, xs = (pp >> 2) & 3;
+        const char* const rec = lds + L::EOFF + pp * 64;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {                                   // channel tile c2 = waves 4 c2 .. 4 c2 + 3
+            f32x4 u0[4], u1[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                u0[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp) ^ xs) << 4));
+                u1[q4] = *(const f32x4*)(rec + (4 * c2 + q4) * L::EIMG + (((2 * qp + 1) ^ xs) << 4));
+            }
+            const f32x4 s0 = ((u0[0] + u0[1]) + u0[2]) + u0[3];
+            const f32x4 s1 = ((u1[0] + u1[1]) + u1[2]) + u1[3];
+            float* const dst0 = a.dP1 + sn * G::P1SZ + (16 * c2 + 8 * qp) * NPP + pp;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float* const dst = dst0 + r * NPP;
+                const float v = (r < 4 ? s0[r & 3] : s1[r & 3]) * out_scale;   // over the forward's P1 (dead after this read): sigmoid / tanh take act' from it
+                const float o = smooth_act<ACT>() ? v * act_grad_from_value<ACT>(*dst) : v;
+                *dst = o;
+                omax = fmaxf(omax, fabsf(o));
+            }
+        }
+    }
+    if (G::CIN >= RBNN_CONV1_BWD_X3_MINCIN) {                              // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+        float* const wm = (float*)(lds + L::MOFF);
+        if (lane == 0) wm[wave] = omax;
+        ring_wait_barrier<0>();
+        if (tid == 0) {
+            float m = wm[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) m = fmaxf(m, wm[w]);
+            a.G[sn * G::DIN] = m;
+        }
+    }
 #ifdef RBNN_DENSE_STAMPS
     DSTAMP_ADD(24, __builtin_amdgcn_s_memtime() - tstart);
     DSTAMP_ADD(25, 1);
     DSTAMP_ADD(26, barw);
 #endif
 }
+}  // namespace
 
 // =====================================================================================================
 // Both triple images of model.3.weight — the forward's tap-major grouped rows image and the dense conv2^T image — from the fp32 stack in ONE
@@ -1048,7 +1001,7 @@ __global__ void __launch_bounds__(256) conv_k2_images_kernel(const float* __rest
         }
     }
     if (dense_img) {
-        // dense image: [sample][K step = these 32 hc][tap][input-channel half][3 pieces][16 ci][32 hc] halves; item = (tap, ci, unit of 8 hc)
+        // dense image: [sample][K step = these 32 hc][tap][input-channel half][3 pieces][4 units of 8 hc][16 ci][8 hc] halves; item = (tap, ci, unit of 8 hc)
         for (int it = tid; it < 25 * 32 * 4; it += 256) {
             const int u = it & 3, ci = (it >> 2) & 31, tap = it >> 7;
             U o[3];
@@ -1059,7 +1012,7 @@ __global__ void __launch_bounds__(256) conv_k2_images_kernel(const float* __rest
                 o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
             }
             const long long T = (((long long)s * KS + ks) * 25 + tap) * 2 + (ci >> 4);
-            uint4* const out = dense_img + (T * 3) * 64 + (ci & 15) * 4 + u;
+            uint4* const out = dense_img + (T * 3) * 64 + u * 16 + (ci & 15);      // a piece is [4 K chunks][16 ci][16 B]: lane (li, lg) of the dense kernel owns unit 16 lg + li
             out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
         }
     }

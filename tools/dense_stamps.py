@@ -21,7 +21,7 @@ except SystemExit:
     pass
 buf = (C.c_ulonglong * 64)()
 assert lib.rbnn_debug_dense_stamps(buf, 1) == 0
-for w, base in ((0, 0), (3, 32)):
+for w, base in ((os.environ.get("STAMP_WA", "0"), 0), (os.environ.get("STAMP_WB", "3"), 32)):
     v = [buf[base + i] for i in range(32)]
     nb = max(v[25], 1)
     print(f"wave {w}: blocks {v[25]}  cycles/block {v[24] / nb:9.0f}")
