@@ -687,14 +687,15 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // byte offsets of this thread's four windows' cells inside a staging buffer (channel j of its quad: + j * NP2 cells).  The stash code
     // that routes window w here is w (argmax) with bit 2 = the pre-activation was positive; stash bytes are <= 7 by construction, so they
     // are compared WHOLE (no masking), and a window off the map (or a lane past the last position: its image row is zeros) reads the byte 8
-    int adq[4], ast[4];
+    // ONE register per window: the cell index c — its dQ2 float sits at 4 c, its stash byte at NFL * 4 + c.  A window off the map (or a lane past
+    // the last position) names cell NFL: its "stash byte" is the first never-matching byte (NFL * 5; + j NP2 <= 4 NP2 of them) and its "float" four
+    // stash bytes (values <= 8 each: a finite, tiny number, multiplied by a zero factor)
+    int cw[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {                                          // window w = 2dy + dx of the <= 4 stride-1 pooling windows containing (gy, gx)
         const int py = gy - (w >> 1), px = gx - (w & 1);
         const bool ok = gp < NPOS_ && py >= 0 && py < P2W_ && px >= 0 && px < P2W_;
-        const int cell = 4 * qd * NP2_ + (ok ? py * P2W_ + px : 0);
-        adq[w] = 4 * cell;
-        ast[w] = ok ? NFL * 4 + cell : NFL * 5;                            // off the map (or a lane past the last position): the never-matching byte (+ j NP2 <= 4 NP2 of them)
+        cw[w] = ok ? 4 * qd * NP2_ + py * P2W_ + px : NFL;
     }
     const int rec = lane * 64 + (((qd >> 1) ^ swz(lane)) * 16) + (qd & 1) * 8;   // this thread's 8 bytes of a piece plane
     // routing of ONE channel (j of this thread's quad) of K step ks from staging buffer sbuf: pool-2 argmax + activation derivative (gather
@@ -709,8 +710,8 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         const char* const sb = lds + L::SOFF + sbuf * L::STG;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {                                      // eight independent LDS reads
-            in.st[w] = *(const unsigned char*)(sb + ast[w] + j * NP2_);
-            in.dq[w] = *(const float*)(sb + adq[w] + 4 * j * NP2_);
+            in.st[w] = *(const unsigned char*)(sb + NFL * 4 + j * NP2_ + cw[w]);
+            in.dq[w] = *(const float*)(sb + 4 * j * NP2_ + 4 * cw[w]);
         }
     };
     auto route_calc = [&](int ks, int j, const RouteIn& in, Q& p0, Q& p1, Q& p2) {
