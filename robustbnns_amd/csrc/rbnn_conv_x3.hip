@@ -593,6 +593,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     const long long sn = (long long)s * a.N + n;
     const int F = a.Hc * NP2_, KS = (a.Hc + 31) / 32;
     const float slope = ACT == RBNN_ACT_RELU ? 0.f : LEAKY_SLOPE;
+#ifndef RBNN_DENSE_PRIO
+#define RBNN_DENSE_PRIO 1
+#endif
+    // A SIMD issues from its OLDEST ready wave: of the two waves that share one, the lower-numbered ran ahead every K step and its partner did the
+    // rest of its taps alone, its stalls uncovered (stamps: a 7-tap wave 47k of 189k K-loop cycles at the barrier, its partner 15k).  The wave of a
+    // SIMD that must not be the one left alone — the 7-tap waves (0, 5), the staging waves (2, 7) — takes the higher issue priority.
+    if (RBNN_DENSE_PRIO && (wave == 0 || wave == 5 || wave == 2 || wave == 7)) __builtin_amdgcn_s_setprio(1);
 #ifdef RBNN_DENSE_STAMPS
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tprev;
