@@ -50,6 +50,24 @@ __device__ __forceinline__ bool item_of_block(int b, int M, int& id) {
     return true;
 }
 
+// Softmax backward dZ_c = p_c (g_c - <g, p>) for p = softmax(z), evaluated WITHOUT the cancellation of that form.  A trained net's softmax saturates
+// (p_max = 1 - 1e-6): for c = argmax the difference g_c - <g, p> = g_c (1 - p_c) - sum_{k != c} g_k p_k then cancels to O(1 - p_max) with an absolute
+// error of an ulp of g — several per cent of the result (torch's autograd evaluates exactly that form: the reference's own fp32 gradients sit up to
+// 5e-3 from an fp64 evaluation on the trained fixtures, tests/conftest.py).  Since sum_k p_k = 1,   g_c - <g, p> = sum_{k != c} p_k (g_c - g_k):
+// every term is a product of accurately known factors (the small p_k come out of exp(z_k - z_max) with full relative precision), nothing cancels.
+// C (<= CM <= 16) live classes; C^2 multiply-adds per (sample, point) instead of 2 C — nothing beside the GEMMs.  The one definition all kernels use
+// (loss_dlogits_kernel, step_tail_x3_kernel, the lowdim kernels), so the fused and the separate forms stay bit-identical.
+template <int CM> __device__ __forceinline__ void softmax_backward(const float (&g)[CM], const float (&p)[CM], int C, float (&out)[CM]) {
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < CM; ++k)
+            if (k != c && k < C) acc = fmaf(p[k], g[c] - g[k], acc);
+        out[c] = (c < C) ? acc * p[c] : 0.f;
+    }
+}
+
 // compile-time loop: the body sees its index as a constant (sched_group_barrier sizes must be constant expressions)
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }

@@ -526,11 +526,7 @@ __global__ void loss_dlogits_kernel(int mode, const float* __restrict__ P, const
 #pragma unroll
         for (int c = 0; c < 16; ++c) out[c] = g[c];
     } else {
-        float dot = 0.f;                                       // softmax backward: (g - <g,p>) * p
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c < C) dot += g[c] * p[c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) out[c] = (c < C) ? (g[c] - dot) * p[c] : 0.f;
+        softmax_backward<16>(g, p, C, out);                    // (g - <g,p>) * p in its cancellation-free form (rbnn_common.hpp)
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)

@@ -319,11 +319,7 @@ __global__ void __launch_bounds__(256) lowdim_kernel(const LowArgs a) {
 #pragma unroll
                         for (int c = 0; c < CM; ++c) ps[c] = (c < C) ? pp[c] : 0.f;
                     }
-                    float dot = 0.f;                                  // softmax backward: (g - <g,p>) p
-#pragma unroll
-                    for (int c = 0; c < CM; ++c) if (c < C) dot += g[c] * ps[c];
-#pragma unroll
-                    for (int c = 0; c < CM; ++c) dz[c] = (c < C) ? (g[c] - dot) * ps[c] : 0.f;
+                    softmax_backward<CM>(g, ps, C, dz);               // (g - <g,p>) p, cancellation-free (rbnn_common.hpp)
                 }
                 backward_sample<ACT, DQ, CM>(sv, H, C, x, dz, gx);
             }
@@ -543,15 +539,12 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) { e[c] = (c < C) ? expf(e[c] - m) : 0.f; den += e[c]; }
-            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
+            if (a.loss != RBNN_LOSS_MEAN_LOGIT) softmax_backward<16>(g, z, C, dz);      // (g - <g,p>) p, cancellation-free (rbnn_common.hpp)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
-                dot += g[c] * z[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                dz[c] = (a.loss == RBNN_LOSS_MEAN_LOGIT) ? g[c] : (g[c] - dot) * z[c];
+                if (a.loss == RBNN_LOSS_MEAN_LOGIT) dz[c] = g[c];
                 if (!(n < N && c < C)) dz[c] = 0.f;
             }
 #pragma unroll
@@ -664,15 +657,12 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) { e[c] = (c < C) ? expf(e[c] - m) : 0.f; den += e[c]; }
-            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
+            if (a.loss != RBNN_LOSS_MEAN_LOGIT) softmax_backward<16>(g, z, C, dz);      // (g - <g,p>) p, cancellation-free (rbnn_common.hpp)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
-                dot += g[c] * z[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                dz[c] = (a.loss == RBNN_LOSS_MEAN_LOGIT) ? g[c] : (g[c] - dot) * z[c];
+                if (a.loss == RBNN_LOSS_MEAN_LOGIT) dz[c] = g[c];
                 if (!(n < N && c < C)) dz[c] = 0.f;
             }
 #pragma unroll

@@ -647,11 +647,7 @@ __device__ __forceinline__ void tail_dz(const float* __restrict__ prow, const fl
 #pragma unroll
         for (int c = 0; c < 16; ++c) out[c] = g[c];
     } else {
-        float dot = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) if (c < C) dot += g[c] * p[c];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) out[c] = (c < C) ? (g[c] - dot) * p[c] : 0.f;
+        softmax_backward<16>(g, p, C, out);                    // loss_dlogits_kernel's, bit for bit
     }
 }
 

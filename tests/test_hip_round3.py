@@ -83,7 +83,8 @@ def test_trained_halfmoons_attack_and_evaluation(golden, name, kind, monkeypatch
         out = net.forward(xg, n_samples=ns)
         torch.nn.CrossEntropyLoss(reduction="sum")(out, lab.to(DEV)).backward()
         g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), m["arch"], m["act"], ns, kind=okind)
-        relaxed += assert_close_to_reference(xg.grad.cpu(), ref_g, g64, TOL, saturation_noise(x, post, m["arch"], m["act"], ns, okind), f"{kind} ns={ns}")
+        relaxed += assert_close_to_reference(xg.grad.cpu(), ref_g, g64, TOL, saturation_noise(x, post, m["arch"], m["act"], ns, okind), f"{kind} ns={ns}",
+                                             sharp=(kind == "bnn"))     # (an ensemble's loss sits on the mean LOGITS: its ill-conditioned step, p_y - 1 of a saturated softmax, is torch's own cross-entropy backward — identical in the reference and here)
         for e, eps in enumerate(m["eps_list"]):
             ref_adv = g.t(kind + "_fgsm_adv")[e, k]
             adv = AA.attack(net=net, x_test=x, y_test=y, dataset_name=m["dataset"], device=DEV, method="fgsm", filename=net.name,
@@ -176,7 +177,7 @@ def test_trained_mnist_shaped(golden, name, precision, monkeypatch):
     xg = x.clone().to(DEV).requires_grad_(True)
     torch.nn.CrossEntropyLoss(reduction="sum")(bnn.forward(xg, n_samples=ns), lab.to(DEV)).backward()
     g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), arch, act, ns)
-    relaxed = assert_close_to_reference(xg.grad.cpu(), g.t(f"bnn_fgsm_grad_ns{ns}"), g64, TOL, saturation_noise(x, post, arch, act, ns), "gradient")
+    relaxed = assert_close_to_reference(xg.grad.cpu(), g.t(f"bnn_fgsm_grad_ns{ns}"), g64, TOL, saturation_noise(x, post, arch, act, ns), "gradient", sharp=True)
     print(f"{name} [{precision}]: {relaxed} of {len(x)} gradient rows at the fp32 saturation floor")
     print(relaxed_summary())
     P = m["pgd_points"]
