@@ -474,7 +474,7 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
         lazy_kind = (eng.precision if eng.precision in ("lowdim", "triple") and kind == "svi" and not pipe and w["arch"] != "conv"
                      and os.environ.get("RBNN_LAZY_DRAW", "1") != "0" else None)
         lazy_draw = lazy_kind == "lowdim" and getattr(post_, "lazy_capable", lambda: False)()
-        key = 0x5EED0000 + rank
+        key = 0x5EED0000 + (rank if shard == "samples" else 0)          # point-sharded: every rank draws the SAME samples (the job's n_samples, replicated)
 
         timed = [0]
         # triple engines: the draw writes the images the kernels read (rbnn_svi_draw_images); the fp32 W1 stack + its pack_rows4 copy (40 % of a

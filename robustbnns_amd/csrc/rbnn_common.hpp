@@ -51,21 +51,29 @@ __device__ __forceinline__ bool item_of_block(int b, int M, int& id) {
 }
 
 // Softmax backward dZ_c = p_c (g_c - <g, p>) for p = softmax(z), evaluated WITHOUT the cancellation of that form.  A trained net's softmax saturates
-// (p_max = 1 - 1e-6): for c = argmax the difference g_c - <g, p> = g_c (1 - p_c) - sum_{k != c} g_k p_k then cancels to O(1 - p_max) with an absolute
+// (p_max = 1 - 1e-6): for the WINNING class m the difference g_m - <g, p> = g_m (1 - p_m) - sum_{k != m} g_k p_k cancels to O(1 - p_max) with an absolute
 // error of an ulp of g — several per cent of the result (torch's autograd evaluates exactly that form: the reference's own fp32 gradients sit up to
-// 5e-3 from an fp64 evaluation on the trained fixtures, tests/conftest.py).  Since sum_k p_k = 1,   g_c - <g, p> = sum_{k != c} p_k (g_c - g_k):
-// every term is a product of accurately known factors (the small p_k come out of exp(z_k - z_max) with full relative precision), nothing cancels.
-// C (<= CM <= 16) live classes; C^2 multiply-adds per (sample, point) instead of 2 C — nothing beside the GEMMs.  The one definition all kernels use
-// (loss_dlogits_kernel, step_tail_x3_kernel, the lowdim kernels), so the fused and the separate forms stay bit-identical.
+// 3e-3 from an fp64 evaluation on the trained fixtures, tests/conftest.py).  Since sum_k p_k = 1,   g_m - <g, p> = sum_k p_k (g_m - g_k)   (the k = m
+// term is exactly 0): every term is a product of accurately known factors (the small p_k come out of exp(z_k - z_max) with full relative
+// precision), nothing cancels.  The other classes need nothing special: g_c - <g, p> is then a difference of O(1) numbers with an O(1) result.
+// ~5 C operations per (sample, point) (the all-pairs form, C^2, made step_tail_x3_kernel 76 -> 132 us at C2: it evaluates this twice per pair).
+// C (<= CM <= 16) live classes.  The one definition all kernels use (loss_dlogits_kernel, step_tail_x3_kernel, the lowdim kernels), so the fused
+// and the separate forms stay bit-identical.
 template <int CM> __device__ __forceinline__ void softmax_backward(const float (&g)[CM], const float (&p)[CM], int C, float (&out)[CM]) {
+    float dot = 0.f, pm = -INFINITY, gm = 0.f;
+    int m = 0;
 #pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        float acc = 0.f;
+    for (int c = 0; c < CM; ++c)
+        if (c < C) {
+            dot += g[c] * p[c];
+            if (p[c] > pm) { pm = p[c]; gm = g[c]; m = c; }             // the first maximum
+        }
+    float sm = 0.f;
 #pragma unroll
-        for (int k = 0; k < CM; ++k)
-            if (k != c && k < C) acc = fmaf(p[k], g[c] - g[k], acc);
-        out[c] = (c < C) ? acc * p[c] : 0.f;
-    }
+    for (int k = 0; k < CM; ++k)
+        if (k < C) sm = fmaf(p[k], gm - g[k], sm);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) out[c] = (c < C) ? (c == m ? sm : g[c] - dot) * p[c] : 0.f;
 }
 
 // compile-time loop: the body sees its index as a constant (sched_group_barrier sizes must be constant expressions)
