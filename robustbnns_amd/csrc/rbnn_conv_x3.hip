@@ -599,7 +599,11 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // A SIMD issues from its OLDEST ready wave: of the two waves that share one, the lower-numbered ran ahead every K step and its partner did the
     // rest of its taps alone, its stalls uncovered (stamps: a 7-tap wave 47k of 189k K-loop cycles at the barrier, its partner 15k).  The wave of a
     // SIMD that must not be the one left alone — the 7-tap waves (0, 5), the staging waves (2, 7) — takes the higher issue priority.
-    if (RBNN_DENSE_PRIO && (wave == 0 || wave == 5 || wave == 2 || wave == 7)) __builtin_amdgcn_s_setprio(1);
+    // (RBNN_DENSE_PRIO: 1 = those four waves, always — the default; 2 = the 7-tap waves only; 3 = the four, but only through tap 3 of every K step;
+    //  4 = the OTHER four waves; measured in profiles/r05q/dense_prio.txt)
+    const bool prio_wave = RBNN_DENSE_PRIO == 4 ? !(wave == 0 || wave == 5 || wave == 2 || wave == 7)
+                         : (wave == 0 || wave == 5 || (RBNN_DENSE_PRIO != 2 && (wave == 2 || wave == 7)));
+    if (RBNN_DENSE_PRIO && prio_wave) __builtin_amdgcn_s_setprio(1);
 #ifdef RBNN_DENSE_STAMPS
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tprev;
@@ -808,6 +812,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             ATile& cur = ic == 0 ? A0 : (ic == 1 ? A1 : A2);
             ATile& nxt = in == 0 ? A0 : (in == 1 ? A1 : A2);
             // a later tap's tile into a free register set (the compiler places the counted wait in front of the first MFMA that reads `cur`)
+            if constexpr (RBNN_DENSE_PRIO == 3) {                          // (wave-uniform scalar branches: two per K step)
+                if (t == 0 && prio_wave) __builtin_amdgcn_s_setprio(1);
+                if (t == 4 && prio_wave) __builtin_amdgcn_s_setprio(0);
+            }
             tile_load((t + LA) / NT ? ksn : ks, (t + LA) % NT, nxt);
             // (the staging role is a compile-time fact here, so that the counted waits of the other waves know of no staging piece)
             if constexpr (t == 0 && STGR != 0) stage_issue(min(ks + 2, KS - 1), ks & 1, WHOLEC, STGC);   // behind tap 2's request: first covered by the wait of tap 3
