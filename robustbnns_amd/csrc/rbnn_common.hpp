@@ -25,7 +25,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #if (RBNN_ABL != 0) || defined(RBNN_X3FWD_ABL_NOFILL) || defined(RBNN_X3FWD_ABL_NOEPI) || defined(RBNN_DENSE_ABL_NOA) || \
     defined(RBNN_DENSE_ABL_NOMFMA) || defined(RBNN_DENSE_ABL_NOB) || defined(RBNN_DENSE_ABL_NOBAR) || defined(RBNN_DENSE_ABL_NOAREAD) || \
     defined(RBNN_DENSE_ABL_NOROUTE) || defined(RBNN_DENSE_ABL_NOEPI) || defined(RBNN_X3_L1_ABL_NOSTORE) || defined(RBNN_X3_L1_ABL_SMALL) || \
-    defined(RBNN_FAST_BUILD) || defined(RBNN_DENSE_STAMPS) || defined(RBNN_DENSE_ABL_PARTA)
+    defined(RBNN_FAST_BUILD) || defined(RBNN_DENSE_STAMPS) || defined(RBNN_DENSE_ABL_PARTA) || defined(RBNN_DENSE_ABL_HALFBAR)
 #ifndef RBNN_ALLOW_ABLATION
 #error "a timing-only ablation switch (RBNN_ABL / RBNN_*_ABL_* / RBNN_FAST_BUILD) is set: such a build computes wrong results; pass -DRBNN_ALLOW_ABLATION to build it on purpose"
 #endif

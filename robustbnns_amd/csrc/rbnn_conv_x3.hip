@@ -788,6 +788,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
 #if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
         const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RBNN_DENSE_ABL_HALFBAR
+        if (ks & 1) {                                                      // ablation (timing only, wrong results): a barrier every OTHER K step — what a 64-channel step could gain at most
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(VMCNT_LGKM0((STGR ? 6 : 3)));
+            asm volatile("" ::: "memory");
+        } else
+#endif
         ring_wait_barrier<(STGR ? 6 : 3)>();
 #if defined(RBNN_DENSE_STAMPS) && RBNN_DENSE_STAMPS >= 2
         barw += __builtin_amdgcn_s_memtime() - tb_;
