@@ -164,6 +164,10 @@ def test_c4_share_loss_gradients_and_fgsm(precision):
     from robustbnns_amd import _hip
     G = eng.gradient(eng.pad_inputs(x), lab.int().to(DEV), None, S, _hip.LOSS_MEAN_PROB)[:, :D].cpu()
     assert float((adv - torch.clamp(x.reshape(N, -1) + 0.3 * G.sign(), 0, 1)).abs().max()) == 0.0     # exactly x +- eps (or x), clamped
+    # the config's step as bench.py runs it since round 5 — both gradients from ONE forward (AttackEngine.loss_gradients_and_fgsm): at full
+    # size, every tile plan of the 250-sample grid, bit for bit the two calls above
+    lg2, adv2 = eng.loss_gradients_and_fgsm(x, y, S, 0.3)
+    assert torch.equal(lg2.cpu().reshape(N, -1), lg) and torch.equal(adv2.cpu().reshape(N, -1), adv)
 
 
 # ------------------------------------------------------------------ split vs exact
