@@ -614,19 +614,19 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
     def roofline(mode, evs_by_name, ms_per_step, svi_kind=False):
         kernels = {}
         passes_timed = args.steps * passes * w["iters"]
-        for name, evs in evs_by_name.items():
+        for kname_, evs in evs_by_name.items():           # (not `name`: that is the workload, read again below for the counter record)
             if not evs:
                 continue
-            if name == "lowdim":        # one launch = `iters` passes, forward AND backward (the backward's recomputed pre-activations not counted)
+            if kname_ == "lowdim":        # one launch = `iters` passes, forward AND backward (the backward's recomputed pre-activations not counted)
                 ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
-                kernels[name] = {"launches": len(evs), "launches_per_pass": 1.0 / w["iters"], "avg_ms": ms,
+                kernels[kname_] = {"launches": len(evs), "launches_per_pass": 1.0 / w["iters"], "avg_ms": ms,
                                  "tflops": 2 * per_launch * w["iters"] / (ms * 1e-3) / 1e12 if ms else None}
                 continue
             ms = sum(a.elapsed_time(b) for a, b in evs) / max(1, len(evs))
             # launches per hot-path pass: 1, or the number of point blocks when the sample-sharded step is pipelined over blocks
             # (each launch then covers 1/blocks of the points) or a conv job is cut into point blocks
             lpp = max(1, round(len(evs) / max(1, passes_timed)))
-            kernels[name] = {"launches": len(evs), "launches_per_pass": lpp, "avg_ms": ms,
+            kernels[kname_] = {"launches": len(evs), "launches_per_pass": lpp, "avg_ms": ms,
                              "tflops": per_launch / lpp / (ms * 1e-3) / 1e12 if ms else None}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         # PMC counters cannot be read inside this run: profiles/pmc_traffic.json is the committed rocprofv3 --pmc pass of the same workload
