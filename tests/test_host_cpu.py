@@ -692,6 +692,8 @@ def _bench_rank(rank, world, port, argv, q):
         sync = staticmethod(lambda: None)
 
     bench.RUNTIME = CpuRuntime()
+    if os.environ.get("RBNN_TEST_BENCH_ROOT"):                  # a test's own profiles/pmc_traffic.json
+        bench.ROOT = os.environ["RBNN_TEST_BENCH_ROOT"]
     sys.argv = ["bench.py"] + argv
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
@@ -749,6 +751,25 @@ def test_bench_explicit_workload_on_two_ranks_is_one_record():
     out = _bench_world(2, ["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "c2", "--points", "16", "--hidden", "32", "--samples", "3",
                            "--posterior", "stored"])
     assert out["config"]["name"] == "c2" and "c2_point_sharded" not in out and out["config"]["samples_per_rank"] == [3, 3] and out["scaling"] == "weak"
+
+
+def test_bench_line_carries_the_counter_traffic_of_its_workload(tmp_path, monkeypatch):
+    """roofline.traffic / roofline.hbm.counter_* come from profiles/pmc_traffic.json, keyed by WORKLOAD and kernel call (round 5 shipped a bench
+    set without them: a loop variable shadowed the workload's name and the lookup missed).  One rank, the test double, a record of this size."""
+    import json
+    (tmp_path / "profiles").mkdir()
+    rec = {"c2": {"points": 16, "samples": 3, "kernels": {"fc_forward": {"hbm_bytes_per_launch": 1000.0}, "fc_input_grad": {"hbm_bytes_per_launch": 3000.0}},
+                  "small": {"attack_step_kernel": {"hbm_bytes_per_launch": 50.0}, "reduce_samples_kernel": {"hbm_bytes_per_launch": 7.0}}},
+           "source": ["a test record"]}
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec))
+    monkeypatch.setenv("RBNN_TEST_BENCH_ROOT", str(tmp_path))
+    out = _bench_world(1, ["--gpus", "1", "--steps", "2", "--warmup", "0", "--points", "16", "--hidden", "32", "--samples", "3", "--posterior", "stored",
+                           "--cpu-seconds", "0", "--no-other-mode"])
+    r = out["roofline"]
+    dom = max(r["kernels"], key=lambda k: r["kernels"][k]["avg_ms"])
+    assert r["traffic"] == {"fc_forward": 1000.0, "fc_input_grad": 3000.0}[dom] and r["traffic_source"] == ["a test record"]
+    assert r["hbm"]["counter_bytes_by_call"] == {"fc_forward": 1000.0, "fc_input_grad": 3000.0}
+    assert r["hbm"]["counter_bytes_per_pass"] == 4000.0 + 50.0 + 7.0 and r["hbm"]["counter_small_kernels_bytes"] == 57.0
 
 
 # ----------------------------------------------------------------------------- files WRITTEN BY THE REFERENCE (SURVEY 8f2)
