@@ -562,7 +562,7 @@ class AttackEngine:
         the forward GEMM runs once and the tail + backward GEMM twice — three GEMMs instead of four.  Every kernel call, its arguments and
         its order of operations are those of the two separate calls: both results are BIT-IDENTICAL to them (tests/test_hip_round5.py).
         Returns (expected loss gradients, adversarial inputs), both of x's shape.  Sample-sharded: the three exchanges of the separate
-        calls (summed per-sample-loss gradients; sum_s p_s; summed mean-loss gradients)."""
+        calls (summed per-sample-loss gradients — overlapped with the second backward; sum_s p_s; summed mean-loss gradients)."""
         if not self.shared_forward or self.precision == "lowdim" or mode != LOSS_MEAN_PROB:
             # (an ensemble's / a deterministic net's attack differentiates the mean LOGITS: its forward leaves logits, the per-sample loss needs
             # probabilities — nothing to share; the lowdim kernels recompute the forward inside their one launch)
@@ -579,16 +579,25 @@ class AttackEngine:
             self._forward_kernels(X, sidx, S, OUT_PROBS, ws)
             G = ws["Gsum"] if "Gsum" in ws else ws["G"]
             n_slabs = self._loss_backward(ws, labels, sidx, S, N, LOSS_PER_SAMPLE, S_tot)
-            self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0 / S_tot, G)
-            self._allreduce(G)
-            expected = self.unpad(G, x)
-            n_slabs = self._loss_backward(ws, labels, sidx, S, N, mode, S_tot)
             if self.world == 1:
+                self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0 / S_tot, G)
+                expected = self.unpad(G, x)
+                n_slabs = self._loss_backward(ws, labels, sidx, S, N, mode, S_tot)
                 self.k.attack_step(X, None, ws["slabs"], n_slabs, N * p.Dp, p.Dp, None, float(epsilon), 0.0, False, p.D)
             else:
+                # sample-sharded: the exchange of the per-sample-loss gradients (N x D_pad fp32, its own buffer) is STARTED here and runs on the
+                # collective's stream under the second tail + backward GEMM; the mean-loss pass then has its two exchanges as in a plain step
+                G1 = ws.get("G_expected")
+                if G1 is None:
+                    G1 = ws["G_expected"] = torch.empty_like(G)
+                self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0 / S_tot, G1)
+                pending = self._allreduce_async(G1)
+                n_slabs = self._loss_backward(ws, labels, sidx, S, N, mode, S_tot)
                 self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0, G)
                 self._allreduce(G)
                 self.k.attack_step(X, None, G, 1, 0, p.Dp, None, float(epsilon), 0.0, False, p.D)
+                pending.wait()
+                expected = self.unpad(G1, x)
         finally:
             self._scales = None
         return expected, self.unpad(X, x)

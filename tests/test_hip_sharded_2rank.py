@@ -58,6 +58,10 @@ def _worker(rank, world, port, precision, q, arch="fc", S_fc=6):
         out = {"probs": eng.forward(x, eng.post.S).cpu(), "lg": eng.loss_gradients(x, y, eng.post.S).cpu(),
                "gm": eng.gradient(eng.pad_inputs(x), lab, None, eng.post.S, _hip.LOSS_MEAN_PROB)[:, :D].cpu().clone(),
                "fgsm": eng.fgsm(x, y, eng.post.S, 0.3).cpu(), "pgd": eng.pgd(x[:NP], y[:NP], eng.post.S, 0.3, iters=4).cpu()}
+        # BASELINE config 4's step on ONE forward, sample-sharded (its first gradient exchange overlapped with the second backward): the two
+        # calls' results, bit for bit, on every rank (the fc engine pipelines fgsm() over two point blocks here, the shared call does not)
+        both = eng.loss_gradients_and_fgsm(x, y, eng.post.S, 0.3)
+        assert torch.equal(both[0].cpu(), out["lg"]) and torch.equal(both[1].cpu(), out["fgsm"])
         torch.cuda.synchronize()
         t = out["fgsm"].clone()                                  # every rank holds the same (replicated) adversarial images
         dist.broadcast(t, src=0)
