@@ -76,6 +76,30 @@ template <int CM> __device__ __forceinline__ void softmax_backward(const float (
     for (int c = 0; c < CM; ++c) out[c] = (c < C) ? (c == m ? sm : g[c] - dot) * p[c] : 0.f;
 }
 
+// Item -> (point tile, column group, chunk) of the input-gradient GEMM kernels.  Kernels that GENERATE their A operand read no A from memory:
+// point tiles run fastest, so that the blocks resident on an XCD together share one (chunk, column group)'s W1 slices in its L2.  fc2's step
+// through W1 READS its A operand — dL/d(pre-activation 1) of (point tile, chunk), 32 KB per stage — and every column group reads it again: with
+// the point tiles fastest the seven readers of a tile ran 40 items apart and each fetched it from beyond the L2 (PMC, profiles/r05p/fc2: 18.5 GB
+// per backward call, 4 TB/s under a 3.9-ms kernel).  a_from_memory: the order is blocked 2-D — TB point tiles x all column groups, column
+// group fastest — so that the ~56 blocks an XCD holds at a time read 8 A tiles and 7 W1 slices per stage between them.  Same work per item:
+// results bit-identical.  fc2-512 backward 6.61 -> 6.17 ms, fc2-1024 17.74 -> 16.73 (same box, profiles/r05s).
+#ifndef RBNN_GRAD_STEP2_TB
+#define RBNN_GRAD_STEP2_TB 8
+#endif
+__device__ __forceinline__ void grad_item(int id, int NT, int ND, bool a_from_memory, int& ntile, int& dg, int& ch) {
+    if (a_from_memory && RBNN_GRAD_STEP2_TB > 0) {
+        constexpr int TB = RBNN_GRAD_STEP2_TB > 0 ? RBNN_GRAD_STEP2_TB : 1;
+        const int per = NT * ND, blk = TB * ND, full = NT / TB;
+        ch = id / per;
+        const int il = id - ch * per;
+        const int tb = min(il / blk, full), r = il - tb * blk;   // (the last block of point tiles may hold fewer than TB)
+        dg = r % ND;
+        ntile = tb * TB + r / ND;
+    } else {
+        ntile = id % NT; dg = (id / NT) % ND; ch = id / (NT * ND);
+    }
+}
+
 // compile-time loop: the body sees its index as a constant (sched_group_barrier sizes must be constant expressions)
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
