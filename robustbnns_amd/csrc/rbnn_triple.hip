@@ -1036,6 +1036,49 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
         return;
     }
     // ---- epilogue: acc[nt][dt][r] = D[n = nb + nt*16 + 4*lg + r][d = dc0 + dt*16 + li], un-scaled per point ----
+#ifndef RBNN_X3_GRAD_EPI_LDS
+#define RBNN_X3_GRAD_EPI_LDS 1
+#endif
+    if constexpr (RBNN_X3_GRAD_EPI_LDS) {
+        // (round 5) Straight from the registers a store instruction covered four point rows x 64 BYTES — 128 of them per wave, half-line writes
+        // (and, fc2 step 1, a mask-word load per element).  The timing ablation without epilogues priced them at 1.1 of the fc2 backward's
+        // 6.2 ms (profiles/r05s).  Now each 16-point tile of a wave goes through a wave-private LDS tile [16 points][LD + 4] (row pitch = 4 mod 16
+        // floats: the four row groups of a ds_write_b32 land 16 banks apart) and leaves as 16-BYTE stores of whole rows: a store instruction is
+        // 64 x 16 B of at most 2 rows' contiguous runs; the stash word of the layer below is loaded once per 16 bytes.  The loop buffers are free:
+        // every wave has passed the last stage's barrier.  Same values, same order of operations per element: bit-identical results.
+        constexpr int LDW = LD + 4, C4 = LD / 4, E4 = 16 * C4;
+        static_assert(NW * 16 * LDW * 4 <= 2 * BUFB + DZB, "the waves' transposition tiles fit the loop buffers");
+        float* const tw = (float*)ldsb + wave * (16 * LDW);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + nt * 16 + 4 * lg + r;
+                const float gs = (MODE == X3_FC2_STEP1) ? a.out_scale : (n < a.N ? a.gscale[n] : 0.f) * a.out_scale;
+#pragma unroll
+                for (int dt = 0; dt < TD; ++dt) tw[(4 * lg + r) * LDW + dt * 16 + li] = acc[nt][dt][r] * gs;
+            }
+#pragma unroll
+            for (int i = 0; i < (E4 + 63) / 64; ++i) {
+                const int e4 = i * 64 + lane, row = e4 / C4, c4 = e4 - row * C4;
+                const int n = nb + nt * 16 + row, d = dc0 + 4 * c4;
+                if (e4 < E4 && n < a.N && d < Dp) {                       // (Dp is a multiple of 16: a quad is in or out as a whole)
+                    f32x4 v = *(const f32x4*)(tw + row * LDW + 4 * c4);
+                    if (MODE == X3_FC2_STEP1) {                           // derivative of the layer below: units d .. d + 3 of point n, sample ch
+                        if (BITMASK) {
+                            const unsigned w = a.omask[((long long)ch * a.OHW + (d >> 5)) * a.n_pad + n] >> (d & 31);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = ((w >> k) & 1u) ? v[k] : (ACT == RBNN_ACT_RELU ? 0.f : v[k] * LEAKY_SLOPE);
+                        } else {
+                            v *= *(const f32x4*)(a.odact + ((long long)ch * a.N + n) * a.ldo + d);
+                        }
+                    }
+                    *(f32x4*)(a.out + ((long long)ch * a.N + n) * a.ldo + d) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
