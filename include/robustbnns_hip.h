@@ -398,7 +398,7 @@ typedef struct rbnn_triple_workspace {
     void  *X_triple;               /* [ceil16(N), ld_rows] grouped triple-rows image of the current inputs (rbnn_triple_rows_grouped) */
     void  *dZ_gen;                 /* [S, N_pad, 64 B] dA-generator image of dZ, written by rbnn_fc_input_grad_triple               */
     float *g_scale;                /* [N_pad] per-point 2^-e(n) of that image                                                       */
-    void  *hid_triple;             /* fc2: triple image of the hidden activations, [S, H/32 stages, ceil(N/16) groups, 3 pieces, 16 points, 32 units] */
+    void  *hid_triple;             /* fc2: the hidden activations x 2^h1_exp as FP32, [S, H/32 stages, ceil(N/16) groups, 16 points, 32 units] (ABI 9; until then three fp16 pieces); layer 2 splits at its operand read */
 } rbnn_triple_workspace;
 typedef struct rbnn_triple_workspace_sizes { size_t X_triple, dZ_gen, g_scale, hid_triple; } rbnn_triple_workspace_sizes;
 

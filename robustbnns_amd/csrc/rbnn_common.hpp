@@ -120,6 +120,23 @@ __device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one,
 }
 
 
+// The same, for pieces that a MATRIX instruction reads next: the last instruction of the block writes ONE HALF of d2 (op_sel on the destination), and
+// hipcc's hazard recognizer cannot see into an asm block — an MFMA that takes d2 as an operand straight behind it read a stale half on gfx950
+// (fc2's layer 2 with the fp32 hidden image: exactly the LAST point tile's fragments were off by the low pieces, 7e-4, at the 8-wave configuration;
+// the other users of split3_plain_pair store their pieces, far behind).  Two idle issue slots close the window.
+__device__ __forceinline__ void split3_plain_pair_for_mfma(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
+    float re, ro;
+    asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"
+        "v_fma_mix_f32 %[re], %[ve], %[one], -%[d0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %[ro], %[vo], %[one], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t"
+        "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro)
+        : [ve] "v"(ve), [vo] "v"(vo), [one] "v"(one));
+}
+
 // row stride (in words) of the 1-bit activation stash [S][H/32][N_pad]: padded to the gradient kernel's 256-point block so that
 // a block's words of one row are one aligned 1-KiB LDS-DMA piece
 __host__ __device__ __forceinline__ long long mask_ld(int N) { return ((long long)N + 255) / 256 * 256; }

@@ -155,7 +155,7 @@ struct FwdX3Args {
     unsigned x_group_bytes, x_stage_bytes;
 };
 
-template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
+template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2, bool XF32 = false>      // XF32: the X operand is fc2's fp32 hidden image (layer 2 of fc2 only)
 __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kernel(const FwdX3Args a) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int PLANEB = (BH + BN) * 64;                     // one plane of a stage tile
@@ -199,6 +199,13 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     const unsigned src_off = (unsigned)(prow * 64 + ((lane & 3) ^ swz(prow)) * 16);   // inside a 1-KiB piece of a grouped image: row prow, logical chunk
     // fragment read of row li (any 16-row tile), K chunk lg
     const int foff = li * 64 + ((lg ^ swz(li)) * 16);
+    // XF32: the X operand is the fp32 hidden image — a 16-point group of a stage is [16 points][32 units] floats = two 1-KiB DMA pieces (rows 0-7,
+    // 8-15; lane p lands at row p >> 3, physical 16-byte chunk p & 7 and fetches logical chunk (p & 7) ^ sw8(row)); lane (li, lg) of a fragment
+    // reads logical chunks 2 lg and 2 lg + 1 of row li.  sw8(r) = bit 1 of r | bit 2 of r << 2 makes both reads conflict-free over all four 16-lane
+    // service groups of ds_read_b128 (enumerated: 192 of the 512 GF(2)-linear maps of r & 7 do; it must not depend on bit 3, the piece).
+    auto sw8 = [](int r) { return ((r >> 1) & 1) | (((r >> 2) & 1) << 2); };
+    const unsigned src_off_f = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ sw8(lane >> 3)) * 16));
+    const int foff_f0 = li * 128 + (((2 * lg) ^ sw8(li)) * 16), foff_f1 = li * 128 + (((2 * lg + 1) ^ sw8(li)) * 16);
 
     f32x4 zacc[NTW];
 #pragma unroll
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     // the h chunk: the chunk's base goes into the uniform part of the address.  Point groups past N repeat the last one (never stored).
     unsigned xrow[XPP], wrow[WPP];
 #pragma unroll
-    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min((n0 >> 4) + wave + NW * i, ((a.N + 15) >> 4) - 1) * a.x_group_bytes + src_off;
+    for (int i = 0; i < XPP; ++i) xrow[i] = (unsigned)min((n0 >> 4) + wave + NW * i, ((a.N + 15) >> 4) - 1) * a.x_group_bytes + (XF32 ? src_off_f : src_off);
 #pragma unroll
     for (int i = 0; i < WPP; ++i) wrow[i] = (unsigned)(wave + NW * i) * (unsigned)a.KT * 3072u + src_off;
 
@@ -235,7 +242,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         const auto ldst = (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)dst;
         __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);
+        if (!(XF32 && j >= WPP)) __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 2048, 0);      // (an fp32 X group is 2 KiB: two pieces)
     };
 #pragma unroll
     for (int i = 0; i < PPS; ++i) piece(0, 0, 0, i);
@@ -260,11 +267,31 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
             for (int i = 0; i < PPS; ++i) piece(chn, ktn, buf ^ 1, i);
         }
+        if constexpr (XF32) {
+            // fp32 hidden activations (already x 2^h1_exp) -> the three pieces of the B fragment, in registers: 8 values, four split3 pairs
+            const char* const Xf = ldsb + buf * TILEB + (BH / 16 + wave_n * NTW) * 3072;
+            f32x4 x0[NTW], x1[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            b0[nt] = *(const f16x8*)(Xt + nt * 3072);
-            b1[nt] = *(const f16x8*)(Xt + nt * 3072 + 1024);
-            b2[nt] = *(const f16x8*)(Xt + nt * 3072 + 2048);
+            for (int nt = 0; nt < NTW; ++nt) {
+                x0[nt] = *(const f32x4*)(Xf + nt * 3072 + foff_f0);
+                x1[nt] = *(const f32x4*)(Xf + nt * 3072 + foff_f1);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                union { f16x8 v; unsigned w[4]; } q0, q1, q2;
+                split3_plain_pair_for_mfma(x0[nt][0], x0[nt][1], 1.f, q0.w[0], q1.w[0], q2.w[0]);
+                split3_plain_pair_for_mfma(x0[nt][2], x0[nt][3], 1.f, q0.w[1], q1.w[1], q2.w[1]);
+                split3_plain_pair_for_mfma(x1[nt][0], x1[nt][1], 1.f, q0.w[2], q1.w[2], q2.w[2]);
+                split3_plain_pair_for_mfma(x1[nt][2], x1[nt][3], 1.f, q0.w[3], q1.w[3], q2.w[3]);
+                b0[nt] = q0.v; b1[nt] = q1.v; b2[nt] = q2.v;
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                b0[nt] = *(const f16x8*)(Xt + nt * 3072);
+                b1[nt] = *(const f16x8*)(Xt + nt * 3072 + 1024);
+                b2[nt] = *(const f16x8*)(Xt + nt * 3072 + 2048);
+            }
         }
         a0 = *(const f16x8*)(Wt);
         a1 = *(const f16x8*)(Wt + 1024);
@@ -370,32 +397,21 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) zacc[nt] = MFMA16(w2f[r], hv[r], zacc[nt]);
                 } else {
-                    union { _Float16 h[4]; unsigned w[2]; } q0, q1, q2;
-#if RBNN_X3_L1_PAIR
-                    split3_plain_pair(hv[0] * hid_scale, hv[1] * hid_scale, 1.f, q0.w[0], q1.w[0], q2.w[0]);
-                    split3_plain_pair(hv[2] * hid_scale, hv[3] * hid_scale, 1.f, q0.w[1], q1.w[1], q2.w[1]);
-#else
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) split3(hv[r] * hid_scale, q0.h[r], q1.h[r], q2.h[r]);
-#endif
-                    // stage-major grouped image [S][H/32 stages][N/16 groups][3 pieces][16 points][32 units]: this lane's four units of tile ht
-                    // are 8 bytes per piece, at byte (ht & 1) * 32 + lg * 8 of its point's 64-byte row; a tile's 16 points are one 3-KiB block, so
-                    // the six 8-byte stores of a lane (two tiles x three pieces) fill whole lines between them — no LDS staging, no barrier
+                    // stage-major fp32 image [S][H/32 stages][N/16 groups][16 points][32 units]: this lane's four units of tile ht are 16 bytes at
+                    // byte ((hrow >> 4) & 1) * 64 + lg * 16 of its point's 128-byte row; a tile's 16 points are one 2-KiB block, and the two h tiles of a
+                    // stage fill its lines between them — no LDS staging, no split here (layer 2 splits at its operand read)
 #ifdef RBNN_X3_L1_ABL_NOSTORE
-                    if (n < a.N && q0.w[0] == 0x12345678u) {               // ablation (timing only): pieces computed, never stored
+                    if (n < a.N && hv[0] == 1.2345e-30f) {                 // ablation (timing only): never stored
 #else
                     if (n < a.N) {
 #endif
-                        // block of (stage, 16-point group) = [3 pieces][16 points][64 B]: this lane's point is row n & 15 of its group
                         const long long blk = ((long long)s * HW + (hrow >> 5)) * ((a.N + 15) >> 4) + (n >> 4);
 #ifdef RBNN_X3_L1_ABL_SMALL
-                        char* const row = a.hid + ((blk * 3072) & 0xFFC00) + (n & 15) * 64 + ((hrow >> 4) & 1) * 32 + lg * 8;   // ablation: all stores into 1 MB
+                        char* const row = a.hid + ((blk * 2048) & 0xFFC00) + (n & 15) * 128 + ((hrow >> 4) & 1) * 64 + lg * 16;   // ablation: all stores into 1 MB
 #else
-                        char* const row = a.hid + blk * 3072 + (n & 15) * 64 + ((hrow >> 4) & 1) * 32 + lg * 8;
+                        char* const row = a.hid + blk * 2048 + (n & 15) * 128 + ((hrow >> 4) & 1) * 64 + lg * 16;
 #endif
-                        *(uint2*)(row) = make_uint2(q0.w[0], q0.w[1]);
-                        *(uint2*)(row + 1024) = make_uint2(q1.w[0], q1.w[1]);
-                        *(uint2*)(row + 2048) = make_uint2(q2.w[0], q2.w[1]);
+                        *(f32x4*)row = hv * hid_scale;
                     }
                 }
             }
@@ -448,13 +464,13 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
     }
 }
 
-template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2>
+template <int ACT, int WH, int HTW, int WN, int NTW, bool LAYER2, bool XF32>
 int launch_forward_x3_cfg(FwdX3Args a, hipStream_t st) {
     constexpr int BH = WH * HTW * 16, BN = WN * NTW * 16;
     constexpr int LDSB = 2 * 3 * (BH + BN) * 64;
     static_assert(LDSB <= 160 * 1024, "LDS");
     a.NT = (a.N + BN - 1) / BN;
-    auto kern = fc_forward_x3_kernel<ACT, WH, HTW, WN, NTW, LAYER2>;
+    auto kern = fc_forward_x3_kernel<ACT, WH, HTW, WN, NTW, LAYER2, XF32>;
     static unsigned long long attr_done = 0;                    // per instantiation, one bit per device
     if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.S);
@@ -466,23 +482,23 @@ int launch_forward_x3_cfg(FwdX3Args a, hipStream_t st) {
 #define RBNN_X3_FWD_CFG 4, 4, 2, 4                              // 256 h x 128 n, 8 waves of 64 h x 64 n, 144 KB of LDS
 #endif
 
-template <int ACT, bool LAYER2>
+template <int ACT, bool LAYER2, bool XF32>
 int launch_forward_x3_act(const FwdX3Args& a, hipStream_t st) {
-    if (a.H % 256 == 0) return launch_forward_x3_cfg<ACT, RBNN_X3_FWD_CFG, LAYER2>(a, st);
-    if (a.H % 128 == 0) return launch_forward_x3_cfg<ACT, 2, 4, 2, 4, LAYER2>(a, st);   // 128 h x 128 n, 4 waves
+    if (a.H % 256 == 0) return launch_forward_x3_cfg<ACT, RBNN_X3_FWD_CFG, LAYER2, XF32>(a, st);
+    if (a.H % 128 == 0) return launch_forward_x3_cfg<ACT, 2, 4, 2, 4, LAYER2, XF32>(a, st);   // 128 h x 128 n, 4 waves
     return RBNN_ERR_UNSUPPORTED;
 }
 
-template <bool LAYER2>
+template <bool LAYER2, bool XF32 = false>
 int launch_forward_x3(int act, const FwdX3Args& a, hipStream_t st) {
     switch (act) {
 #ifndef RBNN_FAST_BUILD
-        case RBNN_ACT_RELU:  return launch_forward_x3_act<RBNN_ACT_RELU, LAYER2>(a, st);
+        case RBNN_ACT_RELU:  return launch_forward_x3_act<RBNN_ACT_RELU, LAYER2, XF32>(a, st);
 #endif
-        case RBNN_ACT_LEAKY: return launch_forward_x3_act<RBNN_ACT_LEAKY, LAYER2>(a, st);
+        case RBNN_ACT_LEAKY: return launch_forward_x3_act<RBNN_ACT_LEAKY, LAYER2, XF32>(a, st);
 #ifndef RBNN_FAST_BUILD
-        case RBNN_ACT_SIGM:  return launch_forward_x3_act<RBNN_ACT_SIGM, LAYER2>(a, st);
-        case RBNN_ACT_TANH:  return launch_forward_x3_act<RBNN_ACT_TANH, LAYER2>(a, st);
+        case RBNN_ACT_SIGM:  return launch_forward_x3_act<RBNN_ACT_SIGM, LAYER2, XF32>(a, st);
+        case RBNN_ACT_TANH:  return launch_forward_x3_act<RBNN_ACT_TANH, LAYER2, XF32>(a, st);
 #endif
     }
     return RBNN_ERR_UNSUPPORTED;
@@ -1250,7 +1266,7 @@ int rbnn_triple_workspace_query(const rbnn_posterior* net, const rbnn_triple_ima
     z.X_triple = (size_t)((N + 15) / 16 * 16) * tp->ld_rows * 6;          // grouped image: whole 16-row groups
     z.dZ_gen = (size_t)S * mask_ld(N) * 64;
     z.g_scale = (size_t)mask_ld(N) * sizeof(float);
-    z.hid_triple = net->arch == RBNN_ARCH_FC2 ? (size_t)S * ((N + 15) / 16 * 16) * net->hidden * 6 : 0;
+    z.hid_triple = net->arch == RBNN_ARCH_FC2 ? (size_t)S * ((N + 15) / 16 * 16) * net->hidden * 4 : 0;   // fp32 x 2^h1_exp (round 5; the name stays: ABI)
     *out = z;
     return RBNN_OK;
 }
@@ -1287,12 +1303,12 @@ int rbnn_fc_forward_triple(const rbnn_posterior* net, const rbnn_triple_images* 
     if (rc) return rc;
     FwdX3Args b = a;
     const int NG = (N + 15) / 16;
-    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)NG * 16 * H * 6; b.x_group_bytes = 3072u; b.x_stage_bytes = (unsigned)NG * 3072u;
+    b.X = (const char*)tws->hid_triple; b.ldx = H; b.x_sample_bytes = (long long)NG * 16 * H * 4; b.x_group_bytes = 2048u; b.x_stage_bytes = (unsigned)NG * 2048u;
     b.W = (const char*)tp->Wm_rows; b.w_sample_bytes = (long long)H * H * 6; b.ldw = H; b.KT = H / 32;
     b.b = net->bm; b.out_scale = ldexpf(1.f, -((dev_scales ? 0 : tp->h1_exp) + tp->wm_exp));
     b.x_ds = dev_scales ? dev_scales + 1 : nullptr; b.hid_ds = nullptr;
     b.mask = ws->mask2; b.dact = ws->dact2; b.hid = nullptr;
-    return launch_forward_x3<true>(net->activation, b, st);
+    return launch_forward_x3<true, true>(net->activation, b, st);      // layer 2: its X operand is the fp32 hidden image
 }
 
 int rbnn_step_tail_triple(int32_t mode, const float* P, const int32_t* labels, int32_t S, float inv_S, int32_t N, int32_t C, float* Psum_out,

@@ -277,9 +277,9 @@ class AttackEngine:
 
     def _fc2_groups(self, N, S, chunk):
         """(forward, backward) sample-group sizes of the triple-mode fc2 path.  Layer 1 writes the hidden activations of every (sample,
-        point) as a triple image for layer 2 to read back (3 GB at C2's size, S x N x H x 6 B), and the backward does the same with dhid1
+        point) as an fp32 image for layer 2 to read back and split at its operand read (2 GB at C2's size, S x N x H x 4 B; rounds 2-4: the three pieces, 6 B), and the backward does the same with dhid1
         (fp32, 2 GB).  Run group after group through ONE buffer of g samples, the image a layer reads is the one the layer before it has
-        just written — inside the 256 MB Infinity Cache when g x N x H x 6 B fits — and the workspace shrinks by (S - g) / S.
+        just written — inside the 256 MB Infinity Cache when g x N x H x 4 B fits — and the workspace shrinks by (S - g) / S.
         RBNN_FC2_GROUP (both) / RBNN_FC2_GROUP_FWD / RBNN_FC2_GROUP_BWD override (0 = one group of S); the backward's group is rounded
         to a multiple of the slab chunk (a slab sums the samples of one chunk)."""
         if getattr(self.post, "arch", None) != "fc2":
@@ -287,7 +287,7 @@ class AttackEngine:
         both = os.environ.get("RBNN_FC2_GROUP")
         want_f = os.environ.get("RBNN_FC2_GROUP_FWD", both)
         want_b = os.environ.get("RBNN_FC2_GROUP_BWD", both)
-        per_sample = (N + 15) // 16 * 16 * self.post.Hp * 6
+        per_sample = (N + 15) // 16 * 16 * self.post.Hp * 4
         auto = max(1, int(self._FC2_GROUP_BYTES // per_sample)) if self._FC2_GROUP_BYTES else S
         gf = int(want_f) if want_f not in (None, "") else auto
         gb = int(want_b) if want_b not in (None, "") else auto

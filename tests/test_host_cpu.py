@@ -183,7 +183,7 @@ def test_triple_abi_rejects_bad_arguments():
     net.arch, net.in_features, net.hidden = 1, 784, 512
     img.ld_rows = 800
     assert lib.rbnn_triple_workspace_query(C.byref(net), C.byref(img), 100, 7, C.byref(sizes)) == 0
-    assert (sizes.X_triple, sizes.hid_triple, sizes.g_scale) == (112 * 800 * 6, 7 * 112 * 512 * 6, 256 * 4)   # grouped images: whole 16-row groups
+    assert (sizes.X_triple, sizes.hid_triple, sizes.g_scale) == (112 * 800 * 6, 7 * 112 * 512 * 4, 256 * 4)   # grouped images: whole 16-row groups (the hidden image: fp32 since round 5)
     cnet = _hip.ConvPosterior()
     assert lib.rbnn_conv_forward_triple(C.byref(cnet), None, 0, 0, None, None, 784, 4, None, 1, 0, None, None) != 0
     assert lib.rbnn_conv_input_grad_dense(C.byref(cnet), None, 0, 1.0, None, 1, 4, None, None) != 0
