@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) fc_grad_kernel(const GradArgs a) {
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
     int ntile, dg, ch;
-    grad_item(id, a.NT, a.ND, A_MEM, ntile, dg, ch);
+    grad_item(id, a.NT, a.ND, A_MEM || !BITMASK, ntile, dg, ch);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int nb = ntile * BM + wave * (NTW * 16);            // this wave's first point
     const int dc0 = dg * TD * 16;                              // this block's first column

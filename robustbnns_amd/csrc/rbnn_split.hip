@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(64 * NW, (TD * NTW > 32 ? 1 : 2)) fc_grad_spli
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
     int ntile, dg, ch;
-    grad_item(id, a.NT, a.ND, MODE == GRAD_FC2_STEP2, ntile, dg, ch);
+    grad_item(id, a.NT, a.ND, STREAM, ntile, dg, ch);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
     const int nb = ntile * BM + wave * (NTW * 16);
     const int dc0 = dg * LD;

@@ -850,7 +850,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
     int id;
     if (!item_of_block(blockIdx.x, a.NT * a.ND * a.nchunks, id)) return;
     int ntile, dg, ch;
-    grad_item(id, a.NT, a.ND, MODE == X3_FC2_STEP2, ntile, dg, ch);   // (step 2 reads its A operand from memory: 2-D blocked order, rbnn_common.hpp)
+    grad_item(id, a.NT, a.ND, STREAM, ntile, dg, ch);          // (a per-lane fp32 operand — step 2's A, or sigmoid / tanh's act' — is read from memory by every column group: 2-D blocked order, rbnn_common.hpp)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: LDS-DMA destinations (M0) and piece selection become SALU work
     const int nb = ntile * BM + wave * (NTW * 16);
