@@ -800,7 +800,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         barw += __builtin_amdgcn_s_memtime() - tb_;
 #endif
         const int ksn = min(ks + 1, KS - 1);
-        const char* const I = lds + (ks & 1) * L::IMG + foff;
+        // (the fragment offset is re-derived from a fresh lane id in every step — a volatile asm: as a builtin the lane id is loop-invariant, hoisted,
+        // held over the loop and spilled.  Held in a register it was the one value the <3,32> instantiations reloaded from scratch at the top of every
+        // step, behind s_waitcnt vmcnt(0))
+        int lane_s;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
+        const int foff_s = (lane_s & 15) * 64 + (((lane_s >> 4) ^ swz(lane_s & 15)) * 16);
+        const char* const I = lds + (ks & 1) * L::IMG + foff_s;
         f16x8 b0[NPT], b1[NPT], b2[NPT];
         // (plane by plane, in the order the first tap's product groups want them: the first group starts after four reads, not ten)
 #pragma unroll
@@ -958,8 +964,12 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         }
     }
     if (G::CIN >= RBNN_CONV1_BWD_X3_MINCIN) {                              // max |dP1| of this (sample, point) -> G[sn][0]: the scale of conv1_bwd_x3_kernel (which reads it before it writes G)
+        // (the butterfly's lane indices from a fresh lane id: those of set_scales() at the top of the block, kept for reuse here, were five registers
+        // spilled over the K loops)
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+        for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __int_as_float(__builtin_amdgcn_ds_bpermute((lane_e ^ o) << 2, __float_as_int(omax))));
         float* const wm = (float*)(lds + L::MOFF);
         if (lane == 0) wm[wave] = omax;
         ring_wait_barrier<0>();
