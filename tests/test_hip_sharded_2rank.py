@@ -61,7 +61,10 @@ def _worker(rank, world, port, precision, q, arch="fc", S_fc=6):
         # BASELINE config 4's step on ONE forward, sample-sharded (its first gradient exchange overlapped with the second backward): the two
         # calls' results, bit for bit, on every rank (the fc engine pipelines fgsm() over two point blocks here, the shared call does not)
         both = eng.loss_gradients_and_fgsm(x, y, eng.post.S, 0.3)
-        assert torch.equal(both[0].cpu(), out["lg"]) and torch.equal(both[1].cpu(), out["fgsm"])
+        d_lg, d_adv = (both[0].cpu() - out["lg"]).abs(), (both[1].cpu() - out["fgsm"]).abs()
+        assert torch.equal(both[0].cpu(), out["lg"]) and torch.equal(both[1].cpu(), out["fgsm"]), (
+            f"rank {rank}: shared call vs two calls — gradients differ in {int((d_lg > 0).sum())} of {d_lg.numel()} (max {float(d_lg.max()):.3e}, "
+            f"points {sorted(set((d_lg.reshape(N, -1) > 0).any(1).nonzero().flatten().tolist()))[:12]}), adversarial inputs in {int((d_adv > 0).sum())} (max {float(d_adv.max()):.3e})")
         torch.cuda.synchronize()
         t = out["fgsm"].clone()                                  # every rank holds the same (replicated) adversarial images
         dist.broadcast(t, src=0)
