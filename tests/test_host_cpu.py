@@ -850,3 +850,21 @@ def test_reads_result_pickles_written_by_the_reference(monkeypatch, tmp_path):
     # torch.save's persistent id): mask that decimal key, everything else — protocol, classes, flags, strides, payload — is byte-equal
     key = lambda raw: re.sub(rb"X.\x00\x00\x00\d{8,20}", b"<storage key>", raw)
     assert key(open(tmp_path / "a.pkl", "rb").read()) == key(b) and key(b) != b
+
+
+def test_bench_path_kernels_use_no_scratch():
+    """VERDICT r4 (C5's dominant kernel: 'scratch 0'): the kernels the BASELINE configs dispatch — triple-mode fc forward / gradient and the conv2 pair,
+    relu and leaky — hold everything in registers; read from the code objects inside the built library (tools/kernel_resources.py: no GPU)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources as KR
+    if not os.path.exists(KR.READELF):
+        pytest.skip("llvm-readelf not in this image")
+    res = KR.kernel_resources()
+    assert len(res) > 100, len(res)
+    hot = {n: r for n, r in res.items() if re.search(r"(conv_bwd_dense_x3_kernel|conv2_pool_x3_kernel|fc_forward_x3_kernel|fc_grad_x3_kernel|lowdim_kernel)<[01],", n)}
+    assert len(hot) >= 20, sorted(hot)
+    bad = {n: r["scratch"] for n, r in hot.items() if r["scratch"] or r["spill_vgpr"]}
+    assert not bad, bad
+    assert all(r["scratch"] == 0 for n, r in res.items() if "conv_bwd_dense_x3_kernel" in n)       # every activation, both geometries
+    assert max(r["vgpr"] + r["agpr"] for r in res.values()) <= 512
