@@ -780,6 +780,13 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
     // runs PAR = 0; a 7-tap wave alternates, so its loop below is unrolled over two K steps.  A step is straight-line code: a tap is one
     // scheduling region (the whole step as one region: the scheduler hoists the routing reads across taps into 256 registers and scratch), tile
     // and staging requests are ALWAYS issued (past the end: the last step's tile / rows again, never read).
+    // (a volatile asm: as a builtin the lane id is loop-invariant — hoisted, held over the loop, spilled again)
+    auto fresh_foff = [&]() {
+        int l_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l_));
+        return (l_ & 15) * 64 + (((l_ >> 4) ^ swz(l_ & 15)) * 16);
+    };
+    int foff_next = fresh_foff();
     auto kstep = [&](int ks, auto NTC, auto PARC, auto WHOLEC, auto STGC) {
         constexpr int NT = decltype(NTC)::value, PAR = decltype(PARC)::value, STGR = decltype(STGC)::value;
         // image ks complete; every wave's staging pieces of step ks + 1 landed (issued a whole step ago: older than the three weight loads in
@@ -800,12 +807,10 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
         barw += __builtin_amdgcn_s_memtime() - tb_;
 #endif
         const int ksn = min(ks + 1, KS - 1);
-        // (the fragment offset is re-derived from a fresh lane id in every step — a volatile asm: as a builtin the lane id is loop-invariant, hoisted,
-        // held over the loop and spilled.  Held in a register it was the one value the <3,32> instantiations reloaded from scratch at the top of every
-        // step, behind s_waitcnt vmcnt(0))
-        int lane_s;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_s));
-        const int foff_s = (lane_s & 15) * 64 + (((lane_s >> 4) ^ swz(lane_s & 15)) * 16);
+        // (the fragment offset: held in a register over the whole K loop it was the one value the <3,32> instantiations reloaded from scratch at
+        // the top of every step, behind s_waitcnt vmcnt(0).  It is re-derived from a fresh lane id under the LAST tap's MFMAs of the previous
+        // step — fresh_foff() below — and so lives only from there to the twelve reads here: no spill, and nothing in front of the reads)
+        const int foff_s = foff_next;
         const char* const I = lds + (ks & 1) * L::IMG + foff_s;
         f16x8 b0[NPT], b1[NPT], b2[NPT];
         // (plane by plane, in the order the first tap's product groups want them: the first group starts after four reads, not ten)
@@ -852,6 +857,7 @@ __global__ void __launch_bounds__(512, 2) conv_bwd_dense_x3_kernel(const ConvBwd
             if constexpr (t < 4) route_load((ks + 1) & 1, t, rin);
             if constexpr (t == 4) route_store((ks + 1) & 1, p0, p1, p2);
 #endif
+            if constexpr (t == NT - 1) foff_next = fresh_foff();            // for the next step's fragment reads (see the top of the step)
             __builtin_amdgcn_sched_barrier(0);
         });
     };
