@@ -103,8 +103,13 @@ __global__ void __launch_bounds__(conv1_threads<G>(), RBNN_CONV1_WAVES) conv1_po
                             // acc.{lo,hi} += w.{lo,hi} * pair.{half}: the broadcast is the instruction's op_sel (written as a vector splat,
                             // the compiler hoisted 108 materialised (p, p) pairs out of the channel loop: 252 registers)
                             const f32x2 pp = patch[ci][dy + ky][(dx + kx) >> 1];
-                            if ((dx + kx) & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(v4[dy * 2 + dx]) : "v"(wv), "v"(pp));
-                            else               asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(v4[dy * 2 + dx]) : "v"(wv), "v"(pp));
+                            // The BROADCAST operand (the patch pair, one half of it for both result lanes) is src0: op_sel / op_sel_hi bit 0.  Rounds 3-5 had it as
+                            // src1 (op_sel:[0,1,0]) — a form hipcc itself never emits (it canonicalises a packed-fp32 broadcast onto src0) and that is NOT reliable
+                            // on gfx950 when waves of another kernel share the SIMD: with two processes on one GPU the low result lane intermittently took the
+                            // other half of the pair (46 of 320 forward calls differed from their own reference; 0 of 320 in this form; profiles/r05w).  The
+                            // product is commutative: results are bit-identical to the old form's (one process).
+                            if ((dx + kx) & 1) asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(v4[dy * 2 + dx]) : "v"(wv), "v"(pp));
+                            else               asm("v_pk_fma_f32 %0, %2, %1, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(v4[dy * 2 + dx]) : "v"(wv), "v"(pp));
                         }
                 }
         }

@@ -125,18 +125,37 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
     const int prow = lane >> 2;
     const unsigned src_off = (unsigned)(prow * 64 + ((lane & 3) ^ swz(prow)) * 16);   // inside a 1-KiB piece: row prow, logical chunk (lane & 3) ^ swz(row)
     const int foff = li * 64 + ((lg ^ swz(li)) * 16);
-    // image position of output position 16pt + li (tap 0,0); positions past NPOS read (0,0), never stored
-    int pbase[NPT], ybase[NPT];
+    // RBNN_X3FWD_PAIR13 (round 5; geometries whose NPOS is not a multiple of 16, i.e. 3x32x32): the two points of a block are tiled TOGETHER —
+    // combined position c = 100 * point + position, 200 positions = 13 tiles of 16 instead of 2 x 7 (7.1 % fewer MFMAs: eight idle columns per
+    // pair instead of twenty-four).  The wave of the pair's first point takes tiles 0 .. 6 (its last tile: 4 positions of point 0, 12 of point 1,
+    // which it writes into its partner's pooling tile), the other wave tiles 7 .. 12; the two waves of a channel group share a SIMD (wave & 3),
+    // so every SIMD issues 13 tiles per tap instead of 14.  Same-box: 14.37 -> 13.97 ms per C5 forward call (profiles/r05w).
+#ifndef RBNN_X3FWD_PAIR13
+#define RBNN_X3FWD_PAIR13 1
+#endif
+    constexpr bool PAIR = RBNN_X3FWD_PAIR13 && (NPOS_ % 16 != 0) && !RBNN_CONVX3_OLD_IMG;
+    static_assert(!PAIR || (2 * NPOS_ + 15) / 16 == 2 * NPT - 1, "13 = 7 + 6 tiles");
+    const char* const img = imgs + wp * L::IMGB;
+    constexpr int CPITCH = NPOS_ + 4, EIT = (16 * NP2_ / 4 + 63) / 64;
+    auto body = [&](auto NTC) {
+    constexpr int NT = decltype(NTC)::value;                              // position tiles of this wave
+    const int c0 = PAIR && wp ? 16 * NPT : 0;                              // (PAIR) first combined position of the wave
+    // image position of output position 16pt + li (tap 0,0); idle lanes of the last tile read distinct valid positions, never stored
+    int pbase[NT], ybase[NT];
+    int ioff_s = 0;                                                        // (PAIR, first point's wave, last tile) the lane's image relative to `img`: 0 / IMGB
 #pragma unroll
-    for (int pt = 0; pt < NPT; ++pt) {
+    for (int pt = 0; pt < NT; ++pt) {
         int pos = pt * 16 + li;
-        if (pos >= NPOS_) pos = RBNN_CONVX3_OLD_IMG ? 0 : pos - NPOS_;  // idle lanes of the last tile: distinct valid positions (never stored)
+        if (PAIR) {
+            int c = c0 + pos;
+            if (c >= 2 * NPOS_) c -= NPOS_;                               // idle lanes of the pair's last tile: valid positions of point 1
+            const int point = c >= NPOS_ ? 1 : 0;
+            pos = c - point * NPOS_;
+            if (pt == NT - 1 && NT == NPT) ioff_s = (point - wp) * L::IMGB;
+        } else if (pos >= NPOS_) pos = RBNN_CONVX3_OLD_IMG ? 0 : pos - NPOS_;
         ybase[pt] = pos / O2W_;
         pbase[pt] = ybase[pt] * IPITCH + pos % O2W_;
     }
-    const char* const img = imgs + wp * L::IMGB;
-    // epilogue roles: lane handles the four consecutive pooled cells 4 * (lane + 64 it) .. of a 16-channel tile; their offsets in the wave's tile
-    constexpr int CPITCH = NPOS_ + 4, EIT = (16 * NP2_ / 4 + 63) / 64;
     int pbase_e[EIT][4];
 #pragma unroll
     for (int it = 0; it < EIT; ++it)
@@ -146,11 +165,11 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
             pbase_e[it][j] = hl * CPITCH + (p / P2W_) * O2W_ + (p % P2W_);
         }
     for (int hc0 = 0; hc0 < a.Hc; hc0 += WROWS) {
-        f32x4 acc[HTW][NPT];
+        f32x4 acc[HTW][NT];
 #pragma unroll
         for (int ht = 0; ht < HTW; ++ht)
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         auto stage = [&](int tap, int buf) {
             // the weight image is grouped [16 channels][tap][3 pieces][16 rows][64 B] (conv.py::_build_triple) and a 16-channel group sits in the
             // stage tile the same way — [group][3 pieces][1 KiB]: the immediate offset of global_load_lds applies to the global AND the LDS
@@ -172,19 +191,19 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
         // after the first) read ONE TAP AHEAD into a second register set, under the current tap's MFMAs (the two sets alternate: no copies)
         // (3x32x32: seven position tiles x three planes x two sets do not fit beside the accumulators — only the plane of the FIRST product group,
         // b2, is read ahead there; b0 / b1 follow behind the barrier and land under that group's MFMAs)
-        constexpr bool PF_ALL = RBNN_X3FWD_BPREFETCH && NPT <= 4;
-        auto load_b = [&](int tap, f16x8 (&b0)[NPT], f16x8 (&b1)[NPT], f16x8 (&b2)[NPT], bool lo, bool hi) {
+        constexpr bool PF_ALL = RBNN_X3FWD_BPREFETCH && NT <= 4;
+        auto load_b = [&](int tap, f16x8 (&b0)[NT], f16x8 (&b1)[NT], f16x8 (&b2)[NT], bool lo, bool hi) {
             const int ky = tap / 5, toff = ky * IPITCH + (tap % 5);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) {
+            for (int pt = 0; pt < NT; ++pt) {
                 const int p = pbase[pt] + toff;
-                const char* const src = img + p * 64 + ((lg ^ x3_img_swz<G>(p, ybase[pt] + ky)) * 16);
+                const char* const src = img + ((PAIR && NT == NPT && pt == NT - 1) ? ioff_s : 0) + p * 64 + ((lg ^ x3_img_swz<G>(p, ybase[pt] + ky)) * 16);
                 if (lo) { b0[pt] = *(const f16x8*)src; b1[pt] = *(const f16x8*)(src + L::IMGP); }
                 if (hi) b2[pt] = *(const f16x8*)(src + 2 * L::IMGP);
             }
         };
-        f16x8 bA0[NPT], bA1[NPT], bA2[NPT], bB0[PF_ALL ? NPT : 1], bB1[PF_ALL ? NPT : 1], bB2[NPT];
-        auto tap_body = [&](int tap, f16x8 (&b0)[NPT], f16x8 (&b1)[NPT], f16x8 (&b2)[NPT], auto& n0, auto& n1, f16x8 (&n2)[NPT]) {
+        f16x8 bA0[NT], bA1[NT], bA2[NT], bB0[PF_ALL ? NT : 1], bB1[PF_ALL ? NT : 1], bB2[NT];
+        auto tap_body = [&](int tap, f16x8 (&b0)[NT], f16x8 (&b1)[NT], f16x8 (&b2)[NT], auto& n0, auto& n1, f16x8 (&n2)[NT]) {
             const int buf = tap & 1;
             if (tap + 1 < 25) {
                 stage(tap + 1, buf ^ 1);
@@ -196,17 +215,17 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
                 const f16x8 a0 = *(const f16x8*)(Wt + ht * 3072), a1 = *(const f16x8*)(Wt + ht * 3072 + 1024),
                             a2 = *(const f16x8*)(Wt + ht * 3072 + 2048);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b2[pt], acc[ht][pt]);
+                for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = MFMA_H(a0, b2[pt], acc[ht][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a2, b0[pt], acc[ht][pt]);
+                for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = MFMA_H(a2, b0[pt], acc[ht][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a1, b1[pt], acc[ht][pt]);
+                for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = MFMA_H(a1, b1[pt], acc[ht][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a1, b0[pt], acc[ht][pt]);
+                for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = MFMA_H(a1, b0[pt], acc[ht][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b1[pt], acc[ht][pt]);
+                for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = MFMA_H(a0, b1[pt], acc[ht][pt]);
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) acc[ht][pt] = MFMA_H(a0, b0[pt], acc[ht][pt]);
+                for (int pt = 0; pt < NT; ++pt) acc[ht][pt] = MFMA_H(a0, b0[pt], acc[ht][pt]);
             }
             ring_wait_barrier<0>();                                      // tap+1's weights landed; everyone is done with this tile
         };
@@ -230,7 +249,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #pragma unroll
             for (int ht = 0; ht < HTW; ++ht)
 #pragma unroll
-                for (int pt = 0; pt < NPT; ++pt) sink += acc[ht][pt][0] + acc[ht][pt][1] + acc[ht][pt][2] + acc[ht][pt][3];
+                for (int pt = 0; pt < NT; ++pt) sink += acc[ht][pt][0] + acc[ht][pt][1] + acc[ht][pt][2] + acc[ht][pt][3];
             if (sink == 1.2345e-30f) a.Q2[sn * F] = sink;
             __syncthreads();
             continue;
@@ -239,22 +258,31 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #pragma unroll
         for (int ht = 0; ht < HTW; ++ht) {
             const int hcb = hc0 + (wq * HTW + ht) * 16;                    // wave-uniform
-            if (hcb >= a.Hc) break;
+            // (PAIR: the block meets at two barriers per channel tile — a channel group past Hc skips the work, not the barriers)
+            const bool valid = hcb < a.Hc;
+            if (!PAIR && !valid) break;
+            if (valid) {
             const f32x4 bias = *(const f32x4*)(a.K2b + (long long)sw * a.Hc + hcb + 4 * lg);
 #pragma unroll
-            for (int pt = 0; pt < NPT; ++pt)
+            for (int pt = 0; pt < NT; ++pt) {
+                // PAIR: combined position c of this lane's column -> the pooling tile of ITS point (wave wq + 4 * point)
+                const int c = c0 + pt * 16 + li, point = (PAIR && c >= NPOS_) ? 1 : 0, pos = c - point * NPOS_;
+                float* const T = PAIR ? (float*)ldsb + (wq + 4 * point) * 16 * CPITCH : my;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (pt * 16 + li < NPOS_) {
+                    if (PAIR ? c < 2 * NPOS_ : pos < NPOS_) {
                         const float pre = acc[ht][pt][r] * out_scale + bias[r];   // sigmoid / tanh are pooled on their VALUES, as torch does
-                        my[(4 * lg + r) * CPITCH + pt * 16 + li] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
+                        T[(4 * lg + r) * CPITCH + pos] = smooth_act<ACT>() ? act_fwd<ACT>(pre) : pre;
                     }
+            }
+            }
+            if (PAIR) __syncthreads();                                     // both waves of a channel group have written the point's tile
             // four consecutive pooled cells per lane: one 16-byte store of Q2 and one 4-byte store of the stash (the tile's 16 x NP2
             // cells are contiguous in both)
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
                 const int i4 = lane + 64 * it;
-                if (i4 < 16 * NP2_ / 4 && live) {
+                if (i4 < 16 * NP2_ / 4 && live && valid) {
                     f32x4 q;
                     unsigned stw = 0;
 #pragma unroll
@@ -278,9 +306,13 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #endif
                 }
             }
+            if (PAIR && ht + 1 < HTW) __syncthreads();                     // the tiles are rewritten by the next channel tile (the partner's wave writes into this one's)
         }
         __syncthreads();                                                 // the pooling tiles alias the weight buffers of the next chunk
     }
+    };
+    if (PAIR && wp) body(std::integral_constant<int, PAIR ? NPT - 1 : NPT>{});
+    else body(std::integral_constant<int, NPT>{});
 }
 
 template <int ACT, class G>
