@@ -199,6 +199,12 @@ def _concurrent_worker(rank, world, port, q):
             d = {k: int((ws[k] != ref[k]).sum()) for k in keys}
             if any(d.values()):
                 bad.append((i, d))
+        # ... and the whole step (forward + the backward kernels): the expected loss gradients of 20 calls against the first call's
+        g0 = eng.loss_gradients(xd, y, Sl).clone()
+        for i in range(20):
+            n_diff = int((eng.loss_gradients(xd, y, Sl) != g0).sum())
+            if n_diff:
+                bad.append((100 + i, {"loss_gradients": n_diff}))
         dist.barrier()
         q.put((rank, bad[:3], len(bad)))
     finally:
@@ -209,7 +215,7 @@ def test_two_processes_sharing_the_gpu_do_not_disturb_each_other():
     """Found with this setup in round 5 (profiles/r05w): conv1_pool_kernel's packed FMA had its broadcast operand as src1 (op_sel on src1) — a form that
     gfx950 does not execute reliably when waves of another kernel share the SIMD: with two processes at once, one in seven forward calls left a P1 that
     differed from the process's own reference (the low result lane took the other half of a patch pair).  Two processes, different posteriors, no
-    collectives: every call's whole forward workspace must reproduce the first call's, bit for bit, in both."""
+    collectives: every call's whole forward workspace — and then the gradients of the whole step — must reproduce the first call's, bit for bit, in both."""
     assert torch.cuda.is_available(), "this test needs the MI355X"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -223,5 +229,5 @@ def test_two_processes_sharing_the_gpu_do_not_disturb_each_other():
     for p in procs:
         p.join(timeout=120)
     assert all(p.exitcode == 0 for p in procs)
-    print(f"[2 processes at once, conv forward x 40] differing calls: {[(r, n) for r, _, n in res]}")
+    print(f"[2 processes at once, conv forward x 40 + loss_gradients x 20] differing calls: {[(r, n) for r, _, n in res]}")
     assert all(n == 0 for _, _, n in res), res
