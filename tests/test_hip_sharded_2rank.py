@@ -177,26 +177,27 @@ def test_point_sharded_two_ranks_real_kernels_match_single_process():
     assert errs["probs"] < 1e-6 and errs["lg"] < 1e-5 and errs["fgsm_bad"] == 0 and errs["pgd_frac"] < 0.02, errs
 
 
-def _concurrent_worker(rank, world, port, q):
-    """This process's own two-sample conv posterior, no group, no collectives: 40 forward calls while the OTHER process runs its own."""
+def _concurrent_worker(rank, world, port, q, arch):
+    """This process's own posterior shard, no group, no collectives: forward calls, then whole steps, while the OTHER process runs its own."""
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from robustbnns_amd.factory import make_engine
         dev = "cuda:0"
-        full, part, x, y, D, S, N, NP = _problem("conv", dev)
+        full, part, x, y, D, S, N, NP = _problem(arch, dev)
         eng = make_engine(part(rank, world), precision="auto")
-        xd, Sl = x.to(dev), S // world
-        ws = eng.workspace(N, Sl)
-        keys = ("P1", "st1", "Q2", "st2", "P")
+        xd, Sl = x.to(dev), eng.post.S
+        keys = ("P1", "st1", "Q2", "st2", "P") if arch == "conv" else ()      # conv: the forward's whole workspace, stage by stage
+        ws = eng.workspace(N, Sl) if keys else {}
         dist.barrier()
-        eng.forward(xd, Sl); torch.cuda.synchronize()
+        p0 = eng.forward(xd, Sl).clone(); torch.cuda.synchronize()
         ref = {k: ws[k].clone() for k in keys}
         bad = []
         for i in range(40):
-            eng.forward(xd, Sl); torch.cuda.synchronize()
+            pi = eng.forward(xd, Sl); torch.cuda.synchronize()
             d = {k: int((ws[k] != ref[k]).sum()) for k in keys}
+            d["probs"] = int((pi != p0).sum())
             if any(d.values()):
                 bad.append((i, d))
         # ... and the whole step (forward + the backward kernels): the expected loss gradients of 20 calls against the first call's
@@ -211,10 +212,11 @@ def _concurrent_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_processes_sharing_the_gpu_do_not_disturb_each_other():
+@pytest.mark.parametrize("arch", ["conv", "fc"])
+def test_two_processes_sharing_the_gpu_do_not_disturb_each_other(arch):
     """Found with this setup in round 5 (profiles/r05w): conv1_pool_kernel's packed FMA had its broadcast operand as src1 (op_sel on src1) — a form that
     gfx950 does not execute reliably when waves of another kernel share the SIMD: with two processes at once, one in seven forward calls left a P1 that
-    differed from the process's own reference (the low result lane took the other half of a patch pair).  Two processes, different posteriors, no
+    differed from the process's own reference (the low result lane took the other half of a patch pair).  Two processes, different posteriors (conv; and the fc-512 net), no
     collectives: every call's whole forward workspace — and then the gradients of the whole step — must reproduce the first call's, bit for bit, in both."""
     assert torch.cuda.is_available(), "this test needs the MI355X"
     ctx = mp.get_context("spawn")
@@ -222,12 +224,12 @@ def test_two_processes_sharing_the_gpu_do_not_disturb_each_other():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_concurrent_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_concurrent_worker, args=(r, 2, port, q, arch)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=120)
     assert all(p.exitcode == 0 for p in procs)
-    print(f"[2 processes at once, conv forward x 40 + loss_gradients x 20] differing calls: {[(r, n) for r, _, n in res]}")
+    print(f"[2 processes at once, {arch}: forward x 40 + loss_gradients x 20] differing calls: {[(r, n) for r, _, n in res]}")
     assert all(n == 0 for _, _, n in res), res
