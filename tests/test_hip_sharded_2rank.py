@@ -32,6 +32,15 @@ def _problem(arch, dev, S_fc=6):
         x, y = O.synthetic_inputs(N, (1, 28, 28), C, seed=5)
         return full, (lambda r, w: full.shard(r, w)), x, y, D, S, N, 600
     from robustbnns_amd.conv import ConvStackedPosterior
+    if arch == "conv3":                                          # 3x32x32 (BASELINE config 5's geometry): conv1 over three input channels, the pair-tiled conv2 forward
+        shape, Hc, C, S, N = (3, 32, 32), 32, 10, 4, 24
+        D = shape[0] * shape[1] * shape[2]
+        q2 = ((shape[1] - 4) // 2) - 5
+        post = O.synthetic_posterior("conv", D, Hc, C, S, 0.05, in_ch=shape[0], head=q2 * q2 * Hc)
+        full = ConvStackedPosterior("leaky", shape, C, Hc, post, dev)
+        x, y = O.synthetic_inputs(N, shape, C, seed=7)
+        part = lambda r, w: ConvStackedPosterior("leaky", shape, C, Hc, {k: v[r * S // w:(r + 1) * S // w] for k, v in post.items()}, dev)
+        return full, part, x, y, D, S, N, 8
     D, Hc, C, S, N = 784, 32, 10, 4, 48
     post = O.synthetic_posterior("conv", D, Hc, C, S, 0.05)
     full = ConvStackedPosterior("leaky", (1, 28, 28), C, Hc, post, dev)
@@ -188,7 +197,7 @@ def _concurrent_worker(rank, world, port, q, arch):
         full, part, x, y, D, S, N, NP = _problem(arch, dev)
         eng = make_engine(part(rank, world), precision="auto")
         xd, Sl = x.to(dev), eng.post.S
-        keys = ("P1", "st1", "Q2", "st2", "P") if arch == "conv" else ()      # conv: the forward's whole workspace, stage by stage
+        keys = ("P1", "st1", "Q2", "st2", "P") if arch != "fc" else ()      # conv: the forward's whole workspace, stage by stage
         ws = eng.workspace(N, Sl) if keys else {}
         dist.barrier()
         p0 = eng.forward(xd, Sl).clone(); torch.cuda.synchronize()
@@ -212,11 +221,11 @@ def _concurrent_worker(rank, world, port, q, arch):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("arch", ["conv", "fc"])
+@pytest.mark.parametrize("arch", ["conv", "conv3", "fc"])
 def test_two_processes_sharing_the_gpu_do_not_disturb_each_other(arch):
     """Found with this setup in round 5 (profiles/r05w): conv1_pool_kernel's packed FMA had its broadcast operand as src1 (op_sel on src1) — a form that
     gfx950 does not execute reliably when waves of another kernel share the SIMD: with two processes at once, one in seven forward calls left a P1 that
-    differed from the process's own reference (the low result lane took the other half of a patch pair).  Two processes, different posteriors (conv; and the fc-512 net), no
+    differed from the process's own reference (the low result lane took the other half of a patch pair).  Two processes, different posteriors (conv on 1x28x28 and on 3x32x32; the fc-512 net), no
     collectives: every call's whole forward workspace — and then the gradients of the whole step — must reproduce the first call's, bit for bit, in both."""
     assert torch.cuda.is_available(), "this test needs the MI355X"
     ctx = mp.get_context("spawn")
