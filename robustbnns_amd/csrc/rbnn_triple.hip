@@ -948,8 +948,9 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
                 union { f16x8 v; unsigned u[4]; } o0, o1, o2;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    split3_plain_pair(am[nt][t][0], am[nt][t][1], 1.f, o0.u[2 * t], o1.u[2 * t], o2.u[2 * t]);
-                    split3_plain_pair(am[nt][t][2], am[nt][t][3], 1.f, o0.u[2 * t + 1], o1.u[2 * t + 1], o2.u[2 * t + 1]);
+                    // (registers -> MFMA operands: the form with the wait states behind its last, half-register write — rbnn_common.hpp)
+                    split3_plain_pair_for_mfma(am[nt][t][0], am[nt][t][1], 1.f, o0.u[2 * t], o1.u[2 * t], o2.u[2 * t]);
+                    split3_plain_pair_for_mfma(am[nt][t][2], am[nt][t][3], 1.f, o0.u[2 * t + 1], o1.u[2 * t + 1], o2.u[2 * t + 1]);
                 }
                 da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
             }
