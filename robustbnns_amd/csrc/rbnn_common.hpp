@@ -107,24 +107,12 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 
 // The three fp16 pieces (rbnn_triple.hip split3: p0 = f16(v), p1 = f16(v - p0), p2 = f16(v - p0 - p1), round-to-nearest-even) of TWO fp32 values,
 // packed [even | odd << 16] per piece: 6 vector instructions per pair (plain C++ compiles to ~12 per value).  `one` must hold 1.0f.
+// The block's last instruction writes ONE HALF of d2 (op_sel on the destination) and hipcc's hazard recognizer cannot see into an asm block: it pads ONE
+// wait state behind the block, the half-register forwarding window on gfx950 is longer — a consumer straight behind the block (an MFMA taking d2 as an
+// operand; a compiler-made v_mov that gathers the pieces into a fragment) read a stale half: fc2's layer 2 on the fp32 hidden image was off by the low
+// pieces, 7e-4, on exactly the last point tile of the 8-wave configuration; with the pad only behind the LAST of a fragment's four pairs it failed again
+// (DESIGN §3z).  `s_nop 1` inside the string closes the window for every consumer, whatever the scheduler puts there; it is part of the block everywhere.
 __device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
-    float re, ro;
-    asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"
-        "v_fma_mix_f32 %[re], %[ve], %[one], -%[d0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mix_f32 %[ro], %[vo], %[one], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t"
-        "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro)
-        : [ve] "v"(ve), [vo] "v"(vo), [one] "v"(one));
-}
-
-
-// The same, for pieces that a MATRIX instruction reads next: the last instruction of the block writes ONE HALF of d2 (op_sel on the destination), and
-// hipcc's hazard recognizer cannot see into an asm block — an MFMA that takes d2 as an operand straight behind it read a stale half on gfx950
-// (fc2's layer 2 with the fp32 hidden image: exactly the LAST point tile's fragments were off by the low pieces, 7e-4, at the 8-wave configuration;
-// the other users of split3_plain_pair store their pieces, far behind).  Two idle issue slots close the window.
-__device__ __forceinline__ void split3_plain_pair_for_mfma(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
     float re, ro;
     asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"
         "v_fma_mix_f32 %[re], %[ve], %[one], -%[d0] op_sel_hi:[0,0,1]\n\t"

@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_x3_kernel(const ConvBwdArgs 
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int e = 0; e < 8; e += 2)
-                split3_plain_pair_for_mfma(wv[mt][e] * wsc, wv[mt][e + 1] * wsc, 1.f, aw0[mt].w[e >> 1], aw1[mt].w[e >> 1], aw2[mt].w[e >> 1]);
+                split3_plain_pair(wv[mt][e] * wsc, wv[mt][e + 1] * wsc, 1.f, aw0[mt].w[e >> 1], aw1[mt].w[e >> 1], aw2[mt].w[e >> 1]);
     }
     int eg = 0;
     if (gmax > 0.f && gmax < INFINITY) eg = max(-100, min(100, 13 - ilogbf(gmax)));
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256, 2) conv1_bwd_x3_kernel(const ConvBwdArgs 
                 for (int e = 0; e < 8; e += 2) {
                     const float ve = (ar(pt, e >> 2, e & 3) == 2 * half) ? gv[pt][e >> 2][e & 3] : 0.f;               // arg = 2*dy + dx
                     const float vo = (ar(pt, (e + 1) >> 2, (e + 1) & 3) == 2 * half) ? gv[pt][(e + 1) >> 2][(e + 1) & 3] : 0.f;
-                    split3_plain_pair_for_mfma(ve, vo, 1.f, b0[pt].w[e >> 1], b1[pt].w[e >> 1], b2[pt].w[e >> 1]);   // (registers -> MFMA operands: the wait states of rbnn_common.hpp)
+                    split3_plain_pair(ve, vo, 1.f, b0[pt].w[e >> 1], b1[pt].w[e >> 1], b2[pt].w[e >> 1]);
                 }
             f32x4 acc[MT][2];
 #pragma unroll

@@ -279,10 +279,10 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 union { f16x8 v; unsigned w[4]; } q0, q1, q2;
-                split3_plain_pair_for_mfma(x0[nt][0], x0[nt][1], 1.f, q0.w[0], q1.w[0], q2.w[0]);
-                split3_plain_pair_for_mfma(x0[nt][2], x0[nt][3], 1.f, q0.w[1], q1.w[1], q2.w[1]);
-                split3_plain_pair_for_mfma(x1[nt][0], x1[nt][1], 1.f, q0.w[2], q1.w[2], q2.w[2]);
-                split3_plain_pair_for_mfma(x1[nt][2], x1[nt][3], 1.f, q0.w[3], q1.w[3], q2.w[3]);
+                split3_plain_pair(x0[nt][0], x0[nt][1], 1.f, q0.w[0], q1.w[0], q2.w[0]);
+                split3_plain_pair(x0[nt][2], x0[nt][3], 1.f, q0.w[1], q1.w[1], q2.w[1]);
+                split3_plain_pair(x1[nt][0], x1[nt][1], 1.f, q0.w[2], q1.w[2], q2.w[2]);
+                split3_plain_pair(x1[nt][2], x1[nt][3], 1.f, q0.w[3], q1.w[3], q2.w[3]);
                 b0[nt] = q0.v; b1[nt] = q1.v; b2[nt] = q2.v;
             }
         } else {
@@ -948,9 +948,8 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
                 union { f16x8 v; unsigned u[4]; } o0, o1, o2;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    // (registers -> MFMA operands: the form with the wait states behind its last, half-register write — rbnn_common.hpp)
-                    split3_plain_pair_for_mfma(am[nt][t][0], am[nt][t][1], 1.f, o0.u[2 * t], o1.u[2 * t], o2.u[2 * t]);
-                    split3_plain_pair_for_mfma(am[nt][t][2], am[nt][t][3], 1.f, o0.u[2 * t + 1], o1.u[2 * t + 1], o2.u[2 * t + 1]);
+                    split3_plain_pair(am[nt][t][0], am[nt][t][1], 1.f, o0.u[2 * t], o1.u[2 * t], o2.u[2 * t]);
+                    split3_plain_pair(am[nt][t][2], am[nt][t][3], 1.f, o0.u[2 * t + 1], o1.u[2 * t + 1], o2.u[2 * t + 1]);
                 }
                 da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
             }
