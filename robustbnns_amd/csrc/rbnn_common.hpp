@@ -107,9 +107,9 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 
 // The three fp16 pieces (rbnn_triple.hip split3: p0 = f16(v), p1 = f16(v - p0), p2 = f16(v - p0 - p1), round-to-nearest-even) of TWO fp32 values,
 // packed [even | odd << 16] per piece: 6 vector instructions per pair (plain C++ compiles to ~12 per value).  `one` must hold 1.0f.
-// The block's last instruction writes ONE HALF of d2 (op_sel on the destination) and hipcc's hazard recognizer cannot see into an asm block: it pads ONE
-// wait state behind the block, the half-register forwarding window on gfx950 is longer — a consumer straight behind the block (an MFMA taking d2 as an
-// operand; a compiler-made v_mov that gathers the pieces into a fragment) read a stale half: fc2's layer 2 on the fp32 hidden image was off by the low
+// A VGPR written by a vector instruction needs TWO wait states before an MFMA takes it as an operand; hipcc's hazard recognizer cannot see into an asm
+// block and pads ONE state behind it — an MFMA scheduled straight behind the block (any block: these are plain asm statements, the scheduler orders
+// them freely) read a stale d2: fc2's layer 2 on the fp32 hidden image was off by the low
 // pieces, 7e-4, on exactly the last point tile of the 8-wave configuration; with the pad only behind the LAST of a fragment's four pairs it failed again
 // (DESIGN §3z).  `s_nop 1` inside the string closes the window for every consumer, whatever the scheduler puts there; it is part of the block everywhere.
 __device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
