@@ -2,7 +2,7 @@
 time, (b) one after the other?  Compares the forward's workspace (P1, st1, Q2, st2, P) of 40 calls with the first call's."""
 import os, socket, sys
 import torch, torch.distributed as dist, torch.multiprocessing as mp
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/diagnostics/ -> repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def run(eng, x, N, Sl, tag, reps=40):

@@ -2,7 +2,7 @@
 inputs and reports the calls that differ from the first."""
 import os, socket, sys
 import torch, torch.distributed as dist, torch.multiprocessing as mp
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/diagnostics/ -> repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def worker(rank, world, port, sharded):
