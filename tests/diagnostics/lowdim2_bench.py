@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-pass time of the fc2 lowdim path on the reference's half-moons grid cells (grid_search_halfMoons.py:159-169: fc2, hidden 32 .. 512,
 250 samples, 100 test points): HIP events around back-to-back FGSM / expected-gradient passes, labels already int32 on the device.
-usage: python tools/lowdim2_bench.py [hidden ...]      (run it under `rocprofv3 --kernel-trace --stats` for the per-kernel durations)"""
+usage: python tests/diagnostics/lowdim2_bench.py [hidden ...]      (run it under `rocprofv3 --kernel-trace --stats` for the per-kernel durations)"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))   # tests/diagnostics/ -> repository root
 from oracle import bnn_oracle as O                                     # noqa: E402  (synthetic posterior generator only)
 from robustbnns_amd import AttackEngine, StackedPosterior               # noqa: E402
 
