@@ -166,6 +166,13 @@ class FgsmGrid:
         self._grad, self._clean = {}, {}
         self.gradient_passes = self.clean_forwards = 0          # what the grid cost (printed by the drivers' tests)
 
+    def _key(self, n_samples, eng):
+        """A cached gradient / clean output is valid for ONE engine on ONE posterior and for the inputs as they were: the key names the engine and
+        its posterior (set_posterior_samples / a reload builds new ones; the cache entry holds the engine, so its id cannot be recycled meanwhile)
+        and the identity + in-place version of x_test / y_test — a replaced posterior or edited inputs miss the cache instead of returning stale
+        results."""
+        return (n_samples, id(eng), id(eng.post), self.x_test.data_ptr(), self.x_test._version, self.y_test.data_ptr(), self.y_test._version)
+
     def attack(self, epsilon, n_samples, filename, savedir=None):
         """attack(net, ..., method="fgsm", hyperparams={"epsilon": epsilon}, n_samples=n_samples) — adversarialAttacks.py:111-143."""
         hyper = {"epsilon": epsilon}
@@ -175,12 +182,13 @@ class FgsmGrid:
         print(f"\nProducing fgsm attacks on {self.dataset_name}:")
         images = self.x_test.to(self.device)
         eng, S, seeds, mode = _hot_path(self.net, n_samples, False)
-        if n_samples not in self._grad:
-            self._grad[n_samples] = eng.attack_gradient(images, self.y_test.argmax(-1).to(self.device), S, seeds=seeds, mode=mode)
+        key = self._key(n_samples, eng)
+        if key not in self._grad:
+            self._grad[key] = (eng, eng.attack_gradient(images, self.y_test.argmax(-1).to(self.device), S, seeds=seeds, mode=mode))
             self.gradient_passes += 1
         if images.is_leaf:
             images.requires_grad = True                        # fgsm_attack's visible side effect (:73)
-        adversarial_attack = eng.fgsm_from_gradient(images, self._grad[n_samples], epsilon).to(images.device).requires_grad_(True)
+        adversarial_attack = eng.fgsm_from_gradient(images, self._grad[key][1], epsilon).to(images.device).requires_grad_(True)
         _attack_side_effects(self.x_test, adversarial_attack, "fgsm", filename, savedir, n_samples)
         return adversarial_attack
 
@@ -195,11 +203,12 @@ class FgsmGrid:
         set_rng_seed(0)
         eng, S, _, mode = _hot_path(self.net, n_samples, False)
         logits = mode == _hip.LOSS_MEAN_LOGIT
-        if n_samples not in self._clean:
-            self._clean[n_samples] = eng.clean_outputs(self.x_test.to(self.device), S, logits=logits)
+        key = self._key(n_samples, eng)
+        if key not in self._clean:
+            self._clean[key] = (eng, eng.clean_outputs(self.x_test.to(self.device), S, logits=logits))
             self.clean_forwards += 1
         original_accuracy, adversarial_accuracy, rob, _, _ = eng.evaluate(
-            self.x_test.to(self.device), x_attack.to(self.device), self.y_test, S, logits=logits, clean=self._clean[n_samples])
+            self.x_test.to(self.device), x_attack.to(self.device), self.y_test, S, logits=logits, clean=self._clean[key][1])
         return _evaluation_report(original_accuracy, adversarial_accuracy, rob)
 
 

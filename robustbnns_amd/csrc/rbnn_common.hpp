@@ -76,6 +76,25 @@ template <int CM> __device__ __forceinline__ void softmax_backward(const float (
     for (int c = 0; c < CM; ++c) out[c] = (c < C) ? (c == m ? sm : g[c] - dot) * p[c] : 0.f;
 }
 
+// dL/dt of L = CE(softmax(t), y) (times inv_S): softmax(t) - e_y.  For the LABEL class the textbook form t_y / den - 1 cancels to O(1 - p_y): on a trained
+// net (p_y = 1 - 1e-6) that is an absolute error of an ulp of 1 on a result of 1e-6 — several per cent; torch's cross-entropy backward (the reference)
+// evaluates exactly that.  Since sum_k softmax_k = 1 the label class is -(sum_{k != y} e_k) / den: a sum of accurately known positive terms, nothing
+// cancels.  The other classes are e_c / den as they were.  One definition for every kernel that forms a loss gradient (loss_dlogits_kernel,
+// step_tail_x3_kernel, the lowdim kernels): the fused and the separate forms stay bit-identical.  t[c] is read for c < C only.
+template <int CM> __device__ __forceinline__ void ce_softmax_grad(const float (&t)[CM], int C, int y, float inv_S, float (&g)[CM]) {
+    float e[CM], m = -INFINITY, den = 0.f, rest = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) if (c < C) m = fmaxf(m, t[c]);
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        e[c] = (c < C) ? expf(t[c] - m) : 0.f;
+        den += e[c];
+        if (c != y) rest += e[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) g[c] = (c < C) ? ((c == y ? -rest : e[c]) / den) * inv_S : 0.f;
+}
+
 // Item -> (point tile, column group, chunk) of the input-gradient GEMM kernels.  Kernels that GENERATE their A operand read no A from memory:
 // point tiles run fastest, so that the blocks resident on an XCD together share one (chunk, column group)'s W1 slices in its L2.  fc2's step
 // through W1 READS its A operand — dL/d(pre-activation 1) of (point tile, chunk), 32 KB per stage — and every column group reads it again: with
@@ -111,7 +130,9 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // block and pads ONE state behind it — an MFMA scheduled straight behind the block (any block: these are plain asm statements, the scheduler orders
 // them freely) read a stale d2: fc2's layer 2 on the fp32 hidden image was off by the low
 // pieces, 7e-4, on exactly the last point tile of the 8-wave configuration; with the pad only behind the LAST of a fragment's four pairs it failed again
-// (DESIGN §3z).  `s_nop 1` inside the string closes the window for every consumer, whatever the scheduler puts there; it is part of the block everywhere.
+// (DESIGN §3z).  `s_nop 1` inside the string closes the window for every consumer, whatever the scheduler puts there; it is part of EVERY
+// asm block whose outputs feed an MFMA (this one; split3_pair / split3_pair_m in rbnn_triple.hip), and the built library is scanned for the
+// hazard itself: tools/kernel_resources.py::mfma_operand_hazards (tests/test_host_cpu.py::test_no_mfma_reads_a_vgpr_inside_the_valu_write_window).
 __device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
     float re, ro;
     asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"

@@ -511,16 +511,10 @@ __global__ void loss_dlogits_kernel(int mode, const float* __restrict__ P, const
         for (int c = 0; c < 16; ++c) g[c] = (c < C) ? Gup[(long long)n * ldp + c] * inv_S : 0.f;
     } else {
         // softmax of what the loss saw: mean probs (double softmax), this sample's probs, or mean logits
-        float t[16], m = -INFINITY, den = 0.f;
+        float t[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            t[c] = (c < C) ? ((mode == RBNN_LOSS_PER_SAMPLE) ? p[c] : Psum[(long long)n * ldp + c] * inv_S) : -INFINITY;
-            m = fmaxf(m, t[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? expf(t[c] - m) : 0.f; den += t[c]; }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (t[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+        for (int c = 0; c < 16; ++c) t[c] = (c < C) ? ((mode == RBNN_LOSS_PER_SAMPLE) ? p[c] : Psum[(long long)n * ldp + c] * inv_S) : 0.f;
+        ce_softmax_grad<16>(t, C, y, inv_S, g);                // softmax(t) - e_y, the label class without its cancellation (rbnn_common.hpp)
     }
     float out[16];
     if (mode == RBNN_LOSS_MEAN_LOGIT || mode == RBNN_LOSS_UPSTREAM_LOGIT) {        // P holds logits: dZ_s = dL/d(mean logits) / S, no softmax backward

@@ -150,13 +150,7 @@ template <int CM> __device__ __forceinline__ void softmax_inplace(float (&v)[CM]
 
 // dL/d(what the loss saw), as rbnn_loss_dlogits: softmax(t) - onehot(y), times inv_S
 template <int CM> __device__ __forceinline__ void loss_grad(const float (&t)[CM], int C, int y, float inv_S, float (&g)[CM]) {
-    float e[CM], m = -INFINITY, den = 0.f;
-#pragma unroll
-    for (int c = 0; c < CM; ++c) if (c < C) m = fmaxf(m, t[c]);
-#pragma unroll
-    for (int c = 0; c < CM; ++c) { e[c] = (c < C) ? expf(t[c] - m) : 0.f; den += e[c]; }
-#pragma unroll
-    for (int c = 0; c < CM; ++c) g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+    ce_softmax_grad<CM>(t, C, y, inv_S, g);                          // the label class without its cancellation (rbnn_common.hpp)
 }
 
 template <int ACT, int DQ, int CM>
@@ -531,16 +525,9 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             }
             float g[16], e[16], dz[16];                                   // (as the recomputing backward below: rbnn_loss_dlogits on what the forward launch left in P)
             const int y = (n < N) ? a.labels[n] : 0;
-            float m = -INFINITY, den = 0.f;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                e[c] = (n < N && c < C) ? a.Psum[(long long)n * RBNN_CPAD + c] * a.inv_S : 0.f;
-                if (c < C) m = fmaxf(m, e[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { e[c] = (c < C) ? expf(e[c] - m) : 0.f; den += e[c]; }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
+            for (int c = 0; c < 16; ++c) e[c] = (n < N && c < C) ? a.Psum[(long long)n * RBNN_CPAD + c] * a.inv_S : 0.f;
+            ce_softmax_grad<16>(e, C, y, a.inv_S, g);
             if (a.loss != RBNN_LOSS_MEAN_LOGIT) softmax_backward<16>(g, z, C, dz);      // (g - <g,p>) p, cancellation-free (rbnn_common.hpp)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
@@ -649,16 +636,9 @@ __global__ void __launch_bounds__(64 * NW) low2_kernel(const Low2Args a) {
             // dL/dlogits of this sample, exactly as rbnn_loss_dlogits: the loss gradient g on what the loss saw, through this sample's softmax
             float g[16], e[16], dz[16];
             const int y = (n < N) ? a.labels[n] : 0;
-            float m = -INFINITY, den = 0.f;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                e[c] = (a.loss == RBNN_LOSS_PER_SAMPLE) ? z[c] : ((n < N && c < C) ? a.Psum[(long long)n * RBNN_CPAD + c] * a.inv_S : 0.f);
-                if (c < C) m = fmaxf(m, e[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { e[c] = (c < C) ? expf(e[c] - m) : 0.f; den += e[c]; }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (e[c] / den - (c == y ? 1.f : 0.f)) * a.inv_S : 0.f;
+            for (int c = 0; c < 16; ++c) e[c] = (a.loss == RBNN_LOSS_PER_SAMPLE) ? z[c] : ((n < N && c < C) ? a.Psum[(long long)n * RBNN_CPAD + c] * a.inv_S : 0.f);
+            ce_softmax_grad<16>(e, C, y, a.inv_S, g);
             if (a.loss != RBNN_LOSS_MEAN_LOGIT) softmax_backward<16>(g, z, C, dz);      // (g - <g,p>) p, cancellation-free (rbnn_common.hpp)
 #pragma unroll
             for (int c = 0; c < 16; ++c) {

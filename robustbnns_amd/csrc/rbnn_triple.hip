@@ -51,7 +51,9 @@ __device__ __forceinline__ void split3(float v, _Float16& p0, _Float16& p1, _Flo
 // and writes its half of the packed result — 11 vector instructions per pair.  (Plain C++ compiles to ~18: hipcc re-derives
 // the pieces through f32 round trips and SLP-packs them into v_pk_* ops, and the kernel is bound by vector-instruction ISSUE.)
 // FIRST: these are the first reads of a generator MFMA's result — the 7 wait states an XDL write needs before a VALU read
-// (the compiler cannot see into the asm to insert them).
+// (the compiler cannot see into the asm to insert them).  The trailing `s_nop 1`: d0 / d1 / d2 are MFMA A operands and the block ends in a
+// vector write — the two wait states a VALU-written VGPR needs before an MFMA reads it are part of the block (as in split3_plain_pair,
+// rbnn_common.hpp), and tools/kernel_resources.py --hazards scans the built library's disassembly for any MFMA closer than that to its writer.
 #define RBNN_X3_PAIR_BODY \
     "v_bfe_i32 %[me], %[mw], %[b0], 1\n\t" \
     "v_bfe_i32 %[mo], %[mw], %[b1], 1\n\t" \
@@ -63,7 +65,8 @@ __device__ __forceinline__ void split3(float v, _Float16& p0, _Float16& p1, _Flo
     "v_fma_mix_f32 %[ro], %[go], %[mo], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
     "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t" \
     "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t" \
-    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+    "s_nop 1"
 #define RBNN_X3_PAIR_OPS \
     : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [me] "=&v"(me), [mo] "=&v"(mo), [re] "=&v"(re), [ro] "=&v"(ro) \
     : [ge] "v"(ge), [go] "v"(go), [mw] "v"(mw), [cp] "v"(cp), [cn] "v"(cn), [one] "v"(one), [b0] "n"(BIT), [b1] "n"(BIT + 1)
@@ -87,7 +90,8 @@ __device__ __forceinline__ void split3_pair_m(float ge, float go, float me, floa
     "v_fma_mix_f32 %[ro], %[go], %[mo], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
     "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t" \
     "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t" \
-    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
+    "s_nop 1"
 #define RBNN_X3_PAIRM_OPS \
     : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro) \
     : [ge] "v"(ge), [go] "v"(go), [me] "v"(me), [mo] "v"(mo), [one] "v"(one)
@@ -648,13 +652,7 @@ __device__ __forceinline__ void tail_dz(const float* __restrict__ prow, const fl
         for (int r = 0; r < 4; ++r) p[4 * q + r] = v[r];
     }
     if (MODE == RBNN_LOSS_PER_SAMPLE) {
-        float t[16], m = -INFINITY, den = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? p[c] : -INFINITY; m = fmaxf(m, t[c]); }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? expf(t[c] - m) : 0.f; den += t[c]; }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) g[c] = (c < C) ? (t[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+        ce_softmax_grad<16>(p, C, y, inv_S, g);                // loss_dlogits_kernel's, bit for bit
     } else {
 #pragma unroll
         for (int c = 0; c < 16; ++c) g[c] = gmean[c];
@@ -691,13 +689,10 @@ __global__ void __launch_bounds__(256) step_tail_x3_kernel(const float* __restri
     const int y = (n < N) ? labels[n] : 0;
     float gmean[16];
     if (MODE != RBNN_LOSS_PER_SAMPLE) {
-        float t[16], m = -INFINITY, den = 0.f;
+        float t[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? psum[p][c] * inv_S : -INFINITY; m = fmaxf(m, t[c]); }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) { t[c] = (c < C) ? expf(t[c] - m) : 0.f; den += t[c]; }
-#pragma unroll
-        for (int c = 0; c < 16; ++c) gmean[c] = (c < C) ? (t[c] / den - (c == y ? 1.f : 0.f)) * inv_S : 0.f;
+        for (int c = 0; c < 16; ++c) t[c] = (c < C) ? psum[p][c] * inv_S : 0.f;
+        ce_softmax_grad<16>(t, C, y, inv_S, gmean);
     } else {
 #pragma unroll
         for (int c = 0; c < 16; ++c) gmean[c] = 0.f;

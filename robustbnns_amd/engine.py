@@ -59,7 +59,38 @@ class _DifferentiableForward(torch.autograd.Function):
         return g.to(x.device), None, None, None, None
 
 
+class CommStats:
+    """What the collectives of a run did, as the LAUNCH stream saw it (attached by bench.py: AttackEngine.comm_stats; None = nothing is recorded).
+    `exposed`: event pairs on the launch stream around every point where that stream waits for an exchange — a blocking all-reduce, or the
+    .wait() of an asynchronous one.  Nothing else is enqueued on the stream between the two events, so their distance is the time the compute
+    stream stood still for the collective: the part of the exchange NOT hidden under kernels (SURVEY 8e; VERDICT r5 next #5)."""
+
+    def __init__(self, event_factory):
+        self.event = event_factory
+        self.on = False
+        self.calls = 0
+        self.bytes = 0
+        self.exposed = []
+
+    def count(self, t):
+        if self.on:
+            self.calls += 1
+            self.bytes += t.numel() * t.element_size()
+
+    def around(self, fn):
+        if not self.on:
+            return fn()
+        e0, e1 = self.event(), self.event()
+        e0.record()
+        r = fn()
+        e1.record()
+        self.exposed.append((e0, e1))
+        return r
+
+
 class AttackEngine:
+    comm_stats = None                       # a CommStats while bench.py measures a sharded run
+
     def __init__(self, posterior, kernels=None, group=None, total_samples=None, precision=None):
         """posterior: StackedPosterior holding THIS rank's samples.  group: a torch.distributed process
         group when the posterior is sample-sharded across ranks (SURVEY 8e); total_samples: samples over
@@ -74,12 +105,14 @@ class AttackEngine:
             if os.environ.get("RBNN_FORCE_COLLECTIVES") == "1":
                 self.world = max(self.world, 2)    # diagnostics: run the all-reduce path even in a 1-rank group
         self._S_total = total_samples
-        self._fake_comm = os.environ.get("RBNN_FAKE_COLLECTIVES") == "1" and os.environ.get("RBNN_FORCE_COLLECTIVES") == "1"
+        # diagnostics only (tools/collectives_ab.sh): the sharded launch sequence with NO exchange.  In a group of more than one rank that would
+        # silently return every rank's partial sums as the result, so it is refused there.  An engine WITHOUT a group never exchanges anything
+        # (bench's point-sharded and other-mode engines, SVI hot-path engines): the pair of switches leaves it alone
+        self._fake_comm = (group is not None and os.environ.get("RBNN_FAKE_COLLECTIVES") == "1"
+                           and os.environ.get("RBNN_FORCE_COLLECTIVES") == "1")
         if self._fake_comm:
-            # diagnostics only (tools/collectives_ab.sh): the sharded launch sequence with NO exchange.  In a group of more than one rank that
-            # would silently return every rank's partial sums as the result, so it is refused there
             import torch.distributed as dist
-            if group is None or dist.get_world_size(group) != 1:
+            if dist.get_world_size(group) != 1:
                 raise _hip.HipError("RBNN_FAKE_COLLECTIVES=1 skips every all-reduce: it is a timing diagnostic for a 1-rank group "
                                     "(with RBNN_FORCE_COLLECTIVES=1), never valid with more than one rank")
         self._ws_cache = {}
@@ -134,15 +167,27 @@ class AttackEngine:
     def _allreduce(self, t):
         if self.world > 1 and not self._fake_comm:
             import torch.distributed as dist
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            cs = self.comm_stats
+            if cs is None:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                cs.count(t)
+                cs.around(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
 
     def _allreduce_async(self, t):
-        """Start the all-reduce (RCCL runs it on its own stream) and return the work handle; .wait() orders the current
+        """Start the all-reduce (RCCL runs it on its own stream) and return the work handle; _wait(handle) orders the current
         stream after it.  Kernels launched in between overlap the exchange."""
         if self._fake_comm:                      # diagnostics (RBNN_FAKE_COLLECTIVES=1 with RBNN_FORCE_COLLECTIVES=1): the sharded launch sequence
             return self._NoWork()                # without any collective — separates what the sequence costs from what RCCL costs
         import torch.distributed as dist
+        if self.comm_stats is not None:
+            self.comm_stats.count(t)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _wait(self, h):
+        """The launch stream waits for an asynchronous all-reduce; with comm_stats attached the wait sits between two events (its exposed part)."""
+        cs = self.comm_stats
+        return h.wait() if cs is None else cs.around(h.wait)
 
     def total_samples(self, S_local):
         """Samples over all ranks taking part in this call."""
@@ -514,13 +559,13 @@ class AttackEngine:
         pending = []
         for lo, hi, ws, h in blocks:                            # loss + backward; start the large exchange
             if h is not None:
-                h.wait()
+                self._wait(h)
             self.k.loss_dlogits(mode, ws["P"], ws["Psum"] if need_psum else None, None, labels[lo:hi], S, inv_S, hi - lo, C, ws["dZ"])
             n_slabs = self._grad_kernels(sidx, S, hi - lo, ws)
             self.k.sum_slabs(ws["slabs"], n_slabs, hi - lo, p.Dp, 1.0, ws["G"])
             pending.append(self._allreduce_async(ws["G"]))
         for (lo, hi, ws, _), h in zip(blocks, pending):         # identical sign / project / clamp on every rank's replica of x
-            h.wait()
+            self._wait(h)
             self.k.attack_step(X[lo:hi], None if X0 is None else X0[lo:hi], ws["G"], 1, 0, p.Dp,
                                None if alpha is None else alpha[lo:hi], alpha_scalar, eps, project, p.D)
 
@@ -596,7 +641,7 @@ class AttackEngine:
                 self.k.sum_slabs(ws["slabs"], n_slabs, N, p.Dp, 1.0, G)
                 self._allreduce(G)
                 self.k.attack_step(X, None, G, 1, 0, p.Dp, None, float(epsilon), 0.0, False, p.D)
-                pending.wait()
+                self._wait(pending)
                 expected = self.unpad(G1, x)
         finally:
             self._scales = None

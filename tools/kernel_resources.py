@@ -14,6 +14,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "robustbnns_amd", "csrc", "librbnn_hip.so")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
@@ -72,7 +73,65 @@ def kernel_resources(lib=LIB):
     return res
 
 
+def _regs(op):
+    """'v12' / 'v[4:7]' / 'a[0:3]' (with an optional leading '-' or '|') -> ('v' | 'a', set of register numbers); anything else -> (None, empty)."""
+    m = re.match(r"^[-|]?([va])(?:(\d+)|\[(\d+):(\d+)\])\|?$", op.strip())
+    if not m:
+        return None, set()
+    lo = int(m.group(2) if m.group(2) is not None else m.group(3))
+    hi = int(m.group(2) if m.group(2) is not None else m.group(4))
+    return m.group(1), set(range(lo, hi + 1))
+
+
+def mfma_operand_hazards(lib=LIB, need=2):
+    """-> [(kernel, mfma line, writer line, wait states seen)]: every v_mfma that takes as an operand a VGPR some non-MFMA vector instruction wrote
+    fewer than `need` wait states earlier (gfx90a+ rule 'VALU writes VGPR -> MFMA reads it: 2 wait states', LLVM's LegacyVALUWritesVGPRWaitStates).
+    hipcc pads this hazard itself between instructions it can see; it cannot see INTO an inline-asm string, so a block that ends in a vector
+    write (the v_fma_mixhi_f16 of the pair splits) must carry its own `s_nop 1` — this scan over the disassembly of the built library is the fence
+    (tests/test_host_cpu.py).  Linear scan per kernel: an instruction is one wait state, `s_nop N` is N + 1."""
+    bad = []
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        kern, recent = "?", []                                   # recent: [(states since issue, vgprs written, text)], youngest first
+        for line in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                kern, recent = m.group(1), []
+                continue
+            ins = line.split("//")[0].strip()
+            if not ins or ins.startswith("."):
+                continue
+            mn, _, rest = ins.partition(" ")
+            ops = [o.strip() for o in rest.split(",")]
+            if mn.startswith("v_mfma") or mn.startswith("v_smfma"):
+                srcs = set()
+                for o in ops[1:4]:
+                    k, r = _regs(o.split(" ")[0])
+                    if k == "v":
+                        srcs |= r
+                for age, regs, text in recent:
+                    if age < need and regs & srcs:
+                        bad.append((kern, ins, text, age))
+            states = (int(rest.strip().split()[0], 0) + 1) if mn == "s_nop" else 1
+            recent = [(a + states, r, t) for a, r, t in recent if a + states < need]
+            if mn.startswith("v_") and not (mn.startswith("v_mfma") or mn.startswith("v_smfma") or mn.startswith("v_cmp") or mn.startswith("v_accvgpr_write")):
+                k, r = _regs(ops[0].split(" ")[0])
+                if k == "v":
+                    recent.insert(0, (0, r, ins))
+    names = demangle([b[0] for b in bad])
+    return [(n,) + b[1:] for n, b in zip(names, bad)]
+
+
 if __name__ == "__main__":
+    if "--hazards" in sys.argv:
+        hz = mfma_operand_hazards()
+        for h in hz:
+            print(h)
+        print(len(hz), "VALU-write -> MFMA-read pairs closer than 2 wait states")
+        sys.exit(1 if hz else 0)
     lib = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else LIB
     flt = sys.argv[-1] if len(sys.argv) > 1 and not os.path.exists(sys.argv[-1]) else ""
     res = kernel_resources(lib)

@@ -31,6 +31,7 @@ if [ "$STAGE" = "bench" ]; then
   python bench.py --workload fc2_1024 --steps 3 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_fc2_1024.json
   python bench.py --workload conv1024 --steps 3 --warmup 1 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_conv1024.json
   python bench.py --workload c1 --steps 200 --warmup 20 --cpu-seconds 5 2>/dev/null | tail -1 > $OUT/bench_c1.json
+  python bench.py --workload eval --steps 10 --warmup 2 --cpu-seconds 10 2>/dev/null | tail -1 > $OUT/bench_eval.json
   RBNN_FORCE_COLLECTIVES=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 2 --cpu-seconds 0 --no-other-mode 2>/dev/null | tail -1 > $OUT/bench_c2_torchrun_1rank_forced_collectives.json
   for f in $OUT/bench*.json; do python3 -c "import json,sys; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$(basename $f)', d['precision_mode'], '%.4g' % d['value'], '%.4g ms' % d['ms_per_step'])"; done
 fi
@@ -61,6 +62,7 @@ for wl in $WLS; do
     c5)       prof c5 c5 512 62 --points 512 --iters 3 --steps 1 --warmup 1 --no-other-mode ;;
     conv)     prof conv conv 2048 16 --steps 3 --warmup 1 ;;
     conv1024) prof conv1024 conv1024 1024 16 --steps 3 --warmup 1 --no-other-mode ;;
+    eval)     prof eval eval 10000 100 --steps 3 --warmup 1 --no-other-mode ;;
     *) echo "unknown workload $wl" ;;
   esac
 done
