@@ -161,6 +161,27 @@ def relaxed_summary(reset=True):
     return "\n".join(lines)
 
 
+def cancellation_condition(x, lab, post, arch, act, n_samples, kind="bnn"):
+    """Per point: sum_s max_d |c_s| / max_d |sum_s c_s| for the per-sample contributions c_s of the mean-loss input gradient (fp64 autograd on the
+    oracle's forward; kind "bnn": CE on the mean probabilities, "ensemble": CE on the mean logits).  The expected gradient is a SUM over samples of
+    terms that can cancel: where they cancel k : 1, one rounding of a shared factor (the loss gradient, 2^-24 relative) moves the sum by k 2^-24
+    of itself — in ANY fp32 evaluation, torch's own included (a 2 -> 16 -> 2 net with std-0.5 weights: one point of 300 at 777 : 1, where torch's
+    fp32 evaluation of the oracle's formula is itself 1.9e-5 from fp64)."""
+    from oracle import bnn_oracle as O
+    post64 = O.cast(post, torch.float64)
+    xd = x.double().clone().requires_grad_(True)
+    n, C = x.shape[0], None
+    outs = [O.nn_logits(xd, O.select(post64, [s]), arch, act)[0] for s in range(n_samples)]
+    C = outs[0].shape[-1]
+    onehot = torch.nn.functional.one_hot(torch.as_tensor(lab).long(), C).double()
+    if kind == "bnn":
+        outs = [torch.softmax(o, -1) for o in outs]
+    g = (torch.softmax(torch.stack(outs).mean(0), -1) - onehot).detach()
+    contribs = [torch.autograd.grad((o * g).sum() / n_samples, xd, retain_graph=True)[0].reshape(n, -1) for o in outs]
+    total = sum(contribs).abs().max(1)[0].clamp_min(1e-300)
+    return sum(c.abs().max(1)[0] for c in contribs) / total
+
+
 def assert_close_to_truth(val, truth64, tol=1e-5, noise=None, what="", rows=None, fp32_yardstick=None):
     """`val` (an fp32 result) within `tol` of the fp64 evaluation, per point relative to the point's largest component — or within twice
     the fp32 saturation noise floor of the point (saturation_noise) where that is larger — or, when given, within twice the WORST error

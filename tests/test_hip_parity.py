@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import pgd_whole_attack_statistic, rel_err
+from conftest import cancellation_condition, pgd_whole_attack_statistic, rel_err, rel_err_points
 from oracle import bnn_oracle as O
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("built_library")]
@@ -290,7 +290,13 @@ def test_against_fp64_oracle(arch, act, shape, C, H, S, N, std, precision):
     for mode, kind in ((_hip.LOSS_MEAN_PROB, "bnn"), (_hip.LOSS_MEAN_LOGIT, "ensemble")):
         G = eng.gradient(eng.pad_inputs(x), labd, None, S, mode)[:, :D].cpu().reshape(x.shape)
         ref = O.meanprob_gradients(x.double(), lab, p64, arch, act, S, kind=kind)
-        assert rel_err(G[ok], ref[ok]) < TOL
+        # 1e-5 per point — except where the samples' contributions to the expected gradient cancel k : 1 with k 2^-23 > 1e-5: there one rounding
+        # of the shared loss gradient moves the sum by more than the bar in ANY fp32 evaluation (conftest.cancellation_condition; the half-moons-sized
+        # case has one such point of 300, at 777 : 1, where torch's own fp32 evaluation of the oracle sits 1.9e-5 from fp64)
+        bound = torch.clamp(2.0 ** -23 * cancellation_condition(x, lab, post, arch, act, S, kind), min=TOL)
+        e = rel_err_points(G, ref)
+        assert not bool((e > bound)[ok].any()), (kind, float((e / bound)[ok].max()), int((e / bound)[ok].argmax()))
+        assert int((bound > TOL)[ok].sum()) <= max(1, N // 100)
         adv = eng.fgsm(x, y, S, 0.1, mode=mode).cpu()
         adv_equal(adv[ok], torch.clamp(x + 0.1 * ref.sign().float(), 0, 1)[ok], ref[ok])
     # a seeds subset in shuffled order == the same samples gathered on the host
