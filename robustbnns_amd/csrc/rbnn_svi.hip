@@ -79,13 +79,12 @@ __device__ void draw_matrix_tile(const DrawArgs& a, const Rng& rng, int tensor, 
         //     [piece][16 rows][4 groups of 8 columns]
         const int hl = t >> 3, g = t & 7, d = d0 + 8 * g;
         if (d < ld_rows) {
-            union { f16x8 v; uint4 u; } o[3];
+            // (the 6-instruction pair split of rbnn_common.hpp — the same pieces as split3, bit for bit; plain C spends ~12 vector instructions per
+            // VALUE, and with Philox + Box-Muller this kernel is bound by vector issue, not by its stores: 3.4 of ~6 TB/s)
+            union { unsigned w[4]; uint4 u; } o[3];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 p0, p1, p2;
-                split3(tile[hl][8 * g + j] * img_scale, p0, p1, p2);
-                o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
-            }
+            for (int j = 0; j < 8; j += 2)
+                split3_plain_pair(tile[hl][8 * g + j] * img_scale, tile[hl][8 * g + j + 1] * img_scale, 1.f, o[0].w[j >> 1], o[1].w[j >> 1], o[2].w[j >> 1]);
             const long long r = (long long)s * H + 32 * hb + hl;
             uint4* const out = rows_img + (((r >> 4) * (ld_rows >> 5) + (d >> 5)) * 192 + (r & 15) * 4 + ((d >> 3) & 3));
             out[0] = o[0].u; out[64] = o[1].u; out[128] = o[2].u;
@@ -93,13 +92,11 @@ __device__ void draw_matrix_tile(const DrawArgs& a, const Rng& rng, int tensor, 
         // (4) triple cols: out[s][hb][lg][p][d][j] = piece p of W[32 hb + 16 (j>>2) + 4 lg + (j&3)][d]
         const int lg = t >> 6, dl = t & 63, dc = d0 + dl;
         if (dc < ld_cols) {
-            union { f16x8 v; uint4 u; } o[3];
+            union { unsigned w[4]; uint4 u; } o[3];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 p0, p1, p2;
-                split3(tile[16 * (j >> 2) + 4 * lg + (j & 3)][dl] * img_scale, p0, p1, p2);
-                o[0].v[j] = p0; o[1].v[j] = p1; o[2].v[j] = p2;
-            }
+            for (int j = 0; j < 8; j += 2)
+                split3_plain_pair(tile[16 * (j >> 2) + 4 * lg + (j & 3)][dl] * img_scale, tile[16 * ((j + 1) >> 2) + 4 * lg + ((j + 1) & 3)][dl] * img_scale, 1.f,
+                                  o[0].w[j >> 1], o[1].w[j >> 1], o[2].w[j >> 1]);
             const long long base = ((((long long)s * (H / 32) + hb) * 4 + lg) * 3) * ld_cols;
             cols_img[base + dc] = o[0].u;
             cols_img[base + ld_cols + dc] = o[1].u;

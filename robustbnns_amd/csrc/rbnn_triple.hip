@@ -140,9 +140,6 @@ __global__ void triple_rows_kernel(const float* __restrict__ src, long long rows
 // in 1-KiB pieces of 16 rows; physical 16-B chunk of logical chunk c in row r is c ^ swz(r), applied on the SOURCE address.
 // Epilogue = the exact kernel's (bias, activation, 1-bit stash, skinny H->C layer on the fp32 MFMA, softmax).
 // ===================================================================================================
-#ifndef RBNN_X3_L1_PAIR
-#define RBNN_X3_L1_PAIR 1                                       // fc2 layer 1's hidden image: pieces by split3_plain_pair (6 instructions per pair) / plain C++
-#endif
 struct FwdX3Args {
     const char* X;  int ldx;  int N;                           // grouped triple-rows image of the inputs [ceil16(N)][ldx] (ldx elements, % 32 == 0)
     const char* W;  long long w_sample_bytes;  int ldw;  int KT;   // grouped triple-rows image of W1 [S_total][H][ldw]; KT = ldw / 32
