@@ -158,11 +158,7 @@ __device__ __forceinline__ int swz(int row) { return (0x1320 >> (((row >> 2) & 3
 // ds_read_b128 is served in four NON-contiguous 16-lane groups — {0-3,12-15,20-27}, {4-11,16-19,28-31}, same +32 — i.e. rows
 // {0-3,12-15} of chunk pair lg together with rows {4-11} of chunk pair lg+1; physical chunk = c ^ row_swz(row) makes every group
 // cover 16 distinct 16-B slots of the 256-B bank row (the plain (r>>1)&7 swizzle measured 48 % conflict cycles).
-#ifndef RBNN_OLD_SWZ
 __device__ __forceinline__ int row_swz(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
-#else
-__device__ __forceinline__ int row_swz(int r) { return (r >> 1) & 7; }
-#endif
 
 // Asynchronous 16-B-per-lane global -> LDS copy (global_load_lds_dwordx4): per-lane source, LDS destination =
 // wave-uniform base + lane*16.  Completion is tracked by vmcnt; __syncthreads() drains it before the barrier.

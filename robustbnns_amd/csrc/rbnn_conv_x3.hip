@@ -49,9 +49,6 @@ __device__ __forceinline__ void conv_split3(float v, _Float16& p0, _Float16& p1,
 
 #define RBNN_X3FWD_BPREFETCH 0                                           // 1: the B fragments of tap t + 1 read under tap t's MFMAs (round 4) — measured SLOWER: 1x28x28 8.42 -> 8.58 ms per forward call,
                                                                           // 3x32x32 15.1 -> 16.5 (spills beside 56 accumulators): with two waves per SIMD the other wave fills a tap's post-barrier round trip
-#ifndef RBNN_CONVX3_OLD_IMG
-#define RBNN_CONVX3_OLD_IMG 0                                            // 1: the round-2 image layout (pitch = P1W, chunk swizzle by (pos >> 2) & 1 only)
-#endif
 // Image layout of conv2_pool_x3_kernel: position (y, x) of the pooled conv1 image is a 64-B record (32 channels) at index y * IPITCH + x;
 // 16-B channel octet o is stored at o ^ x3_img_swz(index, y).  A ds_read_b128 is served in four 16-lane groups {0-3, 12-15, 20-27},
 // {4-11, 16-19, 28-31}, +32 (rbnn_common.hpp); lane (li, lg) gathers octet lg of the position of output li + a tap offset.  Enumerating
@@ -62,8 +59,8 @@ __device__ __forceinline__ void conv_split3(float v, _Float16& p0, _Float16& p1,
 // per point instead of 37) with the idle lanes spread over positions 0..11 brings it to 1.14.
 template <class G> struct ConvX3Img {
     static constexpr bool MNIST = G::P1W == 12;
-    static constexpr int IPITCH = RBNN_CONVX3_OLD_IMG ? G::P1W : (MNIST ? 12 : 18);
-    static constexpr int ROWX = (!RBNN_CONVX3_OLD_IMG && MNIST) ? 1 : 0;
+    static constexpr int IPITCH = MNIST ? 12 : 18;
+    static constexpr int ROWX = MNIST ? 1 : 0;
 };
 template <class G> __device__ __forceinline__ int x3_img_swz(int idx, int y) {
     return ((((idx >> 2) & 1) << 1) ^ (ConvX3Img<G>::ROWX * (y & 1)));
@@ -135,7 +132,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
 #ifndef RBNN_X3FWD_PAIR13
 #define RBNN_X3FWD_PAIR13 1
 #endif
-    constexpr bool PAIR = RBNN_X3FWD_PAIR13 && (NPOS_ % 16 != 0) && !RBNN_CONVX3_OLD_IMG;
+    constexpr bool PAIR = RBNN_X3FWD_PAIR13 && (NPOS_ % 16 != 0);
     static_assert(!PAIR || (2 * NPOS_ + 15) / 16 == 2 * NPT - 1, "13 = 7 + 6 tiles");
     const char* const img = imgs + wp * L::IMGB;
     constexpr int CPITCH = NPOS_ + 4, EIT = (16 * NP2_ / 4 + 63) / 64;
@@ -154,7 +151,7 @@ __global__ void __launch_bounds__(512, 2) conv2_pool_x3_kernel(const ConvArgs a,
             const int point = c >= NPOS_ ? 1 : 0;
             pos = c - point * NPOS_;
             if (pt == NT - 1 && NT == NPT) ioff_s = (point - wp) * L::IMGB;
-        } else if (pos >= NPOS_) pos = RBNN_CONVX3_OLD_IMG ? 0 : pos - NPOS_;
+        } else if (pos >= NPOS_) pos = pos - NPOS_;
         ybase[pt] = pos / O2W_;
         pbase[pt] = ybase[pt] * IPITCH + pos % O2W_;
     }

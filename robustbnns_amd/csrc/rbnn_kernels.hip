@@ -729,17 +729,10 @@ int launch_forward_cfg(const FwdArgs& a, bool layer2, hipStream_t st) {
 template <int ACT>
 int launch_forward_act(const FwdArgs& a, bool layer2, hipStream_t st) {
     const int H = a.H;
-#if defined(RBNN_FWD8)
-    if (H % 512 == 0) return launch_forward_cfg<ACT, 4, 8, 2, 2>(a, layer2, st);   // 512 h x  64 n per block, 8 waves of 128 h x 32 n
-#elif defined(RBNN_FWD512)
-    if (H % 512 == 0) return launch_forward_cfg<ACT, 4, 8, 1, 4>(a, layer2, st);   // 512 h x  64 n per block
-#elif defined(RBNN_FWD256W8)
-    if (H % 512 == 0) return launch_forward_cfg<ACT, 2, 8, 4, 4>(a, layer2, st);   // 256 h x 256 n per block, 8 waves
-#else
     // 256 h x 128 n per block, H/256 chunks per item: 33% fewer L2->LDS bytes per MAC than 512 h x 64 n (measured
-    // 83.8% vs 81.0% of the fp32 MFMA peak at C2; the Z^T accumulators persist across the h chunks)
+    // 83.8% vs 81.0% of the fp32 MFMA peak at C2; the Z^T accumulators persist across the h chunks; the 8-wave 512 x 64 and 256 x 256 tilings
+    // lost their round-1 A/Bs too: HISTORY.md)
     if (H % 512 == 0) return launch_forward_cfg<ACT, 2, 8, 2, 4>(a, layer2, st);
-#endif
     if (H == 256)     return launch_forward_cfg<ACT, 2, 8, 2, 4>(a, layer2, st);   // 256 h x 128 n
     if (H == 128)     return launch_forward_cfg<ACT, 1, 8, 4, 4>(a, layer2, st);   // 128 h x 256 n
     if (H == 64)      return launch_forward_cfg<ACT, 1, 4, 4, 4>(a, layer2, st);   //  64 h x 256 n

@@ -32,9 +32,6 @@
 #ifndef RBNN_X3_BARRIER_END
 #define RBNN_X3_BARRIER_END 0
 #endif
-#ifndef RBNN_X3_SPREAD
-#define RBNN_X3_SPREAD 0                                      // 1: LDS-DMA pieces issued one at a time inside the MFMA / vector-only phases instead of at the
-#endif                                                        //    stage top — measured equal (forward) to 1 % slower (backward): profiles/r02t/experiments.txt
 
 namespace {
 
@@ -264,7 +261,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         const char* const Wt = ldsb + buf * TILEB + (wave_h * HTW) * 3072 + foff;
         const char* const Xt = ldsb + buf * TILEB + (BH / 16 + wave_n * NTW) * 3072 + foff;
         f16x8 b0[NTW], b1[NTW], b2[NTW], a0, a1, a2, a0n, a1n, a2n;
-        if (!RBNN_X3_SPREAD && !(RBNN_ABL & 1)) {
+        if (!(RBNN_ABL & 1)) {
 #pragma unroll
             for (int i = 0; i < PPS; ++i) piece(chn, ktn, buf ^ 1, i);
         }
@@ -298,8 +295,6 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
         a1 = *(const f16x8*)(Wt + 1024);
         a2 = *(const f16x8*)(Wt + 2048);
         a0n = a0; a1n = a1; a2n = a2;
-        constexpr int PER_HT = (PPS + 1) / 2;                   // pieces issued inside h tile 0 and inside h tile 1
-        static_assert(PER_HT <= 6, "one piece after each of an h tile's six product groups at most");
 #pragma unroll
         for (int ht = 0; ht < HTW; ++ht) {
             // six product groups of NTW MFMAs, smallest terms first; between them (fenced: the scheduler would otherwise cluster all
@@ -312,21 +307,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
                     const f16x8 bv = (k == 0) ? b2[nt] : ((k == 2 || k == 4) ? b1[nt] : b0[nt]);
                     acc[ht][nt] = MFMA_H(av, bv, acc[ht][nt]);
                 }
-                if (RBNN_X3_SPREAD) {
-                    const int i = ht * PER_HT + k;
-                    if (ht < 2 && k < PER_HT && i < PPS && !(RBNN_ABL & 1)) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        piece(chn, ktn, buf ^ 1, i);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (k == 2 && ht + 1 < HTW) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        a0n = *(const f16x8*)(Wt + (ht + 1) * 3072);
-                        a1n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 1024);
-                        a2n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 2048);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if (k == 0 && ht + 1 < HTW) {
+                if (k == 0 && ht + 1 < HTW) {
                     a0n = *(const f16x8*)(Wt + (ht + 1) * 3072);
                     a1n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 1024);
                     a2n = *(const f16x8*)(Wt + (ht + 1) * 3072 + 2048);
@@ -334,7 +315,7 @@ __global__ void __launch_bounds__(64 * WH * WN, WH * WN / 4) fc_forward_x3_kerne
             }
             a0 = a0n; a1 = a1n; a2 = a2n;
         }
-        if (!RBNN_X3_SPREAD) {
+        {
             // pin the order: B fragments + A(0) first, then per h tile half its MFMAs, the next tile's three reads, the rest
             __builtin_amdgcn_sched_group_barrier(0x100, 3 * NTW + 3, 0);
 #pragma unroll
@@ -799,9 +780,6 @@ __global__ void __launch_bounds__(256) attack_step_x3_kernel(float* __restrict__
 // wave's own 64 points (4 KiB per sample) lives in a SINGLE buffer: the wave itself re-fills it for the next sample during
 // the last stage of the current one, after its generator reads (two blocks per CU need <= 80 KB each).
 // ===================================================================================================
-#ifndef RBNN_X3_GRAD_BCOPY
-#define RBNN_X3_GRAD_BCOPY 0
-#endif
 #define GEN_Q3 (-17)                                           // |generator| <= 16 * 2^14 * 2^14 = 2^32  ->  |dA| <= 2^15 < fp16 max
 
 struct GradX3Args {
@@ -819,17 +797,13 @@ struct GradX3Args {
 };
 enum { X3_FC = 0, X3_FC2_STEP1 = 1, X3_FC2_STEP2 = 2 };
 
-template <int ACT, int TD, int MODE, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args a) {
+template <int ACT, int TD, int MODE>
+__global__ void __launch_bounds__(256, 2) fc_grad_x3_kernel(const GradX3Args a) {
+    constexpr int NW = 4;                                      // 4 waves x (64 points x TD*16 columns), two blocks per CU
     constexpr bool GEN = MODE != X3_FC2_STEP2;                 // dA generated from dZ, or read from memory
     constexpr bool BITMASK = (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY);   // act' from the 1-bit stash, or an fp32 stream (sigmoid / tanh)
     constexpr bool STREAM = !GEN || !BITMASK;                  // a per-lane fp32 operand (A itself, or act') is prefetched from memory
-    // NW = 4 (default): 4 waves x (64 points x TD*16 columns), two blocks per CU.  NW = 8 ("wide": TD = 14): 8 waves x (32 points x 224
-    // columns), one block per CU — the same 28 accumulator tiles per wave and the same 256-point block, but a column group is twice as
-    // wide, so the dA generator + split (a quarter of this kernel: every column group re-derives dA) runs for 4 groups instead of 7 at
-    // D = 784, at the price of twice the B-fragment LDS reads per MFMA (a fragment feeds 2 point tiles instead of 4).
     constexpr int NTW = 16 / NW, BM = 256, LD = TD * 16;
-    static_assert(NW == 4 || NW == 8, "256-point blocks of 4 or 8 waves");
     constexpr int W1B = 12 * LD * 16;                          // bytes: [4 lg][3 pieces][LD columns][16 B]
     constexpr int NPIECE = W1B / 1024, PPW = (NPIECE + NW - 1) / NW;
     constexpr int BUFB = W1B + 4096 + 1024;                    // + 2 generator tiles of 2 KiB + 256 stash words
@@ -874,7 +848,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
     };
     // The DMA pieces of a stage, per wave: 0 .. PPW-1 its W1 pieces, PPW its generator-tile piece (tiles 2*hb, 2*hb + 1 of the sample
     // are 4 KiB contiguous: one piece per wave), PPW + 1 the stash words (the block's 256 points = 1 KiB; last wave only).
-    constexpr int NDMA = GEN ? (BITMASK ? PPW + 2 : PPW + 1) : PPW, DPN = (NDMA + NTW - 1) / NTW;   // issued DPN at a time between the generator's point tiles
+    constexpr int NDMA = GEN ? (BITMASK ? PPW + 2 : PPW + 1) : PPW;
     struct StageSrc { const char* W; const char* G; const char* M; char* B; };
     auto stage_src = [&](int st, int buf) {
         const int si = st / HS, hb = st % HS, s = s_begin + si;
@@ -890,7 +864,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
         if (i < PPW) {
             if (wave + NW * i < NPIECE) glds16((const float*)(q.W + goff[i < PPW ? i : 0]), (float*)(q.B + (wave + NW * i) * 1024));
         } else if (i == PPW) {
-            if (NW == 4 || wave < 4) glds16((const float*)(q.G + loff), (float*)(q.B + W1B + wave * 1024));   // the two generator tiles are 4 pieces
+            glds16((const float*)(q.G + loff), (float*)(q.B + W1B + wave * 1024));   // the two generator tiles are 4 pieces: one per wave
         } else if (BITMASK && i == PPW + 1) {
             if (wave == NW - 1) glds16((const float*)(q.M + loff), (float*)(q.B + W1B + 4096));
         }
@@ -946,7 +920,7 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
                 da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
             }
         }
-        if (more && (!gen_on || !RBNN_X3_SPREAD)) {
+        if (more) {
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) issue_piece(q, i);
         }
@@ -986,10 +960,6 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
                     split3_pair_m<false>(g1[2], g1[3], dm[q * nt][1][2], dm[q * nt][1][3], 1.f, o0.u[3], o1.u[3], o2.u[3]);
                 }
                 da0[nt] = o0.v; da1[nt] = o1.v; da2[nt] = o2.v;
-                if (RBNN_X3_SPREAD && more) {
-#pragma unroll
-                    for (int i = nt * DPN; i < (nt + 1) * DPN && i < NDMA; ++i) issue_piece(q, i);
-                }
             }
         }
         if (GEN && !(RBNN_ABL & 1) && hb == HS - 1 && st + 1 < nst) {  // last stage of a sample: the dZ reads above are this wave's last of it
@@ -1008,9 +978,9 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
 #pragma unroll
         for (int dt = 0; dt < TD; ++dt) {
             if (dt < ntd) {                                     // block-uniform; the loop stays fully unrolled (acc in registers)
-                f16x8 (&bc)[3] = bb[RBNN_X3_GRAD_BCOPY ? 0 : (dt & 1)];
+                f16x8 (&bc)[3] = bb[dt & 1];
                 if (dt + 1 < TD) {
-                    f16x8 (&bn)[3] = bb[RBNN_X3_GRAD_BCOPY ? 1 : ((dt + 1) & 1)];
+                    f16x8 (&bn)[3] = bb[(dt + 1) & 1];
                     bn[0] = *(const f16x8*)(Bw + (dt + 1) * 256);
                     bn[1] = *(const f16x8*)(Bw + LD * 16 + (dt + 1) * 256);
                     bn[2] = *(const f16x8*)(Bw + 2 * LD * 16 + (dt + 1) * 256);
@@ -1027,7 +997,6 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
                 for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], bc[1], acc[nt][dt]);
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) acc[nt][dt] = MFMA_H(da0[nt], bc[0], acc[nt][dt]);
-                if (RBNN_X3_GRAD_BCOPY) { bb[0][0] = bb[1][0]; bb[0][1] = bb[1][1]; bb[0][2] = bb[1][2]; }   // (the round-2 form, kept for A/B runs)
             }
         }
         if (!(RBNN_ABL & 2)) ring_wait_barrier<0>();           // next stage landed; everyone is done with this one
@@ -1113,27 +1082,20 @@ __global__ void __launch_bounds__(64 * NW, 2) fc_grad_x3_kernel(const GradX3Args
         }
 }
 
-template <int ACT, int TD, int MODE, int NW = 4>
+template <int ACT, int TD, int MODE>
 int launch_grad_x3_cfg(GradX3Args a, hipStream_t st) {
     constexpr int LDSB = 2 * (12 * TD * 16 * 16 + 5120) + 256 * 64;
-    static_assert((NW == 4 ? 2 : 1) * LDSB <= 160 * 1024, "two 4-wave blocks or one 8-wave block per CU");
+    static_assert(2 * LDSB <= 160 * 1024, "two blocks per CU");
     a.NT = (a.N + 255) / 256;
     a.ND = (a.Dt + TD - 1) / TD;
-    auto kern = fc_grad_x3_kernel<ACT, TD, MODE, NW>;
+    auto kern = fc_grad_x3_kernel<ACT, TD, MODE>;
     static unsigned long long attr_done = 0;
     if (!ensure_dynamic_lds((const void*)kern, LDSB, attr_done)) return RBNN_ERR_LAUNCH;
     const int grid = grid_for_items((long long)a.NT * a.ND * a.nchunks);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), LDSB, st, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, st, a);
     return launch_status();
 }
 
-// fc (MODE X3_FC), relu / leaky: 8 waves x (32 points x 224 columns) where that saves column groups.  MEASURED SLOWER at C2 (round 3, same
-// box, alternating runs): gradient kernel 3.98 / 4.14 ms wide vs 3.75 / 3.69 ms narrow — the generator + split work it saves (4 column
-// groups instead of 7) is smaller than what the doubled B-fragment LDS traffic per MFMA costs.  Compiled in only with -DRBNN_X3_GRAD_WIDE=1
-// (then switchable with the environment variable RBNN_X3_GRAD_WIDE=0|1).
-#ifndef RBNN_X3_GRAD_WIDE
-#define RBNN_X3_GRAD_WIDE 0
-#endif
 #ifndef RBNN_X3_GRAD_TD9
 #define RBNN_X3_GRAD_TD9 1
 #endif
@@ -1155,7 +1117,7 @@ bool x3_grad_two_blocks() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     if (!ok[dev]) {
         constexpr int LDSB = 2 * (12 * TD * 16 * 16 + 5120) + 256 * 64;
-        auto kern = fc_grad_x3_kernel<ACT, TD, MODE, 4>;
+        auto kern = fc_grad_x3_kernel<ACT, TD, MODE>;
         static unsigned long long attr_done = 0;
         int nb = 0;
         const bool fine = ensure_dynamic_lds((const void*)kern, LDSB, attr_done) &&
@@ -1169,10 +1131,6 @@ bool x3_grad_two_blocks() {
 // that saves a group (a partial last group skips its missing tiles' MFMAs)
 template <int ACT, int MODE>
 int launch_grad_x3(const GradX3Args& a, hipStream_t st) {
-    if constexpr (RBNN_X3_GRAD_WIDE && MODE == X3_FC && (ACT == RBNN_ACT_RELU || ACT == RBNN_ACT_LEAKY)) {
-        static const bool wide = [] { const char* e = getenv("RBNN_X3_GRAD_WIDE"); return !e || e[0] != '0'; }();
-        if (wide && (a.Dt + 13) / 14 < (a.Dt + 6) / 7) return launch_grad_x3_cfg<ACT, 14, MODE, 8>(a, st);
-    }
 #if RBNN_X3_GRAD_TD9
     // 9 column tiles per block (two blocks' LDS = exactly 160 KB): 6 column groups instead of 7 at D = 784, i.e. one generator + split
     // pass in seven less: 3.71 / 3.68 -> 3.59 / 3.59 ms at C2 (alternating builds, same box).  Environment RBNN_X3_GRAD_TD9=0 switches

@@ -30,9 +30,6 @@ int main(int argc, char** argv) {
     {
         int nf = 0, ng = 0;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)fc_forward_kernel<RBNN_ACT_LEAKY, 4, 8, 1, 4, true>, 256, 0);
-#ifdef RBNN_FWD8
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, (const void*)fc_forward_kernel<RBNN_ACT_LEAKY, 4, 8, 2, 2, true>, 512, 0);
-#endif
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&ng, (const void*)fc_grad_kernel<RBNN_ACT_LEAKY, 7, 3, false, false, 32>, 256, 0);
         printf("occupancy API: fwd %d blocks/CU, grad %d blocks/CU; chunk %d n_slabs %d\n", nf, ng, sz.chunk, sz.n_slabs);
     }
