@@ -904,6 +904,22 @@ def test_reads_result_pickles_written_by_the_reference(monkeypatch, tmp_path):
     assert key(open(tmp_path / "a.pkl", "rb").read()) == key(b) and key(b) != b
 
 
+def test_reference_trained_posteriors_are_far_inside_the_dynamic_range_guard(golden):
+    """`auto` leaves a posterior to the fp32-MFMA kernels (half the triple mode's rate) when a weight tensor's largest magnitude
+    exceeds 2^12 x its mean magnitude (posterior.narrow_range).  How often does a TRAINED posterior trip that?  Every net the reference's own
+    NN.train produced for the fixtures — fc, fc2, conv; half-moons and MNIST-shaped — sits between 2 and 11, four hundred times inside the guard."""
+    import glob
+    from robustbnns_amd.posterior import narrow_range
+    names = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_*.npz")))
+    assert len(names) >= 5
+    worst = 0.0
+    for name in names:
+        post = golden(name).posterior()
+        assert narrow_range(*post.values())
+        worst = max(worst, max(float(v.abs().max() / v.abs().double().mean()) for v in post.values()))
+    assert 2.0 < worst < 16.0, worst
+
+
 def test_no_mfma_reads_a_vgpr_inside_the_valu_write_window():
     """a VGPR written by a vector instruction needs two wait states before an MFMA takes it as an operand; hipcc pads that between
     instructions it sees but not behind an inline-asm block (the pair splits end in v_fma_mixhi_f16).  The disassembly of the BUILT library is
