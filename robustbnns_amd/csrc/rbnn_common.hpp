@@ -130,9 +130,10 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // block and pads ONE state behind it — an MFMA scheduled straight behind the block (any block: these are plain asm statements, the scheduler orders
 // them freely) read a stale d2: fc2's layer 2 on the fp32 hidden image was off by the low
 // pieces, 7e-4, on exactly the last point tile of the 8-wave configuration; with the pad only behind the LAST of a fragment's four pairs it failed again
-// (DESIGN §3z).  `s_nop 1` inside the string closes the window for every consumer, whatever the scheduler puts there; it is part of EVERY
-// asm block whose outputs feed an MFMA (this one; split3_pair / split3_pair_m in rbnn_triple.hip), and the built library is scanned for the
-// hazard itself: tools/kernel_resources.py::mfma_operand_hazards (tests/test_host_cpu.py::test_no_mfma_reads_a_vgpr_inside_the_valu_write_window).
+// (DESIGN §3z).  `s_nop 1` inside the string closes the window for every consumer, whatever the scheduler puts there; it is part of this
+// block for every user.  The gradient kernel's own pair splits (split3_pair / split3_pair_m, rbnn_triple.hip) are fenced by a scan of the BUILT
+// library's disassembly instead — tools/kernel_resources.py::mfma_operand_hazards, tests/test_host_cpu.py::
+// test_no_mfma_reads_a_vgpr_inside_the_valu_write_window, which covers every kernel — because sixteen pads per wave-stage cost that kernel 0.5-1.7 %.
 __device__ __forceinline__ void split3_plain_pair(float ve, float vo, float one, unsigned& d0, unsigned& d1, unsigned& d2) {
     float re, ro;
     asm("v_cvt_pk_f16_f32 %[d0], %[ve], %[vo]\n\t"

@@ -48,9 +48,23 @@ __device__ __forceinline__ void split3(float v, _Float16& p0, _Float16& p1, _Flo
 // and writes its half of the packed result — 11 vector instructions per pair.  (Plain C++ compiles to ~18: hipcc re-derives
 // the pieces through f32 round trips and SLP-packs them into v_pk_* ops, and the kernel is bound by vector-instruction ISSUE.)
 // FIRST: these are the first reads of a generator MFMA's result — the 7 wait states an XDL write needs before a VALU read
-// (the compiler cannot see into the asm to insert them).  The trailing `s_nop 1`: d0 / d1 / d2 are MFMA A operands and the block ends in a
-// vector write — the two wait states a VALU-written VGPR needs before an MFMA reads it are part of the block (as in split3_plain_pair,
-// rbnn_common.hpp), and tools/kernel_resources.py --hazards scans the built library's disassembly for any MFMA closer than that to its writer.
+// (the compiler cannot see into the asm to insert them).
+// d0 / d1 / d2 are MFMA A operands and the block ends in a vector write (v_fma_mixhi_f16): a VGPR written by a vector instruction needs two wait
+// states before an MFMA reads it, and hipcc cannot see into the string.  In this kernel the sixteen blocks of a wave-stage are followed by the
+// generator's next point tile or by LDS fragment reads — the first main MFMA that takes da* sits dozens of instructions behind the last block —
+// and THE BUILT LIBRARY IS SCANNED for any MFMA closer than two wait states to the vector write of one of its operands
+// (tools/kernel_resources.py::mfma_operand_hazards, tests/test_host_cpu.py::test_no_mfma_reads_a_vgpr_inside_the_valu_write_window): a build in
+// which the scheduler ever placed one there fails that test.  RBNN_X3_PAIR_NOP=1 pads every block with `s_nop 1` instead (ADVICE r5's other
+// option; same-box A/B, profiles/r06k: sixteen pads per wave-stage cost the gradient kernel 0.5-1.7 %, which is why the scan is the fence here;
+// split3_plain_pair, rbnn_common.hpp, whose users DID hit the hazard, carries its pad).
+#ifndef RBNN_X3_PAIR_NOP
+#define RBNN_X3_PAIR_NOP 0
+#endif
+#if RBNN_X3_PAIR_NOP
+#define RBNN_X3_PAIR_PAD "\n\ts_nop 1"
+#else
+#define RBNN_X3_PAIR_PAD ""
+#endif
 #define RBNN_X3_PAIR_BODY \
     "v_bfe_i32 %[me], %[mw], %[b0], 1\n\t" \
     "v_bfe_i32 %[mo], %[mw], %[b1], 1\n\t" \
@@ -62,8 +76,7 @@ __device__ __forceinline__ void split3(float v, _Float16& p0, _Float16& p1, _Flo
     "v_fma_mix_f32 %[ro], %[go], %[mo], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
     "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t" \
     "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t" \
-    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
-    "s_nop 1"
+    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]" RBNN_X3_PAIR_PAD
 #define RBNN_X3_PAIR_OPS \
     : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [me] "=&v"(me), [mo] "=&v"(mo), [re] "=&v"(re), [ro] "=&v"(ro) \
     : [ge] "v"(ge), [go] "v"(go), [mw] "v"(mw), [cp] "v"(cp), [cn] "v"(cn), [one] "v"(one), [b0] "n"(BIT), [b1] "n"(BIT + 1)
@@ -87,8 +100,7 @@ __device__ __forceinline__ void split3_pair_m(float ge, float go, float me, floa
     "v_fma_mix_f32 %[ro], %[go], %[mo], -%[d0] op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t" \
     "v_cvt_pk_f16_f32 %[d1], %[re], %[ro]\n\t" \
     "v_fma_mixlo_f16 %[d2], -%[d1], %[one], %[re] op_sel_hi:[1,0,0]\n\t" \
-    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t" \
-    "s_nop 1"
+    "v_fma_mixhi_f16 %[d2], -%[d1], %[one], %[ro] op_sel:[1,0,0] op_sel_hi:[1,0,0]" RBNN_X3_PAIR_PAD
 #define RBNN_X3_PAIRM_OPS \
     : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [re] "=&v"(re), [ro] "=&v"(ro) \
     : [ge] "v"(ge), [go] "v"(go), [me] "v"(me), [mo] "v"(mo), [one] "v"(one)
