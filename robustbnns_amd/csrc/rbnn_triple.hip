@@ -85,6 +85,9 @@ __device__ __forceinline__ void split3_pair(float ge, float go, unsigned mw, uns
                                             unsigned& d0, unsigned& d1, unsigned& d2) {
     unsigned me, mo;
     float re, ro;
+    // (FIRST: eight wait states behind v_mfma_f32_16x16x32_f16 before its result is read — hipcc's own padding for that pair; the built library is
+    // scanned for it: tools/kernel_resources.py::mfma_result_hazards.  Counting the block's four mask instructions towards them, `s_nop 3`, measured
+    // equal — 3.66 vs 3.69 ms, profiles/r06k/first_nop_ab.txt: the result is not there earlier either way — so the full pad stays)
     if constexpr (FIRST) asm volatile("s_nop 7\n\t" RBNN_X3_PAIR_BODY RBNN_X3_PAIR_OPS);
     else asm volatile(RBNN_X3_PAIR_BODY RBNN_X3_PAIR_OPS);   // volatile: the pairs of one MFMA result stay behind the FIRST one
 }

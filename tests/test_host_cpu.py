@@ -931,6 +931,8 @@ def test_no_mfma_reads_a_vgpr_inside_the_valu_write_window():
         pytest.skip("llvm-objdump not in this image")
     assert KR.mfma_operand_hazards() == []
     assert len(KR.mfma_operand_hazards(need=3)) > 1000       # the scan sees the kernels' MFMAs: hipcc's own padding sits at exactly two states
+    # the reverse direction: a vector instruction reading an MFMA's result too early (the FIRST pair split of a generator result pads inside its asm block)
+    assert KR.mfma_result_hazards() == []
 
 
 def test_bench_path_kernels_use_no_scratch():

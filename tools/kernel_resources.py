@@ -125,13 +125,70 @@ def mfma_operand_hazards(lib=LIB, need=2):
     return [(n,) + b[1:] for n, b in zip(names, bad)]
 
 
+def _mfma_result_wait(mn):
+    """instructions' worth of wait states (an instruction = 1, `s_nop N` = N + 1) that must lie BETWEEN an MFMA and a vector instruction that reads
+    its result.  Calibrated on hipcc 7.2's own padding for gfx950 in this library (the closest pairs it emits: 8 behind v_mfma_f32_16x16x32_f16,
+    10 behind v_mfma_f32_16x16x4_f32); anything else is held to the 16-pass figure."""
+    if "16x16x32" in mn:
+        return 8
+    if "16x16x4_f32" in mn or "16x16x4f32" in mn:
+        return 10
+    return 18
+
+
+def mfma_result_hazards(lib=LIB):
+    """-> [(kernel, vector instruction, mfma, wait states seen, needed)]: every non-MFMA vector instruction that READS a VGPR an MFMA wrote fewer wait
+    states earlier than the MFMA's passes need ('XDL write VGPR -> VALU read').  hipcc pads this between instructions it sees; the first read of a
+    generator MFMA's result INSIDE an asm block (split3_pair<.., FIRST>) relies on the block's own leading `s_nop` plus the mask instructions in
+    front of that read — this scan counts them in the built code."""
+    bad = []
+    for co in code_objects(lib):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        kern, recent = "?", []                                   # recent: [(states since issue, vgprs written, needed, text)]
+        for line in txt.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                kern, recent = m.group(1), []
+                continue
+            ins = line.split("//")[0].strip()
+            if not ins or ins.startswith("."):
+                continue
+            mn, _, rest = ins.partition(" ")
+            ops = [o.strip() for o in rest.split(",")]
+            is_mfma = mn.startswith("v_mfma") or mn.startswith("v_smfma")
+            if mn.startswith("v_") and not is_mfma:
+                srcs = set()
+                for o in ops[1:]:
+                    k, r = _regs(o.split(" ")[0])
+                    if k == "v":
+                        srcs |= r
+                for age, regs, need, text in recent:
+                    if age < need and regs & srcs:
+                        bad.append((kern, ins, text, age, need))
+            states = (int(rest.strip().split()[0], 0) + 1) if mn == "s_nop" else 1
+            recent = [(a + states, r, n, t) for a, r, n, t in recent if a + states < n]
+            if is_mfma:
+                k, r = _regs(ops[0].split(" ")[0])
+                if k == "v":
+                    recent.insert(0, (0, r, _mfma_result_wait(mn), ins))
+    names = demangle([b[0] for b in bad])
+    return [(n,) + b[1:] for n, b in zip(names, bad)]
+
+
 if __name__ == "__main__":
     if "--hazards" in sys.argv:
         hz = mfma_operand_hazards()
         for h in hz:
             print(h)
         print(len(hz), "VALU-write -> MFMA-read pairs closer than 2 wait states")
-        sys.exit(1 if hz else 0)
+        hr = mfma_result_hazards()
+        for h in hr[:20]:
+            print(h)
+        print(len(hr), "MFMA-write -> VALU-read pairs closer than the MFMA's passes need")
+        sys.exit(1 if (hz or hr) else 0)
     lib = sys.argv[1] if len(sys.argv) > 1 and os.path.exists(sys.argv[1]) else LIB
     flt = sys.argv[-1] if len(sys.argv) > 1 and not os.path.exists(sys.argv[-1]) else ""
     res = kernel_resources(lib)
