@@ -516,8 +516,20 @@ int launch_conv1_pool_x3(const ConvArgs& a, hipStream_t st) {
     const char* const pe = getenv("RBNN_CONV1_X3_PW");                     // (read per launch: the tests set it per case)
     const int pw_env = pe ? atoi(pe) : 0;
     const long long pairs = (long long)a.N * a.S;
-    // (measured at N = 512, S = 62 on 3x32x32, profiles/r06c: pw 1 / 2 / 4 / 8 -> 0.93 / 0.86 / 0.80 / 0.77 ms; the fp32 VALU kernel: 1.71)
-    const int pw = pw_env > 0 ? pw_env : (int)std::max(1LL, std::min(8LL, pairs / (4LL * 512 * 2)));
+    // (measured at N = 512, S = 62 on 3x32x32, profiles/r06c: pw 1 / 2 / 4 / 8 -> 0.93 / 0.86 / 0.80 / 0.77 ms; the fp32 VALU kernel: 1.71.)  A block
+    // runs pw points per wave after a set-up worth ~0.25 of a point, and the grid runs in ROUNDS of 2 blocks per CU: pw = the value in 1 .. 8 that
+    // minimises rounds x (pw + 0.25) — a plain "as large as possible" picked 7 at that size, 2.3 rounds = three of 7 instead of two of 8 (0.90 ms).
+    int pw = pw_env;
+    if (pw <= 0) {
+        const long long slots = 2LL * device_cus();
+        double best = 1e300;
+        for (int c = 1; c <= 8; ++c) {
+            const long long blocks = ((a.N + 4LL * c - 1) / (4LL * c)) * a.S;
+            const double cost = (double)((blocks + slots - 1) / slots) * (c + 0.25);
+            if (cost < best - 1e-9) { best = cost; pw = c; }
+        }
+    }
+    (void)pairs;
     static unsigned long long attr = 0;
     if (!ensure_dynamic_lds((const void*)conv1_pool_x3_kernel<ACT, G>, T::LDSB, attr)) return RBNN_ERR_LAUNCH;
     const long long groups = (a.N + 4LL * pw - 1) / (4LL * pw);
