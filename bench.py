@@ -566,6 +566,7 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
                     if rank == 0 and w["iters"] * w["N"] >= 200000:        # a step of minutes (c5 at its full definition): a heartbeat on stderr
                         print(f"[bench] {name}: eps={e:.5f} attack enqueued, t={time.perf_counter() - t_start:.0f} s", file=sys.stderr, flush=True)
 
+        t_w = time.perf_counter()
         for _ in range(args.warmup):
             step()
         if pipe:                                                          # the draw's own duration: stand-alone launches, outside the timed region
@@ -578,28 +579,34 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
                 draw_ev.append((e0, e1))
             post_._prefetched = False                                     # (those overwrote the front set: start the timed region with a fresh draw)
         rt.sync()
+        warm_ms = 1e3 * (time.perf_counter() - t_w) / max(1, args.warmup)
         barrier()
         rt.sync()
         kern.on = comm.on = True
         step_ev = []
+        # one event pair per step on the launch stream: the line then carries min / median / max beside the mean, so that a box's clock wander
+        # (+-5 % on the power-limited f16 kernels) shows up in the record itself.  A launch-bound step (C1: 31 us, one launch)
+        # would pay for the two event records themselves (+10 us): steps shorter than ~1 ms are bracketed in groups of `grp` consecutive steps
+        grp = 1 if (args.warmup == 0 or warm_ms >= 1.0) else max(1, min(args.steps, int(round(2.0 / max(warm_ms, 1e-3)))))
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            # one event pair per step on the launch stream: the line then carries min / median / max beside the mean, so that a box's clock
-            # wander (+-5 % on the power-limited f16 kernels) shows up in the record itself
-            e0, e1 = rt.event(), rt.event()
-            e0.record()
+        for i in range(args.steps):
+            if i % grp == 0:
+                e0 = rt.event()
+                e0.record()
             step()
-            e1.record()
-            step_ev.append((e0, e1))
+            if (i + 1) % grp == 0 or i + 1 == args.steps:
+                e1 = rt.event()
+                e1.record()
+                step_ev.append((e0, e1, i % grp + 1))
         rt.sync()
         barrier()
         rt.sync()
         dt = time.perf_counter() - t0
         kern.on = comm.on = False
-        step_ms = sorted(a.elapsed_time(b) for a, b in step_ev)
+        step_ms = sorted(a.elapsed_time(b) / k for a, b, k in step_ev)
         extra = {"ms_per_step_min": step_ms[0], "ms_per_step_median": step_ms[len(step_ms) // 2] if len(step_ms) % 2 else
                  0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]), "ms_per_step_max": step_ms[-1],
-                 "comm_calls": comm.calls, "comm_bytes": comm.bytes, "comm_exposed_ms": sum(a.elapsed_time(b) for a, b in comm.exposed),
+                 "steps_per_event_pair": grp, "comm_calls": comm.calls, "comm_bytes": comm.bytes, "comm_exposed_ms": sum(a.elapsed_time(b) for a, b in comm.exposed),
                  "comm_waits": len(comm.exposed)}
         if world > 1:
             import torch.distributed as dist
@@ -817,6 +824,7 @@ def bench_one(args, name, shard, rt, rank, world, device, group, sub_record=Fals
             # HIP events around every single step on the launch stream (rank 0's): the spread a box's clock puts on `ms_per_step` (the mean over the
             # barrier-bracketed region, max over ranks)
             "ms_per_step_min": extra["ms_per_step_min"], "ms_per_step_median": extra["ms_per_step_median"], "ms_per_step_max": extra["ms_per_step_max"],
+            "steps_per_event_pair": extra["steps_per_event_pair"],
             # which workload / sharding this line is, at the top level (a c4 line must not be read against an older record's c2 number)
             "workload": name, "shard": shard if world > 1 else "none",
             "dtype": DTYPES[mode], "precision_mode": mode, "data": "synthetic",
