@@ -12,7 +12,7 @@ everything resident in HBM before the timed region.  One step = one pass of the 
 forward over all (point, sample) pairs, CE on the mean probabilities, hand-rolled input gradient, sign/clamp.
 attack-samples = points x posterior samples x iterations (1 for FGSM).  Other workloads (--workload): c1, c3 (PGD T=40,
 S=500), c4 (the per-GPU share of S=2000 sharded 8-way: loss_gradients + FGSM per step), c5 (CIFAR-shaped conv-BNN, PGD
-T=100 over eps in {2,4,8}/255; build-defined shapes, parity unpinned), conv, fc2.
+T=100 over eps in {2,4,8}/255; build-defined shapes, parity unpinned), conv, fc2, conv1024, fc2_1024, eval.
 
 Posterior (`--posterior`, default `config` = what BASELINE.json names for the workload): c2 and c1 say "SVI" — the weights are then a
 variational guide (loc ~ N(0, std^2), raw scale -3: SURVEY 8d) and EVERY STEP REDRAWS all S samples inside the timed region, in place,
@@ -35,6 +35,12 @@ terms per fp32 product on v_mfma_f32_16x16x32_f16, fp32 accumulation — nothing
 accumulation as on the fp32 MFMA (tests/test_hip_triple.py: error vs fp64 below the fp32-MFMA kernels').  "split" (opt-in): two
 fp16 pieces, 3 products — operands 22-23 bits, narrower than fp32.  The modes that are not on top are timed afterwards at N=1
 and reported as sub-records (`exact_fp32_mode`, `triple_f16x6_mode`, `split_f16x3_mode`).
+
+`--workload eval` times adversarialAttacks.attack_evaluation at C2's size (clean + adversarial batched forward + rbnn_eval_metrics: forward only).
+Beside the mean `ms_per_step` the line carries `ms_per_step_min / _median / _max` from one HIP-event pair per step (per group of steps when a step is
+shorter than ~1 ms), `workload` / `shard` at the top level, and — whenever a process group exists — a `comm` record: backend, world size as the
+library reports it, the ranks an all-reduce of ones summed, RCCL's version, all-reduce calls / bytes per step and the time per step the launch stream
+stood waiting for an exchange.
 
 The JSON line carries `roofline` for the dominant kernel (the other GEMM kernel is listed beside it under roofline.kernels),
 timed with HIP events on the launch stream inside the timed region, and `cpu_baseline`: the loop-structured oracle port
