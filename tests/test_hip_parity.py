@@ -433,6 +433,18 @@ def test_sharded_step_with_real_kernels_and_rccl(precision, blocks, monkeypatch)
         pg = eng.pgd(x, y, S, 0.25, iters=3).cpu()
         assert float(((pg - ref_p).abs() > 1e-6).double().mean()) < 0.01
         assert rel_err(eng.forward(x, S).cpu(), plain.forward(x, S).cpu()) < 1e-6
+        # what bench.py's `comm` record is made of (engine.CommStats): every all-reduce of a step counted with its bytes, and an event pair on the
+        # launch stream around every point where that stream waits for one — two per point block here (sum_s p_s [n, 16]; the gradients [n, D_pad])
+        from robustbnns_amd.engine import CommStats
+        cs = CommStats(lambda: torch.cuda.Event(enable_timing=True))
+        eng.comm_stats = cs
+        cs.on = True
+        adv_equal(eng.fgsm(x, y, S, 0.25).cpu(), ref_f, G)
+        cs.on = False
+        torch.cuda.synchronize()
+        assert cs.calls == 2 * blocks and cs.bytes == 4 * N * (16 + sp.Dp) and len(cs.exposed) == 2 * blocks
+        waits = [a.elapsed_time(b) for a, b in cs.exposed]
+        assert all(0.0 <= w < 50.0 for w in waits), waits
     finally:
         dist.destroy_process_group()
 
