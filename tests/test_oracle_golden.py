@@ -133,3 +133,23 @@ def test_deterministic_and_ensemble(golden):
         oa, aa, rob = O.attack_evaluation(x, g.t(tag + "_pgd"), y, post, arch, act, S_, kind="ensemble")
         assert (oa, aa) == (float(g.arr[tag + "_eval_pgd_orig_acc"]), float(g.arr[tag + "_eval_pgd_adv_acc"]))
         assert float((rob - g.t(tag + "_eval_pgd_softmax_rob")).abs().max()) < 1e-6
+
+
+def test_cancellation_condition_marks_the_point_where_any_fp32_evaluation_misses_1e5():
+    """conftest.cancellation_condition (the bound of tests/test_hip_parity.py::test_against_fp64_oracle): on the half-moons-sized oracle case the samples'
+    contributions to the mean-logit gradient cancel 777 : 1 at exactly one of 300 points, and there torch's OWN fp32 evaluation of the oracle's formula is
+    1.9e-5 from the fp64 one — the 1e-5 bar is not a property any fp32 arithmetic has at that point; everywhere else fp32 torch is within 1e-5."""
+    import torch
+    from conftest import cancellation_condition, rel_err_points
+    arch, act, shape, C, H, S, N, std = "fc", "leaky", (1, 2, 1), 2, 16, 4, 300, 0.5
+    post = O.synthetic_posterior(arch, 2, H, C, S, std)
+    x, y = O.synthetic_inputs(N, shape, C, seed=H + N)
+    lab = y.argmax(-1)
+    cond = cancellation_condition(x, lab, post, arch, act, S, "ensemble")
+    flagged = 2.0 ** -23 * cond > 1e-5
+    assert int(flagged.sum()) == 1 and 500 < float(cond.max()) < 1500
+    g64 = O.meanprob_gradients(x.double(), lab, O.cast(post, torch.float64), arch, act, S, kind="ensemble")
+    g32 = O.meanprob_gradients(x.float(), lab, post, arch, act, S, kind="ensemble")
+    e = rel_err_points(g32, g64)
+    assert float(e[flagged].max()) > 1e-5 and float(e[~flagged].max()) < 1e-5
+    assert bool((e <= torch.clamp(2.0 ** -23 * cond, min=1e-5)).all())
